@@ -1,0 +1,132 @@
+/*
+ * lsgpu_icp.h -- C ABI of the MI355X-native ICP scan-matching path (liblsgpu_icp.so).
+ *
+ * The reference exposes no FFI for this path: `icp_` is a concrete PointMatcher::ICP member
+ * (laser_slam/include/laser_slam/laser_track.hpp:217, incremental_estimator.hpp:70) and the two
+ * call sites are
+ *     icp_.compute(last_scan.scan, sub_map, T_init)        laser_slam/src/laser_track.cpp:496
+ *     icp_.compute(sub_map_b, sub_map_a, T_init)           laser_slam/src/incremental_estimator.cpp:108
+ * This header is the seam a maintainer binds instead (INTEGRATION.md shows the C++ shim): one
+ * handle == one `icp_` member == one device + one HIP stream.  Handles are independent (tracks run
+ * concurrently, laser_track.hpp:211 holds one mutex per track); a handle is not thread safe.
+ *
+ * Data layout == PointMatcher<float>::DataPoints (laser_slam/include/laser_slam/common.hpp:14-17):
+ *   features    (dim+1) x N column major  ->  AoS x,y,z,1 float, 16 B / point  ("xyz1")
+ *   descriptors "normals" 3 x N column major -> 12 B / point
+ *   TransformationParameters 4x4 float column major; p_reference = T * p_reading.
+ * Every pointer argument may be host memory or device (HBM) memory of the handle's device; the
+ * library detects which.  Host buffers are copied, never retained.  No exceptions cross this ABI.
+ */
+#ifndef LSGPU_ICP_H_
+#define LSGPU_ICP_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LSGPU_ABI_VERSION 1
+
+/* Return codes.  NO_CONVERGENCE is PointMatcher::ConvergenceError: laser_track.cpp:499-502 catches it
+ * and keeps the odometry guess; incremental_estimator.cpp:108 lets it propagate. */
+enum {
+  LSGPU_OK = 0,
+  LSGPU_NO_CONVERGENCE = 1,
+  LSGPU_BAD_CONFIG = 2,
+  LSGPU_HIP_ERROR = 3,
+  LSGPU_BAD_ARG = 4
+};
+
+typedef struct lsgpu_icp lsgpu_icp;
+
+/* Device-side part of the chain in laser_slam/configurations/icp_default.yaml:9-27. */
+typedef struct lsgpu_icp_config {
+  float trim_ratio;       /* TrimmedDistOutlierFilter ratio            yaml:16  (0.75)  */
+  int   max_iterations;   /* CounterTransformationChecker              yaml:23  (40)    */
+  float min_diff_rot;     /* Differential... minDiffRotErr   [rad]     yaml:25  (0.001) */
+  float min_diff_trans;   /* Differential... minDiffTransErr [m]       yaml:26  (0.01)  */
+  int   smooth_length;    /* Differential... smoothLength              yaml:27  (4)     */
+  float cell_size;        /* finest voxel edge [m]; <= 0: automatic                      */
+  int   profile_kernels;  /* 1: HIP-event time every kNN launch (see lsgpu_icp_stats)    */
+  int   reserved[8];
+} lsgpu_icp_config;
+
+/* icp_default.yaml values / ICP::setDefault() values (laser_track.cpp:17,20). */
+void lsgpu_icp_config_yaml(lsgpu_icp_config* c);
+void lsgpu_icp_config_default(lsgpu_icp_config* c);
+
+typedef struct lsgpu_icp_stats {
+  int     iterations;
+  int     converged;         /* 1 stopped by the differential checker, 0 by the counter */
+  float   final_limit;       /* last trimmed squared-distance limit                     */
+  int64_t final_n_used;      /* pairs with weight 1 in the last iteration               */
+  int64_t stragglers;        /* queries resolved by the exact fallback search, summed   */
+  double  t_total_ms;        /* host wall time of the call                              */
+  double  t_knn_ms;          /* sum of kNN kernel time (HIP events; profile_kernels=1)  */
+  int     knn_launches;
+  double  t_reserved[4];
+} lsgpu_icp_stats;
+
+/* One record per iteration (optional parity/debug trace; replaces the VTKFileInspector dump of
+ * icp_default.yaml:32-40). */
+typedef struct lsgpu_iter_trace {
+  float   T_iter[16];
+  float   limit;
+  int64_t n_used;
+  double  A[36];
+  double  b[6];
+  double  x[6];
+} lsgpu_iter_trace;
+
+int  lsgpu_icp_create(const lsgpu_icp_config* cfg, int device, lsgpu_icp** out);
+void lsgpu_icp_destroy(lsgpu_icp* h);
+
+/* Steps 2-3 of ICP::compute: centre the (already filtered) reference on its mean, build the voxel
+ * grid.  `normals` = the descriptor SamplingSurfaceNormalDataPointsFilter attached (yaml:5-7). */
+int lsgpu_icp_set_reference(lsgpu_icp* h, const float* ref_xyz1, const float* ref_normals, int64_t nr);
+
+/* Steps 5-7 of ICP::compute on the (already filtered) reading.  T_out = T_init on failure. */
+int lsgpu_icp_align(lsgpu_icp* h, const float* reading_xyz1, int64_t nq, const float T_init[16],
+                    float T_out[16], lsgpu_icp_stats* stats);
+
+/* Per-iteration records of the last align; returns the number written. */
+int lsgpu_icp_get_trace(lsgpu_icp* h, lsgpu_iter_trace* out, int cap);
+
+/* The float mean subtracted from the reference (T_refIn_refMean translation). */
+int lsgpu_icp_get_reference_mean(lsgpu_icp* h, float mean[3]);
+
+/* ---- kernel-level entry points (parity tests / profiling); all in the reference-MEAN frame ---- */
+
+/* KDTreeMatcher::findClosests knn=1 eps=0 (yaml:9-12): ids index the reference as given to
+ * set_reference, d2 = squared distance.  T (may be NULL = identity) is applied to each query on load. */
+int lsgpu_knn(lsgpu_icp* h, const float* query_xyz1, int64_t nq, const float T[16], int32_t* ids,
+              float* d2);
+/* TrimmedDistOutlierFilter (yaml:14-16): limit = sorted(d2)[floor(n*ratio)]. */
+int lsgpu_trim_limit(lsgpu_icp* h, const float* d2, int64_t n, float ratio, float* limit);
+/* PointToPlaneErrorMinimizer accumulation (yaml:18-19): out = 21 upper-tri of sum J J^T (row major
+ * order a<=c), 6 of -sum J r, sum w, sum w r^2  -> double[29]. */
+int lsgpu_normal_eq(lsgpu_icp* h, const float* query_xyz1, int64_t nq, const float T[16],
+                    const int32_t* ids, const float* d2, float limit, double out[29]);
+/* RigidTransformation::compute on features (laser_track.cpp:265,485): out = T * xyz1. */
+int lsgpu_transform_points(lsgpu_icp* h, const float T[16], const float* xyz1, int64_t n, float* out);
+
+/* ---- host-side modules of the chain (run on the CPU; the reference runs them there too) ---- */
+
+/* RandomSamplingDataPointsFilter (yaml:1-3): keep i iff rand()/RAND_MAX < prob; seed >= 0 -> srand. */
+int64_t lsgpu_filter_random_sampling(int64_t n, float prob, int64_t seed, int64_t* keep_idx);
+/* SamplingSurfaceNormalDataPointsFilter (yaml:5-7), samplingMethod 0, keepNormals 1. */
+int64_t lsgpu_filter_sampling_surface_normal(const float* xyz1, int64_t n, int knn, float ratio,
+                                             int64_t seed, float* out_xyz1, float* out_normals);
+/* RigidTransformation::checkParameters / correctParameters (common.hpp:136-149). */
+int  lsgpu_check_rigid(const float T[16]);
+void lsgpu_correct_rigid(const float T[16], float out[16]);
+
+const char* lsgpu_strerror(int code);
+const char* lsgpu_last_error(lsgpu_icp* h); /* detail of the last failure on this handle */
+int         lsgpu_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

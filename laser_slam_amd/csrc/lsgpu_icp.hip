@@ -1,0 +1,624 @@
+// lsgpu_icp.hip -- C-ABI shim (include/lsgpu_icp.h) over the gfx950 kernels.
+//
+// Host-side control flow restates PointMatcher::ICP::compute as called from
+// laser_slam/src/laser_track.cpp:496 and laser_slam/src/incremental_estimator.cpp:108:
+//   set_reference : steps 2-3 (centre on mean, matcher init)
+//   align         : steps 5-7 (move reading by T_refMean_dataIn, iterate, compose)
+// Kernels: lsgpu_kernels.hip.h.  No CPU fallback exists: every failure is returned to the caller.
+#include <cstring>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <string>
+#include <vector>
+#include <chrono>
+
+#include <hip/hip_runtime.h>
+#include <rocprim/device/device_radix_sort.hpp>
+
+#include "../../include/lsgpu_icp.h"
+#include "lsgpu_kernels.hip.h"
+#include "lsgpu_host_math.h"
+
+using namespace lsgpu;
+
+#define HIPC(expr)                                                                      \
+  do {                                                                                  \
+    hipError_t e__ = (expr);                                                            \
+    if (e__ != hipSuccess) {                                                            \
+      char buf__[256];                                                                  \
+      snprintf(buf__, sizeof buf__, "%s:%d %s -> %s", __FILE__, __LINE__, #expr,        \
+               hipGetErrorString(e__));                                                 \
+      h->err = buf__;                                                                   \
+      (void)hipGetLastError();                                                          \
+      return LSGPU_HIP_ERROR;                                                           \
+    }                                                                                   \
+  } while (0)
+
+namespace {
+
+template <class T>
+struct DevBuf {
+  T* p = nullptr;
+  size_t cap = 0;
+  hipError_t reserve(size_t n) {
+    if (n <= cap) return hipSuccess;
+    if (p) (void)hipFree(p);
+    p = nullptr; cap = 0;
+    const size_t want = n + n / 8 + 256;
+    hipError_t e = hipMalloc((void**)&p, want * sizeof(T));
+    if (e == hipSuccess) cap = want;
+    return e;
+  }
+  void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+};
+
+bool is_device_ptr(const void* p) {
+  hipPointerAttribute_t a;
+  if (hipPointerGetAttributes(&a, p) != hipSuccess) { (void)hipGetLastError(); return false; }
+  return a.type == hipMemoryTypeDevice || a.type == hipMemoryTypeManaged;
+}
+
+Mat34 to_mat34(const float* Tcm) {  // column-major 4x4 -> rows
+  Mat34 m;
+  for (int r = 0; r < 3; ++r)
+    for (int c = 0; c < 4; ++c) m.m[r * 4 + c] = Tcm[c * 4 + r];
+  return m;
+}
+
+double wall_ms() {
+  return std::chrono::duration<double, std::milli>(
+             std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+inline int nblk(int64_t n) { return (int)((n + 255) / 256); }
+
+}  // namespace
+
+struct lsgpu_icp {
+  lsgpu_icp_config cfg;
+  int device = 0;
+  hipStream_t stream = nullptr;
+  std::string err;
+
+  // reference (steps 2-3)
+  int64_t nr = 0;
+  float mean[3] = {0, 0, 0};
+  GridDev grid;
+  int ls = 0;  // start level of the main kNN pass
+  DevBuf<float4> ref_in;   DevBuf<float> nrm_in;
+  DevBuf<uint64_t> keys, keys_alt;
+  DevBuf<uint32_t> vals, vals_alt;
+  DevBuf<char> sort_tmp;
+  DevBuf<float4> pts, nrm;
+  DevBuf<uint32_t> ref_inv;
+  DevBuf<HashEntry> tables;
+  DevBuf<RefStats> stat_partials;
+  DevBuf<uint32_t> counters;  // [0..16] cell counts, [32] straggler count
+
+  // reading
+  int64_t nq = 0;
+  DevBuf<float4> q_in, rdq;
+  DevBuf<int> ids;   DevBuf<float> d2;
+  DevBuf<int> ids_io; DevBuf<float> d2_io;
+  DevBuf<uint32_t> strag;
+  DevBuf<uint32_t> hist;      // 3 * kHistBins
+  DevBuf<SelState> sel;       // [0] input rank, [1] after pass 2, [2] after pass 3
+  DevBuf<double> ne_partials; // kNeBlocks * 32
+  DevBuf<double> ne_out;      // 32 (29 + limit slot)
+  DevBuf<float> limit_dev;
+  double* h_pinned = nullptr; // 64 doubles of pinned host staging
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> knn_events;
+  std::vector<lsgpu_iter_trace> trace;
+};
+
+static constexpr int kNeBlocks = 1024;
+static constexpr int kStatBlocks = 512;
+static constexpr int kHistBlocks = 256;
+static constexpr int kFallbackBlocks = 2048;
+
+extern "C" {
+
+void lsgpu_icp_config_yaml(lsgpu_icp_config* c) {  // icp_default.yaml:14-27
+  std::memset(c, 0, sizeof(*c));
+  c->trim_ratio = 0.75f;
+  c->max_iterations = 40;
+  c->min_diff_rot = 0.001f;
+  c->min_diff_trans = 0.01f;
+  c->smooth_length = 4;
+  c->cell_size = 0.f;
+}
+
+void lsgpu_icp_config_default(lsgpu_icp_config* c) {  // ICP::setDefault(), laser_track.cpp:20
+  std::memset(c, 0, sizeof(*c));
+  c->trim_ratio = 0.85f;
+  c->max_iterations = 40;
+  c->min_diff_rot = 0.001f;
+  c->min_diff_trans = 0.001f;
+  c->smooth_length = 3;
+  c->cell_size = 0.f;
+}
+
+int lsgpu_abi_version(void) { return LSGPU_ABI_VERSION; }
+
+const char* lsgpu_strerror(int code) {
+  switch (code) {
+    case LSGPU_OK: return "ok";
+    case LSGPU_NO_CONVERGENCE: return "ICP did not converge (PointMatcher::ConvergenceError)";
+    case LSGPU_BAD_CONFIG: return "bad configuration";
+    case LSGPU_HIP_ERROR: return "HIP runtime error";
+    case LSGPU_BAD_ARG: return "bad argument";
+    default: return "unknown";
+  }
+}
+
+const char* lsgpu_last_error(lsgpu_icp* h) { return h ? h->err.c_str() : "null handle"; }
+
+int lsgpu_icp_create(const lsgpu_icp_config* cfg, int device, lsgpu_icp** out) {
+  if (!cfg || !out) return LSGPU_BAD_ARG;
+  *out = nullptr;
+  if (!(cfg->trim_ratio > 0.f && cfg->trim_ratio <= 1.f) || cfg->max_iterations < 1 ||
+      cfg->smooth_length < 1)
+    return LSGPU_BAD_CONFIG;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) {
+    (void)hipGetLastError();
+    return LSGPU_HIP_ERROR;  // no silent CPU path: the caller must see that there is no GPU
+  }
+  lsgpu_icp* h = new lsgpu_icp();
+  h->cfg = *cfg;
+  h->device = device;
+  std::memset(&h->grid, 0, sizeof(h->grid));
+  if (hipSetDevice(device) != hipSuccess ||
+      hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess ||
+      hipHostMalloc((void**)&h->h_pinned, 64 * sizeof(double), hipHostMallocDefault) != hipSuccess ||
+      hipEventCreate(&h->ev0) != hipSuccess || hipEventCreate(&h->ev1) != hipSuccess) {
+    (void)hipGetLastError();
+    delete h;
+    return LSGPU_HIP_ERROR;
+  }
+  *out = h;
+  return LSGPU_OK;
+}
+
+void lsgpu_icp_destroy(lsgpu_icp* h) {
+  if (!h) return;
+  (void)hipSetDevice(h->device);
+  if (h->stream) (void)hipStreamSynchronize(h->stream);
+  h->ref_in.release(); h->nrm_in.release(); h->keys.release(); h->keys_alt.release();
+  h->vals.release(); h->vals_alt.release(); h->sort_tmp.release(); h->pts.release();
+  h->nrm.release(); h->ref_inv.release(); h->tables.release(); h->stat_partials.release();
+  h->counters.release(); h->q_in.release(); h->rdq.release(); h->ids.release(); h->d2.release();
+  h->ids_io.release(); h->d2_io.release(); h->strag.release(); h->hist.release();
+  h->sel.release(); h->ne_partials.release(); h->ne_out.release(); h->limit_dev.release();
+  for (auto& e : h->knn_events) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
+  if (h->ev0) (void)hipEventDestroy(h->ev0);
+  if (h->ev1) (void)hipEventDestroy(h->ev1);
+  if (h->h_pinned) (void)hipHostFree(h->h_pinned);
+  if (h->stream) (void)hipStreamDestroy(h->stream);
+  delete h;
+}
+
+}  // extern "C"
+
+// ---------------------------------------------------------------- internals
+
+static int sort_pairs(lsgpu_icp* h, int64_t n, int nbits) {
+  HIPC(h->keys_alt.reserve(n));
+  HIPC(h->vals_alt.reserve(n));
+  size_t bytes = 0;
+  HIPC(rocprim::radix_sort_pairs(nullptr, bytes, h->keys.p, h->keys_alt.p, h->vals.p,
+                                 h->vals_alt.p, (size_t)n, 0, nbits, h->stream));
+  HIPC(h->sort_tmp.reserve(bytes));
+  bytes = h->sort_tmp.cap;
+  HIPC(rocprim::radix_sort_pairs((void*)h->sort_tmp.p, bytes, h->keys.p, h->keys_alt.p, h->vals.p,
+                                 h->vals_alt.p, (size_t)n, 0, nbits, h->stream));
+  return LSGPU_OK;  // sorted: keys_alt / vals_alt
+}
+
+// Stage a cloud on the device: returns a device pointer valid on h->stream.
+static int stage_points(lsgpu_icp* h, const float* src, int64_t n, DevBuf<float4>& buf,
+                        const float4** out) {
+  if (is_device_ptr(src)) { *out = reinterpret_cast<const float4*>(src); return LSGPU_OK; }
+  HIPC(buf.reserve(n));
+  HIPC(hipMemcpyAsync(buf.p, src, (size_t)n * 16, hipMemcpyHostToDevice, h->stream));
+  *out = buf.p;
+  return LSGPU_OK;
+}
+
+static int ensure_loop_buffers(lsgpu_icp* h, int64_t nq) {
+  HIPC(h->ids.reserve(nq));
+  HIPC(h->d2.reserve(nq));
+  HIPC(h->strag.reserve(nq));
+  HIPC(h->hist.reserve(3 * kHistBins));
+  HIPC(h->sel.reserve(4));
+  HIPC(h->ne_partials.reserve((size_t)kNeBlocks * 32));
+  HIPC(h->ne_out.reserve(32));
+  HIPC(h->limit_dev.reserve(4));
+  HIPC(h->counters.reserve(64));
+  return LSGPU_OK;
+}
+
+// Sort the reading coarsely (own frame), move it by T (rows) -> h->rdq (w = caller index).
+static int prepare_queries(lsgpu_icp* h, const float* q_xyz1, int64_t nq, const Mat34& T) {
+  const float4* src = nullptr;
+  int rc = stage_points(h, q_xyz1, nq, h->q_in, &src);
+  if (rc) return rc;
+  HIPC(h->keys.reserve(nq));
+  HIPC(h->vals.reserve(nq));
+  HIPC(h->rdq.reserve(nq));
+  const int qbits = 10;
+  hipLaunchKernelGGL(k_query_keys, dim3(nblk(nq)), dim3(256), 0, h->stream, src, nq, 1.0f / 0.25f,
+                     qbits, h->keys.p, h->vals.p);
+  rc = sort_pairs(h, nq, 3 * qbits);
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_query_gather, dim3(nblk(nq)), dim3(256), 0, h->stream, src, nq,
+                     h->vals_alt.p, T, h->rdq.p);
+  HIPC(hipGetLastError());
+  h->nq = nq;
+  return ensure_loop_buffers(h, nq);
+}
+
+// findClosests for the queries in h->rdq moved by T: fills h->ids (sorted-reference index), h->d2.
+static int run_knn(lsgpu_icp* h, const Mat34& T, bool timed) {
+  const int nq = (int)h->nq;
+  uint32_t* scount = h->counters.p + 32;
+  HIPC(hipMemsetAsync(scount, 0, sizeof(uint32_t), h->stream));
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  if (timed) {
+    HIPC(hipEventCreate(&e0));
+    HIPC(hipEventCreate(&e1));
+    HIPC(hipEventRecord(e0, h->stream));
+  }
+  hipLaunchKernelGGL(k_knn_main, dim3(nblk(nq)), dim3(256), 0, h->stream, h->rdq.p, nq, T, h->grid,
+                     h->ls, h->pts.p, h->ids.p, h->d2.p, h->strag.p, scount);
+  hipLaunchKernelGGL(k_knn_fallback, dim3(kFallbackBlocks), dim3(256), 0, h->stream, h->rdq.p, T,
+                     h->grid, h->pts.p, h->ids.p, h->d2.p, h->strag.p, scount);
+  if (timed) {
+    HIPC(hipEventRecord(e1, h->stream));
+    h->knn_events.emplace_back(e0, e1);
+  }
+  HIPC(hipGetLastError());
+  return LSGPU_OK;
+}
+
+// TrimmedDist order statistic of d2[0..n) -> rank k; leaves hist3 + sel[2] for select_limit().
+static int run_select(lsgpu_icp* h, const float* d2, int n, uint32_t k) {
+  HIPC(hipMemsetAsync(h->hist.p, 0, 3 * kHistBins * sizeof(uint32_t), h->stream));
+  SelState s0{0u, k};
+  std::memcpy(h->h_pinned + 48, &s0, sizeof(s0));
+  HIPC(hipMemcpyAsync(h->sel.p, h->h_pinned + 48, sizeof(SelState), hipMemcpyHostToDevice, h->stream));
+  const int nb = std::min(kHistBlocks, nblk(n));
+  hipLaunchKernelGGL(k_hist1, dim3(nb), dim3(256), 0, h->stream, d2, n, h->hist.p);
+  hipLaunchKernelGGL(k_hist_refine<2>, dim3(nb), dim3(256), 0, h->stream, d2, n, h->hist.p,
+                     h->sel.p, h->sel.p + 1, h->hist.p + kHistBins);
+  hipLaunchKernelGGL(k_hist_refine<3>, dim3(nb), dim3(256), 0, h->stream, d2, n,
+                     h->hist.p + kHistBins, h->sel.p + 1, h->sel.p + 2, h->hist.p + 2 * kHistBins);
+  HIPC(hipGetLastError());
+  return LSGPU_OK;
+}
+
+static uint32_t trim_rank(int64_t n, float ratio) {
+  int64_t k = (int64_t)((float)n * ratio);  // values.size() * ratio, truncated
+  if (k >= n) k = n - 1;
+  if (k < 0) k = 0;
+  return (uint32_t)k;
+}
+
+extern "C" {
+
+int lsgpu_icp_get_reference_mean(lsgpu_icp* h, float mean[3]) {
+  if (!h || !mean) return LSGPU_BAD_ARG;
+  if (h->nr <= 0) return LSGPU_BAD_ARG;
+  std::memcpy(mean, h->mean, 3 * sizeof(float));
+  return LSGPU_OK;
+}
+
+int lsgpu_icp_set_reference(lsgpu_icp* h, const float* ref_xyz1, const float* ref_normals,
+                            int64_t nr) {
+  if (!h) return LSGPU_BAD_ARG;
+  h->err.clear();
+  if (!ref_xyz1 || nr <= 0 || nr > 0x7FFFFFF0ll) { h->err = "set_reference: empty or oversize cloud"; h->nr = 0; return LSGPU_BAD_ARG; }
+  HIPC(hipSetDevice(h->device));
+  h->nr = 0;
+  const float4* src = nullptr;
+  int rc = stage_points(h, ref_xyz1, nr, h->ref_in, &src);
+  if (rc) return rc;
+  const float* nsrc = nullptr;
+  if (ref_normals) {
+    if (is_device_ptr(ref_normals)) nsrc = ref_normals;
+    else {
+      HIPC(h->nrm_in.reserve(3 * nr));
+      HIPC(hipMemcpyAsync(h->nrm_in.p, ref_normals, (size_t)nr * 12, hipMemcpyHostToDevice, h->stream));
+      nsrc = h->nrm_in.p;
+    }
+  }
+  // ---- mean + bounding box (step 2)
+  HIPC(h->stat_partials.reserve(kStatBlocks + 1));
+  const int sb = std::min(kStatBlocks, nblk(nr));
+  hipLaunchKernelGGL(k_ref_stats, dim3(sb), dim3(256), 0, h->stream, src, nr, h->stat_partials.p);
+  hipLaunchKernelGGL(k_ref_stats_final, dim3(1), dim3(64), 0, h->stream, h->stat_partials.p, sb,
+                     h->stat_partials.p + kStatBlocks);
+  RefStats* hs = reinterpret_cast<RefStats*>(h->h_pinned);
+  HIPC(hipMemcpyAsync(hs, h->stat_partials.p + kStatBlocks, sizeof(RefStats), hipMemcpyDeviceToHost, h->stream));
+  HIPC(hipStreamSynchronize(h->stream));
+  float mn[3], mx[3];
+  for (int d = 0; d < 3; ++d) {
+    h->mean[d] = (float)(hs->sum[d] / (double)nr);
+    mn[d] = hs->mn[d] - h->mean[d];
+    mx[d] = hs->mx[d] - h->mean[d];
+    if (!std::isfinite(mn[d]) || !std::isfinite(mx[d])) { h->err = "set_reference: non-finite coordinates"; return LSGPU_BAD_ARG; }
+  }
+  // ---- grid geometry
+  const float ext = std::max(std::max(mx[0] - mn[0], mx[1] - mn[1]), mx[2] - mn[2]);
+  const int bits = 11;
+  float h0 = h->cfg.cell_size > 0.f ? h->cfg.cell_size : 0.125f;
+  const float need = ext * 1.0001f / (float)((1 << bits) - 1);
+  while (h0 < need) h0 *= 2.f;
+  GridDev g;
+  std::memset(&g, 0, sizeof(g));
+  g.ox = mn[0]; g.oy = mn[1]; g.oz = mn[2];
+  g.h0 = h0; g.inv_h0 = 1.0f / h0; g.bits = bits;
+  // main-pass level: cell edge ~0.5 m (guaranteed radius 0.25..0.5 m)
+  int ls = 0;
+  while (ls < bits && h0 * (float)(1 << ls) < 0.5f) ++ls;
+  h->ls = ls;
+  // ---- keys, sort, gather
+  HIPC(h->keys.reserve(nr)); HIPC(h->vals.reserve(nr));
+  HIPC(h->pts.reserve(nr)); HIPC(h->nrm.reserve(nr)); HIPC(h->ref_inv.reserve(nr));
+  hipLaunchKernelGGL(k_ref_keys, dim3(nblk(nr)), dim3(256), 0, h->stream, src, nr, h->mean[0],
+                     h->mean[1], h->mean[2], g, h->keys.p, h->vals.p);
+  rc = sort_pairs(h, nr, 3 * bits);
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_ref_gather, dim3(nblk(nr)), dim3(256), 0, h->stream, src, nsrc, nr,
+                     h->vals_alt.p, h->mean[0], h->mean[1], h->mean[2], h->pts.p, h->nrm.p,
+                     h->ref_inv.p);
+  // ---- cell tables
+  HIPC(h->counters.reserve(64));
+  HIPC(hipMemsetAsync(h->counters.p, 0, 64 * sizeof(uint32_t), h->stream));
+  hipLaunchKernelGGL(k_cells_count, dim3(nblk(nr)), dim3(256), 0, h->stream, h->keys_alt.p, nr, bits,
+                     h->counters.p);
+  uint32_t* hc = reinterpret_cast<uint32_t*>(h->h_pinned);
+  HIPC(hipMemcpyAsync(hc, h->counters.p, kMaxLevels * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
+  HIPC(hipStreamSynchronize(h->stream));
+  size_t total = 0, off[kMaxLevels];
+  uint32_t cap[kMaxLevels];
+  for (int l = 0; l <= bits; ++l) {
+    uint32_t c = 4;
+    while (c < 2u * hc[l]) c <<= 1;
+    cap[l] = c; off[l] = total; total += c;
+  }
+  HIPC(h->tables.reserve(total));
+  HIPC(hipMemsetAsync(h->tables.p, 0xFF, total * sizeof(HashEntry), h->stream));
+  TableSet ts;
+  std::memset(&ts, 0, sizeof(ts));
+  for (int l = 0; l <= bits; ++l) {
+    ts.tab[l] = h->tables.p + off[l]; ts.mask[l] = cap[l] - 1;
+    g.tab[l] = ts.tab[l]; g.mask[l] = ts.mask[l];
+  }
+  hipLaunchKernelGGL(k_cells_fill, dim3(nblk(nr)), dim3(256), 0, h->stream, h->keys_alt.p, nr, bits, ts);
+  HIPC(hipGetLastError());
+  HIPC(hipStreamSynchronize(h->stream));
+  h->grid = g;
+  h->nr = nr;
+  return LSGPU_OK;
+}
+
+int lsgpu_knn(lsgpu_icp* h, const float* query_xyz1, int64_t nq, const float T[16], int32_t* ids,
+              float* d2) {
+  if (!h) return LSGPU_BAD_ARG;
+  h->err.clear();
+  if (h->nr <= 0) { h->err = "knn: no reference set"; return LSGPU_BAD_ARG; }
+  if (nq == 0) return LSGPU_OK;
+  if (!query_xyz1 || !ids || !d2 || nq < 0 || nq > 0x7FFFFFF0ll) return LSGPU_BAD_ARG;
+  HIPC(hipSetDevice(h->device));
+  float I[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+  const Mat34 Tm = to_mat34(T ? T : I);
+  // the transform is applied inside the search kernels; sorting uses the raw coordinates
+  const Mat34 Id = to_mat34(I);
+  int rc = prepare_queries(h, query_xyz1, nq, Id);
+  if (rc) return rc;
+  rc = run_knn(h, Tm, false);
+  if (rc) return rc;
+  const bool dev_out = is_device_ptr(ids);
+  int* ids_o = ids; float* d2_o = d2;
+  if (!dev_out) {
+    HIPC(h->ids_io.reserve(nq)); HIPC(h->d2_io.reserve(nq));
+    ids_o = h->ids_io.p; d2_o = h->d2_io.p;
+  }
+  hipLaunchKernelGGL(k_knn_unpermute, dim3(nblk(nq)), dim3(256), 0, h->stream, h->rdq.p, (int)nq,
+                     h->ids.p, h->d2.p, h->pts.p, ids_o, d2_o);
+  HIPC(hipGetLastError());
+  if (!dev_out) {
+    HIPC(hipMemcpyAsync(ids, ids_o, (size_t)nq * 4, hipMemcpyDeviceToHost, h->stream));
+    HIPC(hipMemcpyAsync(d2, d2_o, (size_t)nq * 4, hipMemcpyDeviceToHost, h->stream));
+  }
+  HIPC(hipStreamSynchronize(h->stream));
+  return LSGPU_OK;
+}
+
+int lsgpu_trim_limit(lsgpu_icp* h, const float* d2, int64_t n, float ratio, float* limit) {
+  if (!h || !limit) return LSGPU_BAD_ARG;
+  h->err.clear();
+  if (n <= 0 || !d2) return LSGPU_NO_CONVERGENCE;  // "no outlier to filter"
+  if (n > 0x7FFFFFF0ll) return LSGPU_BAD_ARG;
+  HIPC(hipSetDevice(h->device));
+  int rc = ensure_loop_buffers(h, 1);
+  if (rc) return rc;
+  const float* src = d2;
+  if (!is_device_ptr(d2)) {
+    HIPC(h->d2_io.reserve(n));
+    HIPC(hipMemcpyAsync(h->d2_io.p, d2, (size_t)n * 4, hipMemcpyHostToDevice, h->stream));
+    src = h->d2_io.p;
+  }
+  rc = run_select(h, src, (int)n, trim_rank(n, ratio));
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_limit_out, dim3(1), dim3(256), 0, h->stream, h->hist.p + 2 * kHistBins,
+                     h->sel.p + 2, h->limit_dev.p);
+  float* hl = reinterpret_cast<float*>(h->h_pinned);
+  HIPC(hipMemcpyAsync(hl, h->limit_dev.p, 4, hipMemcpyDeviceToHost, h->stream));
+  HIPC(hipStreamSynchronize(h->stream));
+  *limit = *hl;
+  return LSGPU_OK;
+}
+
+int lsgpu_normal_eq(lsgpu_icp* h, const float* query_xyz1, int64_t nq, const float T[16],
+                    const int32_t* ids, const float* d2, float limit, double out[29]) {
+  if (!h || !out) return LSGPU_BAD_ARG;
+  h->err.clear();
+  if (h->nr <= 0) { h->err = "normal_eq: no reference set"; return LSGPU_BAD_ARG; }
+  if (nq <= 0 || !query_xyz1 || !ids || !d2 || nq > 0x7FFFFFF0ll) return LSGPU_BAD_ARG;
+  HIPC(hipSetDevice(h->device));
+  int rc = ensure_loop_buffers(h, nq);
+  if (rc) return rc;
+  const float4* q = nullptr;
+  rc = stage_points(h, query_xyz1, nq, h->q_in, &q);
+  if (rc) return rc;
+  const int* idp = ids; const float* dp = d2;
+  if (!is_device_ptr(ids)) {
+    HIPC(h->ids_io.reserve(nq));
+    HIPC(hipMemcpyAsync(h->ids_io.p, ids, (size_t)nq * 4, hipMemcpyHostToDevice, h->stream));
+    idp = h->ids_io.p;
+  }
+  if (!is_device_ptr(d2)) {
+    HIPC(h->d2_io.reserve(nq));
+    HIPC(hipMemcpyAsync(h->d2_io.p, d2, (size_t)nq * 4, hipMemcpyHostToDevice, h->stream));
+    dp = h->d2_io.p;
+  }
+  float I[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+  const Mat34 Tm = to_mat34(T ? T : I);
+  const int nb = std::min(kNeBlocks, nblk(nq));
+  hipLaunchKernelGGL((k_normal_eq<true, false>), dim3(nb), dim3(256), 0, h->stream, q, (int)nq, Tm,
+                     idp, dp, h->pts.p, h->nrm.p, h->ref_inv.p, (const uint32_t*)nullptr,
+                     (const SelState*)nullptr, limit, (float*)nullptr, h->ne_partials.p);
+  hipLaunchKernelGGL(k_ne_final, dim3(1), dim3(64), 0, h->stream, h->ne_partials.p, nb, h->ne_out.p);
+  HIPC(hipGetLastError());
+  HIPC(hipMemcpyAsync(h->h_pinned, h->ne_out.p, kNe * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIPC(hipStreamSynchronize(h->stream));
+  std::memcpy(out, h->h_pinned, kNe * sizeof(double));
+  return LSGPU_OK;
+}
+
+int lsgpu_transform_points(lsgpu_icp* h, const float T[16], const float* xyz1, int64_t n,
+                           float* out) {
+  if (!h || !T || !out) return LSGPU_BAD_ARG;
+  h->err.clear();
+  if (n == 0) return LSGPU_OK;
+  if (!xyz1 || n < 0) return LSGPU_BAD_ARG;
+  HIPC(hipSetDevice(h->device));
+  const float4* src = nullptr;
+  int rc = stage_points(h, xyz1, n, h->q_in, &src);
+  if (rc) return rc;
+  const bool dev_out = is_device_ptr(out);
+  float4* dst = reinterpret_cast<float4*>(out);
+  if (!dev_out) { HIPC(h->rdq.reserve(n)); dst = h->rdq.p; }
+  hipLaunchKernelGGL(k_transform, dim3(nblk(n)), dim3(256), 0, h->stream, src, n, to_mat34(T), dst);
+  HIPC(hipGetLastError());
+  if (!dev_out) HIPC(hipMemcpyAsync(out, dst, (size_t)n * 16, hipMemcpyDeviceToHost, h->stream));
+  HIPC(hipStreamSynchronize(h->stream));
+  return LSGPU_OK;
+}
+
+int lsgpu_icp_align(lsgpu_icp* h, const float* reading_xyz1, int64_t nq, const float T_init[16],
+                    float T_out[16], lsgpu_icp_stats* stats) {
+  if (!h || !T_init || !T_out) return LSGPU_BAD_ARG;
+  h->err.clear();
+  std::memcpy(T_out, T_init, 16 * sizeof(float));
+  lsgpu_icp_stats st;
+  std::memset(&st, 0, sizeof(st));
+  if (stats) *stats = st;
+  h->trace.clear();
+  if (h->nr <= 0 || nq <= 0 || !reading_xyz1) {  // empty cloud: ConvergenceError upstream
+    h->err = "align: empty reading or no reference";
+    return LSGPU_NO_CONVERGENCE;
+  }
+  if (nq > 0x7FFFFFF0ll) return LSGPU_BAD_ARG;
+  HIPC(hipSetDevice(h->device));
+  const double t0 = wall_ms();
+  for (auto& e : h->knn_events) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
+  h->knn_events.clear();
+
+  // step 5: T_refMean_dataIn = T_refIn_refMean^-1 * T_init (pure translation inverse)
+  float T_rm_in[16];
+  std::memcpy(T_rm_in, T_init, sizeof(T_rm_in));
+  for (int d = 0; d < 3; ++d) T_rm_in[12 + d] = T_init[12 + d] - h->mean[d];
+  int rc = prepare_queries(h, reading_xyz1, nq, to_mat34(T_rm_in));
+  if (rc) return rc;
+
+  // step 6
+  float T_iter[16];
+  hostmath::identity4(T_iter);
+  hostmath::Checkers ck(h->cfg.max_iterations, h->cfg.smooth_length, h->cfg.min_diff_rot,
+                        h->cfg.min_diff_trans, T_iter);
+  const uint32_t k = trim_rank(nq, h->cfg.trim_ratio);
+  const int nb = std::min(kNeBlocks, nblk(nq));
+  bool iterate = true, by_diff = false;
+  int it = 0;
+  rc = LSGPU_OK;
+  while (iterate) {
+    const Mat34 Tm = to_mat34(T_iter);
+    rc = run_knn(h, Tm, h->cfg.profile_kernels != 0);                                  // 6a+6b
+    if (rc) return rc;
+    rc = run_select(h, h->d2.p, (int)nq, k);                                            // 6c
+    if (rc) return rc;
+    hipLaunchKernelGGL((k_normal_eq<false, true>), dim3(nb), dim3(256), 0, h->stream, h->rdq.p,
+                       (int)nq, Tm, h->ids.p, h->d2.p, h->pts.p, h->nrm.p, h->ref_inv.p,
+                       h->hist.p + 2 * kHistBins, h->sel.p + 2, 0.f, h->limit_dev.p,
+                       h->ne_partials.p);                                               // 6d
+    hipLaunchKernelGGL(k_ne_final, dim3(1), dim3(64), 0, h->stream, h->ne_partials.p, nb, h->ne_out.p);
+    HIPC(hipGetLastError());
+    HIPC(hipMemcpyAsync(h->h_pinned, h->ne_out.p, kNe * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIPC(hipMemcpyAsync(h->h_pinned + 32, h->limit_dev.p, sizeof(float), hipMemcpyDeviceToHost, h->stream));
+    HIPC(hipMemcpyAsync(h->h_pinned + 33, h->counters.p + 32, sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
+    HIPC(hipStreamSynchronize(h->stream));
+    float limit; uint32_t nstrag;
+    std::memcpy(&limit, h->h_pinned + 32, sizeof(float));
+    std::memcpy(&nstrag, h->h_pinned + 33, sizeof(uint32_t));
+    st.stragglers += nstrag;
+    const double* ne = h->h_pinned;
+    const int64_t used = (int64_t)ne[27];
+    if (used <= 0) { rc = LSGPU_NO_CONVERGENCE; h->err = "no point to minimize"; break; }
+    double A[36], b[6];
+    hostmath::unpack_normal_eq(ne, A, b);
+    float x[6], dT[16];
+    if (!hostmath::llt_solve6(A, b, x)) { rc = LSGPU_NO_CONVERGENCE; h->err = "normal matrix not positive definite"; break; }
+    hostmath::delta_from_x(x, dT);
+    hostmath::mul4(dT, T_iter, T_iter);
+    lsgpu_iter_trace tr;
+    std::memcpy(tr.T_iter, T_iter, sizeof(T_iter));
+    tr.limit = limit; tr.n_used = used;
+    std::memcpy(tr.A, A, sizeof(A)); std::memcpy(tr.b, b, sizeof(b));
+    for (int i = 0; i < 6; ++i) tr.x[i] = x[i];
+    h->trace.push_back(tr);
+    st.final_limit = limit; st.final_n_used = used;
+    ++it;
+    if (!ck.check(T_iter, &iterate, &by_diff)) { rc = LSGPU_NO_CONVERGENCE; h->err = "NaN in transformation checker"; break; }
+  }
+  st.iterations = it;
+  st.converged = by_diff ? 1 : 0;
+  if (rc == LSGPU_OK) {  // step 7
+    float Tmean[16], tmp[16];
+    hostmath::identity4(Tmean);
+    for (int d = 0; d < 3; ++d) Tmean[12 + d] = h->mean[d];
+    hostmath::mul4(T_iter, T_rm_in, tmp);
+    hostmath::mul4(Tmean, tmp, T_out);
+  }
+  for (auto& e : h->knn_events) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, e.first, e.second) == hipSuccess) { st.t_knn_ms += ms; st.knn_launches++; }
+    else (void)hipGetLastError();
+  }
+  st.t_total_ms = wall_ms() - t0;
+  if (stats) *stats = st;
+  return rc;
+}
+
+int lsgpu_icp_get_trace(lsgpu_icp* h, lsgpu_iter_trace* out, int cap) {
+  if (!h || !out || cap <= 0) return 0;
+  const int n = std::min<int>(cap, (int)h->trace.size());
+  std::memcpy(out, h->trace.data(), (size_t)n * sizeof(lsgpu_iter_trace));
+  return n;
+}
+
+}  // extern "C"

@@ -1,0 +1,357 @@
+"""Host-side mirror of the ICP object seam the reference calls (seam B2).
+
+The reference owns a ``PointMatcher::ICP icp_`` (laser_slam/include/laser_slam/laser_track.hpp:217,
+incremental_estimator.hpp:70) and uses exactly three members of it:
+
+    icp_.loadFromYaml(std::istream&)      laser_slam/src/laser_track.cpp:17
+    icp_.setDefault()                     laser_slam/src/laser_track.cpp:20
+    icp_.compute(reading, reference, T)   laser_slam/src/laser_track.cpp:496,
+                                          laser_slam/src/incremental_estimator.cpp:108
+
+``ICP`` below keeps those names/semantics (snake_case) over the C ABI in include/lsgpu_icp.h;
+``IcpHandle`` is the thin 1:1 wrapper of that ABI.  Clouds are (N,4) float32 x,y,z,1 arrays
+(DataPoints.features transposed: memory is identical to Eigen's column-major 4xN); they may be numpy
+arrays (host) or torch CUDA tensors (HBM-resident, zero copy).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass, field
+from typing import Optional
+
+import numpy as np
+
+from . import _lib
+from ._lib import ConvergenceError, IcpConfig, IcpStats, IterTrace, LsgpuError
+
+try:  # torch is plumbing only (device memory); the package works without it
+    import torch
+except Exception:  # pragma: no cover
+    torch = None
+
+
+def _is_torch(x) -> bool:
+    return torch is not None and isinstance(x, torch.Tensor)
+
+
+def _as_f32(x, cols: int):
+    """-> (address, keepalive, n_rows).  numpy: C-contiguous float32 copy if needed."""
+    if _is_torch(x):
+        if x.dtype != torch.float32 or not x.is_contiguous():
+            x = x.to(torch.float32).contiguous()
+        if x.dim() != 2 or x.shape[1] != cols:
+            raise ValueError(f"expected (N,{cols}) tensor, got {tuple(x.shape)}")
+        return (x.data_ptr() if x.numel() else None), x, x.shape[0]
+    a = np.ascontiguousarray(x, np.float32)
+    if a.ndim != 2 or a.shape[1] != cols:
+        raise ValueError(f"expected (N,{cols}) array, got {a.shape}")
+    return (a.ctypes.data if a.size else None), a, a.shape[0]
+
+
+def _t16(T) -> np.ndarray:
+    """4x4 (row-major numpy) or 16 column-major floats -> 16 float32 column-major."""
+    T = np.asarray(T)
+    if T.shape == (4, 4):
+        return np.ascontiguousarray(T.astype(np.float32).T).reshape(16)
+    if T.size == 16:
+        return np.ascontiguousarray(T, np.float32).reshape(16)
+    raise ValueError("transform must be 4x4 or 16 floats")
+
+
+def _fp(a: np.ndarray):
+    return a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+def _raise(code: int, what: str, h=None):
+    detail = ""
+    if h is not None:
+        detail = _lib.lib().lsgpu_last_error(h).decode()
+    if code == _lib.NO_CONVERGENCE:
+        raise ConvergenceError(code, what, detail)
+    raise LsgpuError(code, what, detail)
+
+
+class IcpHandle:
+    """One lsgpu_icp handle == one reference ``icp_`` member: one device, one HIP stream."""
+
+    def __init__(self, cfg: Optional[IcpConfig] = None, device: int = 0):
+        L = _lib.lib()
+        if cfg is None:
+            cfg = IcpConfig()
+            L.lsgpu_icp_config_yaml(C.byref(cfg))
+        self.cfg = cfg
+        self._h = C.c_void_p()
+        rc = L.lsgpu_icp_create(C.byref(cfg), device, C.byref(self._h))
+        if rc != _lib.OK:
+            self._h = None
+            _raise(rc, "lsgpu_icp_create (is a ROCm GPU visible?)")
+
+    def close(self):
+        if getattr(self, "_h", None):
+            _lib.lib().lsgpu_icp_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    # ---- ICP::compute steps 2-3
+    def set_reference(self, ref_xyz1, ref_normals):
+        p, _k1, n = _as_f32(ref_xyz1, 4)
+        q, _k2, m = _as_f32(ref_normals, 3)
+        if m != n:
+            raise ValueError("normals must have one row per reference point")
+        rc = _lib.lib().lsgpu_icp_set_reference(self._h, p, q, n)
+        if rc != _lib.OK:
+            _raise(rc, "lsgpu_icp_set_reference", self._h)
+
+    def reference_mean(self) -> np.ndarray:
+        m = np.zeros(3, np.float32)
+        rc = _lib.lib().lsgpu_icp_get_reference_mean(self._h, _fp(m))
+        if rc != _lib.OK:
+            _raise(rc, "lsgpu_icp_get_reference_mean", self._h)
+        return m
+
+    # ---- ICP::compute steps 5-7
+    def align(self, reading_xyz1, T_init):
+        """-> (T 4x4 float32, IcpStats).  Raises ConvergenceError like PointMatcher."""
+        p, _k, n = _as_f32(reading_xyz1, 4)
+        ti = _t16(T_init)
+        to = np.empty(16, np.float32)
+        st = IcpStats()
+        rc = _lib.lib().lsgpu_icp_align(self._h, p, n, _fp(ti), _fp(to), C.byref(st))
+        if rc != _lib.OK:
+            _raise(rc, "lsgpu_icp_align", self._h)
+        return to.reshape(4, 4).T.copy(), st
+
+    def trace(self, cap: int = 64):
+        buf = (IterTrace * cap)()
+        n = _lib.lib().lsgpu_icp_get_trace(self._h, buf, cap)
+        out = []
+        for i in range(n):
+            t = buf[i]
+            out.append(dict(T_iter=np.array(t.T_iter[:], np.float32), limit=t.limit,
+                            n_used=t.n_used, A=np.array(t.A[:]).reshape(6, 6),
+                            b=np.array(t.b[:]), x=np.array(t.x[:])))
+        return out
+
+    # ---- kernel-level entry points (reference-mean frame)
+    def knn(self, query_xyz1, T=None):
+        p, _k, n = _as_f32(query_xyz1, 4)
+        ids = np.empty(n, np.int32)
+        d2 = np.empty(n, np.float32)
+        tp = _fp(_t16(T)) if T is not None else None
+        rc = _lib.lib().lsgpu_knn(self._h, p, n, tp, ids.ctypes.data if n else None,
+                                  d2.ctypes.data if n else None)
+        if rc != _lib.OK:
+            _raise(rc, "lsgpu_knn", self._h)
+        return ids, d2
+
+    def trim_limit(self, d2, ratio: float) -> float:
+        a = np.ascontiguousarray(d2, np.float32)
+        lim = C.c_float()
+        rc = _lib.lib().lsgpu_trim_limit(self._h, a.ctypes.data if a.size else None, a.size,
+                                         ratio, C.byref(lim))
+        if rc != _lib.OK:
+            _raise(rc, "lsgpu_trim_limit", self._h)
+        return lim.value
+
+    def normal_eq(self, query_xyz1, T, ids, d2, limit: float):
+        """-> (A 6x6, b 6, n_used, sum r^2), double."""
+        p, _k, n = _as_f32(query_xyz1, 4)
+        ids = np.ascontiguousarray(ids, np.int32)
+        d2 = np.ascontiguousarray(d2, np.float32)
+        out = np.zeros(29)
+        tp = _fp(_t16(T)) if T is not None else None
+        rc = _lib.lib().lsgpu_normal_eq(self._h, p, n, tp, ids.ctypes.data, d2.ctypes.data, limit,
+                                        out.ctypes.data_as(C.POINTER(C.c_double)))
+        if rc != _lib.OK:
+            _raise(rc, "lsgpu_normal_eq", self._h)
+        A = np.zeros((6, 6))
+        k = 0
+        for a in range(6):
+            for c in range(a, 6):
+                A[a, c] = A[c, a] = out[k]
+                k += 1
+        return A, out[21:27].copy(), int(out[27]), float(out[28])
+
+    def transform_points(self, T, xyz1):
+        p, _k, n = _as_f32(xyz1, 4)
+        out = np.empty((n, 4), np.float32)
+        rc = _lib.lib().lsgpu_transform_points(self._h, _fp(_t16(T)), p, n,
+                                               out.ctypes.data if n else None)
+        if rc != _lib.OK:
+            _raise(rc, "lsgpu_transform_points", self._h)
+        return out
+
+
+# ---------------------------------------------------------------------------------------------
+# host-side modules (CPU in the reference too)
+
+def random_sampling(n: int, prob: float, seed: int = -1) -> np.ndarray:
+    """RandomSamplingDataPointsFilter (icp_default.yaml:1-3) -> kept indices."""
+    keep = np.empty(max(n, 1), np.int64)
+    m = _lib.lib().lsgpu_filter_random_sampling(n, prob, seed,
+                                                keep.ctypes.data_as(C.POINTER(C.c_int64)))
+    return keep[:m].copy()
+
+
+def sampling_surface_normal(xyz1, knn: int = 10, ratio: float = 0.5, seed: int = -1):
+    """SamplingSurfaceNormalDataPointsFilter (icp_default.yaml:5-7) -> (xyz1', normals)."""
+    a = np.ascontiguousarray(xyz1, np.float32)
+    n = a.shape[0]
+    o = np.empty((max(n, 1), 4), np.float32)
+    nr = np.empty((max(n, 1), 3), np.float32)
+    m = _lib.lib().lsgpu_filter_sampling_surface_normal(a.ctypes.data if n else None, n, knn, ratio,
+                                                        seed, o.ctypes.data, nr.ctypes.data)
+    return o[:m].copy(), nr[:m].copy()
+
+
+def check_rigid(T) -> bool:
+    return bool(_lib.lib().lsgpu_check_rigid(_fp(_t16(T))))
+
+
+def correct_rigid(T) -> np.ndarray:
+    out = np.empty(16, np.float32)
+    _lib.lib().lsgpu_correct_rigid(_fp(_t16(T)), _fp(out))
+    return out.reshape(4, 4).T.copy()
+
+
+# ---------------------------------------------------------------------------------------------
+
+_SUPPORTED = {
+    "readingDataPointsFilters": {"RandomSamplingDataPointsFilter"},
+    "referenceDataPointsFilters": {"SamplingSurfaceNormalDataPointsFilter"},
+    "matcher": {"KDTreeMatcher"},
+    "outlierFilters": {"TrimmedDistOutlierFilter"},
+    "errorMinimizer": {"PointToPlaneErrorMinimizer"},
+    "transformationCheckers": {"CounterTransformationChecker", "DifferentialTransformationChecker"},
+}
+
+
+@dataclass
+class ChainConfig:
+    """The module chain of laser_slam/configurations/icp_default.yaml, as parameters."""
+    reading_sampling_prob: float = 0.5      # yaml:3   (module default 0.75)
+    surface_normal_knn: int = 10            # yaml:7   (module default 7)
+    surface_normal_ratio: float = 0.5       # module default
+    trim_ratio: float = 0.75                # yaml:16  (module default 0.85)
+    max_iterations: int = 40                # yaml:23
+    min_diff_rot: float = 0.001             # yaml:25
+    min_diff_trans: float = 0.01            # yaml:26  (module default 0.001)
+    smooth_length: int = 4                  # yaml:27  (module default 3)
+    seed: int = -1                          # >= 0: srand(seed) before the filters
+    extra: dict = field(default_factory=dict)
+
+
+class ICP:
+    """Drop-in for the reference's ``PointMatcher::ICP icp_`` member."""
+
+    def __init__(self, device: int = 0):
+        self.device = device
+        self.chain = ChainConfig()
+        self._handle: Optional[IcpHandle] = None
+        self.last_stats: Optional[IcpStats] = None
+
+    # -- laser_track.cpp:20
+    def set_default(self):
+        self.chain = ChainConfig(reading_sampling_prob=0.75, surface_normal_knn=7,
+                                 surface_normal_ratio=0.5, trim_ratio=0.85, max_iterations=40,
+                                 min_diff_rot=0.001, min_diff_trans=0.001, smooth_length=3)
+        self._handle = None
+
+    # -- laser_track.cpp:17
+    def load_from_yaml(self, stream):
+        """stream: file object, path or YAML text.  Unsupported modules raise (bad config), as
+        PointMatcher's registrar does for unknown module names."""
+        import yaml
+        if hasattr(stream, "read"):
+            doc = yaml.safe_load(stream.read())
+        else:
+            try:
+                with open(stream) as f:
+                    doc = yaml.safe_load(f.read())
+            except (OSError, ValueError):
+                doc = yaml.safe_load(stream)
+        if not isinstance(doc, dict):
+            raise LsgpuError(_lib.BAD_CONFIG, "load_from_yaml", "not a YAML mapping")
+        ch = ChainConfig(reading_sampling_prob=0.75, surface_normal_knn=7, trim_ratio=0.85,
+                         min_diff_trans=0.001, smooth_length=3)  # module defaults
+
+        def modules(section):
+            v = doc.get(section)
+            if v is None:
+                return []
+            items = v if isinstance(v, list) else [v]
+            out = []
+            for it in items:
+                if isinstance(it, str):
+                    out.append((it, {}))
+                elif isinstance(it, dict):
+                    for k, p in it.items():
+                        out.append((k, p or {}))
+            return out
+
+        for section, allowed in _SUPPORTED.items():
+            for name, params in modules(section):
+                if name not in allowed:
+                    raise LsgpuError(_lib.BAD_CONFIG, "load_from_yaml",
+                                     f"{section}: module {name} is not implemented on the HIP path")
+                if name == "RandomSamplingDataPointsFilter":
+                    ch.reading_sampling_prob = float(params.get("prob", 0.75))
+                elif name == "SamplingSurfaceNormalDataPointsFilter":
+                    ch.surface_normal_knn = int(params.get("knn", 7))
+                    ch.surface_normal_ratio = float(params.get("ratio", 0.5))
+                    if int(params.get("samplingMethod", 0)) != 0:
+                        raise LsgpuError(_lib.BAD_CONFIG, "load_from_yaml", "samplingMethod != 0")
+                elif name == "KDTreeMatcher":
+                    if int(params.get("knn", 1)) != 1 or float(params.get("epsilon", 0)) != 0.0:
+                        raise LsgpuError(_lib.BAD_CONFIG, "load_from_yaml",
+                                         "only knn 1 / epsilon 0 is implemented")
+                elif name == "TrimmedDistOutlierFilter":
+                    ch.trim_ratio = float(params.get("ratio", 0.85))
+                elif name == "CounterTransformationChecker":
+                    ch.max_iterations = int(params.get("maxIterationCount", 40))
+                elif name == "DifferentialTransformationChecker":
+                    ch.min_diff_rot = float(params.get("minDiffRotErr", 0.001))
+                    ch.min_diff_trans = float(params.get("minDiffTransErr", 0.001))
+                    ch.smooth_length = int(params.get("smoothLength", 3))
+        if modules("readingStepDataPointsFilters"):
+            raise LsgpuError(_lib.BAD_CONFIG, "load_from_yaml", "readingStepDataPointsFilters")
+        # inspector / logger (yaml:32-44) only produce debug dumps: accepted and ignored
+        self.chain = ch
+        self._handle = None
+
+    def _ensure_handle(self) -> IcpHandle:
+        if self._handle is None:
+            cfg = IcpConfig()
+            _lib.lib().lsgpu_icp_config_yaml(C.byref(cfg))
+            cfg.trim_ratio = self.chain.trim_ratio
+            cfg.max_iterations = self.chain.max_iterations
+            cfg.min_diff_rot = self.chain.min_diff_rot
+            cfg.min_diff_trans = self.chain.min_diff_trans
+            cfg.smooth_length = self.chain.smooth_length
+            self._handle = IcpHandle(cfg, self.device)
+        return self._handle
+
+    # -- laser_track.cpp:496 / incremental_estimator.cpp:108
+    def compute(self, reading_xyz1, reference_xyz1, T_init) -> np.ndarray:
+        """T (4x4 float32) with p_reference = T p_reading.  Raises ConvergenceError."""
+        h = self._ensure_handle()
+        ch = self.chain
+        ref = np.ascontiguousarray(reference_xyz1, np.float32)
+        rd = np.ascontiguousarray(reading_xyz1, np.float32)
+        if ch.seed >= 0:
+            random_sampling(0, 0.0, ch.seed)  # srand once, reference filters then reading filters
+        rf, rn = sampling_surface_normal(ref, ch.surface_normal_knn, ch.surface_normal_ratio, -1)
+        if rf.shape[0] == 0 or rd.shape[0] == 0:
+            raise ConvergenceError(_lib.NO_CONVERGENCE, "compute", "empty cloud after filtering")
+        h.set_reference(rf, rn)
+        keep = random_sampling(rd.shape[0], ch.reading_sampling_prob, -1)
+        T, st = h.align(rd[keep], T_init)
+        self.last_stats = st
+        return T

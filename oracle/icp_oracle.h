@@ -1,0 +1,120 @@
+/*
+ * icp_oracle.h -- CPU restatement of the ICP chain laser_slam configures.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing in the product (laser_slam_amd/, include/)
+ * links, loads or calls this library; only tests/, __graft_entry__.smoke() and
+ * bench.py's cpu_baseline leg do, and there only as checker / baseline.
+ *
+ * PARITY UNPINNED: the arithmetic of this path lives in libpointmatcher +
+ * libnabo + Eigen (dependencies.rosinstall:23-28, un-vendored, un-pinned), none
+ * of which is under /root/reference or installed here, and the reference holds
+ * no golden vectors (laser_slam/test/test_empty.cpp:3-5 is its whole test
+ * suite).  This file restates the published libpointmatcher algorithm for the
+ * module chain of laser_slam/configurations/icp_default.yaml:1-29 and is
+ * anchored on the reference's call sites (laser_slam/src/laser_track.cpp:496,
+ * laser_slam/src/incremental_estimator.cpp:108).  It is cross-checked against
+ * brute force, scipy.cKDTree (dev only) and analytic known-answer scenes.
+ *
+ * Conventions (laser_slam/include/laser_slam/common.hpp:14-17):
+ *   clouds are PointMatcher<float>::DataPoints.features, (dim+1) x N column
+ *   major  ==  AoS  x,y,z,1  (16 B / point);  normals are 3 x N column major.
+ *   4x4 transforms are column major float (Eigen default).
+ *   T maps reading -> reference:  p_ref = T * p_reading.
+ *
+ * Arithmetic definitions shared with the HIP path (so integer results are
+ * bit-comparable):
+ *   transform : x' = fma(m02,z, fma(m01,y, fma(m00,x, m03)))   (per row)
+ *   dist^2    : fma(dz,dz, fma(dy,dy, dx*dx))
+ */
+#ifndef LS_ICP_ORACLE_H_
+#define LS_ICP_ORACLE_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* icp_default.yaml:1-29 (values) / ICP::setDefault (laser_track.cpp:18-21). */
+typedef struct lso_config {
+  float reading_sampling_prob;  /* RandomSamplingDataPointsFilter prob   (yaml 0.5, default 0.75) */
+  int   surface_normal_knn;     /* SamplingSurfaceNormal knn             (yaml 10,  default 7)    */
+  float surface_normal_ratio;   /* SamplingSurfaceNormal ratio           (default 0.5)            */
+  float trim_ratio;             /* TrimmedDistOutlierFilter ratio        (yaml 0.75, default .85) */
+  int   max_iterations;         /* CounterTransformationChecker          (40)                     */
+  float min_diff_rot;           /* DifferentialTransformationChecker minDiffRotErr   (0.001)      */
+  float min_diff_trans;         /* DifferentialTransformationChecker minDiffTransErr (yaml 0.01)  */
+  int   smooth_length;          /* DifferentialTransformationChecker smoothLength    (yaml 4)     */
+  int   accum_double;           /* 0: float A,b as libpointmatcher; 1: double accumulation        */
+  int   num_threads;            /* OpenMP threads for the NN query loop (libnabo: omp if built so)*/
+} lso_config;
+
+void lso_config_yaml(lso_config* c);     /* icp_default.yaml values   */
+void lso_config_default(lso_config* c);  /* ICP::setDefault() values  */
+
+/* One record per ICP iteration, for CPU-vs-GPU trace diffs. */
+typedef struct lso_iter_trace {
+  float  T_iter[16];   /* after this iteration's left-multiply */
+  float  limit;        /* trimmed squared-distance limit       */
+  int64_t n_used;      /* number of weights == 1               */
+  double A[36];        /* normal matrix (row-major, symmetric) */
+  double b[6];
+  double x[6];         /* solution [rot(3); trans(3)]          */
+} lso_iter_trace;
+
+typedef struct lso_stats {
+  int   iterations;
+  int   converged;        /* 1: differential checker stopped it, 0: counter */
+  float final_limit;
+  int64_t final_n_used;
+  double t_filter_ms, t_build_ms, t_loop_ms;
+} lso_stats;
+
+enum { LSO_OK = 0, LSO_NO_CONVERGENCE = 1, LSO_BAD_ARG = 2 };
+
+/* RigidTransformation::compute on features / normals descriptor. */
+void lso_transform_points(const float T[16], const float* xyz1, int64_t n, float* out_xyz1);
+void lso_rotate_normals(const float T[16], const float* nrm, int64_t n, float* out_nrm);
+/* RigidTransformation::checkParameters / correctParameters (common.hpp:136-149). */
+int  lso_check_rigid(const float T[16]);
+void lso_correct_rigid(const float T[16], float out[16]);
+
+/* RandomSamplingDataPointsFilter: keep i iff rand()/RAND_MAX < prob.  If seed>=0 srand(seed) first. */
+int64_t lso_random_sampling(int64_t n, float prob, int64_t seed, int64_t* keep_idx);
+/* SamplingSurfaceNormalDataPointsFilter (samplingMethod 0, keepNormals 1). Returns n_out. */
+int64_t lso_sampling_surface_normal(const float* xyz1, int64_t n, int knn, float ratio,
+                                    int64_t seed, float* out_xyz1, float* out_normals);
+
+/* KDTreeMatcher knn=1 epsilon=0: exact nearest neighbour, squared distances. */
+void* lso_kdtree_build(const float* ref_xyz1, int64_t nr);
+void  lso_kdtree_free(void* tree);
+void  lso_kdtree_nn(const void* tree, const float* q_xyz1, int64_t nq, int32_t* ids, float* d2,
+                    int num_threads);
+void  lso_brute_nn(const float* ref_xyz1, int64_t nr, const float* q_xyz1, int64_t nq,
+                   int32_t* ids, float* d2);
+
+/* TrimmedDistOutlierFilter: limit = values[floor(n_valid*ratio)] of finite d2; w = d2 <= limit. */
+int lso_trim_limit(const float* d2, int64_t n, float ratio, float* limit);
+
+/* PointToPlaneErrorMinimizer: builds A (6x6), b (6) over pairs with d2<=limit, solves (float LLT),
+ * returns dT (4x4 col major).  p_xyz1 = reading already moved by T_iter.                           */
+int lso_point_to_plane(const float* p_xyz1, const float* ref_xyz1, const float* ref_nrm,
+                       const int32_t* ids, const float* d2, float limit, int64_t nq,
+                       int accum_double, double A[36], double b[6], double x[6], float dT[16],
+                       int64_t* n_used);
+
+/* Steps 2..7 of ICP::compute on ALREADY FILTERED clouds (reference carries normals). */
+int lso_icp_compute(const lso_config* cfg, const float* reading_xyz1, int64_t nq,
+                    const float* ref_xyz1, const float* ref_nrm, int64_t nr,
+                    const float T_init[16], float T_out[16], lso_stats* stats,
+                    lso_iter_trace* trace, int trace_cap);
+
+/* Whole ICP::compute incl. both filter chains (K1, K2) -- laser_track.cpp:496. */
+int lso_icp_compute_full(const lso_config* cfg, const float* reading_xyz1, int64_t nq,
+                         const float* ref_xyz1, int64_t nr, const float T_init[16],
+                         int64_t seed, float T_out[16], lso_stats* stats);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

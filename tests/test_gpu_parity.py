@@ -1,0 +1,252 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the CPU oracle on identical inputs.
+
+Bars (BASELINE.json north_star): ids / squared distances / trim limit / weights bit-exact (ties in
+distance are equivalent neighbours, libnabo's tie order is implementation defined); final transform
+within 1e-4 m / 1e-5 rad of the CPU path on identical filtered clouds.
+"""
+import numpy as np
+import pytest
+
+from laser_slam_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+TOL_T = 1e-4    # m
+TOL_R = 1e-5    # rad
+
+
+@pytest.fixture(scope="module")
+def icp_mod():
+    from laser_slam_amd import icp
+    return icp
+
+
+def _filtered(icp_mod, pair, ratio=1.0, seed=11):
+    rf, rn = icp_mod.sampling_surface_normal(pair["ref"], 10, ratio, seed)
+    return rf, rn
+
+
+def _check_nn(oracle, ref_c, q, ids, d2):
+    """ids/d2 from the GPU for queries q against centred reference ref_c."""
+    kd = oracle.KdTree(ref_c)
+    oid, od2 = kd.nn(q)
+    assert np.array_equal(d2.view(np.uint32), od2.view(np.uint32)), \
+        f"d2 differs at {np.flatnonzero(d2 != od2)[:5]}"
+    neq = np.flatnonzero(ids != oid)
+    if neq.size:  # ties: the GPU's neighbour must be at exactly the same distance
+        diff = q[neq, :3] - ref_c[ids[neq], :3]
+        # same arithmetic as the definition: fma(dz,dz,fma(dy,dy,dx*dx)) in float32
+        dx, dy, dz = (diff[:, k].astype(np.float32) for k in range(3))
+        dd = np.float32(dx * dx)
+        dd = (dy.astype(np.float64) * dy + dd).astype(np.float32)
+        dd = (dz.astype(np.float64) * dz + dd).astype(np.float32)
+        assert np.array_equal(dd, od2[neq])
+    return oid, od2
+
+
+def test_knn_exact_small(icp_mod, oracle, pair4k):
+    rf, rn = _filtered(icp_mod, pair4k)
+    with icp_mod.IcpHandle() as h:
+        h.set_reference(rf, rn)
+        mean = h.reference_mean()
+        ref_c = rf.copy()
+        ref_c[:, :3] -= mean
+        T = synth.colmajor(pair4k["T_init"]).copy()
+        T[12:15] -= mean
+        ids, d2 = h.knn(pair4k["rd"], T)
+        q = oracle.transform_points(T, pair4k["rd"])
+        _check_nn(oracle, ref_c, q, ids, d2)
+        # brute force agrees as well (independent of the kd-tree)
+        bi, bd = oracle.brute_nn(ref_c, q[:512])
+        assert np.array_equal(bd, d2[:512])
+
+
+def test_knn_exact_64k(icp_mod, oracle, pair64k):
+    rf, rn = _filtered(icp_mod, pair64k)
+    with icp_mod.IcpHandle() as h:
+        h.set_reference(rf, rn)
+        mean = h.reference_mean()
+        ref_c = rf.copy()
+        ref_c[:, :3] -= mean
+        T = synth.colmajor(pair64k["T_init"]).copy()
+        T[12:15] -= mean
+        ids, d2 = h.knn(pair64k["rd"], T)
+        q = oracle.transform_points(T, pair64k["rd"])
+        _check_nn(oracle, ref_c, q, ids, d2)
+
+
+def test_knn_far_and_outside_queries(icp_mod, oracle, pair4k):
+    """Queries far outside the reference bounding box and in empty space: fallback path, exact."""
+    rf, rn = _filtered(icp_mod, pair4k)
+    rng = np.random.default_rng(5)
+    q = np.ones((3000, 4), np.float32)
+    q[:1000, :3] = rng.uniform(-300, 300, (1000, 3))
+    q[1000:2000, :3] = rng.uniform(-30, 30, (1000, 3))
+    q[2000:, :3] = rng.uniform(-3, 3, (1000, 3))
+    q[0, :3] = (1e4, -1e4, 5e3)
+    with icp_mod.IcpHandle() as h:
+        h.set_reference(rf, rn)
+        mean = h.reference_mean()
+        ref_c = rf.copy()
+        ref_c[:, :3] -= mean
+        ids, d2 = h.knn(q, None)
+        _check_nn(oracle, ref_c, q, ids, d2)
+
+
+def test_knn_tiny_reference_and_duplicates(icp_mod, oracle):
+    ref = np.ones((5, 4), np.float32)
+    ref[:, :3] = [[0, 0, 0], [1, 0, 0], [1, 0, 0], [0, 2, 0], [0, 0, 3]]
+    nrm = np.tile(np.float32([0, 0, 1]), (5, 1))
+    q = np.ones((4, 4), np.float32)
+    q[:, :3] = [[0.9, 0.1, 0], [0, 0, 0], [5, 5, 5], [-1, -1, -1]]
+    with icp_mod.IcpHandle() as h:
+        h.set_reference(ref, nrm)
+        mean = h.reference_mean()
+        ref_c = ref.copy()
+        ref_c[:, :3] -= mean
+        qc = q.copy()
+        qc[:, :3] -= mean
+        ids, d2 = h.knn(qc, None)
+        _check_nn(oracle, ref_c, qc, ids, d2)
+        assert ids[0] in (1, 2)
+        # empty query set is fine
+        e_ids, e_d2 = h.knn(np.zeros((0, 4), np.float32), None)
+        assert e_ids.size == 0
+
+
+def test_trim_limit_exact(icp_mod, oracle):
+    rng = np.random.default_rng(3)
+    with icp_mod.IcpHandle() as h:
+        for n in (1, 2, 7, 1000, 65537, 300001):
+            d2 = (rng.gamma(2.0, 0.01, n) ** 2).astype(np.float32)
+            if n > 10:
+                d2[::7] = d2[3]  # heavy ties
+            for ratio in (0.75, 0.85, 1.0, 0.001):
+                rc, want = oracle.trim_limit(d2, ratio)
+                got = h.trim_limit(d2, ratio)
+                k = min(int(np.float32(n) * np.float32(ratio)), n - 1)
+                assert np.float32(got) == np.float32(want) == np.partition(d2, k)[k], (n, ratio)
+
+
+def test_normal_eq_matches_oracle(icp_mod, oracle, pair4k):
+    rf, rn = _filtered(icp_mod, pair4k)
+    with icp_mod.IcpHandle() as h:
+        h.set_reference(rf, rn)
+        mean = h.reference_mean()
+        ref_c = rf.copy()
+        ref_c[:, :3] -= mean
+        T = synth.colmajor(pair4k["T_init"]).copy()
+        T[12:15] -= mean
+        ids, d2 = h.knn(pair4k["rd"], T)
+        limit = h.trim_limit(d2, 0.75)
+        A, b, used, r2 = h.normal_eq(pair4k["rd"], T, ids, d2, limit)
+        p = oracle.transform_points(T, pair4k["rd"])
+        rc, Ao, bo, xo, dTo, used_o = oracle.point_to_plane(p, ref_c, rn, ids, d2, limit, 1)
+        assert used == used_o == int((d2 <= limit).sum())
+        assert np.linalg.norm(A - Ao) / np.linalg.norm(Ao) < 1e-12
+        assert np.linalg.norm(b - bo) / np.linalg.norm(bo) < 1e-10
+        # float accumulation (libpointmatcher's own) agrees to float round-off
+        rc, Af, bf, *_ = oracle.point_to_plane(p, ref_c, rn, ids, d2, limit, 0)
+        assert np.linalg.norm(A - Af) / np.linalg.norm(Af) < 1e-5
+
+
+def test_transform_points_bit_exact(icp_mod, oracle, pair4k):
+    T = synth.colmajor(pair4k["T_init"])
+    with icp_mod.IcpHandle() as h:
+        got = h.transform_points(T, pair4k["rd"])
+    want = oracle.transform_points(T, pair4k["rd"])
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+
+
+def _run_both(icp_mod, oracle, pair, tight, accum_double):
+    rf, rn = _filtered(icp_mod, pair)
+    kw = dict(min_diff_rot=1e-5, min_diff_trans=1e-4) if tight else {}
+    ocfg = oracle.config_yaml(accum_double=accum_double, **kw)
+    rc, To, sto, tro = oracle.icp_compute(ocfg, pair["rd"], rf, rn, synth.colmajor(pair["T_init"]), 40)
+    assert rc == 0
+    from laser_slam_amd._lib import IcpConfig, lib
+    import ctypes as C
+    cfg = IcpConfig()
+    lib().lsgpu_icp_config_yaml(C.byref(cfg))
+    if tight:
+        cfg.min_diff_rot, cfg.min_diff_trans = 1e-5, 1e-4
+    with icp_mod.IcpHandle(cfg) as h:
+        h.set_reference(rf, rn)
+        Tg, stg = h.align(pair["rd"], pair["T_init"])
+        trg = h.trace()
+    return synth.from_colmajor(To), sto, tro, Tg.astype(np.float64), stg, trg
+
+
+@pytest.mark.parametrize("tight", [False, True])
+def test_align_matches_oracle_trace(icp_mod, oracle, pair4k, tight):
+    To, sto, tro, Tg, stg, trg = _run_both(icp_mod, oracle, pair4k, tight, accum_double=1)
+    assert stg.iterations == sto.iterations
+    assert stg.converged == sto.converged
+    for a, b in zip(trg, tro):  # per-iteration: same limit, same weights, same system
+        assert np.float32(a["limit"]) == np.float32(b["limit"])
+        assert a["n_used"] == b["n_used"]
+        assert np.linalg.norm(a["A"] - b["A"]) / np.linalg.norm(b["A"]) < 1e-5
+    dt, dr = synth.pose_error(To, Tg)
+    assert dt <= TOL_T and dr <= TOL_R, (dt, dr)
+    # and ICP did its job: closer to the truth than the initial guess
+    et, er = synth.pose_error(Tg, pair4k["T_true"])
+    it, ir = synth.pose_error(pair4k["T_init"], pair4k["T_true"])
+    assert et < 0.2 * it and er < 0.2 * ir
+
+
+def test_align_vs_float_accumulating_oracle(icp_mod, oracle, pair64k):
+    """Against libpointmatcher's own float accumulation: 1e-4 m / 1e-5 rad at the tightened checker."""
+    To, sto, tro, Tg, stg, trg = _run_both(icp_mod, oracle, pair64k, True, accum_double=0)
+    dt, dr = synth.pose_error(To, Tg)
+    assert dt <= TOL_T and dr <= TOL_R, (dt, dr)
+
+
+def test_align_device_resident_inputs(icp_mod, oracle, pair4k):
+    import torch
+    rf, rn = _filtered(icp_mod, pair4k)
+    with icp_mod.IcpHandle() as h:
+        h.set_reference(rf, rn)
+        T_host, _ = h.align(pair4k["rd"], pair4k["T_init"])
+        dref = torch.from_numpy(rf).cuda()
+        dnrm = torch.from_numpy(rn).cuda()
+        drd = torch.from_numpy(pair4k["rd"]).cuda()
+        torch.cuda.synchronize()
+        h.set_reference(dref, dnrm)
+        T_dev, _ = h.align(drd, pair4k["T_init"])
+    assert np.array_equal(T_host, T_dev)  # same arithmetic whichever memory the caller used
+
+
+def test_align_is_deterministic(icp_mod, pair4k):
+    rf, rn = _filtered(icp_mod, pair4k)
+    with icp_mod.IcpHandle() as h:
+        h.set_reference(rf, rn)
+        a, _ = h.align(pair4k["rd"], pair4k["T_init"])
+        b, _ = h.align(pair4k["rd"], pair4k["T_init"])
+    assert np.array_equal(a, b)
+
+
+def test_errors_are_loud(icp_mod):
+    from laser_slam_amd._lib import ConvergenceError, LsgpuError
+    with icp_mod.IcpHandle() as h:
+        with pytest.raises(ConvergenceError):  # no reference yet == empty reference cloud
+            h.align(np.ones((10, 4), np.float32), np.eye(4))
+        with pytest.raises(LsgpuError):
+            h.set_reference(np.zeros((0, 4), np.float32), np.zeros((0, 3), np.float32))
+        ref = np.ones((100, 4), np.float32)
+        ref[:, :3] = np.random.default_rng(0).normal(size=(100, 3))
+        h.set_reference(ref, np.tile(np.float32([0, 0, 1]), (100, 1)))
+        with pytest.raises(ConvergenceError):  # empty reading
+            h.align(np.zeros((0, 4), np.float32), np.eye(4))
+
+
+def test_icp_class_compute_recovers_pose(icp_mod, pair64k):
+    """ICP.compute == icp_.compute(reading, reference, T_init) incl. both filter chains."""
+    import os
+    icp = icp_mod.ICP()
+    yaml_path = os.path.join(os.path.dirname(__file__), "golden", "icp_chain.yaml")
+    icp.load_from_yaml(yaml_path)
+    icp.chain.seed = 4
+    T = icp.compute(pair64k["rd"], pair64k["ref"], pair64k["T_init"])
+    et, er = synth.pose_error(T.astype(np.float64), pair64k["T_true"])
+    assert et < 0.02 and er < 2e-3, (et, er)
+    assert icp.last_stats.iterations >= 4
