@@ -1,0 +1,185 @@
+#!/usr/bin/env python3
+"""bench.py -- scans/sec + ms/ICP-iteration of the ICP hot path on 1 M-point Velodyne scans.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+A step = one pass of the hot path over one scan pair: steps 2-7 of PointMatcher::ICP::compute as
+called at laser_slam/src/laser_track.cpp:496 -- centre the reference + build the voxel grid, then
+iterate {transform, exact 1-NN, trimmed weights, point-to-plane 6x6} until the (tightened, 1e-4 m /
+1e-5 rad) differential checker stops it.  Inputs (filtered reading, filtered reference + normals) are
+resident in HBM when the timed region starts.  Workload = BASELINE.json configs[1]: one synthetic
+HDL-64E pair of 64 x 16384 rays, full-density chain (F).  With N > 1 every rank
+registers its own pair (embarrassingly parallel, no data-path collective; "weak" scaling).
+
+Prints ONE JSON line on rank 0.
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s peak
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--n-az", type=int, default=16384, help="azimuth steps (16384 -> 1 M rays)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-threads", type=int, default=1)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a ROCm GPU: the ICP hot path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from laser_slam_amd import synth, icp
+    from laser_slam_amd._lib import IcpConfig, lib
+
+    # ---- synthetic workload (host), then resident in HBM
+    ref, rd, T_true, T_init = synth.scan_pair(args.n_az, noise_seeds=(1 + 2 * rank, 2 + 2 * rank),
+                                              guess_seed=7 + rank)
+    rf, rn = icp.sampling_surface_normal(ref, 10, 1.0, 0)   # chain (F): ratio 1.0, knn 10
+    d_ref = torch.from_numpy(rf).cuda()
+    d_nrm = torch.from_numpy(rn).cuda()
+    d_rd = torch.from_numpy(rd).cuda()
+    torch.cuda.synchronize()
+    nq, nr = rd.shape[0], rf.shape[0]
+
+    cfg = IcpConfig()
+    lib().lsgpu_icp_config_yaml(C.byref(cfg))
+    cfg.min_diff_rot, cfg.min_diff_trans = 1e-5, 1e-4        # configs[1]: "to 1e-4 m tolerance"
+    cfg.profile_kernels = 1
+    h = icp.IcpHandle(cfg, local_rank)
+
+    def step():
+        h.set_reference(d_ref, d_nrm)
+        return h.align(d_rd, T_init)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    iters = 0
+    knn_ms = knn_main_ms = knn_fb_ms = 0.0
+    knn_launches = 0
+    align_ms = 0.0
+    strag = 0
+    T = None
+    for _ in range(args.steps):
+        T, st = step()
+        iters += st.iterations
+        knn_ms += st.t_knn_ms
+        knn_main_ms += st.t_knn_main_ms
+        knn_fb_ms += st.t_knn_fallback_ms
+        knn_launches += st.knn_launches
+        align_ms += st.t_total_ms
+        strag += st.stragglers
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    info = h.info()
+    ncell = int(info.cells[info.search_level])
+    # algorithmic bytes of one kNN launch: 24 Nq + 16 Nr + 8 Ncell
+    b_knn = 24 * nq + 16 * nr + 8 * ncell
+    t_knn = knn_ms / max(knn_launches, 1) * 1e-3
+    achieved = b_knn / t_knn / 1e9 if t_knn > 0 else 0.0
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "knn_traffic.json")
+    if os.path.exists(tpath):
+        try:
+            tj = json.load(open(tpath))
+            if tj.get("n_az") == args.n_az:
+                traffic = tj.get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+
+    et, er = synth.pose_error(T.astype(np.float64), T_true)
+    out = {
+        "metric": "scans_per_sec",
+        "value": world * args.steps / elapsed,
+        "unit": "scans/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3,
+        "ms_per_icp_iteration": align_ms / max(iters, 1),
+        "icp_iterations_per_scan": iters / args.steps,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "config": {"workload": "configs[1]: single 1M-point HDL-64E scan pair (64x%d rays), full-density "
+                               "chain F, point-to-plane ICP, differential checker 1e-4 m / 1e-5 rad" % args.n_az,
+                   "n_reading": nq, "n_reference": nr, "pairs_per_gpu_per_step": 1,
+                   "sharding": "one scan pair per rank, no collective"},
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                     "kernel": "k_knn_main + k_knn_fallback (exact 1-NN correspondence search)",
+                     "algorithmic_bytes_per_launch": b_knn,
+                     "avg_launch_us": t_knn * 1e6,
+                     "avg_main_us": knn_main_ms / max(knn_launches, 1) * 1e3,
+                     "avg_fallback_us": knn_fb_ms / max(knn_launches, 1) * 1e3,
+                     "launches": knn_launches, "occupied_cells": ncell,
+                     "stragglers_per_launch": strag / max(knn_launches, 1)},
+        "final_error_vs_truth": {"trans_m": et, "rot_rad": er},
+    }
+
+    # ---- CPU baseline: the oracle (port) on this box's host cores, same workload, rank 0, N=1 only
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import oracle_py as O
+        ocfg = O.config_yaml(accum_double=0, min_diff_rot=1e-5, min_diff_trans=1e-4,
+                             num_threads=args.cpu_threads)
+        tc = time.perf_counter()
+        rc, To, sto, _ = O.icp_compute(ocfg, rd, rf, rn, synth.colmajor(T_init), 0)
+        cpu_s = time.perf_counter() - tc
+        dt, dr = synth.pose_error(synth.from_colmajor(To), T.astype(np.float64))
+        out["cpu_baseline"] = {
+            "value": 1.0 / cpu_s, "unit": "scans/s", "cores": args.cpu_threads, "kind": "port",
+            "sample": "1 scan pair of the same workload (kd-tree build + %d ICP iterations), "
+                      "host has %d cores" % (sto.iterations, os.cpu_count()),
+            "ms_per_icp_iteration": sto.t_loop_ms / max(sto.iterations, 1),
+            "iterations": sto.iterations,
+            "gpu_vs_cpu_transform": {"trans_m": dt, "rot_rad": dr},
+        }
+    if rank == 0:
+        print(json.dumps(out))
+    h.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

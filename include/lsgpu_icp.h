@@ -63,9 +63,11 @@ typedef struct lsgpu_icp_stats {
   int64_t final_n_used;      /* pairs with weight 1 in the last iteration               */
   int64_t stragglers;        /* queries resolved by the exact fallback search, summed   */
   double  t_total_ms;        /* host wall time of the call                              */
-  double  t_knn_ms;          /* sum of kNN kernel time (HIP events; profile_kernels=1)  */
+  double  t_knn_ms;          /* sum of kNN time, main + fallback (HIP events; profile_kernels=1) */
   int     knn_launches;
-  double  t_reserved[4];
+  double  t_knn_main_ms;     /* k_knn_main only                                         */
+  double  t_knn_fallback_ms; /* k_knn_fallback only                                     */
+  double  t_reserved[2];
 } lsgpu_icp_stats;
 
 /* One record per iteration (optional parity/debug trace; replaces the VTKFileInspector dump of
@@ -92,6 +94,17 @@ int lsgpu_icp_align(lsgpu_icp* h, const float* reading_xyz1, int64_t nq, const f
 
 /* Per-iteration records of the last align; returns the number written. */
 int lsgpu_icp_get_trace(lsgpu_icp* h, lsgpu_iter_trace* out, int cap);
+
+/* Geometry of the voxel-hash pyramid built by the last set_reference (for roofline accounting). */
+typedef struct lsgpu_icp_info {
+  int64_t  n_reference;
+  int      bits_per_axis;      /* level 0 has 2^bits cells per axis        */
+  int      search_level;       /* level the main kNN pass looks up          */
+  float    cell_size;          /* level-0 edge [m]                          */
+  uint32_t cells[17];          /* occupied cells per level                  */
+  uint64_t table_bytes;        /* hash tables, all levels                   */
+} lsgpu_icp_info;
+int lsgpu_icp_get_info(lsgpu_icp* h, lsgpu_icp_info* out);
 
 /* The float mean subtracted from the reference (T_refIn_refMean translation). */
 int lsgpu_icp_get_reference_mean(lsgpu_icp* h, float mean[3]);

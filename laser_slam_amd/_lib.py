@@ -18,7 +18,7 @@ OK, NO_CONVERGENCE, BAD_CONFIG, HIP_ERROR, BAD_ARG = 0, 1, 2, 3, 4
 ABI_SYMBOLS = [
     "lsgpu_icp_config_yaml", "lsgpu_icp_config_default", "lsgpu_icp_create", "lsgpu_icp_destroy",
     "lsgpu_icp_set_reference", "lsgpu_icp_align", "lsgpu_icp_get_trace",
-    "lsgpu_icp_get_reference_mean", "lsgpu_knn", "lsgpu_trim_limit", "lsgpu_normal_eq",
+    "lsgpu_icp_get_reference_mean", "lsgpu_icp_get_info", "lsgpu_knn", "lsgpu_trim_limit", "lsgpu_normal_eq",
     "lsgpu_transform_points", "lsgpu_filter_random_sampling",
     "lsgpu_filter_sampling_surface_normal", "lsgpu_check_rigid", "lsgpu_correct_rigid",
     "lsgpu_strerror", "lsgpu_last_error", "lsgpu_abi_version",
@@ -48,7 +48,9 @@ class IcpStats(C.Structure):
         ("t_total_ms", C.c_double),
         ("t_knn_ms", C.c_double),
         ("knn_launches", C.c_int),
-        ("t_reserved", C.c_double * 4),
+        ("t_knn_main_ms", C.c_double),
+        ("t_knn_fallback_ms", C.c_double),
+        ("t_reserved", C.c_double * 2),
     ]
 
 
@@ -60,6 +62,17 @@ class IterTrace(C.Structure):
         ("A", C.c_double * 36),
         ("b", C.c_double * 6),
         ("x", C.c_double * 6),
+    ]
+
+
+class IcpInfo(C.Structure):
+    _fields_ = [
+        ("n_reference", C.c_int64),
+        ("bits_per_axis", C.c_int),
+        ("search_level", C.c_int),
+        ("cell_size", C.c_float),
+        ("cells", C.c_uint32 * 17),
+        ("table_bytes", C.c_uint64),
     ]
 
 
@@ -98,6 +111,7 @@ def lib() -> C.CDLL:
                                   C.POINTER(IcpStats)]
     L.lsgpu_icp_get_trace.argtypes = [vp, C.POINTER(IterTrace), C.c_int]
     L.lsgpu_icp_get_reference_mean.argtypes = [vp, C.POINTER(C.c_float)]
+    L.lsgpu_icp_get_info.argtypes = [vp, C.POINTER(IcpInfo)]
     L.lsgpu_knn.argtypes = [vp, fp, i64, C.POINTER(C.c_float), fp, fp]
     L.lsgpu_trim_limit.argtypes = [vp, fp, i64, C.c_float, C.POINTER(C.c_float)]
     L.lsgpu_normal_eq.argtypes = [vp, fp, i64, C.POINTER(C.c_float), fp, fp, C.c_float,

@@ -86,6 +86,7 @@ struct lsgpu_icp {
   float mean[3] = {0, 0, 0};
   GridDev grid;
   int ls = 0;  // start level of the main kNN pass
+  lsgpu_icp_info info;
   DevBuf<float4> ref_in;   DevBuf<float> nrm_in;
   DevBuf<uint64_t> keys, keys_alt;
   DevBuf<uint32_t> vals, vals_alt;
@@ -109,7 +110,9 @@ struct lsgpu_icp {
   DevBuf<float> limit_dev;
   double* h_pinned = nullptr; // 64 doubles of pinned host staging
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
-  std::vector<std::pair<hipEvent_t, hipEvent_t>> knn_events;
+  struct KnnEv { hipEvent_t a, b, c; };
+  std::vector<KnnEv> knn_events;   // pool, reused across aligns
+  size_t knn_events_used = 0;
   std::vector<lsgpu_iter_trace> trace;
 };
 
@@ -192,7 +195,7 @@ void lsgpu_icp_destroy(lsgpu_icp* h) {
   h->counters.release(); h->q_in.release(); h->rdq.release(); h->ids.release(); h->d2.release();
   h->ids_io.release(); h->d2_io.release(); h->strag.release(); h->hist.release();
   h->sel.release(); h->ne_partials.release(); h->ne_out.release(); h->limit_dev.release();
-  for (auto& e : h->knn_events) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
+  for (auto& e : h->knn_events) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); (void)hipEventDestroy(e.c); }
   if (h->ev0) (void)hipEventDestroy(h->ev0);
   if (h->ev1) (void)hipEventDestroy(h->ev1);
   if (h->h_pinned) (void)hipHostFree(h->h_pinned);
@@ -265,20 +268,22 @@ static int run_knn(lsgpu_icp* h, const Mat34& T, bool timed) {
   const int nq = (int)h->nq;
   uint32_t* scount = h->counters.p + 32;
   HIPC(hipMemsetAsync(scount, 0, sizeof(uint32_t), h->stream));
-  hipEvent_t e0 = nullptr, e1 = nullptr;
+  lsgpu_icp::KnnEv* ev = nullptr;
   if (timed) {
-    HIPC(hipEventCreate(&e0));
-    HIPC(hipEventCreate(&e1));
-    HIPC(hipEventRecord(e0, h->stream));
+    if (h->knn_events_used == h->knn_events.size()) {
+      lsgpu_icp::KnnEv n{};
+      HIPC(hipEventCreate(&n.a)); HIPC(hipEventCreate(&n.b)); HIPC(hipEventCreate(&n.c));
+      h->knn_events.push_back(n);
+    }
+    ev = &h->knn_events[h->knn_events_used++];
+    HIPC(hipEventRecord(ev->a, h->stream));
   }
   hipLaunchKernelGGL(k_knn_main, dim3(nblk(nq)), dim3(256), 0, h->stream, h->rdq.p, nq, T, h->grid,
                      h->ls, h->pts.p, h->ids.p, h->d2.p, h->strag.p, scount);
+  if (timed) HIPC(hipEventRecord(ev->b, h->stream));
   hipLaunchKernelGGL(k_knn_fallback, dim3(kFallbackBlocks), dim3(256), 0, h->stream, h->rdq.p, T,
                      h->grid, h->pts.p, h->ids.p, h->d2.p, h->strag.p, scount);
-  if (timed) {
-    HIPC(hipEventRecord(e1, h->stream));
-    h->knn_events.emplace_back(e0, e1);
-  }
+  if (timed) HIPC(hipEventRecord(ev->c, h->stream));
   HIPC(hipGetLastError());
   return LSGPU_OK;
 }
@@ -383,10 +388,11 @@ int lsgpu_icp_set_reference(lsgpu_icp* h, const float* ref_xyz1, const float* re
   HIPC(hipMemcpyAsync(hc, h->counters.p, kMaxLevels * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
   HIPC(hipStreamSynchronize(h->stream));
   size_t total = 0, off[kMaxLevels];
-  uint32_t cap[kMaxLevels];
+  uint32_t cap[kMaxLevels], ncell[kMaxLevels];
+  for (int l = 0; l <= bits; ++l) ncell[l] = hc[l];
   for (int l = 0; l <= bits; ++l) {
     uint32_t c = 4;
-    while (c < 2u * hc[l]) c <<= 1;
+    while (c < 2u * ncell[l]) c <<= 1;
     cap[l] = c; off[l] = total; total += c;
   }
   HIPC(h->tables.reserve(total));
@@ -402,6 +408,19 @@ int lsgpu_icp_set_reference(lsgpu_icp* h, const float* ref_xyz1, const float* re
   HIPC(hipStreamSynchronize(h->stream));
   h->grid = g;
   h->nr = nr;
+  std::memset(&h->info, 0, sizeof(h->info));
+  h->info.n_reference = nr;
+  h->info.bits_per_axis = bits;
+  h->info.search_level = ls;
+  h->info.cell_size = h0;
+  for (int l = 0; l <= bits; ++l) h->info.cells[l] = ncell[l];
+  h->info.table_bytes = total * sizeof(HashEntry);
+  return LSGPU_OK;
+}
+
+int lsgpu_icp_get_info(lsgpu_icp* h, lsgpu_icp_info* out) {
+  if (!h || !out || h->nr <= 0) return LSGPU_BAD_ARG;
+  *out = h->info;
   return LSGPU_OK;
 }
 
@@ -536,8 +555,7 @@ int lsgpu_icp_align(lsgpu_icp* h, const float* reading_xyz1, int64_t nq, const f
   if (nq > 0x7FFFFFF0ll) return LSGPU_BAD_ARG;
   HIPC(hipSetDevice(h->device));
   const double t0 = wall_ms();
-  for (auto& e : h->knn_events) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
-  h->knn_events.clear();
+  h->knn_events_used = 0;
 
   // step 5: T_refMean_dataIn = T_refIn_refMean^-1 * T_init (pure translation inverse)
   float T_rm_in[16];
@@ -604,10 +622,12 @@ int lsgpu_icp_align(lsgpu_icp* h, const float* reading_xyz1, int64_t nq, const f
     hostmath::mul4(T_iter, T_rm_in, tmp);
     hostmath::mul4(Tmean, tmp, T_out);
   }
-  for (auto& e : h->knn_events) {
-    float ms = 0.f;
-    if (hipEventElapsedTime(&ms, e.first, e.second) == hipSuccess) { st.t_knn_ms += ms; st.knn_launches++; }
-    else (void)hipGetLastError();
+  for (size_t i = 0; i < h->knn_events_used; ++i) {
+    const auto& e = h->knn_events[i];
+    float m1 = 0.f, m2 = 0.f;
+    if (hipEventElapsedTime(&m1, e.a, e.b) == hipSuccess && hipEventElapsedTime(&m2, e.b, e.c) == hipSuccess) {
+      st.t_knn_main_ms += m1; st.t_knn_fallback_ms += m2; st.t_knn_ms += m1 + m2; st.knn_launches++;
+    } else (void)hipGetLastError();
   }
   st.t_total_ms = wall_ms() - t0;
   if (stats) *stats = st;

@@ -116,6 +116,13 @@ class IcpHandle:
             _raise(rc, "lsgpu_icp_get_reference_mean", self._h)
         return m
 
+    def info(self) -> "_lib.IcpInfo":
+        out = _lib.IcpInfo()
+        rc = _lib.lib().lsgpu_icp_get_info(self._h, C.byref(out))
+        if rc != _lib.OK:
+            _raise(rc, "lsgpu_icp_get_info", self._h)
+        return out
+
     # ---- ICP::compute steps 5-7
     def align(self, reading_xyz1, T_init):
         """-> (T 4x4 float32, IcpStats).  Raises ConvergenceError like PointMatcher."""
