@@ -110,7 +110,7 @@ def main():
         elapsed = float(t.item())
 
     info = h.info()
-    ncell = int(info.cells[info.search_level])
+    ncell = int(info.cells[0])
     # algorithmic bytes of one kNN launch: 24 Nq + 16 Nr + 8 Ncell
     b_knn = 24 * nq + 16 * nr + 8 * ncell
     t_knn = knn_ms / max(knn_launches, 1) * 1e-3
@@ -147,7 +147,7 @@ def main():
                    "sharding": "one scan pair per rank, no collective"},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                     "kernel": "k_knn_main + k_knn_fallback (exact 1-NN correspondence search)",
+                     "kernel": "k_knn_tile + k_knn_fallback (exact 1-NN correspondence search)",
                      "algorithmic_bytes_per_launch": b_knn,
                      "avg_launch_us": t_knn * 1e6,
                      "avg_main_us": knn_main_ms / max(knn_launches, 1) * 1e3,

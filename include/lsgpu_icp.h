@@ -99,8 +99,9 @@ int lsgpu_icp_get_trace(lsgpu_icp* h, lsgpu_iter_trace* out, int cap);
 typedef struct lsgpu_icp_info {
   int64_t  n_reference;
   int      bits_per_axis;      /* level 0 has 2^bits cells per axis        */
-  int      search_level;       /* level the main kNN pass looks up          */
+  int      fine_bits;          /* key bits per axis below level 0           */
   float    cell_size;          /* level-0 edge [m]                          */
+  uint32_t n_chunks;           /* <=64-point chunks (32 B descriptor each)  */
   uint32_t cells[17];          /* occupied cells per level                  */
   uint64_t table_bytes;        /* hash tables, all levels                   */
 } lsgpu_icp_info;

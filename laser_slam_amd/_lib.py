@@ -69,8 +69,9 @@ class IcpInfo(C.Structure):
     _fields_ = [
         ("n_reference", C.c_int64),
         ("bits_per_axis", C.c_int),
-        ("search_level", C.c_int),
+        ("fine_bits", C.c_int),
         ("cell_size", C.c_float),
+        ("n_chunks", C.c_uint32),
         ("cells", C.c_uint32 * 17),
         ("table_bytes", C.c_uint64),
     ]

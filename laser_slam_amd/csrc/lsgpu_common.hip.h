@@ -1,0 +1,145 @@
+// lsgpu_common.hip.h -- shared device helpers of the gfx950 ICP hot path (wave64, CDNA4).
+//
+// Kernel map (module chain of laser_slam/configurations/icp_default.yaml, executed by
+// PointMatcher::ICP::compute at laser_slam/src/laser_track.cpp:496):
+//   lsgpu_grid.hip.h   k_ref_* / k_chunk_* / k_cells_*   KDTreeMatcher::init          (yaml:9-12)
+//   lsgpu_knn.hip.h    k_knn_seed / k_knn_tile / k_knn_fallback  ...::findClosests (knn 1, eps 0)
+//   lsgpu_solve.hip.h  k_hist* / find_bin                TrimmedDistOutlierFilter     (yaml:14-16)
+//                      k_normal_eq / k_ne_final          PointToPlaneErrorMinimizer   (yaml:18-19)
+//   lsgpu_grid.hip.h   k_transform                       RigidTransformation::compute
+//
+// Shared arithmetic definitions (the CPU oracle uses the same, so ids / d2 / weights are
+// bit-comparable):
+//   transform : x' = fma(m02,z, fma(m01,y, fma(m00,x, m03)))
+//   dist^2    : fma(dz,dz, fma(dy,dy, dx*dx))
+// The whole TU is compiled with -ffp-contract=off: every fused op is written out.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace lsgpu {
+
+constexpr int kMaxLevels = 17;       // bits per axis <= 16
+constexpr uint32_t kEmpty = 0xFFFFFFFFu;
+constexpr int kHistBins = 2048;
+
+struct HashEntry {  // 16 B: one dwordx4 per probe
+  uint32_t xy;      // cell x | y << 16
+  uint32_t z;
+  uint32_t start;   // first chunk of the cell
+  uint32_t end;     // one past its last chunk
+};
+
+// A chunk = up to 64 consecutive points of the Morton-sorted reference that lie in ONE level-0 cell,
+// with their bounding box.  32 B: two dwordx4.
+struct ChunkDesc {
+  float lox, loy, loz;
+  uint32_t start;   // first point
+  float hix, hiy, hiz;
+  uint32_t count;   // 1..64
+};
+
+// Voxel-hash pyramid over the Morton-sorted reference.  Keys are quantised at hf = h0 / 2^fine;
+// level l (0..bits) has cell edge h0 * 2^l and a level-l cell is a contiguous range of chunks.
+// Level `bits` is one cell holding every point.
+struct GridDev {
+  float ox, oy, oz;   // origin (reference-mean frame)
+  float inv_hf, hf;   // key quantisation step
+  float h0;           // level-0 cell edge
+  int fine;           // key bits per axis below level 0
+  int bits;           // level-0 cells per axis = 2^bits
+  const HashEntry* tab[kMaxLevels];
+  uint32_t mask[kMaxLevels];
+};
+
+// slack (in fine-key units) that covers float rounding of (c - o) * inv_hf at 16-bit magnitudes
+constexpr float kFineSlack = 0.0625f;
+
+__device__ __forceinline__ int fine_coord(float c, float o, float inv_hf, int lim) {
+  const float t = floorf((c - o) * inv_hf);
+  return (int)fminf(fmaxf(t, 0.f), (float)lim);
+}
+
+struct Mat34 {  // rows of a rigid transform
+  float m[12];  // m[r*4+c]
+};
+
+__device__ __forceinline__ float3 xform(const Mat34& T, float x, float y, float z) {
+  float3 o;
+  o.x = __fmaf_rn(T.m[2], z, __fmaf_rn(T.m[1], y, __fmaf_rn(T.m[0], x, T.m[3])));
+  o.y = __fmaf_rn(T.m[6], z, __fmaf_rn(T.m[5], y, __fmaf_rn(T.m[4], x, T.m[7])));
+  o.z = __fmaf_rn(T.m[10], z, __fmaf_rn(T.m[9], y, __fmaf_rn(T.m[8], x, T.m[11])));
+  return o;
+}
+
+__device__ __forceinline__ float dist2(float dx, float dy, float dz) {
+  return __fmaf_rn(dz, dz, __fmaf_rn(dy, dy, dx * dx));
+}
+
+// ---------------------------------------------------------------- Morton helpers (<= 21 bits/axis)
+__host__ __device__ __forceinline__ uint64_t spread3(uint32_t v) {
+  uint64_t x = v & 0x1FFFFFull;
+  x = (x | x << 32) & 0x1F00000000FFFFull;
+  x = (x | x << 16) & 0x1F0000FF0000FFull;
+  x = (x | x << 8) & 0x100F00F00F00F00Full;
+  x = (x | x << 4) & 0x10C30C30C30C30C3ull;
+  x = (x | x << 2) & 0x1249249249249249ull;
+  return x;
+}
+__host__ __device__ __forceinline__ uint32_t compact3(uint64_t x) {
+  x &= 0x1249249249249249ull;
+  x = (x ^ (x >> 2)) & 0x10C30C30C30C30C3ull;
+  x = (x ^ (x >> 4)) & 0x100F00F00F00F00Full;
+  x = (x ^ (x >> 8)) & 0x1F0000FF0000FFull;
+  x = (x ^ (x >> 16)) & 0x1F00000000FFFFull;
+  x = (x ^ (x >> 32)) & 0x1FFFFFull;
+  return (uint32_t)x;
+}
+__host__ __device__ __forceinline__ uint64_t morton3(uint32_t x, uint32_t y, uint32_t z) {
+  return spread3(x) | (spread3(y) << 1) | (spread3(z) << 2);
+}
+
+__device__ __forceinline__ uint32_t cell_hash(uint32_t x, uint32_t y, uint32_t z) {
+  return (x * 73856093u) ^ (y * 19349663u) ^ (z * 83492791u);
+}
+
+__device__ __forceinline__ bool grid_lookup(const GridDev& g, int l, uint32_t x, uint32_t y,
+                                            uint32_t z, uint32_t& s, uint32_t& e) {
+  const uint32_t xy = x | (y << 16);
+  const uint32_t mask = g.mask[l];
+  const uint4* t = reinterpret_cast<const uint4*>(g.tab[l]);
+  uint32_t slot = cell_hash(x, y, z) & mask;
+  for (;;) {
+    const uint4 en = t[slot];
+    if (en.x == xy && en.y == z) { s = en.z; e = en.w; return true; }
+    if (en.x == kEmpty) return false;
+    slot = (slot + 1) & mask;
+  }
+}
+
+// ---------------------------------------------------------------- wave / block reductions
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_min(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+__device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const unsigned long long w = __shfl_xor(v, o, 64);
+    v = w < v ? w : v;
+  }
+  return v;
+}
+
+}  // namespace lsgpu

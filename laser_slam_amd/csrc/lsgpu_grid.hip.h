@@ -1,0 +1,267 @@
+// lsgpu_grid.hip.h -- reference preparation: the KDTreeMatcher::init stand-in
+// (laser_slam/configurations/icp_default.yaml:9-12; executed once per ICP::compute call,
+// laser_slam/src/laser_track.cpp:496).
+//
+// Pipeline: k_ref_stats (mean, bbox) -> k_ref_keys (fine Morton key) -> radix sort ->
+// k_ref_gather (sorted, centred points + normals) -> k_chunk_flags + scan -> k_chunk_bounds /
+// k_chunk_boxes (<=64-point chunks with AABBs) -> k_cells_count / k_cells_fill (per-level hash
+// tables cell -> chunk range).  All writes are coalesced except the hash inserts.
+#pragma once
+#include "lsgpu_common.hip.h"
+
+namespace lsgpu {
+
+// ---------------------------------------------------------------- reference statistics
+struct RefStats {
+  double sum[3];
+  float mn[3];
+  float mx[3];
+};
+
+__global__ __launch_bounds__(256) void k_ref_stats(const float4* __restrict__ in, int64_t n,
+                                                   RefStats* __restrict__ partials) {
+  double sx = 0, sy = 0, sz = 0;
+  float mnx = INFINITY, mny = INFINITY, mnz = INFINITY, mxx = -INFINITY, mxy = -INFINITY,
+        mxz = -INFINITY;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const float4 p = in[i];
+    sx += p.x; sy += p.y; sz += p.z;
+    mnx = fminf(mnx, p.x); mny = fminf(mny, p.y); mnz = fminf(mnz, p.z);
+    mxx = fmaxf(mxx, p.x); mxy = fmaxf(mxy, p.y); mxz = fmaxf(mxz, p.z);
+  }
+  sx = wave_sum(sx); sy = wave_sum(sy); sz = wave_sum(sz);
+  mnx = wave_min(mnx); mny = wave_min(mny); mnz = wave_min(mnz);
+  mxx = wave_max(mxx); mxy = wave_max(mxy); mxz = wave_max(mxz);
+  __shared__ RefStats sh[4];
+  const int w = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) {
+    sh[w].sum[0] = sx; sh[w].sum[1] = sy; sh[w].sum[2] = sz;
+    sh[w].mn[0] = mnx; sh[w].mn[1] = mny; sh[w].mn[2] = mnz;
+    sh[w].mx[0] = mxx; sh[w].mx[1] = mxy; sh[w].mx[2] = mxz;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    RefStats r = sh[0];
+    for (int k = 1; k < 4; ++k)
+      for (int d = 0; d < 3; ++d) {
+        r.sum[d] += sh[k].sum[d];
+        r.mn[d] = fminf(r.mn[d], sh[k].mn[d]);
+        r.mx[d] = fmaxf(r.mx[d], sh[k].mx[d]);
+      }
+    partials[blockIdx.x] = r;
+  }
+}
+
+// One wave; fixed summation tree => deterministic mean.  nblocks <= 512.
+__global__ __launch_bounds__(64) void k_ref_stats_final(const RefStats* __restrict__ partials,
+                                                        int nblocks, RefStats* __restrict__ out) {
+  const int lane = threadIdx.x;
+  double s[3] = {0, 0, 0};
+  float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+  for (int k = lane; k < nblocks; k += 64)
+    for (int d = 0; d < 3; ++d) {
+      s[d] += partials[k].sum[d];
+      mn[d] = fminf(mn[d], partials[k].mn[d]);
+      mx[d] = fmaxf(mx[d], partials[k].mx[d]);
+    }
+  RefStats r;
+  for (int d = 0; d < 3; ++d) {
+    r.sum[d] = wave_sum(s[d]);
+    r.mn[d] = wave_min(mn[d]);
+    r.mx[d] = wave_max(mx[d]);
+  }
+  if (lane == 0) *out = r;
+}
+
+// ---------------------------------------------------------------- keys
+// Reference: centre on the mean, quantise at hf, Morton key of (fine + bits) bits per axis.
+__global__ __launch_bounds__(256) void k_ref_keys(const float4* __restrict__ in, int64_t n,
+                                                  float mx, float my, float mz, GridDev g,
+                                                  uint64_t* __restrict__ keys,
+                                                  uint32_t* __restrict__ vals) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const float4 p = in[i];
+  const int lim = (1 << (g.bits + g.fine)) - 1;
+  const int ix = fine_coord(p.x - mx, g.ox, g.inv_hf, lim);
+  const int iy = fine_coord(p.y - my, g.oy, g.inv_hf, lim);
+  const int iz = fine_coord(p.z - mz, g.oz, g.inv_hf, lim);
+  keys[i] = morton3((uint32_t)ix, (uint32_t)iy, (uint32_t)iz);
+  vals[i] = (uint32_t)i;
+}
+
+// Reading: fine Morton key in its own frame (2^-7 m steps, 21 bits per axis), only so that the 64
+// queries of a wave are neighbours.  Rigid motion keeps them neighbours in every iteration.
+__global__ __launch_bounds__(256) void k_query_keys(const float4* __restrict__ in, int64_t n,
+                                                    uint64_t* __restrict__ keys,
+                                                    uint32_t* __restrict__ vals) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const float4 p = in[i];
+  const float lim = 2097151.f, half = 1048576.f;
+  const uint32_t ix = (uint32_t)fminf(fmaxf(floorf(p.x * 128.f) + half, 0.f), lim);
+  const uint32_t iy = (uint32_t)fminf(fmaxf(floorf(p.y * 128.f) + half, 0.f), lim);
+  const uint32_t iz = (uint32_t)fminf(fmaxf(floorf(p.z * 128.f) + half, 0.f), lim);
+  keys[i] = morton3(ix, iy, iz);
+  vals[i] = (uint32_t)i;
+}
+
+// sorted reference: pts[j] = {centred xyz, original index}, nrm[j] = {normal, 0}, inv[orig] = j
+__global__ __launch_bounds__(256) void k_ref_gather(const float4* __restrict__ in,
+                                                    const float* __restrict__ nrm_in, int64_t n,
+                                                    const uint32_t* __restrict__ perm, float mx,
+                                                    float my, float mz, float4* __restrict__ pts,
+                                                    float4* __restrict__ nrm,
+                                                    uint32_t* __restrict__ inv) {
+  const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (j >= n) return;
+  const uint32_t s = perm[j];
+  const float4 p = in[s];
+  pts[j] = make_float4(p.x - mx, p.y - my, p.z - mz, __uint_as_float(s));
+  float4 nn = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (nrm_in) { nn.x = nrm_in[3 * (int64_t)s]; nn.y = nrm_in[3 * (int64_t)s + 1]; nn.z = nrm_in[3 * (int64_t)s + 2]; }
+  nrm[j] = nn;
+  inv[s] = (uint32_t)j;
+}
+
+// sorted reading moved by T (step 5 of ICP::compute); w = original index
+__global__ __launch_bounds__(256) void k_query_gather(const float4* __restrict__ in, int64_t n,
+                                                      const uint32_t* __restrict__ perm, Mat34 T,
+                                                      float4* __restrict__ out) {
+  const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (j >= n) return;
+  const uint32_t s = perm[j];
+  const float4 p = in[s];
+  const float3 q = xform(T, p.x, p.y, p.z);
+  out[j] = make_float4(q.x, q.y, q.z, __uint_as_float(s));
+}
+
+__global__ __launch_bounds__(256) void k_transform(const float4* __restrict__ in, int64_t n,
+                                                   Mat34 T, float4* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const float4 p = in[i];
+  const float3 q = xform(T, p.x, p.y, p.z);
+  out[i] = make_float4(q.x, q.y, q.z, p.w);
+}
+
+// ---------------------------------------------------------------- chunks
+// A chunk starts at every level-0 cell boundary and at every 64th sorted point.
+__global__ __launch_bounds__(256) void k_chunk_flags(const uint64_t* __restrict__ keys, int64_t n,
+                                                     int fine, uint32_t* __restrict__ flags) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  uint32_t f = ((i & 63) == 0);
+  if (i > 0 && ((keys[i] ^ keys[i - 1]) >> (3 * fine)) != 0) f = 1;
+  flags[i] = f;
+}
+
+// cidx = inclusive scan of flags.  bounds[c] = first point of chunk c; bounds[nchunks] = n.
+__global__ __launch_bounds__(256) void k_chunk_bounds(const uint32_t* __restrict__ flags,
+                                                      const uint32_t* __restrict__ cidx, int64_t n,
+                                                      uint32_t* __restrict__ bounds) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  if (flags[i]) bounds[cidx[i] - 1] = (uint32_t)i;
+  if (i == n - 1) bounds[cidx[i]] = (uint32_t)n;
+}
+
+// one wave per chunk: bounding box + descriptor
+__global__ __launch_bounds__(256) void k_chunk_boxes(const float4* __restrict__ pts,
+                                                     const uint32_t* __restrict__ bounds,
+                                                     uint32_t nchunks,
+                                                     ChunkDesc* __restrict__ chunks) {
+  const uint32_t c = blockIdx.x * 4u + (threadIdx.x >> 6);
+  if (c >= nchunks) return;
+  const int lane = threadIdx.x & 63;
+  const uint32_t s = bounds[c], e = bounds[c + 1];
+  float lx = INFINITY, ly = INFINITY, lz = INFINITY, hx = -INFINITY, hy = -INFINITY, hz = -INFINITY;
+  if (s + lane < e) {
+    const float4 p = pts[s + lane];
+    lx = hx = p.x; ly = hy = p.y; lz = hz = p.z;
+  }
+  lx = wave_min(lx); ly = wave_min(ly); lz = wave_min(lz);
+  hx = wave_max(hx); hy = wave_max(hy); hz = wave_max(hz);
+  if (lane == 0) {
+    ChunkDesc d;
+    d.lox = lx; d.loy = ly; d.loz = lz; d.start = s;
+    d.hix = hx; d.hiy = hy; d.hiz = hz; d.count = e - s;
+    chunks[c] = d;
+  }
+}
+
+// ---------------------------------------------------------------- cell tables
+// A level-l cell boundary sits between sorted points i-1 and i when their keys differ at or above
+// bit 3*(fine+l).  Returns the highest such level, or -1.
+__device__ __forceinline__ int boundary_level(uint64_t k, uint64_t kp, int fine) {
+  const uint64_t x = k ^ kp;
+  if (x == 0) return -1;
+  return (63 - __clzll((long long)x)) / 3 - fine;
+}
+
+__global__ __launch_bounds__(256) void k_cells_count(const uint64_t* __restrict__ keys, int64_t n,
+                                                     int fine, int bits,
+                                                     uint32_t* __restrict__ counts) {
+  __shared__ uint32_t sh[kMaxLevels];
+  if (threadIdx.x < kMaxLevels) sh[threadIdx.x] = 0;
+  __syncthreads();
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) {
+    int lv = (i == 0) ? bits : boundary_level(keys[i], keys[i - 1], fine);
+    if (lv > bits) lv = bits;
+    for (int l = 0; l <= lv; ++l) atomicAdd(&sh[l], 1u);
+  }
+  __syncthreads();
+  if (threadIdx.x <= bits && sh[threadIdx.x]) atomicAdd(&counts[threadIdx.x], sh[threadIdx.x]);
+}
+
+__device__ __forceinline__ HashEntry* table_slot(HashEntry* tab, uint32_t mask, uint32_t x,
+                                                 uint32_t y, uint32_t z) {
+  const uint32_t xy = x | (y << 16);
+  const unsigned long long want = (unsigned long long)xy | ((unsigned long long)z << 32);
+  uint32_t slot = cell_hash(x, y, z) & mask;
+  for (;;) {
+    unsigned long long* kp = reinterpret_cast<unsigned long long*>(&tab[slot]);
+    const unsigned long long prev = atomicCAS(kp, ~0ull, want);
+    if (prev == ~0ull || prev == want) return &tab[slot];
+    slot = (slot + 1) & mask;
+  }
+}
+
+struct TableSet {
+  HashEntry* tab[kMaxLevels];
+  uint32_t mask[kMaxLevels];
+};
+
+__device__ __forceinline__ HashEntry* cell_of_key(const TableSet& ts, int l, uint64_t key,
+                                                  int fine) {
+  const uint64_t c = key >> (3 * (fine + l));
+  return table_slot(ts.tab[l], ts.mask[l], compact3(c), compact3(c >> 1), compact3(c >> 2));
+}
+
+// entries hold CHUNK ranges: the chunk that starts at point i is cidx[i]-1
+__global__ __launch_bounds__(256) void k_cells_fill(const uint64_t* __restrict__ keys,
+                                                    const uint32_t* __restrict__ cidx, int64_t n,
+                                                    int fine, int bits, TableSet ts) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const uint64_t k = keys[i];
+  if (i == 0) {
+    for (int l = 0; l <= bits; ++l) cell_of_key(ts, l, k, fine)->start = 0;
+  } else {
+    const uint64_t kp = keys[i - 1];
+    int lv = boundary_level(k, kp, fine);
+    if (lv > bits) lv = bits;
+    const uint32_t ch = cidx[i] - 1;
+    for (int l = 0; l <= lv; ++l) {
+      cell_of_key(ts, l, k, fine)->start = ch;
+      cell_of_key(ts, l, kp, fine)->end = ch;
+    }
+  }
+  if (i == n - 1) {
+    const uint32_t nch = cidx[i];
+    for (int l = 0; l <= bits; ++l) cell_of_key(ts, l, k, fine)->end = nch;
+  }
+}
+
+}  // namespace lsgpu

@@ -4,7 +4,7 @@
 // laser_slam/src/laser_track.cpp:496 and laser_slam/src/incremental_estimator.cpp:108:
 //   set_reference : steps 2-3 (centre on mean, matcher init)
 //   align         : steps 5-7 (move reading by T_refMean_dataIn, iterate, compose)
-// Kernels: lsgpu_kernels.hip.h.  No CPU fallback exists: every failure is returned to the caller.
+// Kernels: lsgpu_grid.hip.h, lsgpu_knn.hip.h, lsgpu_solve.hip.h.  No CPU fallback exists: every failure is returned to the caller.
 #include <cstring>
 #include <cmath>
 #include <cstdio>
@@ -15,9 +15,12 @@
 
 #include <hip/hip_runtime.h>
 #include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_scan.hpp>
 
 #include "../../include/lsgpu_icp.h"
-#include "lsgpu_kernels.hip.h"
+#include "lsgpu_grid.hip.h"
+#include "lsgpu_knn.hip.h"
+#include "lsgpu_solve.hip.h"
 #include "lsgpu_host_math.h"
 
 using namespace lsgpu;
@@ -94,6 +97,10 @@ struct lsgpu_icp {
   DevBuf<float4> pts, nrm;
   DevBuf<uint32_t> ref_inv;
   DevBuf<HashEntry> tables;
+  DevBuf<uint32_t> flags, cidx, bounds;
+  DevBuf<ChunkDesc> chunks;
+  uint32_t nchunks = 0;
+  DevBuf<int> prev;          // warm start of every query (sorted-reference index)
   DevBuf<RefStats> stat_partials;
   DevBuf<uint32_t> counters;  // [0..16] cell counts, [32] straggler count
 
@@ -191,7 +198,7 @@ void lsgpu_icp_destroy(lsgpu_icp* h) {
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   h->ref_in.release(); h->nrm_in.release(); h->keys.release(); h->keys_alt.release();
   h->vals.release(); h->vals_alt.release(); h->sort_tmp.release(); h->pts.release();
-  h->nrm.release(); h->ref_inv.release(); h->tables.release(); h->stat_partials.release();
+  h->nrm.release(); h->ref_inv.release(); h->tables.release(); h->flags.release(); h->cidx.release(); h->bounds.release(); h->chunks.release(); h->prev.release(); h->stat_partials.release();
   h->counters.release(); h->q_in.release(); h->rdq.release(); h->ids.release(); h->d2.release();
   h->ids_io.release(); h->d2_io.release(); h->strag.release(); h->hist.release();
   h->sel.release(); h->ne_partials.release(); h->ne_out.release(); h->limit_dev.release();
@@ -251,10 +258,9 @@ static int prepare_queries(lsgpu_icp* h, const float* q_xyz1, int64_t nq, const 
   HIPC(h->keys.reserve(nq));
   HIPC(h->vals.reserve(nq));
   HIPC(h->rdq.reserve(nq));
-  const int qbits = 10;
-  hipLaunchKernelGGL(k_query_keys, dim3(nblk(nq)), dim3(256), 0, h->stream, src, nq, 1.0f / 0.25f,
-                     qbits, h->keys.p, h->vals.p);
-  rc = sort_pairs(h, nq, 3 * qbits);
+  HIPC(h->prev.reserve(nq));
+  hipLaunchKernelGGL(k_query_keys, dim3(nblk(nq)), dim3(256), 0, h->stream, src, nq, h->keys.p, h->vals.p);
+  rc = sort_pairs(h, nq, 63);
   if (rc) return rc;
   hipLaunchKernelGGL(k_query_gather, dim3(nblk(nq)), dim3(256), 0, h->stream, src, nq,
                      h->vals_alt.p, T, h->rdq.p);
@@ -263,11 +269,22 @@ static int prepare_queries(lsgpu_icp* h, const float* q_xyz1, int64_t nq, const 
   return ensure_loop_buffers(h, nq);
 }
 
+static KnnArgs knn_args(lsgpu_icp* h, const Mat34& T) {
+  KnnArgs a;
+  a.rdq = h->rdq.p; a.nq = (int)h->nq; a.T = T; a.g = h->grid; a.pts = h->pts.p;
+  a.chunks = h->chunks.p; a.ids = h->ids.p; a.d2 = h->d2.p; a.prev = h->prev.p;
+  a.strag = h->strag.p; a.strag_count = h->counters.p + 32;
+  a.r_cap = 1.0f; a.group_r = 0.75f;
+  return a;
+}
+
 // findClosests for the queries in h->rdq moved by T: fills h->ids (sorted-reference index), h->d2.
-static int run_knn(lsgpu_icp* h, const Mat34& T, bool timed) {
+// seed: the queries have no warm start yet (first iteration of an align, or the kernel-level API).
+static int run_knn(lsgpu_icp* h, const Mat34& T, bool seed, bool timed) {
   const int nq = (int)h->nq;
-  uint32_t* scount = h->counters.p + 32;
-  HIPC(hipMemsetAsync(scount, 0, sizeof(uint32_t), h->stream));
+  const KnnArgs a = knn_args(h, T);
+  HIPC(hipMemsetAsync(a.strag_count, 0, sizeof(uint32_t), h->stream));
+  if (seed) hipLaunchKernelGGL(k_knn_seed, dim3(nblk(nq)), dim3(256), 0, h->stream, a);
   lsgpu_icp::KnnEv* ev = nullptr;
   if (timed) {
     if (h->knn_events_used == h->knn_events.size()) {
@@ -278,11 +295,9 @@ static int run_knn(lsgpu_icp* h, const Mat34& T, bool timed) {
     ev = &h->knn_events[h->knn_events_used++];
     HIPC(hipEventRecord(ev->a, h->stream));
   }
-  hipLaunchKernelGGL(k_knn_main, dim3(nblk(nq)), dim3(256), 0, h->stream, h->rdq.p, nq, T, h->grid,
-                     h->ls, h->pts.p, h->ids.p, h->d2.p, h->strag.p, scount);
+  hipLaunchKernelGGL(k_knn_tile, dim3(nblk(nq)), dim3(256), 0, h->stream, a);
   if (timed) HIPC(hipEventRecord(ev->b, h->stream));
-  hipLaunchKernelGGL(k_knn_fallback, dim3(kFallbackBlocks), dim3(256), 0, h->stream, h->rdq.p, T,
-                     h->grid, h->pts.p, h->ids.p, h->d2.p, h->strag.p, scount);
+  hipLaunchKernelGGL(k_knn_fallback, dim3(kFallbackBlocks), dim3(256), 0, h->stream, a);
   if (timed) HIPC(hipEventRecord(ev->c, h->stream));
   HIPC(hipGetLastError());
   return LSGPU_OK;
@@ -355,38 +370,49 @@ int lsgpu_icp_set_reference(lsgpu_icp* h, const float* ref_xyz1, const float* re
     mx[d] = hs->mx[d] - h->mean[d];
     if (!std::isfinite(mn[d]) || !std::isfinite(mx[d])) { h->err = "set_reference: non-finite coordinates"; return LSGPU_BAD_ARG; }
   }
-  // ---- grid geometry
+  // ---- grid geometry: level-0 cells of h0 (2^bits per axis), keys quantised at hf = h0 / 2^fine
   const float ext = std::max(std::max(mx[0] - mn[0], mx[1] - mn[1]), mx[2] - mn[2]);
-  const int bits = 11;
+  const int bits = 11, fine = 5;
   float h0 = h->cfg.cell_size > 0.f ? h->cfg.cell_size : 0.125f;
   const float need = ext * 1.0001f / (float)((1 << bits) - 1);
   while (h0 < need) h0 *= 2.f;
   GridDev g;
   std::memset(&g, 0, sizeof(g));
   g.ox = mn[0]; g.oy = mn[1]; g.oz = mn[2];
-  g.h0 = h0; g.inv_h0 = 1.0f / h0; g.bits = bits;
-  // main-pass level: cell edge ~0.5 m (guaranteed radius 0.25..0.5 m)
-  int ls = 0;
-  while (ls < bits && h0 * (float)(1 << ls) < 0.5f) ++ls;
-  h->ls = ls;
+  g.h0 = h0; g.hf = h0 / (float)(1 << fine); g.inv_hf = 1.0f / g.hf; g.fine = fine; g.bits = bits;
   // ---- keys, sort, gather
   HIPC(h->keys.reserve(nr)); HIPC(h->vals.reserve(nr));
   HIPC(h->pts.reserve(nr)); HIPC(h->nrm.reserve(nr)); HIPC(h->ref_inv.reserve(nr));
   hipLaunchKernelGGL(k_ref_keys, dim3(nblk(nr)), dim3(256), 0, h->stream, src, nr, h->mean[0],
                      h->mean[1], h->mean[2], g, h->keys.p, h->vals.p);
-  rc = sort_pairs(h, nr, 3 * bits);
+  rc = sort_pairs(h, nr, 3 * (bits + fine));
   if (rc) return rc;
   hipLaunchKernelGGL(k_ref_gather, dim3(nblk(nr)), dim3(256), 0, h->stream, src, nsrc, nr,
                      h->vals_alt.p, h->mean[0], h->mean[1], h->mean[2], h->pts.p, h->nrm.p,
                      h->ref_inv.p);
-  // ---- cell tables
+  // ---- chunks: flags -> inclusive scan -> bounds
+  HIPC(h->flags.reserve(nr)); HIPC(h->cidx.reserve(nr));
+  hipLaunchKernelGGL(k_chunk_flags, dim3(nblk(nr)), dim3(256), 0, h->stream, h->keys_alt.p, nr, fine,
+                     h->flags.p);
+  {
+    size_t bytes = 0;
+    HIPC(rocprim::inclusive_scan(nullptr, bytes, h->flags.p, h->cidx.p, (size_t)nr,
+                                 rocprim::plus<uint32_t>(), h->stream));
+    HIPC(h->sort_tmp.reserve(bytes));
+    bytes = h->sort_tmp.cap;
+    HIPC(rocprim::inclusive_scan((void*)h->sort_tmp.p, bytes, h->flags.p, h->cidx.p, (size_t)nr,
+                                 rocprim::plus<uint32_t>(), h->stream));
+  }
+  // ---- cell counts per level (+ chunk count) -> host, to size the tables
   HIPC(h->counters.reserve(64));
   HIPC(hipMemsetAsync(h->counters.p, 0, 64 * sizeof(uint32_t), h->stream));
-  hipLaunchKernelGGL(k_cells_count, dim3(nblk(nr)), dim3(256), 0, h->stream, h->keys_alt.p, nr, bits,
-                     h->counters.p);
+  hipLaunchKernelGGL(k_cells_count, dim3(nblk(nr)), dim3(256), 0, h->stream, h->keys_alt.p, nr, fine,
+                     bits, h->counters.p);
   uint32_t* hc = reinterpret_cast<uint32_t*>(h->h_pinned);
   HIPC(hipMemcpyAsync(hc, h->counters.p, kMaxLevels * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
+  HIPC(hipMemcpyAsync(hc + 20, h->cidx.p + (nr - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
   HIPC(hipStreamSynchronize(h->stream));
+  const uint32_t nchunks = hc[20];
   size_t total = 0, off[kMaxLevels];
   uint32_t cap[kMaxLevels], ncell[kMaxLevels];
   for (int l = 0; l <= bits; ++l) ncell[l] = hc[l];
@@ -395,6 +421,12 @@ int lsgpu_icp_set_reference(lsgpu_icp* h, const float* ref_xyz1, const float* re
     while (c < 2u * ncell[l]) c <<= 1;
     cap[l] = c; off[l] = total; total += c;
   }
+  HIPC(h->bounds.reserve((size_t)nchunks + 1));
+  HIPC(h->chunks.reserve(nchunks));
+  hipLaunchKernelGGL(k_chunk_bounds, dim3(nblk(nr)), dim3(256), 0, h->stream, h->flags.p, h->cidx.p,
+                     nr, h->bounds.p);
+  hipLaunchKernelGGL(k_chunk_boxes, dim3((nchunks + 3) / 4), dim3(256), 0, h->stream, h->pts.p,
+                     h->bounds.p, nchunks, h->chunks.p);
   HIPC(h->tables.reserve(total));
   HIPC(hipMemsetAsync(h->tables.p, 0xFF, total * sizeof(HashEntry), h->stream));
   TableSet ts;
@@ -403,16 +435,19 @@ int lsgpu_icp_set_reference(lsgpu_icp* h, const float* ref_xyz1, const float* re
     ts.tab[l] = h->tables.p + off[l]; ts.mask[l] = cap[l] - 1;
     g.tab[l] = ts.tab[l]; g.mask[l] = ts.mask[l];
   }
-  hipLaunchKernelGGL(k_cells_fill, dim3(nblk(nr)), dim3(256), 0, h->stream, h->keys_alt.p, nr, bits, ts);
+  hipLaunchKernelGGL(k_cells_fill, dim3(nblk(nr)), dim3(256), 0, h->stream, h->keys_alt.p, h->cidx.p,
+                     nr, fine, bits, ts);
   HIPC(hipGetLastError());
   HIPC(hipStreamSynchronize(h->stream));
   h->grid = g;
   h->nr = nr;
+  h->nchunks = nchunks;
   std::memset(&h->info, 0, sizeof(h->info));
   h->info.n_reference = nr;
   h->info.bits_per_axis = bits;
-  h->info.search_level = ls;
+  h->info.fine_bits = fine;
   h->info.cell_size = h0;
+  h->info.n_chunks = nchunks;
   for (int l = 0; l <= bits; ++l) h->info.cells[l] = ncell[l];
   h->info.table_bytes = total * sizeof(HashEntry);
   return LSGPU_OK;
@@ -438,7 +473,7 @@ int lsgpu_knn(lsgpu_icp* h, const float* query_xyz1, int64_t nq, const float T[1
   const Mat34 Id = to_mat34(I);
   int rc = prepare_queries(h, query_xyz1, nq, Id);
   if (rc) return rc;
-  rc = run_knn(h, Tm, false);
+  rc = run_knn(h, Tm, true, false);
   if (rc) return rc;
   const bool dev_out = is_device_ptr(ids);
   int* ids_o = ids; float* d2_o = d2;
@@ -511,7 +546,7 @@ int lsgpu_normal_eq(lsgpu_icp* h, const float* query_xyz1, int64_t nq, const flo
   hipLaunchKernelGGL((k_normal_eq<true, false>), dim3(nb), dim3(256), 0, h->stream, q, (int)nq, Tm,
                      idp, dp, h->pts.p, h->nrm.p, h->ref_inv.p, (const uint32_t*)nullptr,
                      (const SelState*)nullptr, limit, (float*)nullptr, h->ne_partials.p);
-  hipLaunchKernelGGL(k_ne_final, dim3(1), dim3(64), 0, h->stream, h->ne_partials.p, nb, h->ne_out.p);
+  hipLaunchKernelGGL(k_ne_final, dim3(1), dim3(1024), 0, h->stream, h->ne_partials.p, nb, h->ne_out.p);
   HIPC(hipGetLastError());
   HIPC(hipMemcpyAsync(h->h_pinned, h->ne_out.p, kNe * sizeof(double), hipMemcpyDeviceToHost, h->stream));
   HIPC(hipStreamSynchronize(h->stream));
@@ -576,7 +611,7 @@ int lsgpu_icp_align(lsgpu_icp* h, const float* reading_xyz1, int64_t nq, const f
   rc = LSGPU_OK;
   while (iterate) {
     const Mat34 Tm = to_mat34(T_iter);
-    rc = run_knn(h, Tm, h->cfg.profile_kernels != 0);                                  // 6a+6b
+    rc = run_knn(h, Tm, it == 0, h->cfg.profile_kernels != 0);                                  // 6a+6b
     if (rc) return rc;
     rc = run_select(h, h->d2.p, (int)nq, k);                                            // 6c
     if (rc) return rc;
@@ -584,7 +619,7 @@ int lsgpu_icp_align(lsgpu_icp* h, const float* reading_xyz1, int64_t nq, const f
                        (int)nq, Tm, h->ids.p, h->d2.p, h->pts.p, h->nrm.p, h->ref_inv.p,
                        h->hist.p + 2 * kHistBins, h->sel.p + 2, 0.f, h->limit_dev.p,
                        h->ne_partials.p);                                               // 6d
-    hipLaunchKernelGGL(k_ne_final, dim3(1), dim3(64), 0, h->stream, h->ne_partials.p, nb, h->ne_out.p);
+    hipLaunchKernelGGL(k_ne_final, dim3(1), dim3(1024), 0, h->stream, h->ne_partials.p, nb, h->ne_out.p);
     HIPC(hipGetLastError());
     HIPC(hipMemcpyAsync(h->h_pinned, h->ne_out.p, kNe * sizeof(double), hipMemcpyDeviceToHost, h->stream));
     HIPC(hipMemcpyAsync(h->h_pinned + 32, h->limit_dev.p, sizeof(float), hipMemcpyDeviceToHost, h->stream));

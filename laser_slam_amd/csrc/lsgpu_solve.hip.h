@@ -1,0 +1,189 @@
+// lsgpu_solve.hip.h -- TrimmedDistOutlierFilter (icp_default.yaml:14-16) as an exact radix select and
+// PointToPlaneErrorMinimizer (icp_default.yaml:18-19) as a deterministic normal-equation reduction.
+#pragma once
+#include "lsgpu_common.hip.h"
+
+namespace lsgpu {
+
+// ---------------------------------------------------------------- trimmed-distance order statistic
+// Exact radix select on the float bit pattern of d2 (non-negative floats order like their bits):
+// pass 1 bits [31:20], pass 2 bits [19:9], pass 3 bits [8:0].
+struct SelState {
+  uint32_t prefix;  // selected high bits so far
+  uint32_t k;       // rank still to find inside the selected bin
+};
+
+// Whole block (256 threads): find bin b with cum(b) <= k < cum(b)+hist[b].
+__device__ void find_bin(const uint32_t* __restrict__ hist, int nbins, uint32_t k, uint32_t* bin,
+                         uint32_t* krem, uint32_t* sh /* >= 260 words */) {
+  const int t = threadIdx.x;
+  const int per = nbins / 256;  // nbins is a multiple of 256
+  uint32_t loc = 0;
+  for (int i = 0; i < per; ++i) loc += hist[t * per + i];
+  sh[t] = loc;
+  __syncthreads();
+  if (t == 0) {
+    uint32_t cum = 0;
+    int sel = 255;
+    for (int i = 0; i < 256; ++i) {
+      if (k < cum + sh[i]) { sel = i; break; }
+      cum += sh[i];
+    }
+    uint32_t b = sel * per;
+    for (int i = 0; i < per; ++i) {
+      const uint32_t c = hist[sel * per + i];
+      b = sel * per + i;
+      if (k < cum + c) break;
+      if (i + 1 < per) cum += c;
+    }
+    sh[256] = b;
+    sh[257] = k - cum;
+  }
+  __syncthreads();
+  *bin = sh[256];
+  *krem = sh[257];
+  __syncthreads();
+}
+
+__global__ __launch_bounds__(256) void k_hist1(const float* __restrict__ d2, int n,
+                                               uint32_t* __restrict__ hist) {
+  __shared__ uint32_t sh[kHistBins];
+  for (int i = threadIdx.x; i < kHistBins; i += 256) sh[i] = 0;
+  __syncthreads();
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256)
+    atomicAdd(&sh[__float_as_uint(d2[i]) >> 20], 1u);
+  __syncthreads();
+  for (int i = threadIdx.x; i < kHistBins; i += 256)
+    if (sh[i]) atomicAdd(&hist[i], sh[i]);
+}
+
+// PASS 2: shift 9, 11 bits, parent = hist1 ; PASS 3: shift 0, 9 bits, parent = hist2
+template <int PASS>
+__global__ __launch_bounds__(256) void k_hist_refine(const float* __restrict__ d2, int n,
+                                                     const uint32_t* __restrict__ parent,
+                                                     const SelState* __restrict__ st_in,
+                                                     SelState* __restrict__ st_out,
+                                                     uint32_t* __restrict__ hist) {
+  __shared__ uint32_t sh[kHistBins];
+  __shared__ uint32_t sc[260];
+  const SelState in = *st_in;
+  uint32_t bin, krem;
+  find_bin(parent, kHistBins, in.k, &bin, &krem, sc);
+  const uint32_t prefix = (PASS == 2) ? bin : ((in.prefix << 11) | bin);
+  if (blockIdx.x == 0 && threadIdx.x == 0) { st_out->prefix = prefix; st_out->k = krem; }
+  for (int i = threadIdx.x; i < kHistBins; i += 256) sh[i] = 0;
+  __syncthreads();
+  constexpr int SH_HI = (PASS == 2) ? 20 : 9;
+  constexpr int SH_LO = (PASS == 2) ? 9 : 0;
+  constexpr uint32_t MASK = (PASS == 2) ? 0x7FFu : 0x1FFu;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+    const uint32_t b = __float_as_uint(d2[i]);
+    if ((b >> SH_HI) == prefix) atomicAdd(&sh[(b >> SH_LO) & MASK], 1u);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < kHistBins; i += 256)
+    if (sh[i]) atomicAdd(&hist[i], sh[i]);
+}
+
+// limit bits = prefix(23 high bits) << 9 | bin
+__device__ __forceinline__ float select_limit(const uint32_t* __restrict__ hist3,
+                                              const SelState* __restrict__ st, uint32_t* sc) {
+  const SelState in = *st;
+  uint32_t bin, krem;
+  find_bin(hist3, kHistBins, in.k, &bin, &krem, sc);
+  return __uint_as_float((in.prefix << 9) | bin);
+}
+
+__global__ __launch_bounds__(256) void k_limit_out(const uint32_t* __restrict__ hist3,
+                                                   const SelState* __restrict__ st,
+                                                   float* __restrict__ out) {
+  __shared__ uint32_t sc[260];
+  const float lim = select_limit(hist3, st, sc);
+  if (threadIdx.x == 0) *out = lim;
+}
+
+// ---------------------------------------------------------------- point-to-plane normal equations
+// Per pair with weight 1: J = [p x n ; n] (float, as libpointmatcher), r = (p - q).n ;
+// accumulate 21 upper-tri J J^T, 6 of -J r, count, r^2 in double.  Per-block partials, then a
+// single-block fixed-order reduction => bitwise reproducible.
+constexpr int kNe = 29;
+
+template <bool IDS_ORIG, bool LIMIT_DEV>
+__global__ __launch_bounds__(256) void k_normal_eq(const float4* __restrict__ rdq, int nq, Mat34 T,
+                                                   const int* __restrict__ ids,
+                                                   const float* __restrict__ d2,
+                                                   const float4* __restrict__ pts,
+                                                   const float4* __restrict__ nrm,
+                                                   const uint32_t* __restrict__ inv,
+                                                   const uint32_t* __restrict__ hist3,
+                                                   const SelState* __restrict__ st, float limit_val,
+                                                   float* __restrict__ limit_out,
+                                                   double* __restrict__ partials) {
+  __shared__ uint32_t sc[260];
+  __shared__ double red[4][kNe];
+  float limit = limit_val;
+  if (LIMIT_DEV) {
+    limit = select_limit(hist3, st, sc);
+    if (blockIdx.x == 0 && threadIdx.x == 0) *limit_out = limit;
+  }
+  double acc[kNe];
+#pragma unroll
+  for (int k = 0; k < kNe; ++k) acc[k] = 0.0;
+  for (int j = blockIdx.x * 256 + threadIdx.x; j < nq; j += gridDim.x * 256) {
+    const float d = d2[j];
+    int id = ids[j];
+    if (!(d <= limit) || id < 0) continue;
+    if (IDS_ORIG) id = (int)inv[id];
+    const float4 r = rdq[j];
+    const float3 p = xform(T, r.x, r.y, r.z);
+    const float4 q = pts[id];
+    const float4 n = nrm[id];
+    float J[6];
+    J[0] = p.y * n.z - p.z * n.y;
+    J[1] = p.z * n.x - p.x * n.z;
+    J[2] = p.x * n.y - p.y * n.x;
+    J[3] = n.x; J[4] = n.y; J[5] = n.z;
+    const float res = (p.x - q.x) * n.x + (p.y - q.y) * n.y + (p.z - q.z) * n.z;
+    int k = 0;
+#pragma unroll
+    for (int a = 0; a < 6; ++a) {
+#pragma unroll
+      for (int c = a; c < 6; ++c) acc[k++] += (double)J[a] * (double)J[c];
+    }
+#pragma unroll
+    for (int a = 0; a < 6; ++a) acc[21 + a] -= (double)J[a] * (double)res;
+    acc[27] += 1.0;
+    acc[28] += (double)res * (double)res;
+  }
+#pragma unroll
+  for (int k = 0; k < kNe; ++k) acc[k] = wave_sum(acc[k]);
+  const int w = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+    for (int k = 0; k < kNe; ++k) red[w][k] = acc[k];
+  }
+  __syncthreads();
+  if (threadIdx.x < kNe)
+    partials[(size_t)blockIdx.x * 32 + threadIdx.x] =
+        ((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x];
+}
+
+// 1024 threads = 32 groups of 32: group r sums rows r, r+32, ... of its column, then the 32 group
+// sums are added in fixed order => deterministic, and ~30x faster than one thread per column.
+__global__ __launch_bounds__(1024) void k_ne_final(const double* __restrict__ partials, int nblocks,
+                                                   double* __restrict__ out) {
+  __shared__ double sh[32][33];
+  const int col = threadIdx.x & 31, grp = threadIdx.x >> 5;
+  double s = 0.0;
+  if (col < kNe)
+    for (int b = grp; b < nblocks; b += 32) s += partials[(size_t)b * 32 + col];
+  sh[grp][col] = s;
+  __syncthreads();
+  if (threadIdx.x < kNe) {
+    double t = 0.0;
+    for (int r = 0; r < 32; ++r) t += sh[r][threadIdx.x];
+    out[threadIdx.x] = t;
+  }
+}
+
+}  // namespace lsgpu
