@@ -49,7 +49,7 @@ typedef struct lsgpu_icp_config {
   int   smooth_length;    /* Differential... smoothLength              yaml:27  (4)     */
   float cell_size;        /* finest voxel edge [m]; <= 0: automatic                      */
   int   profile_kernels;  /* 1: HIP-event time every kNN launch (see lsgpu_icp_stats)    */
-  int   reserved[8];
+  int   reserved[8];      /* reserved[0] = 1 disables the trimmed-radius cap (debug)       */
 } lsgpu_icp_config;
 
 /* icp_default.yaml values / ICP::setDefault() values (laser_track.cpp:17,20). */
@@ -67,7 +67,9 @@ typedef struct lsgpu_icp_stats {
   int     knn_launches;
   double  t_knn_main_ms;     /* k_knn_main only                                         */
   double  t_knn_fallback_ms; /* k_knn_fallback only                                     */
-  double  t_reserved[2];
+  int     cap_retries;       /* iterations repeated because the radius-cap prediction failed */
+  int     pad_;
+  double  t_reserved[1];
 } lsgpu_icp_stats;
 
 /* One record per iteration (optional parity/debug trace; replaces the VTKFileInspector dump of
@@ -79,6 +81,10 @@ typedef struct lsgpu_iter_trace {
   double  A[36];
   double  b[6];
   double  x[6];
+  float   knn_main_us;      /* k_knn_tile duration (HIP events; 0 unless profile_kernels) */
+  float   knn_fallback_us;  /* k_knn_fallback duration                                    */
+  uint32_t stragglers;      /* queries resolved by the fallback in this iteration         */
+  uint32_t reserved;
 } lsgpu_iter_trace;
 
 int  lsgpu_icp_create(const lsgpu_icp_config* cfg, int device, lsgpu_icp** out);

@@ -50,7 +50,9 @@ class IcpStats(C.Structure):
         ("knn_launches", C.c_int),
         ("t_knn_main_ms", C.c_double),
         ("t_knn_fallback_ms", C.c_double),
-        ("t_reserved", C.c_double * 2),
+        ("cap_retries", C.c_int),
+        ("pad_", C.c_int),
+        ("t_reserved", C.c_double * 1),
     ]
 
 
@@ -62,6 +64,10 @@ class IterTrace(C.Structure):
         ("A", C.c_double * 36),
         ("b", C.c_double * 6),
         ("x", C.c_double * 6),
+        ("knn_main_us", C.c_float),
+        ("knn_fallback_us", C.c_float),
+        ("stragglers", C.c_uint32),
+        ("reserved", C.c_uint32),
     ]
 
 

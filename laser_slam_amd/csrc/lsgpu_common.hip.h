@@ -110,27 +110,49 @@ __device__ __forceinline__ bool grid_lookup(const GridDev& g, int l, uint32_t x,
   const uint4* t = reinterpret_cast<const uint4*>(g.tab[l]);
   uint32_t slot = cell_hash(x, y, z) & mask;
   for (;;) {
-    const uint4 en = t[slot];
-    if (en.x == xy && en.y == z) { s = en.z; e = en.w; return true; }
+    const uint4 en = t[slot];  // one dwordx4; the combined compare keeps it a single load
+    if (((en.x ^ xy) | (en.y ^ z)) == 0u) { s = en.z; e = en.w; return true; }
     if (en.x == kEmpty) return false;
     slot = (slot + 1) & mask;
   }
 }
 
 // ---------------------------------------------------------------- wave / block reductions
+// DPP row reductions (no LDS traffic): quad_perm xor1, xor2, row_half_mirror, row_mirror leave the
+// row result in all 16 lanes of each row; the 4 row results are combined through readlane.
+#define LSGPU_DPP(v, ctrl) __builtin_amdgcn_update_dpp(0, (v), (ctrl), 0xF, 0xF, true)
+
+__device__ __forceinline__ float rl_f(float v, int lane) {  // uniform-lane broadcast (v_readlane)
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
+}
+__device__ __forceinline__ uint32_t rl_u(uint32_t v, int lane) {
+  return (uint32_t)__builtin_amdgcn_readlane((int)v, lane);
+}
+
+__device__ __forceinline__ float wave_min(float v) {
+  v = fminf(v, __int_as_float(LSGPU_DPP(__float_as_int(v), 0xB1)));
+  v = fminf(v, __int_as_float(LSGPU_DPP(__float_as_int(v), 0x4E)));
+  v = fminf(v, __int_as_float(LSGPU_DPP(__float_as_int(v), 0x141)));
+  v = fminf(v, __int_as_float(LSGPU_DPP(__float_as_int(v), 0x140)));
+  return fminf(fminf(rl_f(v, 0), rl_f(v, 16)), fminf(rl_f(v, 32), rl_f(v, 48)));
+}
+__device__ __forceinline__ float wave_max(float v) {
+  v = fmaxf(v, __int_as_float(LSGPU_DPP(__float_as_int(v), 0xB1)));
+  v = fmaxf(v, __int_as_float(LSGPU_DPP(__float_as_int(v), 0x4E)));
+  v = fmaxf(v, __int_as_float(LSGPU_DPP(__float_as_int(v), 0x141)));
+  v = fmaxf(v, __int_as_float(LSGPU_DPP(__float_as_int(v), 0x140)));
+  return fmaxf(fmaxf(rl_f(v, 0), rl_f(v, 16)), fmaxf(rl_f(v, 32), rl_f(v, 48)));
+}
+__device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) {
+  v += (uint32_t)LSGPU_DPP((int)v, 0xB1);
+  v += (uint32_t)LSGPU_DPP((int)v, 0x4E);
+  v += (uint32_t)LSGPU_DPP((int)v, 0x141);
+  v += (uint32_t)LSGPU_DPP((int)v, 0x140);
+  return rl_u(v, 0) + rl_u(v, 16) + rl_u(v, 32) + rl_u(v, 48);
+}
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
-}
-__device__ __forceinline__ float wave_min(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o, 64));
-  return v;
-}
-__device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
   return v;
 }
 __device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long v) {

@@ -114,7 +114,10 @@ __global__ __launch_bounds__(256) void k_ref_gather(const float4* __restrict__ i
                                                     float4* __restrict__ nrm,
                                                     uint32_t* __restrict__ inv) {
   const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (j >= n) return;
+  if (j >= n) {  // 8 far pad points behind the array (4-wide point loads may run past the end)
+    if (j < n + 8) pts[j] = make_float4(3e18f, 3e18f, 3e18f, 0.f);
+    return;
+  }
   const uint32_t s = perm[j];
   const float4 p = in[s];
   pts[j] = make_float4(p.x - mx, p.y - my, p.z - mz, __uint_as_float(s));

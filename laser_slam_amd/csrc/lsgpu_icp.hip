@@ -100,6 +100,8 @@ struct lsgpu_icp {
   DevBuf<uint32_t> flags, cidx, bounds;
   DevBuf<ChunkDesc> chunks;
   uint32_t nchunks = 0;
+  DevBuf<uint4> knn_dbg_wave;
+  DevBuf<unsigned long long> knn_dbg;  // LSGPU_KNN_STATS builds: 8 counters
   DevBuf<int> prev;          // warm start of every query (sorted-reference index)
   DevBuf<RefStats> stat_partials;
   DevBuf<uint32_t> counters;  // [0..16] cell counts, [32] straggler count
@@ -198,7 +200,7 @@ void lsgpu_icp_destroy(lsgpu_icp* h) {
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   h->ref_in.release(); h->nrm_in.release(); h->keys.release(); h->keys_alt.release();
   h->vals.release(); h->vals_alt.release(); h->sort_tmp.release(); h->pts.release();
-  h->nrm.release(); h->ref_inv.release(); h->tables.release(); h->flags.release(); h->cidx.release(); h->bounds.release(); h->chunks.release(); h->prev.release(); h->stat_partials.release();
+  h->nrm.release(); h->ref_inv.release(); h->tables.release(); h->flags.release(); h->cidx.release(); h->bounds.release(); h->chunks.release(); h->prev.release(); h->knn_dbg.release(); h->knn_dbg_wave.release(); h->stat_partials.release();
   h->counters.release(); h->q_in.release(); h->rdq.release(); h->ids.release(); h->d2.release();
   h->ids_io.release(); h->d2_io.release(); h->strag.release(); h->hist.release();
   h->sel.release(); h->ne_partials.release(); h->ne_out.release(); h->limit_dev.release();
@@ -274,15 +276,20 @@ static KnnArgs knn_args(lsgpu_icp* h, const Mat34& T) {
   a.rdq = h->rdq.p; a.nq = (int)h->nq; a.T = T; a.g = h->grid; a.pts = h->pts.p;
   a.chunks = h->chunks.p; a.ids = h->ids.p; a.d2 = h->d2.p; a.prev = h->prev.p;
   a.strag = h->strag.p; a.strag_count = h->counters.p + 32;
-  a.r_cap = 1.0f; a.group_r = 0.75f;
+  a.r_cap = 1.0f; a.group_r = 0.75f; a.cap2 = INFINITY;
+  a.dbg = h->knn_dbg.p;
+  a.dbg_wave = h->knn_dbg_wave.p;
   return a;
 }
 
 // findClosests for the queries in h->rdq moved by T: fills h->ids (sorted-reference index), h->d2.
 // seed: the queries have no warm start yet (first iteration of an align, or the kernel-level API).
-static int run_knn(lsgpu_icp* h, const Mat34& T, bool seed, bool timed) {
+// cap2 < INF: lane-per-query search, exact only for neighbours with d2 <= cap2 (see lsgpu_knn.hip.h);
+// the caller verifies limit <= cap2 afterwards.
+static int run_knn(lsgpu_icp* h, const Mat34& T, bool seed, bool timed, float cap2 = INFINITY) {
   const int nq = (int)h->nq;
-  const KnnArgs a = knn_args(h, T);
+  KnnArgs a = knn_args(h, T);
+  a.cap2 = cap2;
   HIPC(hipMemsetAsync(a.strag_count, 0, sizeof(uint32_t), h->stream));
   if (seed) hipLaunchKernelGGL(k_knn_seed, dim3(nblk(nq)), dim3(256), 0, h->stream, a);
   lsgpu_icp::KnnEv* ev = nullptr;
@@ -295,10 +302,16 @@ static int run_knn(lsgpu_icp* h, const Mat34& T, bool seed, bool timed) {
     ev = &h->knn_events[h->knn_events_used++];
     HIPC(hipEventRecord(ev->a, h->stream));
   }
-  hipLaunchKernelGGL(k_knn_tile, dim3(nblk(nq)), dim3(256), 0, h->stream, a);
-  if (timed) HIPC(hipEventRecord(ev->b, h->stream));
-  hipLaunchKernelGGL(k_knn_fallback, dim3(kFallbackBlocks), dim3(256), 0, h->stream, a);
-  if (timed) HIPC(hipEventRecord(ev->c, h->stream));
+  static const bool lane_mode = getenv("LSGPU_KNN_LANE") != nullptr;  // experiment switch
+  if (cap2 < INFINITY && lane_mode) {
+    hipLaunchKernelGGL(k_knn_lane, dim3(nblk(nq)), dim3(256), 0, h->stream, a);
+    if (timed) { HIPC(hipEventRecord(ev->b, h->stream)); HIPC(hipEventRecord(ev->c, h->stream)); }
+  } else {
+    hipLaunchKernelGGL(k_knn_tile, dim3(nblk(nq)), dim3(256), 0, h->stream, a);
+    if (timed) HIPC(hipEventRecord(ev->b, h->stream));
+    hipLaunchKernelGGL(k_knn_fallback, dim3(kFallbackBlocks), dim3(256), 0, h->stream, a);
+    if (timed) HIPC(hipEventRecord(ev->c, h->stream));
+  }
   HIPC(hipGetLastError());
   return LSGPU_OK;
 }
@@ -382,12 +395,12 @@ int lsgpu_icp_set_reference(lsgpu_icp* h, const float* ref_xyz1, const float* re
   g.h0 = h0; g.hf = h0 / (float)(1 << fine); g.inv_hf = 1.0f / g.hf; g.fine = fine; g.bits = bits;
   // ---- keys, sort, gather
   HIPC(h->keys.reserve(nr)); HIPC(h->vals.reserve(nr));
-  HIPC(h->pts.reserve(nr)); HIPC(h->nrm.reserve(nr)); HIPC(h->ref_inv.reserve(nr));
+  HIPC(h->pts.reserve(nr + 8)); HIPC(h->nrm.reserve(nr)); HIPC(h->ref_inv.reserve(nr));
   hipLaunchKernelGGL(k_ref_keys, dim3(nblk(nr)), dim3(256), 0, h->stream, src, nr, h->mean[0],
                      h->mean[1], h->mean[2], g, h->keys.p, h->vals.p);
   rc = sort_pairs(h, nr, 3 * (bits + fine));
   if (rc) return rc;
-  hipLaunchKernelGGL(k_ref_gather, dim3(nblk(nr)), dim3(256), 0, h->stream, src, nsrc, nr,
+  hipLaunchKernelGGL(k_ref_gather, dim3(nblk(nr + 8)), dim3(256), 0, h->stream, src, nsrc, nr,
                      h->vals_alt.p, h->mean[0], h->mean[1], h->mean[2], h->pts.p, h->nrm.p,
                      h->ref_inv.p);
   // ---- chunks: flags -> inclusive scan -> bounds
@@ -609,22 +622,36 @@ int lsgpu_icp_align(lsgpu_icp* h, const float* reading_xyz1, int64_t nq, const f
   bool iterate = true, by_diff = false;
   int it = 0;
   rc = LSGPU_OK;
+  float prev_limit = INFINITY;  // trim limit of the previous iteration (squared distance)
+  std::vector<size_t> ev_of_iter;
   while (iterate) {
     const Mat34 Tm = to_mat34(T_iter);
-    rc = run_knn(h, Tm, it == 0, h->cfg.profile_kernels != 0);                                  // 6a+6b
-    if (rc) return rc;
-    rc = run_select(h, h->d2.p, (int)nq, k);                                            // 6c
-    if (rc) return rc;
-    hipLaunchKernelGGL((k_normal_eq<false, true>), dim3(nb), dim3(256), 0, h->stream, h->rdq.p,
-                       (int)nq, Tm, h->ids.p, h->d2.p, h->pts.p, h->nrm.p, h->ref_inv.p,
-                       h->hist.p + 2 * kHistBins, h->sel.p + 2, 0.f, h->limit_dev.p,
-                       h->ne_partials.p);                                               // 6d
-    hipLaunchKernelGGL(k_ne_final, dim3(1), dim3(1024), 0, h->stream, h->ne_partials.p, nb, h->ne_out.p);
-    HIPC(hipGetLastError());
-    HIPC(hipMemcpyAsync(h->h_pinned, h->ne_out.p, kNe * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-    HIPC(hipMemcpyAsync(h->h_pinned + 32, h->limit_dev.p, sizeof(float), hipMemcpyDeviceToHost, h->stream));
-    HIPC(hipMemcpyAsync(h->h_pinned + 33, h->counters.p + 32, sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
-    HIPC(hipStreamSynchronize(h->stream));
+    // Radius cap for this iteration's search: pairs beyond the trim limit get weight 0, and the limit
+    // shrinks as ICP converges, so neighbours are needed exactly only below ~ the previous limit.
+    // Verified below; a violated prediction repeats the search uncapped (exact in every case).
+    float cap2 = (it > 0 && h->cfg.reserved[0] == 0) ? prev_limit * 2.0f : INFINITY;
+    for (int attempt = 0; attempt < 2; ++attempt) {
+      rc = run_knn(h, Tm, it == 0 && attempt == 0, h->cfg.profile_kernels != 0, cap2);            // 6a+6b
+      if (rc) return rc;
+      rc = run_select(h, h->d2.p, (int)nq, k);                                          // 6c
+      if (rc) return rc;
+      hipLaunchKernelGGL((k_normal_eq<false, true>), dim3(nb), dim3(256), 0, h->stream, h->rdq.p,
+                         (int)nq, Tm, h->ids.p, h->d2.p, h->pts.p, h->nrm.p, h->ref_inv.p,
+                         h->hist.p + 2 * kHistBins, h->sel.p + 2, 0.f, h->limit_dev.p,
+                         h->ne_partials.p);                                             // 6d
+      hipLaunchKernelGGL(k_ne_final, dim3(1), dim3(1024), 0, h->stream, h->ne_partials.p, nb, h->ne_out.p);
+      HIPC(hipGetLastError());
+      HIPC(hipMemcpyAsync(h->h_pinned, h->ne_out.p, kNe * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+      HIPC(hipMemcpyAsync(h->h_pinned + 32, h->limit_dev.p, sizeof(float), hipMemcpyDeviceToHost, h->stream));
+      HIPC(hipMemcpyAsync(h->h_pinned + 33, h->counters.p + 32, sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
+      HIPC(hipStreamSynchronize(h->stream));
+      float lim_chk;
+      std::memcpy(&lim_chk, h->h_pinned + 32, sizeof(float));
+      if (cap2 == INFINITY || lim_chk <= cap2) break;  // the order statistic lies among exact values
+      cap2 = INFINITY;
+      st.cap_retries++;
+    }
+    ev_of_iter.push_back(h->knn_events_used ? h->knn_events_used - 1 : 0);
     float limit; uint32_t nstrag;
     std::memcpy(&limit, h->h_pinned + 32, sizeof(float));
     std::memcpy(&nstrag, h->h_pinned + 33, sizeof(uint32_t));
@@ -643,8 +670,10 @@ int lsgpu_icp_align(lsgpu_icp* h, const float* reading_xyz1, int64_t nq, const f
     tr.limit = limit; tr.n_used = used;
     std::memcpy(tr.A, A, sizeof(A)); std::memcpy(tr.b, b, sizeof(b));
     for (int i = 0; i < 6; ++i) tr.x[i] = x[i];
+    tr.knn_main_us = tr.knn_fallback_us = 0.f; tr.stragglers = nstrag; tr.reserved = 0;
     h->trace.push_back(tr);
     st.final_limit = limit; st.final_n_used = used;
+    prev_limit = limit;
     ++it;
     if (!ck.check(T_iter, &iterate, &by_diff)) { rc = LSGPU_NO_CONVERGENCE; h->err = "NaN in transformation checker"; break; }
   }
@@ -662,11 +691,37 @@ int lsgpu_icp_align(lsgpu_icp* h, const float* reading_xyz1, int64_t nq, const f
     float m1 = 0.f, m2 = 0.f;
     if (hipEventElapsedTime(&m1, e.a, e.b) == hipSuccess && hipEventElapsedTime(&m2, e.b, e.c) == hipSuccess) {
       st.t_knn_main_ms += m1; st.t_knn_fallback_ms += m2; st.t_knn_ms += m1 + m2; st.knn_launches++;
+      for (size_t t = 0; t < h->trace.size() && t < ev_of_iter.size(); ++t)
+        if (ev_of_iter[t] == i) { h->trace[t].knn_main_us = m1 * 1e3f; h->trace[t].knn_fallback_us = m2 * 1e3f; }
     } else (void)hipGetLastError();
   }
   st.t_total_ms = wall_ms() - t0;
   if (stats) *stats = st;
   return rc;
+}
+
+// dev only: per-wave records of the last k_knn_tile launch (LSGPU_KNN_STATS build)
+int lsgpu_dev_knn_wave_stats(lsgpu_icp* h, unsigned int* out, int nwaves) {
+  if (!h) return LSGPU_BAD_ARG;
+  if (!out) { HIPC(h->knn_dbg_wave.reserve((size_t)nwaves)); HIPC(hipMemset(h->knn_dbg_wave.p, 0, (size_t)nwaves * 16)); return LSGPU_OK; }
+  HIPC(hipStreamSynchronize(h->stream));
+  HIPC(hipMemcpy(out, h->knn_dbg_wave.p, (size_t)nwaves * 16, hipMemcpyDeviceToHost));
+  return LSGPU_OK;
+}
+
+// dev only: counters of the LSGPU_KNN_STATS build (zeroed on read)
+int lsgpu_dev_knn_counters(lsgpu_icp* h, unsigned long long out[8]) {
+  if (!h) return LSGPU_BAD_ARG;
+  if (!h->knn_dbg.p) {
+    HIPC(h->knn_dbg.reserve(8));
+    HIPC(hipMemset(h->knn_dbg.p, 0, 64));
+    std::memset(out, 0, 64);
+    return LSGPU_OK;
+  }
+  HIPC(hipStreamSynchronize(h->stream));
+  HIPC(hipMemcpy(out, h->knn_dbg.p, 64, hipMemcpyDeviceToHost));
+  HIPC(hipMemset(h->knn_dbg.p, 0, 64));
+  return LSGPU_OK;
 }
 
 int lsgpu_icp_get_trace(lsgpu_icp* h, lsgpu_iter_trace* out, int cap) {

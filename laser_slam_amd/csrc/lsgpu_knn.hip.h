@@ -12,6 +12,14 @@
 //     needs it are its <= 64 points staged through LDS and broadcast to all lanes.
 //   * lanes whose ball is larger than r_cap go to k_knn_fallback: one wave per query, chunks culled
 //     lane-parallel against the single ball, surviving chunks evaluated one point per lane.
+//   * k_knn_lane: one LANE per query, used once the balls are small (later ICP iterations): each
+//     lane looks up the <= 2x2x2 cells its ball touches and walks their chunks with the same box
+//     test.  Neighbouring lanes read the same cells / chunks, so the loads coalesce.
+//     TrimmedDistOutlierFilter (yaml:14-16) gives every pair beyond the trim limit weight 0, so in
+//     the ICP loop a lane needs an exact neighbour only if it is closer than cap = sqrt(cap2), a
+//     bound the host derives from the previous iteration's limit and verifies after the select
+//     (a violated bound repeats the iteration uncapped).  Lanes with nothing inside the cap keep an
+//     upper bound > cap2 ("far"); their order among themselves never matters.
 // Ties in distance: any nearest point is returned (libnabo's order is implementation defined).
 #pragma once
 #include "lsgpu_common.hip.h"
@@ -35,7 +43,16 @@ struct KnnArgs {
   uint32_t* strag_count;
   float r_cap;              // lanes with a larger ball go to the fallback
   float group_r;            // half extent of one search group inside a wave
+  float cap2;               // k_knn_lane: only neighbours with d2 <= cap2 must be exact (INF: all)
+  unsigned long long* dbg;  // optional counters (LSGPU_KNN_STATS builds only)
+  uint4* dbg_wave;          // optional per-wave {cycles, chunk evals, proxy survivors, groups<<8|level}
 };
+
+#ifdef LSGPU_KNN_STATS
+#define KNN_COUNT(slot, v) do { if (lane == 0 && a.dbg) atomicAdd(&a.dbg[slot], (unsigned long long)(v)); } while (0)
+#else
+#define KNN_COUNT(slot, v) do { } while (0)
+#endif
 
 __device__ __forceinline__ float box_dist2(float lx, float ly, float lz, float hx, float hy,
                                            float hz, float qx, float qy, float qz) {
@@ -77,13 +94,145 @@ __global__ __launch_bounds__(256) void k_knn_seed(KnnArgs a) {
   a.prev[j] = bi;
 }
 
+// ---------------------------------------------------------------- per-lane ball search
+// Exact for every reference point with d2 <= min(best, cap2): looks up the <= 2x2x2 cells the ball
+// touches at the level where it spans at most two cells per axis and walks their chunks.
+// pts is padded by 8 far points, so 4-wide point loads may run past a chunk's end (the extra points
+// are real reference points or pads: evaluating them is harmless).
+__device__ __forceinline__ void lane_ball_search(const KnnArgs& a, float qx, float qy, float qz,
+                                                 float& best, int& bi) {
+  const GridDev& g = a.g;
+  float prune = fminf(best, a.cap2);
+  const float R = sqrtf(prune) * (1.0f + 1e-5f) + 1e-7f + kFineSlack * g.hf;
+  const int lim = (1 << (g.bits + g.fine)) - 1;
+  const int flx = fine_coord(qx - R, g.ox, g.inv_hf, lim), fhx = fine_coord(qx + R, g.ox, g.inv_hf, lim);
+  const int fly = fine_coord(qy - R, g.oy, g.inv_hf, lim), fhy = fine_coord(qy + R, g.oy, g.inv_hf, lim);
+  const int flz = fine_coord(qz - R, g.oz, g.inv_hf, lim), fhz = fine_coord(qz + R, g.oz, g.inv_hf, lim);
+  int l = 0, sh = g.fine;
+  for (; l < g.bits; ++l, ++sh)
+    if ((fhx >> sh) - (flx >> sh) < 2 && (fhy >> sh) - (fly >> sh) < 2 && (fhz >> sh) - (flz >> sh) < 2)
+      break;
+  sh = g.fine + l;
+  const int x0 = flx >> sh, y0 = fly >> sh, z0 = flz >> sh;
+  const int x1 = fhx >> sh, y1 = fhy >> sh, z1 = fhz >> sh;
+  for (int cz = z0; cz <= z1; ++cz)
+    for (int cy = y0; cy <= y1; ++cy)
+      for (int cx = x0; cx <= x1; ++cx) {
+        uint32_t cs, ce;
+        if (!grid_lookup(g, l, (uint32_t)cx, (uint32_t)cy, (uint32_t)cz, cs, ce)) continue;
+        for (uint32_t ch = cs; ch < ce; ++ch) {
+          const float4* cd = reinterpret_cast<const float4*>(a.chunks + ch);
+          const float4 b0 = cd[0], b1 = cd[1];
+          if (!(box_dist2(b0.x, b0.y, b0.z, b1.x, b1.y, b1.z, qx, qy, qz) * kPruneShrink <= prune))
+            continue;
+          const uint32_t st = __float_as_uint(b0.w), cnt = __float_as_uint(b1.w);
+          for (uint32_t t = 0; t < cnt; t += 4) {
+            const float4 p0 = a.pts[st + t], p1 = a.pts[st + t + 1], p2 = a.pts[st + t + 2],
+                         p3 = a.pts[st + t + 3];
+            const float d0 = dist2(qx - p0.x, qy - p0.y, qz - p0.z);
+            const float d1 = dist2(qx - p1.x, qy - p1.y, qz - p1.z);
+            const float d2 = dist2(qx - p2.x, qy - p2.y, qz - p2.z);
+            const float d3 = dist2(qx - p3.x, qy - p3.y, qz - p3.z);
+            if (d0 < best) { best = d0; bi = (int)(st + t); }
+            if (d1 < best) { best = d1; bi = (int)(st + t + 1); }
+            if (d2 < best) { best = d2; bi = (int)(st + t + 2); }
+            if (d3 < best) { best = d3; bi = (int)(st + t + 3); }
+          }
+          prune = fminf(best, a.cap2);
+        }
+      }
+}
+
 // ---------------------------------------------------------------- tile search
+constexpr int kListCap = 256;        // chunk ids queued per wave (LDS)
+constexpr uint32_t kChunkBudget = 1024;  // a whole-wave group is accepted up to this many chunks
+
+struct TileLds {
+  float4 cand[64];          // staged points of the chunk being evaluated
+  uint32_t list[kListCap];  // flattened chunk ids of the region's cells
+};
+
+// Cull 64 queued chunks (one per lane) against the group's query box, then walk the survivors:
+// per-lane box test against the lane's own best, stage + broadcast the chunk if any lane needs it.
+// The next survivor's points are loaded while the current one is evaluated.
+__device__ __forceinline__ void tile_process_batch(const KnnArgs& a, TileLds& lds, int lane, bool valid,
+                                                   uint32_t ch, bool ing, float qx, float qy, float qz,
+                                                   float tlx, float tly, float tlz, float thx, float thy,
+                                                   float thz, float& maxbest, float& best, int& bi,
+                                                   uint32_t& n_eval, uint32_t& n_surv) {
+  float4 b0 = make_float4(0.f, 0.f, 0.f, 0.f), b1 = b0;
+  bool pass = false;
+  if (valid) {
+    const float4* cd = reinterpret_cast<const float4*>(a.chunks + ch);
+    b0 = cd[0]; b1 = cd[1];
+    const float gx = fmaxf(fmaxf(b0.x - thx, tlx - b1.x), 0.f);
+    const float gy = fmaxf(fmaxf(b0.y - thy, tly - b1.y), 0.f);
+    const float gz = fmaxf(fmaxf(b0.z - thz, tlz - b1.z), 0.f);
+    pass = (gx * gx + gy * gy + gz * gz) * kPruneShrink <= maxbest;
+  }
+  unsigned long long m = __ballot(pass);
+  if (!m) return;
+  if (__popcll(m) > 8) {
+    // Many boxes passed the group-level test: refine lane-parallel (lane = chunk) against every
+    // query's own bound before the serial walk, which costs a broadcast + branch per chunk.
+    bool needed = false;
+    unsigned long long qm = __ballot(ing);
+    while (qm) {
+      const int u = __ffsll((long long)qm) - 1;
+      qm &= qm - 1;
+      const float ux = rl_f(qx, u), uy = rl_f(qy, u), uz = rl_f(qz, u);
+      const float ul = rl_f(fminf(best, a.cap2), u);
+      needed = needed || (box_dist2(b0.x, b0.y, b0.z, b1.x, b1.y, b1.z, ux, uy, uz) * kPruneShrink <= ul);
+    }
+    m &= __ballot(pass && needed);
+    if (!m) return;
+  }
+  n_surv += __popcll(m);
+  int k = __ffsll((long long)m) - 1;
+  uint32_t st_n = rl_u(__float_as_uint(b0.w), k), cnt_n = rl_u(__float_as_uint(b1.w), k);
+  float4 p_n = make_float4(kPadCoord, kPadCoord, kPadCoord, 0.f);
+  if ((uint32_t)lane < cnt_n) p_n = a.pts[st_n + lane];
+  while (m) {
+    const int kc = k;
+    const uint32_t st = st_n, cnt = cnt_n;
+    const float4 p = p_n;
+    m &= m - 1;
+    if (m) {  // prefetch the next survivor's points
+      k = __ffsll((long long)m) - 1;
+      st_n = rl_u(__float_as_uint(b0.w), k); cnt_n = rl_u(__float_as_uint(b1.w), k);
+      p_n = make_float4(kPadCoord, kPadCoord, kPadCoord, 0.f);
+      if ((uint32_t)lane < cnt_n) p_n = a.pts[st_n + lane];
+    }
+    const float lx = rl_f(b0.x, kc), ly = rl_f(b0.y, kc), lz = rl_f(b0.z, kc);
+    const float hx = rl_f(b1.x, kc), hy = rl_f(b1.y, kc), hz = rl_f(b1.z, kc);
+    const bool need = ing && box_dist2(lx, ly, lz, hx, hy, hz, qx, qy, qz) * kPruneShrink <= fminf(best, a.cap2);
+    if (!__ballot(need)) continue;
+    n_eval++;
+    lds.cand[lane] = p;
+    const uint32_t cnt4 = (cnt + 3u) & ~3u;
+    for (uint32_t t = 0; t < cnt4; t += 4) {
+#pragma unroll
+      for (uint32_t u = 0; u < 4; ++u) {
+        const float4 cpt = lds.cand[t + u];
+        const float d = dist2(qx - cpt.x, qy - cpt.y, qz - cpt.z);
+        if (d < best) { best = d; bi = (int)(st + t + u); }
+      }
+    }
+  }
+  maxbest = wave_max(ing ? fminf(best, a.cap2) : 0.f);
+}
+
 __global__ __launch_bounds__(256) void k_knn_tile(KnnArgs a) {
-  __shared__ float4 cand[4][64];
+  __shared__ TileLds lds_all[4];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  TileLds& lds = lds_all[w];
   const int j = blockIdx.x * 256 + threadIdx.x;
   const bool act = j < a.nq;
   const GridDev& g = a.g;
+#ifdef LSGPU_KNN_STATS
+  const long long t_begin = clock64();
+#endif
+  uint32_t n_eval = 0, n_surv = 0, n_grp = 0, lvl_max = 0;
 
   float qx = 0.f, qy = 0.f, qz = 0.f, best = 0.f;
   int bi = -1;
@@ -95,33 +244,26 @@ __global__ __launch_bounds__(256) void k_knn_tile(KnnArgs a) {
     const float4 p = a.pts[bi];
     best = dist2(qx - p.x, qy - p.y, qz - p.z);
   }
-  const float R = sqrtf(best) * (1.0f + 1e-5f) + 1e-7f;
+  // only neighbours closer than min(best, cap2) can matter
+  const float R = sqrtf(fminf(best, a.cap2)) * (1.0f + 1e-5f) + 1e-7f;
   const bool straggler = act && !(R <= a.r_cap);
-  unsigned long long todo = __ballot(act && !straggler);
-  const int lim = (1 << (g.bits + g.fine)) - 1;
-
-  while (todo) {
-    // ---- one group: lanes within group_r (Chebyshev) of the first unresolved lane
-    const int piv = __ffsll((long long)todo) - 1;
-    const float px = __shfl(qx, piv, 64), py = __shfl(qy, piv, 64), pz = __shfl(qz, piv, 64);
-    const bool ing = ((todo >> lane) & 1ull) &&
-                     fmaxf(fmaxf(fabsf(qx - px), fabsf(qy - py)), fabsf(qz - pz)) <= a.group_r;
-    todo &= ~__ballot(ing);
-    // query bbox and ball bbox of the group
+  const bool ing = act && !straggler;
+  if (__ballot(ing)) {
+    // query box, largest ball, largest bound of the wave
     const float tlx = wave_min(ing ? qx : INFINITY), thx = wave_max(ing ? qx : -INFINITY);
     const float tly = wave_min(ing ? qy : INFINITY), thy = wave_max(ing ? qy : -INFINITY);
     const float tlz = wave_min(ing ? qz : INFINITY), thz = wave_max(ing ? qz : -INFINITY);
-    const float rlx = wave_min(ing ? qx - R : INFINITY), rhx = wave_max(ing ? qx + R : -INFINITY);
-    const float rly = wave_min(ing ? qy - R : INFINITY), rhy = wave_max(ing ? qy + R : -INFINITY);
-    const float rlz = wave_min(ing ? qz - R : INFINITY), rhz = wave_max(ing ? qz + R : -INFINITY);
-    float maxbest = wave_max(ing ? best : 0.f);
-    // fine-key box of the region (uniform), widened by the rounding slack
-    const int flx = __builtin_amdgcn_readfirstlane(fine_coord(rlx - kFineSlack * g.hf, g.ox, g.inv_hf, lim));
-    const int fly = __builtin_amdgcn_readfirstlane(fine_coord(rly - kFineSlack * g.hf, g.oy, g.inv_hf, lim));
-    const int flz = __builtin_amdgcn_readfirstlane(fine_coord(rlz - kFineSlack * g.hf, g.oz, g.inv_hf, lim));
-    const int fhx = __builtin_amdgcn_readfirstlane(fine_coord(rhx + kFineSlack * g.hf, g.ox, g.inv_hf, lim));
-    const int fhy = __builtin_amdgcn_readfirstlane(fine_coord(rhy + kFineSlack * g.hf, g.oy, g.inv_hf, lim));
-    const int fhz = __builtin_amdgcn_readfirstlane(fine_coord(rhz + kFineSlack * g.hf, g.oz, g.inv_hf, lim));
+    const float Rmax = wave_max(ing ? R : 0.f);
+    float maxbest = wave_max(ing ? fminf(best, a.cap2) : 0.f);
+    const int lim = (1 << (g.bits + g.fine)) - 1;
+    // fine-key box of the region (every lane's ball lies inside), widened by the rounding slack
+    const float pad = Rmax + kFineSlack * g.hf;
+    const int flx = __builtin_amdgcn_readfirstlane(fine_coord(tlx - pad, g.ox, g.inv_hf, lim));
+    const int fly = __builtin_amdgcn_readfirstlane(fine_coord(tly - pad, g.oy, g.inv_hf, lim));
+    const int flz = __builtin_amdgcn_readfirstlane(fine_coord(tlz - pad, g.oz, g.inv_hf, lim));
+    const int fhx = __builtin_amdgcn_readfirstlane(fine_coord(thx + pad, g.ox, g.inv_hf, lim));
+    const int fhy = __builtin_amdgcn_readfirstlane(fine_coord(thy + pad, g.oy, g.inv_hf, lim));
+    const int fhz = __builtin_amdgcn_readfirstlane(fine_coord(thz + pad, g.oz, g.inv_hf, lim));
     int l = 0, sh = g.fine;
     for (; l < g.bits; ++l, ++sh)
       if ((fhx >> sh) - (flx >> sh) < 4 && (fhy >> sh) - (fly >> sh) < 4 && (fhz >> sh) - (flz >> sh) < 4)
@@ -139,50 +281,39 @@ __global__ __launch_bounds__(256) void k_knn_tile(KnnArgs a) {
         }
       }
     }
-    unsigned long long cells = __ballot(ce > cs);
-    while (cells) {
-      const int c = __ffsll((long long)cells) - 1;
-      cells &= cells - 1;
-      const uint32_t ccs = __shfl(cs, c, 64), cce = __shfl(ce, c, 64);
-      for (uint32_t base = ccs; base < cce; base += 64) {
-        // ---- lane-parallel cull of 64 chunk boxes against the group's query bbox
-        const uint32_t ch = base + lane;
-        float4 b0 = make_float4(0.f, 0.f, 0.f, 0.f), b1 = b0;
-        bool pass = false;
-        if (ch < cce) {
-          const float4* cd = reinterpret_cast<const float4*>(a.chunks + ch);
-          b0 = cd[0]; b1 = cd[1];
-          const float gx = fmaxf(fmaxf(b0.x - thx, tlx - b1.x), 0.f);
-          const float gy = fmaxf(fmaxf(b0.y - thy, tly - b1.y), 0.f);
-          const float gz = fmaxf(fmaxf(b0.z - thz, tlz - b1.z), 0.f);
-          pass = (gx * gx + gy * gy + gz * gz) * kPruneShrink <= maxbest;
-        }
-        unsigned long long m = __ballot(pass);
-        while (m) {
-          const int k = __ffsll((long long)m) - 1;
-          m &= m - 1;
-          const float lx = __shfl(b0.x, k, 64), ly = __shfl(b0.y, k, 64), lz = __shfl(b0.z, k, 64);
-          const float hx = __shfl(b1.x, k, 64), hy = __shfl(b1.y, k, 64), hz = __shfl(b1.z, k, 64);
-          // ---- per-lane test against the lane's own best
-          const bool need = ing && box_dist2(lx, ly, lz, hx, hy, hz, qx, qy, qz) * kPruneShrink <= best;
-          if (!__ballot(need)) continue;
-          const uint32_t st = __builtin_amdgcn_readfirstlane(__float_as_uint(__shfl(b0.w, k, 64)));
-          const uint32_t cnt = __builtin_amdgcn_readfirstlane(__float_as_uint(__shfl(b1.w, k, 64)));
-          // ---- stage the chunk's points in this wave's LDS slot, broadcast to every lane
-          float4 p = make_float4(kPadCoord, kPadCoord, kPadCoord, 0.f);
-          if ((uint32_t)lane < cnt) p = a.pts[st + lane];
-          cand[w][lane] = p;
-          const uint32_t cnt4 = (cnt + 3u) & ~3u;
-          for (uint32_t t = 0; t < cnt4; t += 4) {
-#pragma unroll
-            for (uint32_t u = 0; u < 4; ++u) {
-              const float4 cpt = cand[w][t + u];
-              const float d = dist2(qx - cpt.x, qy - cpt.y, qz - cpt.z);
-              if (d < best) { best = d; bi = (int)(st + t + u); }
-            }
+    // A wave whose queries are spread far wider than their balls (sparse far field, Morton jumps)
+    // shares no candidates: its lanes search on their own.
+    const float ext = fmaxf(fmaxf(thx - tlx, thy - tly), thz - tlz);
+    const bool spread = ext > fmaxf(a.group_r, 4.f * Rmax) && wave_sum_u32(ce - cs) > kChunkBudget;
+    if (spread) {
+      if (ing) lane_ball_search(a, qx, qy, qz, best, bi);
+      n_grp = 64;
+    } else {
+      n_grp = 1; lvl_max = l;
+      // ---- flatten the cells' chunk ranges into the LDS list, 64 at a time into the cull
+      unsigned long long cells = __ballot(ce > cs);
+      uint32_t fill = 0;
+      while (cells) {
+        const int c = __ffsll((long long)cells) - 1;
+        cells &= cells - 1;
+        const uint32_t ccs = rl_u(cs, c), cce = rl_u(ce, c);
+        for (uint32_t base = ccs; base < cce; base += 64) {
+          const uint32_t n = (cce - base) < 64u ? (cce - base) : 64u;
+          if ((uint32_t)lane < n) lds.list[fill + lane] = base + lane;
+          fill += n;
+          while (fill >= 64u) {  // a full batch is ready
+            fill -= 64u;
+            const uint32_t ch = lds.list[fill + lane];
+            tile_process_batch(a, lds, lane, true, ch, ing, qx, qy, qz, tlx, tly, tlz, thx, thy, thz,
+                               maxbest, best, bi, n_eval, n_surv);
           }
         }
-        maxbest = wave_max(ing ? best : 0.f);
+      }
+      if (fill) {
+        const bool v = (uint32_t)lane < fill;
+        const uint32_t ch = v ? lds.list[lane] : 0u;
+        tile_process_batch(a, lds, lane, v, ch, ing, qx, qy, qz, tlx, tly, tlz, thx, thy, thz,
+                           maxbest, best, bi, n_eval, n_surv);
       }
     }
   }
@@ -192,6 +323,31 @@ __global__ __launch_bounds__(256) void k_knn_tile(KnnArgs a) {
     a.prev[j] = bi;
     if (straggler) a.strag[atomicAdd(a.strag_count, 1u)] = (uint32_t)j;
   }
+#ifdef LSGPU_KNN_STATS
+  if (lane == 0 && a.dbg) {
+    atomicAdd(&a.dbg[0], (unsigned long long)n_grp); atomicAdd(&a.dbg[3], (unsigned long long)n_surv);
+    atomicAdd(&a.dbg[4], (unsigned long long)n_eval);
+  }
+  if (lane == 0 && a.dbg_wave)
+    a.dbg_wave[blockIdx.x * 4 + w] = make_uint4((uint32_t)(clock64() - t_begin), n_eval, n_surv, (n_grp << 8) | lvl_max);
+#else
+  (void)n_grp; (void)lvl_max;
+#endif
+}
+
+// ---------------------------------------------------------------- lane-per-query search
+__global__ __launch_bounds__(256) void k_knn_lane(KnnArgs a) {
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= a.nq) return;
+  const float4 r = a.rdq[j];
+  const float3 q = xform(a.T, r.x, r.y, r.z);
+  int bi = a.prev[j];
+  const float4 p = a.pts[bi];
+  float best = dist2(q.x - p.x, q.y - p.y, q.z - p.z);
+  lane_ball_search(a, q.x, q.y, q.z, best, bi);
+  a.ids[j] = bi;
+  a.d2[j] = best;
+  a.prev[j] = bi;
 }
 
 // ---------------------------------------------------------------- exact fallback, one wave per query
@@ -232,7 +388,7 @@ __global__ __launch_bounds__(256) void k_knn_fallback(KnnArgs a) {
     while (cells) {
       const int c = __ffsll((long long)cells) - 1;
       cells &= cells - 1;
-      const uint32_t ccs = __shfl(cs, c, 64), cce = __shfl(ce, c, 64);
+      const uint32_t ccs = rl_u(cs, c), cce = rl_u(ce, c);
       for (uint32_t base = ccs; base < cce; base += 64) {
         const uint32_t ch = base + lane;
         float4 b0 = make_float4(0.f, 0.f, 0.f, 0.f), b1 = b0;
@@ -247,11 +403,11 @@ __global__ __launch_bounds__(256) void k_knn_fallback(KnnArgs a) {
           const int k = __ffsll((long long)m) - 1;
           m &= m - 1;
           // the bound may have shrunk since the cull: re-test (uniform)
-          const float lx = __shfl(b0.x, k, 64), ly = __shfl(b0.y, k, 64), lz = __shfl(b0.z, k, 64);
-          const float hx = __shfl(b1.x, k, 64), hy = __shfl(b1.y, k, 64), hz = __shfl(b1.z, k, 64);
+          const float lx = rl_f(b0.x, k), ly = rl_f(b0.y, k), lz = rl_f(b0.z, k);
+          const float hx = rl_f(b1.x, k), hy = rl_f(b1.y, k), hz = rl_f(b1.z, k);
           if (!(box_dist2(lx, ly, lz, hx, hy, hz, q.x, q.y, q.z) * kPruneShrink <= best)) continue;
-          const uint32_t st = __float_as_uint(__shfl(b0.w, k, 64));
-          const uint32_t cnt = __float_as_uint(__shfl(b1.w, k, 64));
+          const uint32_t st = rl_u(__float_as_uint(b0.w), k);
+          const uint32_t cnt = rl_u(__float_as_uint(b1.w), k);
           float d = INFINITY;
           if ((uint32_t)lane < cnt) {
             const float4 p = a.pts[st + lane];

@@ -143,7 +143,9 @@ class IcpHandle:
             t = buf[i]
             out.append(dict(T_iter=np.array(t.T_iter[:], np.float32), limit=t.limit,
                             n_used=t.n_used, A=np.array(t.A[:]).reshape(6, 6),
-                            b=np.array(t.b[:]), x=np.array(t.x[:])))
+                            b=np.array(t.b[:]), x=np.array(t.x[:]),
+                            knn_main_us=t.knn_main_us, knn_fallback_us=t.knn_fallback_us,
+                            stragglers=t.stragglers))
         return out
 
     # ---- kernel-level entry points (reference-mean frame)
