@@ -250,3 +250,93 @@ def test_icp_class_compute_recovers_pose(icp_mod, pair64k):
     et, er = synth.pose_error(T.astype(np.float64), pair64k["T_true"])
     assert et < 0.02 and er < 2e-3, (et, er)
     assert icp.last_stats.iterations >= 4
+
+
+def test_golden_vectors(icp_mod):
+    """Committed fixture (tests/golden/make_golden.py): inputs + oracle outputs of a 4k pair."""
+    import os
+    from laser_slam_amd._lib import IcpConfig, lib
+    import ctypes as C
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "icp_pair4k.npz"))
+    with icp_mod.IcpHandle() as h:
+        h.set_reference(g["ref"], g["nrm"])
+        assert np.array_equal(h.reference_mean(), g["mean"])
+        Tm = g["T_init"].copy()
+        Tm[12:15] -= g["mean"]
+        ids, d2 = h.knn(g["rd"], Tm)
+        assert np.array_equal(d2, g["nn_d2"])
+        same = ids == g["nn_ids"]
+        assert same.mean() > 0.999  # ids may differ only at exact distance ties
+        lim = h.trim_limit(d2, 0.75)
+        assert np.float32(lim) == g["limit0"]
+        A, b, used, _ = h.normal_eq(g["rd"], Tm, g["nn_ids"], g["nn_d2"], lim)
+        assert used == g["used0"]
+        assert np.linalg.norm(A - g["A0"]) / np.linalg.norm(g["A0"]) < 1e-12
+    for tag, kw in (("yaml", None), ("tight", (1e-5, 1e-4))):
+        cfg = IcpConfig()
+        lib().lsgpu_icp_config_yaml(C.byref(cfg))
+        if kw:
+            cfg.min_diff_rot, cfg.min_diff_trans = kw
+        with icp_mod.IcpHandle(cfg) as h:
+            h.set_reference(g["ref"], g["nrm"])
+            T, st = h.align(g["rd"], g["T_init"])
+            tr = h.trace()
+        k = f"{tag}_acc1"
+        assert st.iterations == g[k + "_iters"] and st.converged == g[k + "_converged"]
+        assert np.array_equal(np.array([t["limit"] for t in tr], np.float32), g[k + "_limits"])
+        assert np.array_equal(np.array([t["n_used"] for t in tr]), g[k + "_used"])
+        dt, dr = synth.pose_error(T.astype(np.float64), synth.from_colmajor(g[k + "_T"]))
+        assert dt <= TOL_T and dr <= TOL_R
+        dt, dr = synth.pose_error(T.astype(np.float64), synth.from_colmajor(g[f"{tag}_acc0_T"]))
+        assert dt <= TOL_T and dr <= TOL_R
+
+
+def test_radius_cap_does_not_change_results(icp_mod, pair64k):
+    """The trimmed-radius cap is an exact optimisation: same trace with it disabled."""
+    from laser_slam_amd._lib import IcpConfig, lib
+    import ctypes as C
+    rf, rn = _filtered(icp_mod, pair64k)
+    out = []
+    for disable in (0, 1):
+        cfg = IcpConfig()
+        lib().lsgpu_icp_config_yaml(C.byref(cfg))
+        cfg.min_diff_rot, cfg.min_diff_trans = 1e-5, 1e-4
+        cfg.reserved[0] = disable
+        with icp_mod.IcpHandle(cfg) as h:
+            h.set_reference(rf, rn)
+            T, st = h.align(pair64k["rd"], pair64k["T_init"])
+            out.append((T, st.iterations, [(t["limit"], t["n_used"], t["A"].tobytes()) for t in h.trace()]))
+    assert out[0][1] == out[1][1]
+    assert out[0][2] == out[1][2]
+    assert np.array_equal(out[0][0], out[1][0])
+
+
+def test_full_size_properties(icp_mod):
+    """BASELINE configs[1] size (1M-point pair): size-independent properties instead of the oracle.
+    (a) kNN distances are self-consistent with the returned ids and no sampled brute-force distance
+    beats them; (b) a reference matched against itself returns identity ids and zero distances;
+    (c) alignment converges to the known synthetic motion."""
+    ref, rd, T_true, T_init = synth.scan_pair(16384)
+    rf, rn = icp_mod.sampling_surface_normal(ref, 10, 1.0, 0)
+    with icp_mod.IcpHandle() as h:
+        h.set_reference(rf, rn)
+        mean = h.reference_mean()
+        ref_c = rf.copy()
+        ref_c[:, :3] -= mean
+        T = synth.colmajor(T_init).copy()
+        T[12:15] -= mean
+        ids, d2 = h.knn(rd, T)
+        q = h.transform_points(T, rd)
+        diff = q[:, :3] - ref_c[ids, :3]
+        dd = (diff.astype(np.float64) ** 2).sum(1)
+        assert np.allclose(dd, d2, rtol=1e-5, atol=1e-12)
+        rng = np.random.default_rng(0)
+        pick = rng.choice(rd.shape[0], 256, replace=False)
+        D = ((q[pick, None, :3].astype(np.float64) - ref_c[None, ::1, :3]) ** 2).sum(-1)
+        assert (D.min(1) >= d2[pick] * (1 - 1e-5)).all()
+        ids_self, d2_self = h.knn(ref_c[:200000], None)
+        assert (d2_self == 0).all()
+        assert (np.abs(ref_c[ids_self, :3] - ref_c[:200000, :3]).max() == 0)
+        Tg, st = h.align(rd, T_init)
+    et, er = synth.pose_error(Tg.astype(np.float64), T_true)
+    assert et < 0.02 and er < 1e-3 and st.iterations < 40
