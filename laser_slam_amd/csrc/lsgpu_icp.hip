@@ -277,8 +277,11 @@ static KnnArgs knn_args(lsgpu_icp* h, const Mat34& T) {
   a.chunks = h->chunks.p; a.ids = h->ids.p; a.d2 = h->d2.p; a.prev = h->prev.p;
   a.strag = h->strag.p; a.strag_count = h->counters.p + 32;
   a.r_cap = 1.0f; a.group_r = 0.75f; a.cap2 = INFINITY;
+  a.ntiles = (int)((h->nq + 63) / 64); a.xcd_swizzle = 0;
   a.dbg = h->knn_dbg.p;
   a.dbg_wave = h->knn_dbg_wave.p;
+  { const char* e = getenv("LSGPU_KNN_DBG"); a.dbg_flags = e ? atoi(e) : 0;
+    if ((a.dbg_flags & (64 | 128 | 256)) && h->trace.size() < 6) a.dbg_flags = 0; }  // early-exit ablations from launch 6 on
   return a;
 }
 
@@ -307,7 +310,12 @@ static int run_knn(lsgpu_icp* h, const Mat34& T, bool seed, bool timed, float ca
     hipLaunchKernelGGL(k_knn_lane, dim3(nblk(nq)), dim3(256), 0, h->stream, a);
     if (timed) { HIPC(hipEventRecord(ev->b, h->stream)); HIPC(hipEventRecord(ev->c, h->stream)); }
   } else {
-    hipLaunchKernelGGL(k_knn_tile, dim3(nblk(nq)), dim3(256), 0, h->stream, a);
+    static const int tile_threads = getenv("LSGPU_TILE_THREADS") ? atoi(getenv("LSGPU_TILE_THREADS")) : 64;
+    static const int swz = getenv("LSGPU_XCD_SWIZZLE") ? atoi(getenv("LSGPU_XCD_SWIZZLE")) : 0;
+    static const int extra_lds = getenv("LSGPU_TILE_LDS") ? atoi(getenv("LSGPU_TILE_LDS")) : 0;  // experiment: occupancy throttle
+    a.xcd_swizzle = swz;
+    const int waves_per_block = tile_threads / 64;
+    hipLaunchKernelGGL(k_knn_tile, dim3((a.ntiles + waves_per_block - 1) / waves_per_block), dim3(tile_threads), extra_lds, h->stream, a);
     if (timed) HIPC(hipEventRecord(ev->b, h->stream));
     hipLaunchKernelGGL(k_knn_fallback, dim3(kFallbackBlocks), dim3(256), 0, h->stream, a);
     if (timed) HIPC(hipEventRecord(ev->c, h->stream));

@@ -46,6 +46,9 @@ struct KnnArgs {
   float cap2;               // k_knn_lane: only neighbours with d2 <= cap2 must be exact (INF: all)
   unsigned long long* dbg;  // optional counters (LSGPU_KNN_STATS builds only)
   uint4* dbg_wave;          // optional per-wave {cycles, chunk evals, proxy survivors, groups<<8|level}
+  int ntiles;               // number of 64-query tiles
+  int xcd_swizzle;          // 1: block b -> XCD (b % 8) gets a contiguous eighth of the tiles
+  int dbg_flags;            // LSGPU_KNN_STATS builds: ablation switches (1 no eval, 2 no refine, 4 no search)
 };
 
 #ifdef LSGPU_KNN_STATS
@@ -148,9 +151,20 @@ constexpr int kListCap = 256;        // chunk ids queued per wave (LDS)
 constexpr uint32_t kChunkBudget = 1024;  // a whole-wave group is accepted up to this many chunks
 
 struct TileLds {
-  float4 cand[64];          // staged points of the chunk being evaluated
-  uint32_t list[kListCap];  // flattened chunk ids of the region's cells
+  float cx[64], cy[64], cz[64];  // staged points of the chunk being evaluated (SoA: pairs feed v_pk_*)
+  uint32_t list[kListCap];       // flattened chunk ids of the region's cells
 };
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// d2 of two candidates at once; each half is exactly fma(dz,dz,fma(dy,dy,dx*dx)) (v_pk_add/mul/fma_f32)
+__device__ __forceinline__ f32x2 dist2_pair(f32x2 qx, f32x2 qy, f32x2 qz, f32x2 cx, f32x2 cy, f32x2 cz) {
+  const f32x2 dx = qx - cx, dy = qy - cy, dz = qz - cz;
+  f32x2 d = dx * dx;
+  d = __builtin_elementwise_fma(dy, dy, d);
+  d = __builtin_elementwise_fma(dz, dz, d);
+  return d;
+}
 
 // Cull 64 queued chunks (one per lane) against the group's query box, then walk the survivors:
 // per-lane box test against the lane's own best, stage + broadcast the chunk if any lane needs it.
@@ -158,7 +172,7 @@ struct TileLds {
 __device__ __forceinline__ void tile_process_batch(const KnnArgs& a, TileLds& lds, int lane, bool valid,
                                                    uint32_t ch, bool ing, float qx, float qy, float qz,
                                                    float tlx, float tly, float tlz, float thx, float thy,
-                                                   float thz, float& maxbest, float& best, int& bi,
+                                                   float thz, float& maxbest, float& best, int& grp,
                                                    uint32_t& n_eval, uint32_t& n_surv) {
   float4 b0 = make_float4(0.f, 0.f, 0.f, 0.f), b1 = b0;
   bool pass = false;
@@ -172,7 +186,14 @@ __device__ __forceinline__ void tile_process_batch(const KnnArgs& a, TileLds& ld
   }
   unsigned long long m = __ballot(pass);
   if (!m) return;
+#ifdef LSGPU_KNN_STATS
+  if (a.dbg_flags & 128) { n_surv += __popcll(m); return; }
+#endif
+#ifdef LSGPU_KNN_STATS
+  if (__popcll(m) > ((a.dbg_flags & 2) ? 64 : 8)) {
+#else
   if (__popcll(m) > 8) {
+#endif
     // Many boxes passed the group-level test: refine lane-parallel (lane = chunk) against every
     // query's own bound before the serial walk, which costs a broadcast + branch per chunk.
     bool needed = false;
@@ -205,37 +226,79 @@ __device__ __forceinline__ void tile_process_batch(const KnnArgs& a, TileLds& ld
     }
     const float lx = rl_f(b0.x, kc), ly = rl_f(b0.y, kc), lz = rl_f(b0.z, kc);
     const float hx = rl_f(b1.x, kc), hy = rl_f(b1.y, kc), hz = rl_f(b1.z, kc);
-    const bool need = ing && box_dist2(lx, ly, lz, hx, hy, hz, qx, qy, qz) * kPruneShrink <= fminf(best, a.cap2);
+    bool need = ing && box_dist2(lx, ly, lz, hx, hy, hz, qx, qy, qz) * kPruneShrink <= fminf(best, a.cap2);
+#ifdef LSGPU_KNN_STATS
+    if (a.dbg_flags & 16) {
+      float lx2 = lx; asm volatile("" : "+v"(lx2));
+      need = need && (ing && box_dist2(lx2, ly, lz, hx, hy, hz, qx, qy, qz) * kPruneShrink <= fminf(best, a.cap2));
+    }
+#endif
     if (!__ballot(need)) continue;
     n_eval++;
-    lds.cand[lane] = p;
+#ifdef LSGPU_KNN_STATS
+    if (a.dbg_flags & (1 | 256)) continue;
+#endif
+    lds.cx[lane] = p.x; lds.cy[lane] = p.y; lds.cz[lane] = p.z;
     const uint32_t cnt4 = (cnt + 3u) & ~3u;
+    const f32x2 q2x = {qx, qx}, q2y = {qy, qy}, q2z = {qz, qz};
+    // 4 candidates per step: 12 packed-pair ops for the distances, min3 + min, then ONE compare/select
+    // pair that records the group of 4 holding the new best; the exact index is resolved once at
+    // the end of the kernel (tile_resolve_index).
+#ifdef LSGPU_KNN_STATS
+    for (int rep = (a.dbg_flags & 8) ? 2 : 1; rep > 0; --rep)
+#endif
     for (uint32_t t = 0; t < cnt4; t += 4) {
-#pragma unroll
-      for (uint32_t u = 0; u < 4; ++u) {
-        const float4 cpt = lds.cand[t + u];
-        const float d = dist2(qx - cpt.x, qy - cpt.y, qz - cpt.z);
-        if (d < best) { best = d; bi = (int)(st + t + u); }
-      }
+      const float4 X = *reinterpret_cast<const float4*>(&lds.cx[t]);
+      const float4 Y = *reinterpret_cast<const float4*>(&lds.cy[t]);
+      const float4 Z = *reinterpret_cast<const float4*>(&lds.cz[t]);
+      const f32x2 d0 = dist2_pair(q2x, q2y, q2z, f32x2{X.x, X.y}, f32x2{Y.x, Y.y}, f32x2{Z.x, Z.y});
+      const f32x2 d1 = dist2_pair(q2x, q2y, q2z, f32x2{X.z, X.w}, f32x2{Y.z, Y.w}, f32x2{Z.z, Z.w});
+      const float m4 = fminf(fminf(fminf(d0.x, d0.y), d1.x), d1.y);
+      if (m4 < best) { best = m4; grp = (int)(st + t); }
     }
   }
   maxbest = wave_max(ing ? fminf(best, a.cap2) : 0.f);
+}
+
+// Which point of the recorded group of 4 is at distance `best` (first one; pts is padded, and a point
+// of the following chunk at exactly the same distance would be an equally valid nearest neighbour).
+__device__ __forceinline__ int tile_resolve_index(const KnnArgs& a, int grp, float qx, float qy, float qz,
+                                                  float best, int bi) {
+  if (grp >= 0) {
+    const float4 p0 = a.pts[grp], p1 = a.pts[grp + 1], p2 = a.pts[grp + 2], p3 = a.pts[grp + 3];
+    if (dist2(qx - p3.x, qy - p3.y, qz - p3.z) == best) bi = grp + 3;
+    if (dist2(qx - p2.x, qy - p2.y, qz - p2.z) == best) bi = grp + 2;
+    if (dist2(qx - p1.x, qy - p1.y, qz - p1.z) == best) bi = grp + 1;
+    if (dist2(qx - p0.x, qy - p0.y, qz - p0.z) == best) bi = grp;
+  }
+  return bi;
 }
 
 __global__ __launch_bounds__(256) void k_knn_tile(KnnArgs a) {
   __shared__ TileLds lds_all[4];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   TileLds& lds = lds_all[w];
-  const int j = blockIdx.x * 256 + threadIdx.x;
-  const bool act = j < a.nq;
-  const GridDev& g = a.g;
 #ifdef LSGPU_KNN_STATS
   const long long t_begin = clock64();
 #endif
+  // ---- which tile.  Workgroup b runs on XCD b % 8 (observed dispatch order; speed only): give each
+  // XCD a contiguous range of the Morton-ordered tiles so that neighbouring tiles, which read the
+  // same reference chunks and hash entries, share one L2.
+  const uint32_t wpb = blockDim.x >> 6;
+  uint32_t blk = blockIdx.x;
+  if (a.xcd_swizzle) {
+    const uint32_t nb = gridDim.x, q = nb >> 3, r = nb & 7u, x = blk & 7u, i = blk >> 3;
+    blk = (x < r ? x * (q + 1u) : r * (q + 1u) + (x - r) * q) + i;  // bijective for any grid size
+  }
+  const uint32_t tile = blk * wpb + w;
+  if (tile >= (uint32_t)a.ntiles) return;
+  const int j = (int)(tile * 64u) + lane;
+  const bool act = j < a.nq;
+  const GridDev& g = a.g;
   uint32_t n_eval = 0, n_surv = 0, n_grp = 0, lvl_max = 0;
 
   float qx = 0.f, qy = 0.f, qz = 0.f, best = 0.f;
-  int bi = -1;
+  int bi = -1, grp = -1;
   if (act) {
     const float4 r = a.rdq[j];
     const float3 q = xform(a.T, r.x, r.y, r.z);
@@ -244,11 +307,20 @@ __global__ __launch_bounds__(256) void k_knn_tile(KnnArgs a) {
     const float4 p = a.pts[bi];
     best = dist2(qx - p.x, qy - p.y, qz - p.z);
   }
+#ifdef LSGPU_KNN_STATS
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  const long long t_loaded = clock64();
+  long long t_red = t_loaded, t_look = t_loaded;
+#endif
   // only neighbours closer than min(best, cap2) can matter
   const float R = sqrtf(fminf(best, a.cap2)) * (1.0f + 1e-5f) + 1e-7f;
   const bool straggler = act && !(R <= a.r_cap);
   const bool ing = act && !straggler;
+#ifdef LSGPU_KNN_STATS
+  if (__ballot(ing) && !(a.dbg_flags & 4)) {
+#else
   if (__ballot(ing)) {
+#endif
     // query box, largest ball, largest bound of the wave
     const float tlx = wave_min(ing ? qx : INFINITY), thx = wave_max(ing ? qx : -INFINITY);
     const float tly = wave_min(ing ? qy : INFINITY), thy = wave_max(ing ? qy : -INFINITY);
@@ -264,6 +336,9 @@ __global__ __launch_bounds__(256) void k_knn_tile(KnnArgs a) {
     const int fhx = __builtin_amdgcn_readfirstlane(fine_coord(thx + pad, g.ox, g.inv_hf, lim));
     const int fhy = __builtin_amdgcn_readfirstlane(fine_coord(thy + pad, g.oy, g.inv_hf, lim));
     const int fhz = __builtin_amdgcn_readfirstlane(fine_coord(thz + pad, g.oz, g.inv_hf, lim));
+#ifdef LSGPU_KNN_STATS
+    t_red = clock64();
+#endif
     int l = 0, sh = g.fine;
     for (; l < g.bits; ++l, ++sh)
       if ((fhx >> sh) - (flx >> sh) < 4 && (fhy >> sh) - (fly >> sh) < 4 && (fhz >> sh) - (flz >> sh) < 4)
@@ -281,15 +356,25 @@ __global__ __launch_bounds__(256) void k_knn_tile(KnnArgs a) {
         }
       }
     }
+#ifdef LSGPU_KNN_STATS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    t_look = clock64();
+#endif
     // A wave whose queries are spread far wider than their balls (sparse far field, Morton jumps)
     // shares no candidates: its lanes search on their own.
     const float ext = fmaxf(fmaxf(thx - tlx, thy - tly), thz - tlz);
     const bool spread = ext > fmaxf(a.group_r, 4.f * Rmax) && wave_sum_u32(ce - cs) > kChunkBudget;
+#ifdef LSGPU_KNN_STATS
+    if (spread && (a.dbg_flags & 32)) { /* ablation: drop spread waves */ } else
+#endif
     if (spread) {
-      if (ing) lane_ball_search(a, qx, qy, qz, best, bi);
+      if (ing) lane_ball_search(a, qx, qy, qz, best, bi);  // tracks the exact index itself
       n_grp = 64;
     } else {
       n_grp = 1; lvl_max = l;
+#ifdef LSGPU_KNN_STATS
+      if (a.dbg_flags & 64) return;
+#endif
       // ---- flatten the cells' chunk ranges into the LDS list, 64 at a time into the cull
       unsigned long long cells = __ballot(ce > cs);
       uint32_t fill = 0;
@@ -305,7 +390,7 @@ __global__ __launch_bounds__(256) void k_knn_tile(KnnArgs a) {
             fill -= 64u;
             const uint32_t ch = lds.list[fill + lane];
             tile_process_batch(a, lds, lane, true, ch, ing, qx, qy, qz, tlx, tly, tlz, thx, thy, thz,
-                               maxbest, best, bi, n_eval, n_surv);
+                               maxbest, best, grp, n_eval, n_surv);
           }
         }
       }
@@ -313,11 +398,15 @@ __global__ __launch_bounds__(256) void k_knn_tile(KnnArgs a) {
         const bool v = (uint32_t)lane < fill;
         const uint32_t ch = v ? lds.list[lane] : 0u;
         tile_process_batch(a, lds, lane, v, ch, ing, qx, qy, qz, tlx, tly, tlz, thx, thy, thz,
-                           maxbest, best, bi, n_eval, n_surv);
+                           maxbest, best, grp, n_eval, n_surv);
       }
     }
   }
+#ifdef LSGPU_KNN_STATS
+  if (a.dbg_flags & (64 | 128 | 256)) return;
+#endif
   if (act) {
+    bi = tile_resolve_index(a, grp, qx, qy, qz, best, bi);
     a.ids[j] = bi;
     a.d2[j] = best;
     a.prev[j] = bi;
@@ -325,11 +414,13 @@ __global__ __launch_bounds__(256) void k_knn_tile(KnnArgs a) {
   }
 #ifdef LSGPU_KNN_STATS
   if (lane == 0 && a.dbg) {
+    atomicAdd(&a.dbg[1], (unsigned long long)(t_loaded - t_begin)); atomicAdd(&a.dbg[2], (unsigned long long)(t_red - t_loaded));
+    atomicAdd(&a.dbg[5], (unsigned long long)(t_look - t_red)); atomicAdd(&a.dbg[6], (unsigned long long)(clock64() - t_look));
     atomicAdd(&a.dbg[0], (unsigned long long)n_grp); atomicAdd(&a.dbg[3], (unsigned long long)n_surv);
     atomicAdd(&a.dbg[4], (unsigned long long)n_eval);
   }
   if (lane == 0 && a.dbg_wave)
-    a.dbg_wave[blockIdx.x * 4 + w] = make_uint4((uint32_t)(clock64() - t_begin), n_eval, n_surv, (n_grp << 8) | lvl_max);
+    a.dbg_wave[tile] = make_uint4((uint32_t)(clock64() - t_begin), n_eval, n_surv, (n_grp << 8) | lvl_max);
 #else
   (void)n_grp; (void)lvl_max;
 #endif

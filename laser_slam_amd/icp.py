@@ -87,9 +87,9 @@ class IcpHandle:
             _raise(rc, "lsgpu_icp_create (is a ROCm GPU visible?)")
 
     def close(self):
-        if getattr(self, "_h", None):
-            _lib.lib().lsgpu_icp_destroy(self._h)
-            self._h = None
+        if getattr(self, "_h", None) and _lib is not None and _lib._lib is not None:
+            _lib._lib.lsgpu_icp_destroy(self._h)  # (module globals may be gone at interpreter exit)
+        self._h = None
 
     __del__ = close
 
