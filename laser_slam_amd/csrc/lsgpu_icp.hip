@@ -102,7 +102,7 @@ struct lsgpu_icp {
   uint32_t nchunks = 0;
   DevBuf<uint4> knn_dbg_wave;
   DevBuf<unsigned long long> knn_dbg;  // LSGPU_KNN_STATS builds: 8 counters
-  DevBuf<int> prev;          // warm start of every query (sorted-reference index)
+  DevBuf<float4> prev;       // warm start of every query: its current match {xyz, sorted index}
   DevBuf<RefStats> stat_partials;
   DevBuf<uint32_t> counters;  // [0..16] cell counts, [32] straggler count
 
@@ -125,7 +125,7 @@ struct lsgpu_icp {
   std::vector<lsgpu_iter_trace> trace;
 };
 
-static constexpr int kNeBlocks = 1024;
+static constexpr int kNeBlocks = 512;
 static constexpr int kStatBlocks = 512;
 static constexpr int kHistBlocks = 256;
 static constexpr int kFallbackBlocks = 2048;
@@ -293,7 +293,7 @@ static int run_knn(lsgpu_icp* h, const Mat34& T, bool seed, bool timed, float ca
   const int nq = (int)h->nq;
   KnnArgs a = knn_args(h, T);
   a.cap2 = cap2;
-  HIPC(hipMemsetAsync(a.strag_count, 0, sizeof(uint32_t), h->stream));
+  if (seed) HIPC(hipMemsetAsync(a.strag_count, 0, sizeof(uint32_t), h->stream));  // later launches: re-armed by k_normal_eq_loop
   if (seed) hipLaunchKernelGGL(k_knn_seed, dim3(nblk(nq)), dim3(256), 0, h->stream, a);
   lsgpu_icp::KnnEv* ev = nullptr;
   if (timed) {
@@ -317,7 +317,9 @@ static int run_knn(lsgpu_icp* h, const Mat34& T, bool seed, bool timed, float ca
     const int waves_per_block = tile_threads / 64;
     hipLaunchKernelGGL(k_knn_tile, dim3((a.ntiles + waves_per_block - 1) / waves_per_block), dim3(tile_threads), extra_lds, h->stream, a);
     if (timed) HIPC(hipEventRecord(ev->b, h->stream));
-    hipLaunchKernelGGL(k_knn_fallback, dim3(kFallbackBlocks), dim3(256), 0, h->stream, a);
+    // stragglers exist only where a ball may exceed r_cap: never under a cap below r_cap^2
+    if (!(cap2 <= a.r_cap * a.r_cap))
+      hipLaunchKernelGGL(k_knn_fallback, dim3(kFallbackBlocks), dim3(256), 0, h->stream, a);
     if (timed) HIPC(hipEventRecord(ev->c, h->stream));
   }
   HIPC(hipGetLastError());
@@ -325,11 +327,13 @@ static int run_knn(lsgpu_icp* h, const Mat34& T, bool seed, bool timed, float ca
 }
 
 // TrimmedDist order statistic of d2[0..n) -> rank k; leaves hist3 + sel[2] for select_limit().
-static int run_select(lsgpu_icp* h, const float* d2, int n, uint32_t k) {
-  HIPC(hipMemsetAsync(h->hist.p, 0, 3 * kHistBins * sizeof(uint32_t), h->stream));
-  SelState s0{0u, k};
-  std::memcpy(h->h_pinned + 48, &s0, sizeof(s0));
-  HIPC(hipMemcpyAsync(h->sel.p, h->h_pinned + 48, sizeof(SelState), hipMemcpyHostToDevice, h->stream));
+static int run_select(lsgpu_icp* h, const float* d2, int n, uint32_t k, bool zero_hist = true) {
+  if (zero_hist) HIPC(hipMemsetAsync(h->hist.p, 0, 3 * kHistBins * sizeof(uint32_t), h->stream));
+  if (zero_hist) {  // sel[0] = {0, k}: constant during an align, uploaded once
+    SelState s0{0u, k};
+    std::memcpy(h->h_pinned + 48, &s0, sizeof(s0));
+    HIPC(hipMemcpyAsync(h->sel.p, h->h_pinned + 48, sizeof(SelState), hipMemcpyHostToDevice, h->stream));
+  }
   const int nb = std::min(kHistBlocks, nblk(n));
   hipLaunchKernelGGL(k_hist1, dim3(nb), dim3(256), 0, h->stream, d2, n, h->hist.p);
   hipLaunchKernelGGL(k_hist_refine<2>, dim3(nb), dim3(256), 0, h->stream, d2, n, h->hist.p,
@@ -631,6 +635,8 @@ int lsgpu_icp_align(lsgpu_icp* h, const float* reading_xyz1, int64_t nq, const f
   int it = 0;
   rc = LSGPU_OK;
   float prev_limit = INFINITY;  // trim limit of the previous iteration (squared distance)
+  bool first_select = true;
+  HIPC(hipMemsetAsync(h->counters.p + 32, 0, 2 * sizeof(uint32_t), h->stream));  // stragglers, NE ticket
   std::vector<size_t> ev_of_iter;
   while (iterate) {
     const Mat34 Tm = to_mat34(T_iter);
@@ -641,28 +647,23 @@ int lsgpu_icp_align(lsgpu_icp* h, const float* reading_xyz1, int64_t nq, const f
     for (int attempt = 0; attempt < 2; ++attempt) {
       rc = run_knn(h, Tm, it == 0 && attempt == 0, h->cfg.profile_kernels != 0, cap2);            // 6a+6b
       if (rc) return rc;
-      rc = run_select(h, h->d2.p, (int)nq, k);                                          // 6c
+      rc = run_select(h, h->d2.p, (int)nq, k, first_select);                            // 6c
+      first_select = false;
       if (rc) return rc;
-      hipLaunchKernelGGL((k_normal_eq<false, true>), dim3(nb), dim3(256), 0, h->stream, h->rdq.p,
-                         (int)nq, Tm, h->ids.p, h->d2.p, h->pts.p, h->nrm.p, h->ref_inv.p,
-                         h->hist.p + 2 * kHistBins, h->sel.p + 2, 0.f, h->limit_dev.p,
-                         h->ne_partials.p);                                             // 6d
-      hipLaunchKernelGGL(k_ne_final, dim3(1), dim3(1024), 0, h->stream, h->ne_partials.p, nb, h->ne_out.p);
+      hipLaunchKernelGGL(k_normal_eq_loop, dim3(nb), dim3(256), 0, h->stream, h->rdq.p, (int)nq, Tm,
+                         h->prev.p, h->d2.p, h->nrm.p, h->hist.p, h->sel.p + 2, h->counters.p + 32,
+                         h->counters.p + 33, h->ne_partials.p, h->ne_out.p);             // 6d
       HIPC(hipGetLastError());
-      HIPC(hipMemcpyAsync(h->h_pinned, h->ne_out.p, kNe * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-      HIPC(hipMemcpyAsync(h->h_pinned + 32, h->limit_dev.p, sizeof(float), hipMemcpyDeviceToHost, h->stream));
-      HIPC(hipMemcpyAsync(h->h_pinned + 33, h->counters.p + 32, sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
+      HIPC(hipMemcpyAsync(h->h_pinned, h->ne_out.p, 32 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
       HIPC(hipStreamSynchronize(h->stream));
-      float lim_chk;
-      std::memcpy(&lim_chk, h->h_pinned + 32, sizeof(float));
+      const float lim_chk = (float)h->h_pinned[29];
       if (cap2 == INFINITY || lim_chk <= cap2) break;  // the order statistic lies among exact values
       cap2 = INFINITY;
       st.cap_retries++;
     }
     ev_of_iter.push_back(h->knn_events_used ? h->knn_events_used - 1 : 0);
-    float limit; uint32_t nstrag;
-    std::memcpy(&limit, h->h_pinned + 32, sizeof(float));
-    std::memcpy(&nstrag, h->h_pinned + 33, sizeof(uint32_t));
+    const float limit = (float)h->h_pinned[29];
+    const uint32_t nstrag = (uint32_t)h->h_pinned[30];
     st.stragglers += nstrag;
     const double* ne = h->h_pinned;
     const int64_t used = (int64_t)ne[27];

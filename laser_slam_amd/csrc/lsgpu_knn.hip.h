@@ -38,7 +38,7 @@ struct KnnArgs {
   const ChunkDesc* chunks;
   int* ids;                 // out: sorted-reference index of the NN
   float* d2;                // out: squared distance
-  int* prev;                // in/out: warm start (sorted-reference index)
+  float4* prev;             // in/out: warm start = the query's current match {x,y,z, sorted index bits}
   uint32_t* strag;          // out: straggler list
   uint32_t* strag_count;
   float r_cap;              // lanes with a larger ball go to the fallback
@@ -79,6 +79,7 @@ __global__ __launch_bounds__(256) void k_knn_seed(KnnArgs a) {
   const int fy = fine_coord(q.y, g.oy, g.inv_hf, lim);
   const int fz = fine_coord(q.z, g.oz, g.inv_hf, lim);
   int bi = 0;
+  float4 bp = a.pts[0];
   for (int l = 0; l <= g.bits; ++l) {
     const int sh = g.fine + l;
     uint32_t cs, ce;
@@ -90,11 +91,11 @@ __global__ __launch_bounds__(256) void k_knn_seed(KnnArgs a) {
     for (uint32_t t = 0; t < n; ++t) {
       const float4 p = a.pts[d.start + t];
       const float dd = dist2(q.x - p.x, q.y - p.y, q.z - p.z);
-      if (dd < best) { best = dd; bi = (int)(d.start + t); }
+      if (dd < best) { best = dd; bi = (int)(d.start + t); bp = p; }
     }
     break;
   }
-  a.prev[j] = bi;
+  a.prev[j] = make_float4(bp.x, bp.y, bp.z, __int_as_float(bi));
 }
 
 // ---------------------------------------------------------------- per-lane ball search
@@ -262,16 +263,16 @@ __device__ __forceinline__ void tile_process_batch(const KnnArgs& a, TileLds& ld
 
 // Which point of the recorded group of 4 is at distance `best` (first one; pts is padded, and a point
 // of the following chunk at exactly the same distance would be an equally valid nearest neighbour).
-__device__ __forceinline__ int tile_resolve_index(const KnnArgs& a, int grp, float qx, float qy, float qz,
-                                                  float best, int bi) {
+__device__ __forceinline__ float4 tile_resolve_match(const KnnArgs& a, int grp, float qx, float qy, float qz,
+                                                     float best, float4 mp) {
   if (grp >= 0) {
     const float4 p0 = a.pts[grp], p1 = a.pts[grp + 1], p2 = a.pts[grp + 2], p3 = a.pts[grp + 3];
-    if (dist2(qx - p3.x, qy - p3.y, qz - p3.z) == best) bi = grp + 3;
-    if (dist2(qx - p2.x, qy - p2.y, qz - p2.z) == best) bi = grp + 2;
-    if (dist2(qx - p1.x, qy - p1.y, qz - p1.z) == best) bi = grp + 1;
-    if (dist2(qx - p0.x, qy - p0.y, qz - p0.z) == best) bi = grp;
+    if (dist2(qx - p3.x, qy - p3.y, qz - p3.z) == best) mp = make_float4(p3.x, p3.y, p3.z, __int_as_float(grp + 3));
+    if (dist2(qx - p2.x, qy - p2.y, qz - p2.z) == best) mp = make_float4(p2.x, p2.y, p2.z, __int_as_float(grp + 2));
+    if (dist2(qx - p1.x, qy - p1.y, qz - p1.z) == best) mp = make_float4(p1.x, p1.y, p1.z, __int_as_float(grp + 1));
+    if (dist2(qx - p0.x, qy - p0.y, qz - p0.z) == best) mp = make_float4(p0.x, p0.y, p0.z, __int_as_float(grp));
   }
-  return bi;
+  return mp;
 }
 
 __global__ __launch_bounds__(256) void k_knn_tile(KnnArgs a) {
@@ -299,13 +300,14 @@ __global__ __launch_bounds__(256) void k_knn_tile(KnnArgs a) {
 
   float qx = 0.f, qy = 0.f, qz = 0.f, best = 0.f;
   int bi = -1, grp = -1;
+  float4 mp = make_float4(0.f, 0.f, 0.f, 0.f);  // the current match (point + index)
   if (act) {
     const float4 r = a.rdq[j];
     const float3 q = xform(a.T, r.x, r.y, r.z);
     qx = q.x; qy = q.y; qz = q.z;
-    bi = a.prev[j];
-    const float4 p = a.pts[bi];
-    best = dist2(qx - p.x, qy - p.y, qz - p.z);
+    mp = a.prev[j];  // coalesced: no dependent gather of pts[prev]
+    bi = __float_as_int(mp.w);
+    best = dist2(qx - mp.x, qy - mp.y, qz - mp.z);
   }
 #ifdef LSGPU_KNN_STATS
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -368,7 +370,11 @@ __global__ __launch_bounds__(256) void k_knn_tile(KnnArgs a) {
     if (spread && (a.dbg_flags & 32)) { /* ablation: drop spread waves */ } else
 #endif
     if (spread) {
-      if (ing) lane_ball_search(a, qx, qy, qz, best, bi);  // tracks the exact index itself
+      if (ing) {  // tracks the exact index itself
+        const int before = bi;
+        lane_ball_search(a, qx, qy, qz, best, bi);
+        if (bi != before) { const float4 p = a.pts[bi]; mp = make_float4(p.x, p.y, p.z, __int_as_float(bi)); }
+      }
       n_grp = 64;
     } else {
       n_grp = 1; lvl_max = l;
@@ -406,10 +412,10 @@ __global__ __launch_bounds__(256) void k_knn_tile(KnnArgs a) {
   if (a.dbg_flags & (64 | 128 | 256)) return;
 #endif
   if (act) {
-    bi = tile_resolve_index(a, grp, qx, qy, qz, best, bi);
-    a.ids[j] = bi;
+    mp = tile_resolve_match(a, grp, qx, qy, qz, best, mp);
+    a.ids[j] = __float_as_int(mp.w);
     a.d2[j] = best;
-    a.prev[j] = bi;
+    a.prev[j] = mp;
     if (straggler) a.strag[atomicAdd(a.strag_count, 1u)] = (uint32_t)j;
   }
 #ifdef LSGPU_KNN_STATS
@@ -432,13 +438,15 @@ __global__ __launch_bounds__(256) void k_knn_lane(KnnArgs a) {
   if (j >= a.nq) return;
   const float4 r = a.rdq[j];
   const float3 q = xform(a.T, r.x, r.y, r.z);
-  int bi = a.prev[j];
-  const float4 p = a.pts[bi];
-  float best = dist2(q.x - p.x, q.y - p.y, q.z - p.z);
+  float4 mp = a.prev[j];
+  int bi = __float_as_int(mp.w);
+  const int before = bi;
+  float best = dist2(q.x - mp.x, q.y - mp.y, q.z - mp.z);
   lane_ball_search(a, q.x, q.y, q.z, best, bi);
+  if (bi != before) { const float4 p = a.pts[bi]; mp = make_float4(p.x, p.y, p.z, __int_as_float(bi)); }
   a.ids[j] = bi;
   a.d2[j] = best;
-  a.prev[j] = bi;
+  a.prev[j] = mp;
 }
 
 // ---------------------------------------------------------------- exact fallback, one wave per query
@@ -513,9 +521,10 @@ __global__ __launch_bounds__(256) void k_knn_fallback(KnnArgs a) {
     bestp = wave_min_u64(bestp);
     if (lane == 0) {
       const int id = (int)(uint32_t)(bestp & 0xFFFFFFFFull);
+      const float4 p = a.pts[id];
       a.ids[j] = id;
       a.d2[j] = __uint_as_float((uint32_t)(bestp >> 32));
-      a.prev[j] = id;
+      a.prev[j] = make_float4(p.x, p.y, p.z, __int_as_float(id));
     }
   }
 }

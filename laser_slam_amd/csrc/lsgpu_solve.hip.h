@@ -168,6 +168,111 @@ __global__ __launch_bounds__(256) void k_normal_eq(const float4* __restrict__ rd
         ((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x];
 }
 
+// The align loop's variant: the matched point comes coalesced from the warm-start array (xyz + sorted
+// index of every query's neighbour, written by the kNN kernels), only the normal is gathered.  The
+// LAST block to finish (agent-scope release / ticket / acquire, cdna guide G16) reduces the block
+// partials in a fixed order, publishes {29 sums, limit, straggler count} and re-arms the per-iteration
+// scratch (histograms, straggler counter, ticket) so the next iteration needs no memset launches.
+__global__ __launch_bounds__(256) void k_normal_eq_loop(const float4* __restrict__ rdq, int nq, Mat34 T,
+                                                        const float4* __restrict__ match,
+                                                        const float* __restrict__ d2,
+                                                        const float4* __restrict__ nrm,
+                                                        uint32_t* __restrict__ hist,  // 3 x kHistBins
+                                                        const SelState* __restrict__ st,
+                                                        uint32_t* __restrict__ strag_count,
+                                                        uint32_t* __restrict__ ticket,
+                                                        double* __restrict__ partials,
+                                                        double* __restrict__ out /* 32 doubles */) {
+  __shared__ uint32_t sc[260];
+  __shared__ double red[8][33];
+  __shared__ int is_last;
+  const float limit = select_limit(hist + 2 * kHistBins, st, sc);
+  double acc[kNe];
+#pragma unroll
+  for (int k = 0; k < kNe; ++k) acc[k] = 0.0;
+  for (int j = blockIdx.x * 256 + threadIdx.x; j < nq; j += gridDim.x * 256) {
+    const float d = d2[j];
+    if (!(d <= limit)) continue;
+    const float4 q = match[j];
+    const int id = __float_as_int(q.w);
+    if (id < 0) continue;
+    const float4 r = rdq[j];
+    const float3 p = xform(T, r.x, r.y, r.z);
+    const float4 n = nrm[id];
+    float J[6];
+    J[0] = p.y * n.z - p.z * n.y;
+    J[1] = p.z * n.x - p.x * n.z;
+    J[2] = p.x * n.y - p.y * n.x;
+    J[3] = n.x; J[4] = n.y; J[5] = n.z;
+    const float res = (p.x - q.x) * n.x + (p.y - q.y) * n.y + (p.z - q.z) * n.z;
+    int k = 0;
+#pragma unroll
+    for (int a = 0; a < 6; ++a) {
+#pragma unroll
+      for (int c = a; c < 6; ++c) acc[k++] += (double)J[a] * (double)J[c];
+    }
+#pragma unroll
+    for (int a = 0; a < 6; ++a) acc[21 + a] -= (double)J[a] * (double)res;
+    acc[27] += 1.0;
+    acc[28] += (double)res * (double)res;
+  }
+#pragma unroll
+  for (int k = 0; k < kNe; ++k) acc[k] = wave_sum(acc[k]);
+  const int w = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+    for (int k = 0; k < kNe; ++k) red[w][k] = acc[k];
+  }
+  __syncthreads();
+  if (threadIdx.x < kNe)
+    partials[(size_t)blockIdx.x * 32 + threadIdx.x] =
+        ((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x];
+  // ---- publish, take a ticket
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const uint32_t t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    is_last = (t == gridDim.x - 1);
+  }
+  __syncthreads();
+  if (!is_last) return;
+  if (threadIdx.x == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  __syncthreads();
+  // ---- fixed-order final reduction: 8 groups of 32 columns, group r sums rows r, r+8, ...
+  {
+    const int col = threadIdx.x & 31, grp = threadIdx.x >> 5;
+    double s = 0.0;
+    if (col < kNe) {
+      const int nb = (int)gridDim.x;
+      int b = grp;
+      for (; b + 56 < nb; b += 64) {  // 8 independent loads in flight, summed in row order
+        const double v0 = partials[(size_t)b * 32 + col], v1 = partials[(size_t)(b + 8) * 32 + col];
+        const double v2 = partials[(size_t)(b + 16) * 32 + col], v3 = partials[(size_t)(b + 24) * 32 + col];
+        const double v4 = partials[(size_t)(b + 32) * 32 + col], v5 = partials[(size_t)(b + 40) * 32 + col];
+        const double v6 = partials[(size_t)(b + 48) * 32 + col], v7 = partials[(size_t)(b + 56) * 32 + col];
+        s = ((((((((s + v0) + v1) + v2) + v3) + v4) + v5) + v6) + v7);
+      }
+      for (; b < nb; b += 8) s += partials[(size_t)b * 32 + col];
+    }
+    red[grp][col] = s;
+  }
+  __syncthreads();
+  if (threadIdx.x < kNe) {
+    double t = 0.0;
+    for (int r = 0; r < 8; ++r) t += red[r][threadIdx.x];
+    out[threadIdx.x] = t;
+  }
+  if (threadIdx.x == 32) {
+    out[29] = (double)limit;
+    out[30] = (double)__hip_atomic_load(strag_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(strag_count, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  for (int i = threadIdx.x; i < 3 * kHistBins; i += 256) hist[i] = 0u;  // every block has read hist3 by now
+}
+
 // 1024 threads = 32 groups of 32: group r sums rows r, r+32, ... of its column, then the 32 group
 // sums are added in fixed order => deterministic, and ~30x faster than one thread per column.
 __global__ __launch_bounds__(1024) void k_ne_final(const double* __restrict__ partials, int nblocks,
