@@ -64,6 +64,39 @@ struct Mat34 {  // rows of a rigid transform
   float m[12];  // m[r*4+c]
 };
 
+// Loop state of one align, resident in HBM: written by k_icp_update (one wave per iteration), read by
+// every kernel of the following iteration, so that iterations are enqueued back to back with no
+// host round trip.  done != 0 turns every later launch into an immediate exit.
+struct IcpState {
+  float T_iter[16];   // column major (PointMatcher TransformationParameters)
+  float T_rows[12];   // the same transform as Mat34 rows (what the kernels load)
+  float prev_limit;   // trim limit of the last completed iteration
+  float cap2;         // search cap of the next capped kNN launch (INF: none)
+  int iter;           // completed iterations
+  int done;
+  int status;         // 0 ok; 1 no convergence; 100 = cap prediction failed, host repeats uncapped
+  int err_code;       // 1 no point to minimize, 2 normal matrix not positive definite, 3 NaN in checker
+  int converged;      // stopped by the differential checker
+  int counter, n_hist;  // checker state
+  int cap_enabled;
+  int max_iter, smooth;
+  float lim_rot, lim_trans;
+  unsigned long long stragglers;
+};
+constexpr int kStatusCapFailed = 100;
+
+// T and cap of this launch: from the kernel arguments, or from the loop state.  false => exit now.
+__device__ __forceinline__ bool iter_params(const IcpState* __restrict__ st, const Mat34& T_arg,
+                                            float cap2_arg, int use_state_cap, Mat34& T, float& cap2) {
+  T = T_arg; cap2 = cap2_arg;
+  if (!st) return true;
+  if (st->done) return false;
+#pragma unroll
+  for (int i = 0; i < 12; ++i) T.m[i] = st->T_rows[i];
+  if (use_state_cap) cap2 = st->cap2;
+  return true;
+}
+
 __device__ __forceinline__ float3 xform(const Mat34& T, float x, float y, float z) {
   float3 o;
   o.x = __fmaf_rn(T.m[2], z, __fmaf_rn(T.m[1], y, __fmaf_rn(T.m[0], x, T.m[3])));

@@ -102,6 +102,9 @@ struct lsgpu_icp {
   uint32_t nchunks = 0;
   DevBuf<uint4> knn_dbg_wave;
   DevBuf<unsigned long long> knn_dbg;  // LSGPU_KNN_STATS builds: 8 counters
+  DevBuf<IcpState> state;    // loop state of the running align (device)
+  DevBuf<float> chk_hist;    // checker history: 8 floats x (max_iterations + 2)
+  DevBuf<lsgpu_iter_trace> trace_dev;
   DevBuf<float4> prev;       // warm start of every query: its current match {xyz, sorted index}
   DevBuf<RefStats> stat_partials;
   DevBuf<uint32_t> counters;  // [0..16] cell counts, [32] straggler count
@@ -184,7 +187,7 @@ int lsgpu_icp_create(const lsgpu_icp_config* cfg, int device, lsgpu_icp** out) {
   std::memset(&h->grid, 0, sizeof(h->grid));
   if (hipSetDevice(device) != hipSuccess ||
       hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess ||
-      hipHostMalloc((void**)&h->h_pinned, 64 * sizeof(double), hipHostMallocDefault) != hipSuccess ||
+      hipHostMalloc((void**)&h->h_pinned, 128 * sizeof(double), hipHostMallocDefault) != hipSuccess ||
       hipEventCreate(&h->ev0) != hipSuccess || hipEventCreate(&h->ev1) != hipSuccess) {
     (void)hipGetLastError();
     delete h;
@@ -200,7 +203,7 @@ void lsgpu_icp_destroy(lsgpu_icp* h) {
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   h->ref_in.release(); h->nrm_in.release(); h->keys.release(); h->keys_alt.release();
   h->vals.release(); h->vals_alt.release(); h->sort_tmp.release(); h->pts.release();
-  h->nrm.release(); h->ref_inv.release(); h->tables.release(); h->flags.release(); h->cidx.release(); h->bounds.release(); h->chunks.release(); h->prev.release(); h->knn_dbg.release(); h->knn_dbg_wave.release(); h->stat_partials.release();
+  h->nrm.release(); h->ref_inv.release(); h->tables.release(); h->flags.release(); h->cidx.release(); h->bounds.release(); h->chunks.release(); h->prev.release(); h->state.release(); h->chk_hist.release(); h->trace_dev.release(); h->knn_dbg.release(); h->knn_dbg_wave.release(); h->stat_partials.release();
   h->counters.release(); h->q_in.release(); h->rdq.release(); h->ids.release(); h->d2.release();
   h->ids_io.release(); h->d2_io.release(); h->strag.release(); h->hist.release();
   h->sel.release(); h->ne_partials.release(); h->ne_out.release(); h->limit_dev.release();
@@ -276,7 +279,7 @@ static KnnArgs knn_args(lsgpu_icp* h, const Mat34& T) {
   a.rdq = h->rdq.p; a.nq = (int)h->nq; a.T = T; a.g = h->grid; a.pts = h->pts.p;
   a.chunks = h->chunks.p; a.ids = h->ids.p; a.d2 = h->d2.p; a.prev = h->prev.p;
   a.strag = h->strag.p; a.strag_count = h->counters.p + 32;
-  a.r_cap = 1.0f; a.group_r = 0.75f; a.cap2 = INFINITY;
+  a.r_cap = 1.0f; a.group_r = 0.75f; a.cap2 = INFINITY; a.st = nullptr; a.use_state_cap = 0;
   a.ntiles = (int)((h->nq + 63) / 64); a.xcd_swizzle = 0;
   a.dbg = h->knn_dbg.p;
   a.dbg_wave = h->knn_dbg_wave.p;
@@ -287,13 +290,18 @@ static KnnArgs knn_args(lsgpu_icp* h, const Mat34& T) {
 
 // findClosests for the queries in h->rdq moved by T: fills h->ids (sorted-reference index), h->d2.
 // seed: the queries have no warm start yet (first iteration of an align, or the kernel-level API).
-// cap2 < INF: lane-per-query search, exact only for neighbours with d2 <= cap2 (see lsgpu_knn.hip.h);
-// the caller verifies limit <= cap2 afterwards.
-static int run_knn(lsgpu_icp* h, const Mat34& T, bool seed, bool timed, float cap2 = INFINITY) {
+// findClosests for the queries in h->rdq: fills h->ids (sorted-reference index), h->d2, h->prev.
+//   T / st   : the transform comes from the argument (kernel-level API) or from the loop state
+//   seed     : the queries have no warm start yet (first iteration, kernel-level API)
+//   capped   : search cap from the loop state (exact below cap, see lsgpu_knn.hip.h); otherwise uncapped,
+//              followed by the straggler fallback
+static int run_knn(lsgpu_icp* h, const Mat34& T, const IcpState* st, bool seed, bool capped, bool timed) {
   const int nq = (int)h->nq;
   KnnArgs a = knn_args(h, T);
-  a.cap2 = cap2;
-  if (seed) HIPC(hipMemsetAsync(a.strag_count, 0, sizeof(uint32_t), h->stream));  // later launches: re-armed by k_normal_eq_loop
+  a.st = st;
+  a.use_state_cap = capped ? 1 : 0;
+  if (capped) a.r_cap = INFINITY;  // no fallback pass follows a capped launch: the tile kernel takes every lane
+  if (seed) HIPC(hipMemsetAsync(a.strag_count, 0, sizeof(uint32_t), h->stream));  // later: re-armed by k_normal_eq_loop
   if (seed) hipLaunchKernelGGL(k_knn_seed, dim3(nblk(nq)), dim3(256), 0, h->stream, a);
   lsgpu_icp::KnnEv* ev = nullptr;
   if (timed) {
@@ -306,20 +314,18 @@ static int run_knn(lsgpu_icp* h, const Mat34& T, bool seed, bool timed, float ca
     HIPC(hipEventRecord(ev->a, h->stream));
   }
   static const bool lane_mode = getenv("LSGPU_KNN_LANE") != nullptr;  // experiment switch
-  if (cap2 < INFINITY && lane_mode) {
+  if (capped && lane_mode) {
     hipLaunchKernelGGL(k_knn_lane, dim3(nblk(nq)), dim3(256), 0, h->stream, a);
     if (timed) { HIPC(hipEventRecord(ev->b, h->stream)); HIPC(hipEventRecord(ev->c, h->stream)); }
   } else {
     static const int tile_threads = getenv("LSGPU_TILE_THREADS") ? atoi(getenv("LSGPU_TILE_THREADS")) : 64;
     static const int swz = getenv("LSGPU_XCD_SWIZZLE") ? atoi(getenv("LSGPU_XCD_SWIZZLE")) : 0;
-    static const int extra_lds = getenv("LSGPU_TILE_LDS") ? atoi(getenv("LSGPU_TILE_LDS")) : 0;  // experiment: occupancy throttle
     a.xcd_swizzle = swz;
     const int waves_per_block = tile_threads / 64;
-    hipLaunchKernelGGL(k_knn_tile, dim3((a.ntiles + waves_per_block - 1) / waves_per_block), dim3(tile_threads), extra_lds, h->stream, a);
+    hipLaunchKernelGGL(k_knn_tile, dim3((a.ntiles + waves_per_block - 1) / waves_per_block), dim3(tile_threads), 0, h->stream, a);
     if (timed) HIPC(hipEventRecord(ev->b, h->stream));
-    // stragglers exist only where a ball may exceed r_cap: never under a cap below r_cap^2
-    if (!(cap2 <= a.r_cap * a.r_cap))
-      hipLaunchKernelGGL(k_knn_fallback, dim3(kFallbackBlocks), dim3(256), 0, h->stream, a);
+    // stragglers (balls > r_cap) only exist in uncapped launches
+    if (!capped) hipLaunchKernelGGL(k_knn_fallback, dim3(kFallbackBlocks), dim3(256), 0, h->stream, a);
     if (timed) HIPC(hipEventRecord(ev->c, h->stream));
   }
   HIPC(hipGetLastError());
@@ -327,7 +333,8 @@ static int run_knn(lsgpu_icp* h, const Mat34& T, bool seed, bool timed, float ca
 }
 
 // TrimmedDist order statistic of d2[0..n) -> rank k; leaves hist3 + sel[2] for select_limit().
-static int run_select(lsgpu_icp* h, const float* d2, int n, uint32_t k, bool zero_hist = true) {
+static int run_select(lsgpu_icp* h, const float* d2, int n, uint32_t k, bool zero_hist = true,
+                      const IcpState* st = nullptr) {
   if (zero_hist) HIPC(hipMemsetAsync(h->hist.p, 0, 3 * kHistBins * sizeof(uint32_t), h->stream));
   if (zero_hist) {  // sel[0] = {0, k}: constant during an align, uploaded once
     SelState s0{0u, k};
@@ -335,11 +342,11 @@ static int run_select(lsgpu_icp* h, const float* d2, int n, uint32_t k, bool zer
     HIPC(hipMemcpyAsync(h->sel.p, h->h_pinned + 48, sizeof(SelState), hipMemcpyHostToDevice, h->stream));
   }
   const int nb = std::min(kHistBlocks, nblk(n));
-  hipLaunchKernelGGL(k_hist1, dim3(nb), dim3(256), 0, h->stream, d2, n, h->hist.p);
+  hipLaunchKernelGGL(k_hist1, dim3(nb), dim3(256), 0, h->stream, d2, n, h->hist.p, st);
   hipLaunchKernelGGL(k_hist_refine<2>, dim3(nb), dim3(256), 0, h->stream, d2, n, h->hist.p,
-                     h->sel.p, h->sel.p + 1, h->hist.p + kHistBins);
+                     h->sel.p, h->sel.p + 1, h->hist.p + kHistBins, st);
   hipLaunchKernelGGL(k_hist_refine<3>, dim3(nb), dim3(256), 0, h->stream, d2, n,
-                     h->hist.p + kHistBins, h->sel.p + 1, h->sel.p + 2, h->hist.p + 2 * kHistBins);
+                     h->hist.p + kHistBins, h->sel.p + 1, h->sel.p + 2, h->hist.p + 2 * kHistBins, st);
   HIPC(hipGetLastError());
   return LSGPU_OK;
 }
@@ -498,7 +505,7 @@ int lsgpu_knn(lsgpu_icp* h, const float* query_xyz1, int64_t nq, const float T[1
   const Mat34 Id = to_mat34(I);
   int rc = prepare_queries(h, query_xyz1, nq, Id);
   if (rc) return rc;
-  rc = run_knn(h, Tm, true, false);
+  rc = run_knn(h, Tm, nullptr, true, false, false);
   if (rc) return rc;
   const bool dev_out = is_device_ptr(ids);
   int* ids_o = ids; float* d2_o = d2;
@@ -624,70 +631,105 @@ int lsgpu_icp_align(lsgpu_icp* h, const float* reading_xyz1, int64_t nq, const f
   int rc = prepare_queries(h, reading_xyz1, nq, to_mat34(T_rm_in));
   if (rc) return rc;
 
-  // step 6
-  float T_iter[16];
-  hostmath::identity4(T_iter);
-  hostmath::Checkers ck(h->cfg.max_iterations, h->cfg.smooth_length, h->cfg.min_diff_rot,
-                        h->cfg.min_diff_trans, T_iter);
+  // step 6: the loop runs on the device.  Every iteration is {kNN, select x3, normal equations,
+  // update}; k_icp_update solves, moves T_iter, runs the checkers and raises `done`, after which the
+  // remaining enqueued launches exit immediately.  The host only looks at the state every few iterations.
+  const int max_it = h->cfg.max_iterations;
+  HIPC(h->state.reserve(1));
+  HIPC(h->chk_hist.reserve((size_t)8 * (max_it + 2)));
+  HIPC(h->trace_dev.reserve((size_t)max_it));
+  IcpState* hst = reinterpret_cast<IcpState*>(h->h_pinned + 64);  // pinned staging (<= 512 B)
+  static_assert(sizeof(IcpState) <= 64 * sizeof(double), "IcpState staging");
+  std::memset(hst, 0, sizeof(IcpState));
+  hostmath::identity4(hst->T_iter);
+  for (int r = 0; r < 3; ++r)
+    for (int c = 0; c < 4; ++c) hst->T_rows[r * 4 + c] = hst->T_iter[c * 4 + r];
+  hst->prev_limit = INFINITY; hst->cap2 = INFINITY;
+  hst->cap_enabled = h->cfg.reserved[0] == 0 ? 1 : 0;
+  hst->max_iter = max_it; hst->smooth = h->cfg.smooth_length;
+  hst->lim_rot = h->cfg.min_diff_rot; hst->lim_trans = h->cfg.min_diff_trans;
+  {  // checkers.init(T_iter): history starts with the identity
+    float* hh = reinterpret_cast<float*>(h->h_pinned + 48);
+    hostmath::CheckerState cs{0, 0};
+    hostmath::checker_push(&cs, hh, hst->T_iter);
+    hst->counter = cs.counter; hst->n_hist = cs.n_hist;
+    HIPC(hipMemcpyAsync(h->chk_hist.p, hh, 8 * sizeof(float), hipMemcpyHostToDevice, h->stream));
+  }
+  HIPC(hipMemcpyAsync(h->state.p, hst, sizeof(IcpState), hipMemcpyHostToDevice, h->stream));
+  HIPC(hipMemsetAsync(h->counters.p + 32, 0, 2 * sizeof(uint32_t), h->stream));  // stragglers, NE ticket
+  HIPC(hipStreamSynchronize(h->stream));  // the staging area is reused below
+
   const uint32_t k = trim_rank(nq, h->cfg.trim_ratio);
   const int nb = std::min(kNeBlocks, nblk(nq));
-  bool iterate = true, by_diff = false;
-  int it = 0;
-  rc = LSGPU_OK;
-  float prev_limit = INFINITY;  // trim limit of the previous iteration (squared distance)
+  const bool timed = h->cfg.profile_kernels != 0;
+  const Mat34 Tdummy = to_mat34(hst->T_iter);
   bool first_select = true;
-  HIPC(hipMemsetAsync(h->counters.p + 32, 0, 2 * sizeof(uint32_t), h->stream));  // stragglers, NE ticket
-  std::vector<size_t> ev_of_iter;
-  while (iterate) {
-    const Mat34 Tm = to_mat34(T_iter);
-    // Radius cap for this iteration's search: pairs beyond the trim limit get weight 0, and the limit
-    // shrinks as ICP converges, so neighbours are needed exactly only below ~ the previous limit.
-    // Verified below; a violated prediction repeats the search uncapped (exact in every case).
-    float cap2 = (it > 0 && h->cfg.reserved[0] == 0) ? prev_limit * 2.0f : INFINITY;
-    for (int attempt = 0; attempt < 2; ++attempt) {
-      rc = run_knn(h, Tm, it == 0 && attempt == 0, h->cfg.profile_kernels != 0, cap2);            // 6a+6b
+  std::vector<size_t> ev_of_launch;  // event index of every enqueued iteration
+  auto enqueue_iteration = [&](bool seed, bool capped) -> int {
+    int r = run_knn(h, Tdummy, h->state.p, seed, capped, timed);                         // 6a+6b
+    if (r) return r;
+    ev_of_launch.push_back(h->knn_events_used ? h->knn_events_used - 1 : 0);
+    r = run_select(h, h->d2.p, (int)nq, k, first_select, h->state.p);                    // 6c
+    first_select = false;
+    if (r) return r;
+    hipLaunchKernelGGL(k_normal_eq_loop, dim3(nb), dim3(256), 0, h->stream, h->rdq.p, (int)nq,
+                       h->state.p, h->prev.p, h->d2.p, h->nrm.p, h->hist.p, h->sel.p + 2,
+                       h->counters.p + 32, h->counters.p + 33, h->ne_partials.p, h->ne_out.p);  // 6d
+    hipLaunchKernelGGL(k_icp_update, dim3(1), dim3(64), 0, h->stream, h->state.p, h->ne_out.p,
+                       h->chk_hist.p, h->trace_dev.p, max_it, capped ? 1 : 0);             // 6d+6e
+    return hipGetLastError() == hipSuccess ? LSGPU_OK : LSGPU_HIP_ERROR;
+  };
+  auto fetch_state = [&]() -> int {
+    HIPC(hipMemcpyAsync(hst, h->state.p, sizeof(IcpState), hipMemcpyDeviceToHost, h->stream));
+    HIPC(hipStreamSynchronize(h->stream));
+    return LSGPU_OK;
+  };
+
+  rc = enqueue_iteration(true, false);  // iteration 0: seeded, uncapped
+  if (rc) return rc;
+  int enq = 1, since_check = 1;
+  std::vector<std::pair<int, size_t>> launch_of_iter;  // (enqueue ordinal -> event) bookkeeping below
+  const int group = 6;
+  for (;;) {
+    if (enq < max_it + st.cap_retries && since_check < group) {
+      rc = enqueue_iteration(false, true);
       if (rc) return rc;
-      rc = run_select(h, h->d2.p, (int)nq, k, first_select);                            // 6c
-      first_select = false;
-      if (rc) return rc;
-      hipLaunchKernelGGL(k_normal_eq_loop, dim3(nb), dim3(256), 0, h->stream, h->rdq.p, (int)nq, Tm,
-                         h->prev.p, h->d2.p, h->nrm.p, h->hist.p, h->sel.p + 2, h->counters.p + 32,
-                         h->counters.p + 33, h->ne_partials.p, h->ne_out.p);             // 6d
-      HIPC(hipGetLastError());
-      HIPC(hipMemcpyAsync(h->h_pinned, h->ne_out.p, 32 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-      HIPC(hipStreamSynchronize(h->stream));
-      const float lim_chk = (float)h->h_pinned[29];
-      if (cap2 == INFINITY || lim_chk <= cap2) break;  // the order statistic lies among exact values
-      cap2 = INFINITY;
-      st.cap_retries++;
+      ++enq; ++since_check;
+      continue;
     }
-    ev_of_iter.push_back(h->knn_events_used ? h->knn_events_used - 1 : 0);
-    const float limit = (float)h->h_pinned[29];
-    const uint32_t nstrag = (uint32_t)h->h_pinned[30];
-    st.stragglers += nstrag;
-    const double* ne = h->h_pinned;
-    const int64_t used = (int64_t)ne[27];
-    if (used <= 0) { rc = LSGPU_NO_CONVERGENCE; h->err = "no point to minimize"; break; }
-    double A[36], b[6];
-    hostmath::unpack_normal_eq(ne, A, b);
-    float x[6], dT[16];
-    if (!hostmath::llt_solve6(A, b, x)) { rc = LSGPU_NO_CONVERGENCE; h->err = "normal matrix not positive definite"; break; }
-    hostmath::delta_from_x(x, dT);
-    hostmath::mul4(dT, T_iter, T_iter);
-    lsgpu_iter_trace tr;
-    std::memcpy(tr.T_iter, T_iter, sizeof(T_iter));
-    tr.limit = limit; tr.n_used = used;
-    std::memcpy(tr.A, A, sizeof(A)); std::memcpy(tr.b, b, sizeof(b));
-    for (int i = 0; i < 6; ++i) tr.x[i] = x[i];
-    tr.knn_main_us = tr.knn_fallback_us = 0.f; tr.stragglers = nstrag; tr.reserved = 0;
-    h->trace.push_back(tr);
-    st.final_limit = limit; st.final_n_used = used;
-    prev_limit = limit;
-    ++it;
-    if (!ck.check(T_iter, &iterate, &by_diff)) { rc = LSGPU_NO_CONVERGENCE; h->err = "NaN in transformation checker"; break; }
+    rc = fetch_state();
+    if (rc) return rc;
+    since_check = 0;
+    if (hst->done && hst->status == kStatusCapFailed) {
+      // the cap prediction failed for iteration hst->iter: repeat it uncapped, then carry on
+      st.cap_retries++;
+      hst->done = 0; hst->status = 0;
+      HIPC(hipMemcpyAsync(h->state.p, hst, sizeof(IcpState), hipMemcpyHostToDevice, h->stream));
+      HIPC(hipStreamSynchronize(h->stream));
+      rc = enqueue_iteration(false, false);
+      if (rc) return rc;
+      ++enq; since_check = 1;
+      continue;
+    }
+    if (hst->done) break;
+    if (enq >= max_it + st.cap_retries + 2) break;  // safety: cannot happen (the counter stops it)
   }
+  const int it = hst->iter;
+  rc = hst->status;
+  if (rc == LSGPU_NO_CONVERGENCE)
+    h->err = hst->err_code == 1 ? "no point to minimize" : hst->err_code == 2 ? "normal matrix not positive definite"
+                                                                          : "NaN in transformation checker";
   st.iterations = it;
-  st.converged = by_diff ? 1 : 0;
+  st.converged = hst->converged;
+  st.stragglers = (int64_t)hst->stragglers;
+  float T_iter[16];
+  std::memcpy(T_iter, hst->T_iter, sizeof(T_iter));
+  h->trace.resize((size_t)std::min(it, max_it));
+  if (!h->trace.empty()) {
+    HIPC(hipMemcpy(h->trace.data(), h->trace_dev.p, h->trace.size() * sizeof(lsgpu_iter_trace), hipMemcpyDeviceToHost));
+    st.final_limit = h->trace.back().limit;
+    st.final_n_used = h->trace.back().n_used;
+  }
   if (rc == LSGPU_OK) {  // step 7
     float Tmean[16], tmp[16];
     hostmath::identity4(Tmean);
@@ -695,42 +737,24 @@ int lsgpu_icp_align(lsgpu_icp* h, const float* reading_xyz1, int64_t nq, const f
     hostmath::mul4(T_iter, T_rm_in, tmp);
     hostmath::mul4(Tmean, tmp, T_out);
   }
-  for (size_t i = 0; i < h->knn_events_used; ++i) {
-    const auto& e = h->knn_events[i];
-    float m1 = 0.f, m2 = 0.f;
-    if (hipEventElapsedTime(&m1, e.a, e.b) == hipSuccess && hipEventElapsedTime(&m2, e.b, e.c) == hipSuccess) {
+  // kNN timing: launches that actually ran are the first `it` (+ retries) enqueued ones
+  {
+    size_t t = 0;
+    for (size_t i = 0; i < h->knn_events_used && i < ev_of_launch.size(); ++i) {
+      const auto& e = h->knn_events[ev_of_launch[i]];
+      float m1 = 0.f, m2 = 0.f;
+      if (hipEventElapsedTime(&m1, e.a, e.b) != hipSuccess || hipEventElapsedTime(&m2, e.b, e.c) != hipSuccess) {
+        (void)hipGetLastError();
+        continue;
+      }
+      if ((int)i >= it + st.cap_retries) break;  // exited immediately: not a real launch
       st.t_knn_main_ms += m1; st.t_knn_fallback_ms += m2; st.t_knn_ms += m1 + m2; st.knn_launches++;
-      for (size_t t = 0; t < h->trace.size() && t < ev_of_iter.size(); ++t)
-        if (ev_of_iter[t] == i) { h->trace[t].knn_main_us = m1 * 1e3f; h->trace[t].knn_fallback_us = m2 * 1e3f; }
-    } else (void)hipGetLastError();
+      if (t < h->trace.size()) { h->trace[t].knn_main_us = m1 * 1e3f; h->trace[t].knn_fallback_us = m2 * 1e3f; ++t; }
+    }
   }
   st.t_total_ms = wall_ms() - t0;
   if (stats) *stats = st;
   return rc;
-}
-
-// dev only: per-wave records of the last k_knn_tile launch (LSGPU_KNN_STATS build)
-int lsgpu_dev_knn_wave_stats(lsgpu_icp* h, unsigned int* out, int nwaves) {
-  if (!h) return LSGPU_BAD_ARG;
-  if (!out) { HIPC(h->knn_dbg_wave.reserve((size_t)nwaves)); HIPC(hipMemset(h->knn_dbg_wave.p, 0, (size_t)nwaves * 16)); return LSGPU_OK; }
-  HIPC(hipStreamSynchronize(h->stream));
-  HIPC(hipMemcpy(out, h->knn_dbg_wave.p, (size_t)nwaves * 16, hipMemcpyDeviceToHost));
-  return LSGPU_OK;
-}
-
-// dev only: counters of the LSGPU_KNN_STATS build (zeroed on read)
-int lsgpu_dev_knn_counters(lsgpu_icp* h, unsigned long long out[8]) {
-  if (!h) return LSGPU_BAD_ARG;
-  if (!h->knn_dbg.p) {
-    HIPC(h->knn_dbg.reserve(8));
-    HIPC(hipMemset(h->knn_dbg.p, 0, 64));
-    std::memset(out, 0, 64);
-    return LSGPU_OK;
-  }
-  HIPC(hipStreamSynchronize(h->stream));
-  HIPC(hipMemcpy(out, h->knn_dbg.p, 64, hipMemcpyDeviceToHost));
-  HIPC(hipMemset(h->knn_dbg.p, 0, 64));
-  return LSGPU_OK;
 }
 
 int lsgpu_icp_get_trace(lsgpu_icp* h, lsgpu_iter_trace* out, int cap) {

@@ -43,7 +43,9 @@ struct KnnArgs {
   uint32_t* strag_count;
   float r_cap;              // lanes with a larger ball go to the fallback
   float group_r;            // half extent of one search group inside a wave
-  float cap2;               // k_knn_lane: only neighbours with d2 <= cap2 must be exact (INF: all)
+  float cap2;               // only neighbours with d2 <= cap2 must be exact (INF: all)
+  const IcpState* st;       // loop state (nullable): overrides T (and cap2 if use_state_cap)
+  int use_state_cap;
   unsigned long long* dbg;  // optional counters (LSGPU_KNN_STATS builds only)
   uint4* dbg_wave;          // optional per-wave {cycles, chunk evals, proxy survivors, groups<<8|level}
   int ntiles;               // number of 64-query tiles
@@ -71,8 +73,10 @@ __device__ __forceinline__ float box_dist2(float lx, float ly, float lz, float h
 __global__ __launch_bounds__(256) void k_knn_seed(KnnArgs a) {
   const int j = blockIdx.x * 256 + threadIdx.x;
   if (j >= a.nq) return;
+  Mat34 T; float cap2;
+  if (!iter_params(a.st, a.T, a.cap2, a.use_state_cap, T, cap2)) return;
   const float4 r = a.rdq[j];
-  const float3 q = xform(a.T, r.x, r.y, r.z);
+  const float3 q = xform(T, r.x, r.y, r.z);
   const GridDev& g = a.g;
   const int lim = (1 << (g.bits + g.fine)) - 1;
   const int fx = fine_coord(q.x, g.ox, g.inv_hf, lim);
@@ -103,10 +107,10 @@ __global__ __launch_bounds__(256) void k_knn_seed(KnnArgs a) {
 // touches at the level where it spans at most two cells per axis and walks their chunks.
 // pts is padded by 8 far points, so 4-wide point loads may run past a chunk's end (the extra points
 // are real reference points or pads: evaluating them is harmless).
-__device__ __forceinline__ void lane_ball_search(const KnnArgs& a, float qx, float qy, float qz,
+__device__ __forceinline__ void lane_ball_search(const KnnArgs& a, float cap2, float qx, float qy, float qz,
                                                  float& best, int& bi) {
   const GridDev& g = a.g;
-  float prune = fminf(best, a.cap2);
+  float prune = fminf(best, cap2);
   const float R = sqrtf(prune) * (1.0f + 1e-5f) + 1e-7f + kFineSlack * g.hf;
   const int lim = (1 << (g.bits + g.fine)) - 1;
   const int flx = fine_coord(qx - R, g.ox, g.inv_hf, lim), fhx = fine_coord(qx + R, g.ox, g.inv_hf, lim);
@@ -142,7 +146,7 @@ __device__ __forceinline__ void lane_ball_search(const KnnArgs& a, float qx, flo
             if (d2 < best) { best = d2; bi = (int)(st + t + 2); }
             if (d3 < best) { best = d3; bi = (int)(st + t + 3); }
           }
-          prune = fminf(best, a.cap2);
+          prune = fminf(best, cap2);
         }
       }
 }
@@ -170,7 +174,7 @@ __device__ __forceinline__ f32x2 dist2_pair(f32x2 qx, f32x2 qy, f32x2 qz, f32x2 
 // Cull 64 queued chunks (one per lane) against the group's query box, then walk the survivors:
 // per-lane box test against the lane's own best, stage + broadcast the chunk if any lane needs it.
 // The next survivor's points are loaded while the current one is evaluated.
-__device__ __forceinline__ void tile_process_batch(const KnnArgs& a, TileLds& lds, int lane, bool valid,
+__device__ __forceinline__ void tile_process_batch(const KnnArgs& a, float cap2, TileLds& lds, int lane, bool valid,
                                                    uint32_t ch, bool ing, float qx, float qy, float qz,
                                                    float tlx, float tly, float tlz, float thx, float thy,
                                                    float thz, float& maxbest, float& best, int& grp,
@@ -203,7 +207,7 @@ __device__ __forceinline__ void tile_process_batch(const KnnArgs& a, TileLds& ld
       const int u = __ffsll((long long)qm) - 1;
       qm &= qm - 1;
       const float ux = rl_f(qx, u), uy = rl_f(qy, u), uz = rl_f(qz, u);
-      const float ul = rl_f(fminf(best, a.cap2), u);
+      const float ul = rl_f(fminf(best, cap2), u);
       needed = needed || (box_dist2(b0.x, b0.y, b0.z, b1.x, b1.y, b1.z, ux, uy, uz) * kPruneShrink <= ul);
     }
     m &= __ballot(pass && needed);
@@ -227,11 +231,11 @@ __device__ __forceinline__ void tile_process_batch(const KnnArgs& a, TileLds& ld
     }
     const float lx = rl_f(b0.x, kc), ly = rl_f(b0.y, kc), lz = rl_f(b0.z, kc);
     const float hx = rl_f(b1.x, kc), hy = rl_f(b1.y, kc), hz = rl_f(b1.z, kc);
-    bool need = ing && box_dist2(lx, ly, lz, hx, hy, hz, qx, qy, qz) * kPruneShrink <= fminf(best, a.cap2);
+    bool need = ing && box_dist2(lx, ly, lz, hx, hy, hz, qx, qy, qz) * kPruneShrink <= fminf(best, cap2);
 #ifdef LSGPU_KNN_STATS
     if (a.dbg_flags & 16) {
       float lx2 = lx; asm volatile("" : "+v"(lx2));
-      need = need && (ing && box_dist2(lx2, ly, lz, hx, hy, hz, qx, qy, qz) * kPruneShrink <= fminf(best, a.cap2));
+      need = need && (ing && box_dist2(lx2, ly, lz, hx, hy, hz, qx, qy, qz) * kPruneShrink <= fminf(best, cap2));
     }
 #endif
     if (!__ballot(need)) continue;
@@ -258,7 +262,7 @@ __device__ __forceinline__ void tile_process_batch(const KnnArgs& a, TileLds& ld
       if (m4 < best) { best = m4; grp = (int)(st + t); }
     }
   }
-  maxbest = wave_max(ing ? fminf(best, a.cap2) : 0.f);
+  maxbest = wave_max(ing ? fminf(best, cap2) : 0.f);
 }
 
 // Which point of the recorded group of 4 is at distance `best` (first one; pts is padded, and a point
@@ -293,6 +297,8 @@ __global__ __launch_bounds__(256) void k_knn_tile(KnnArgs a) {
   }
   const uint32_t tile = blk * wpb + w;
   if (tile >= (uint32_t)a.ntiles) return;
+  Mat34 T; float cap2;
+  if (!iter_params(a.st, a.T, a.cap2, a.use_state_cap, T, cap2)) return;
   const int j = (int)(tile * 64u) + lane;
   const bool act = j < a.nq;
   const GridDev& g = a.g;
@@ -303,7 +309,7 @@ __global__ __launch_bounds__(256) void k_knn_tile(KnnArgs a) {
   float4 mp = make_float4(0.f, 0.f, 0.f, 0.f);  // the current match (point + index)
   if (act) {
     const float4 r = a.rdq[j];
-    const float3 q = xform(a.T, r.x, r.y, r.z);
+    const float3 q = xform(T, r.x, r.y, r.z);
     qx = q.x; qy = q.y; qz = q.z;
     mp = a.prev[j];  // coalesced: no dependent gather of pts[prev]
     bi = __float_as_int(mp.w);
@@ -315,7 +321,7 @@ __global__ __launch_bounds__(256) void k_knn_tile(KnnArgs a) {
   long long t_red = t_loaded, t_look = t_loaded;
 #endif
   // only neighbours closer than min(best, cap2) can matter
-  const float R = sqrtf(fminf(best, a.cap2)) * (1.0f + 1e-5f) + 1e-7f;
+  const float R = sqrtf(fminf(best, cap2)) * (1.0f + 1e-5f) + 1e-7f;
   const bool straggler = act && !(R <= a.r_cap);
   const bool ing = act && !straggler;
 #ifdef LSGPU_KNN_STATS
@@ -328,7 +334,7 @@ __global__ __launch_bounds__(256) void k_knn_tile(KnnArgs a) {
     const float tly = wave_min(ing ? qy : INFINITY), thy = wave_max(ing ? qy : -INFINITY);
     const float tlz = wave_min(ing ? qz : INFINITY), thz = wave_max(ing ? qz : -INFINITY);
     const float Rmax = wave_max(ing ? R : 0.f);
-    float maxbest = wave_max(ing ? fminf(best, a.cap2) : 0.f);
+    float maxbest = wave_max(ing ? fminf(best, cap2) : 0.f);
     const int lim = (1 << (g.bits + g.fine)) - 1;
     // fine-key box of the region (every lane's ball lies inside), widened by the rounding slack
     const float pad = Rmax + kFineSlack * g.hf;
@@ -372,7 +378,7 @@ __global__ __launch_bounds__(256) void k_knn_tile(KnnArgs a) {
     if (spread) {
       if (ing) {  // tracks the exact index itself
         const int before = bi;
-        lane_ball_search(a, qx, qy, qz, best, bi);
+        lane_ball_search(a, cap2, qx, qy, qz, best, bi);
         if (bi != before) { const float4 p = a.pts[bi]; mp = make_float4(p.x, p.y, p.z, __int_as_float(bi)); }
       }
       n_grp = 64;
@@ -395,7 +401,7 @@ __global__ __launch_bounds__(256) void k_knn_tile(KnnArgs a) {
           while (fill >= 64u) {  // a full batch is ready
             fill -= 64u;
             const uint32_t ch = lds.list[fill + lane];
-            tile_process_batch(a, lds, lane, true, ch, ing, qx, qy, qz, tlx, tly, tlz, thx, thy, thz,
+            tile_process_batch(a, cap2, lds, lane, true, ch, ing, qx, qy, qz, tlx, tly, tlz, thx, thy, thz,
                                maxbest, best, grp, n_eval, n_surv);
           }
         }
@@ -403,7 +409,7 @@ __global__ __launch_bounds__(256) void k_knn_tile(KnnArgs a) {
       if (fill) {
         const bool v = (uint32_t)lane < fill;
         const uint32_t ch = v ? lds.list[lane] : 0u;
-        tile_process_batch(a, lds, lane, v, ch, ing, qx, qy, qz, tlx, tly, tlz, thx, thy, thz,
+        tile_process_batch(a, cap2, lds, lane, v, ch, ing, qx, qy, qz, tlx, tly, tlz, thx, thy, thz,
                            maxbest, best, grp, n_eval, n_surv);
       }
     }
@@ -436,13 +442,15 @@ __global__ __launch_bounds__(256) void k_knn_tile(KnnArgs a) {
 __global__ __launch_bounds__(256) void k_knn_lane(KnnArgs a) {
   const int j = blockIdx.x * 256 + threadIdx.x;
   if (j >= a.nq) return;
+  Mat34 T; float cap2;
+  if (!iter_params(a.st, a.T, a.cap2, a.use_state_cap, T, cap2)) return;
   const float4 r = a.rdq[j];
-  const float3 q = xform(a.T, r.x, r.y, r.z);
+  const float3 q = xform(T, r.x, r.y, r.z);
   float4 mp = a.prev[j];
   int bi = __float_as_int(mp.w);
   const int before = bi;
   float best = dist2(q.x - mp.x, q.y - mp.y, q.z - mp.z);
-  lane_ball_search(a, q.x, q.y, q.z, best, bi);
+  lane_ball_search(a, cap2, q.x, q.y, q.z, best, bi);
   if (bi != before) { const float4 p = a.pts[bi]; mp = make_float4(p.x, p.y, p.z, __int_as_float(bi)); }
   a.ids[j] = bi;
   a.d2[j] = best;
@@ -453,13 +461,15 @@ __global__ __launch_bounds__(256) void k_knn_lane(KnnArgs a) {
 __global__ __launch_bounds__(256) void k_knn_fallback(KnnArgs a) {
   const int lane = threadIdx.x & 63;
   const uint32_t nw = gridDim.x * 4u;
+  Mat34 T; float cap2_unused;
+  if (!iter_params(a.st, a.T, a.cap2, 0, T, cap2_unused)) return;
   const uint32_t count = *a.strag_count;
   const GridDev& g = a.g;
   const int lim = (1 << (g.bits + g.fine)) - 1;
   for (uint32_t s = blockIdx.x * 4u + (threadIdx.x >> 6); s < count; s += nw) {
     const uint32_t j = a.strag[s];
     const float4 r = a.rdq[j];
-    const float3 q = xform(a.T, r.x, r.y, r.z);
+    const float3 q = xform(T, r.x, r.y, r.z);
     float best = a.d2[j];  // finite: distance to the warm-start point (possibly improved)
     unsigned long long bestp =
         ((unsigned long long)__float_as_uint(best) << 32) | (uint32_t)a.ids[j];

@@ -2,6 +2,8 @@
 // PointToPlaneErrorMinimizer (icp_default.yaml:18-19) as a deterministic normal-equation reduction.
 #pragma once
 #include "lsgpu_common.hip.h"
+#include "lsgpu_host_math.h"
+#include "../../include/lsgpu_icp.h"
 
 namespace lsgpu {
 
@@ -46,8 +48,10 @@ __device__ void find_bin(const uint32_t* __restrict__ hist, int nbins, uint32_t 
 }
 
 __global__ __launch_bounds__(256) void k_hist1(const float* __restrict__ d2, int n,
-                                               uint32_t* __restrict__ hist) {
+                                               uint32_t* __restrict__ hist,
+                                               const IcpState* __restrict__ ist) {
   __shared__ uint32_t sh[kHistBins];
+  if (ist && ist->done) return;
   for (int i = threadIdx.x; i < kHistBins; i += 256) sh[i] = 0;
   __syncthreads();
   for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256)
@@ -63,9 +67,11 @@ __global__ __launch_bounds__(256) void k_hist_refine(const float* __restrict__ d
                                                      const uint32_t* __restrict__ parent,
                                                      const SelState* __restrict__ st_in,
                                                      SelState* __restrict__ st_out,
-                                                     uint32_t* __restrict__ hist) {
+                                                     uint32_t* __restrict__ hist,
+                                                     const IcpState* __restrict__ ist) {
   __shared__ uint32_t sh[kHistBins];
   __shared__ uint32_t sc[260];
+  if (ist && ist->done) return;
   const SelState in = *st_in;
   uint32_t bin, krem;
   find_bin(parent, kHistBins, in.k, &bin, &krem, sc);
@@ -173,7 +179,8 @@ __global__ __launch_bounds__(256) void k_normal_eq(const float4* __restrict__ rd
 // LAST block to finish (agent-scope release / ticket / acquire, cdna guide G16) reduces the block
 // partials in a fixed order, publishes {29 sums, limit, straggler count} and re-arms the per-iteration
 // scratch (histograms, straggler counter, ticket) so the next iteration needs no memset launches.
-__global__ __launch_bounds__(256) void k_normal_eq_loop(const float4* __restrict__ rdq, int nq, Mat34 T,
+__global__ __launch_bounds__(256) void k_normal_eq_loop(const float4* __restrict__ rdq, int nq,
+                                                        const IcpState* __restrict__ ist,
                                                         const float4* __restrict__ match,
                                                         const float* __restrict__ d2,
                                                         const float4* __restrict__ nrm,
@@ -186,6 +193,10 @@ __global__ __launch_bounds__(256) void k_normal_eq_loop(const float4* __restrict
   __shared__ uint32_t sc[260];
   __shared__ double red[8][33];
   __shared__ int is_last;
+  if (ist->done) return;
+  Mat34 T;
+#pragma unroll
+  for (int i = 0; i < 12; ++i) T.m[i] = ist->T_rows[i];
   const float limit = select_limit(hist + 2 * kHistBins, st, sc);
   double acc[kNe];
 #pragma unroll
@@ -289,6 +300,55 @@ __global__ __launch_bounds__(1024) void k_ne_final(const double* __restrict__ pa
     for (int r = 0; r < 32; ++r) t += sh[r][threadIdx.x];
     out[threadIdx.x] = t;
   }
+}
+
+// ---------------------------------------------------------------- per-iteration update (device side)
+// One lane: 6x6 float LLT solve, AngleAxis update, T_iter <- dT * T_iter, Counter + Differential
+// checkers, trace record, next cap.  Same code as the host (lsgpu_host_math.h).
+__global__ __launch_bounds__(64) void k_icp_update(IcpState* __restrict__ st,
+                                                   const double* __restrict__ ne_out,
+                                                   float* __restrict__ chk_hist,
+                                                   lsgpu_iter_trace* __restrict__ trace, int trace_cap,
+                                                   int capped_launch) {
+  if (threadIdx.x != 0 || st->done) return;
+  const float limit = (float)ne_out[29];
+  const unsigned long long nstrag = (unsigned long long)ne_out[30];
+  if (capped_launch && st->cap2 < INFINITY && !(limit <= st->cap2)) {
+    st->status = kStatusCapFailed;  // the order statistic is not among exact values: repeat uncapped
+    st->done = 1;
+    return;
+  }
+  st->stragglers += nstrag;
+  const long long used = (long long)ne_out[27];
+  if (used <= 0) { st->status = LSGPU_NO_CONVERGENCE; st->err_code = 1; st->done = 1; return; }
+  double A[36], b[6];
+  hostmath::unpack_normal_eq(ne_out, A, b);
+  float x[6], dT[16], Tn[16];
+  if (!hostmath::llt_solve6(A, b, x)) { st->status = LSGPU_NO_CONVERGENCE; st->err_code = 2; st->done = 1; return; }
+  hostmath::delta_from_x(x, dT);
+  hostmath::mul4(dT, st->T_iter, Tn);
+  for (int i = 0; i < 16; ++i) st->T_iter[i] = Tn[i];
+  for (int r = 0; r < 3; ++r)
+    for (int c = 0; c < 4; ++c) st->T_rows[r * 4 + c] = Tn[c * 4 + r];
+  const int it = st->iter;
+  if (it < trace_cap) {
+    lsgpu_iter_trace& tr = trace[it];
+    for (int i = 0; i < 16; ++i) tr.T_iter[i] = Tn[i];
+    tr.limit = limit; tr.n_used = used;
+    for (int i = 0; i < 36; ++i) tr.A[i] = A[i];
+    for (int i = 0; i < 6; ++i) { tr.b[i] = b[i]; tr.x[i] = x[i]; }
+    tr.knn_main_us = 0.f; tr.knn_fallback_us = 0.f; tr.stragglers = (uint32_t)nstrag; tr.reserved = 0;
+  }
+  st->prev_limit = limit;
+  st->cap2 = st->cap_enabled ? limit * 2.0f : INFINITY;
+  st->iter = it + 1;
+  hostmath::CheckerState cs{st->counter, st->n_hist};
+  bool iterate = true, by_diff = false;
+  const bool ok = hostmath::checker_check(&cs, chk_hist, st->max_iter, st->smooth, st->lim_rot,
+                                          st->lim_trans, Tn, &iterate, &by_diff);
+  st->counter = cs.counter; st->n_hist = cs.n_hist;
+  if (!ok) { st->status = LSGPU_NO_CONVERGENCE; st->err_code = 3; st->done = 1; return; }
+  if (!iterate) { st->converged = by_diff ? 1 : 0; st->done = 1; }
 }
 
 }  // namespace lsgpu
