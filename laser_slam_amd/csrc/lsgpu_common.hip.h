@@ -70,6 +70,7 @@ struct Mat34 {  // rows of a rigid transform
 struct IcpState {
   float T_iter[16];   // column major (PointMatcher TransformationParameters)
   float T_rows[12];   // the same transform as Mat34 rows (what the kernels load)
+  float T_rows_prev[12];  // T_iter of the previous iteration (query displacement bound)
   float prev_limit;   // trim limit of the last completed iteration
   float cap2;         // search cap of the next capped kNN launch (INF: none)
   int iter;           // completed iterations

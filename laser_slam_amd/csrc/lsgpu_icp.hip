@@ -102,6 +102,7 @@ struct lsgpu_icp {
   uint32_t nchunks = 0;
   DevBuf<uint4> knn_dbg_wave;
   DevBuf<unsigned long long> knn_dbg;  // LSGPU_KNN_STATS builds: 8 counters
+  DevBuf<float> lb;          // per-query lower bound on the NN distance
   DevBuf<IcpState> state;    // loop state of the running align (device)
   DevBuf<float> chk_hist;    // checker history: 8 floats x (max_iterations + 2)
   DevBuf<lsgpu_iter_trace> trace_dev;
@@ -203,7 +204,7 @@ void lsgpu_icp_destroy(lsgpu_icp* h) {
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   h->ref_in.release(); h->nrm_in.release(); h->keys.release(); h->keys_alt.release();
   h->vals.release(); h->vals_alt.release(); h->sort_tmp.release(); h->pts.release();
-  h->nrm.release(); h->ref_inv.release(); h->tables.release(); h->flags.release(); h->cidx.release(); h->bounds.release(); h->chunks.release(); h->prev.release(); h->state.release(); h->chk_hist.release(); h->trace_dev.release(); h->knn_dbg.release(); h->knn_dbg_wave.release(); h->stat_partials.release();
+  h->nrm.release(); h->ref_inv.release(); h->tables.release(); h->flags.release(); h->cidx.release(); h->bounds.release(); h->chunks.release(); h->prev.release(); h->state.release(); h->lb.release(); h->chk_hist.release(); h->trace_dev.release(); h->knn_dbg.release(); h->knn_dbg_wave.release(); h->stat_partials.release();
   h->counters.release(); h->q_in.release(); h->rdq.release(); h->ids.release(); h->d2.release();
   h->ids_io.release(); h->d2_io.release(); h->strag.release(); h->hist.release();
   h->sel.release(); h->ne_partials.release(); h->ne_out.release(); h->limit_dev.release();
@@ -264,6 +265,7 @@ static int prepare_queries(lsgpu_icp* h, const float* q_xyz1, int64_t nq, const 
   HIPC(h->vals.reserve(nq));
   HIPC(h->rdq.reserve(nq));
   HIPC(h->prev.reserve(nq));
+  HIPC(h->lb.reserve(nq));
   hipLaunchKernelGGL(k_query_keys, dim3(nblk(nq)), dim3(256), 0, h->stream, src, nq, h->keys.p, h->vals.p);
   rc = sort_pairs(h, nq, 63);
   if (rc) return rc;
@@ -279,7 +281,7 @@ static KnnArgs knn_args(lsgpu_icp* h, const Mat34& T) {
   a.rdq = h->rdq.p; a.nq = (int)h->nq; a.T = T; a.g = h->grid; a.pts = h->pts.p;
   a.chunks = h->chunks.p; a.ids = h->ids.p; a.d2 = h->d2.p; a.prev = h->prev.p;
   a.strag = h->strag.p; a.strag_count = h->counters.p + 32;
-  a.r_cap = 1.0f; a.group_r = 0.75f; a.cap2 = INFINITY; a.st = nullptr; a.use_state_cap = 0;
+  a.r_cap = 1.0f; a.group_r = 0.75f; a.cap2 = INFINITY; a.st = nullptr; a.use_state_cap = 0; a.lb = nullptr;
   a.ntiles = (int)((h->nq + 63) / 64); a.xcd_swizzle = 0;
   a.dbg = h->knn_dbg.p;
   a.dbg_wave = h->knn_dbg_wave.p;
@@ -299,6 +301,7 @@ static int run_knn(lsgpu_icp* h, const Mat34& T, const IcpState* st, bool seed, 
   const int nq = (int)h->nq;
   KnnArgs a = knn_args(h, T);
   a.st = st;
+  a.lb = st ? h->lb.p : nullptr;
   a.use_state_cap = capped ? 1 : 0;
   if (capped) a.r_cap = INFINITY;  // no fallback pass follows a capped launch: the tile kernel takes every lane
   if (seed) HIPC(hipMemsetAsync(a.strag_count, 0, sizeof(uint32_t), h->stream));  // later: re-armed by k_normal_eq_loop

@@ -20,6 +20,10 @@
 //     bound the host derives from the previous iteration's limit and verifies after the select
 //     (a violated bound repeats the iteration uncapped).  Lanes with nothing inside the cap keep an
 //     upper bound > cap2 ("far"); their order among themselves never matters.
+//   * Lower bounds.  Every query also keeps a LOWER bound lb on its NN distance (exact distance after
+//     an exact search, the verified radius otherwise).  Between two iterations a query moves by
+//     delta = |T_new r - T_old r|, so its new NN distance is >= lb - delta (triangle inequality): if
+//     that already exceeds the cap the lane is "far" without searching at all.
 // Ties in distance: any nearest point is returned (libnabo's order is implementation defined).
 #pragma once
 #include "lsgpu_common.hip.h"
@@ -44,6 +48,7 @@ struct KnnArgs {
   float r_cap;              // lanes with a larger ball go to the fallback
   float group_r;            // half extent of one search group inside a wave
   float cap2;               // only neighbours with d2 <= cap2 must be exact (INF: all)
+  float* lb;                // per-query lower bound on the NN distance (nullable; capped loop only)
   const IcpState* st;       // loop state (nullable): overrides T (and cap2 if use_state_cap)
   int use_state_cap;
   unsigned long long* dbg;  // optional counters (LSGPU_KNN_STATS builds only)
@@ -89,13 +94,21 @@ __global__ __launch_bounds__(256) void k_knn_seed(KnnArgs a) {
     uint32_t cs, ce;
     if (!grid_lookup(g, l, (uint32_t)(fx >> sh), (uint32_t)(fy >> sh), (uint32_t)(fz >> sh), cs, ce))
       continue;
-    const ChunkDesc d = a.chunks[cs];
+    // level 0: every point of the cell (tight seed where the reference is dense); coarser levels only
+    // serve isolated queries: one chunk is enough for a bound
+    const uint32_t p0 = a.chunks[cs].start;
+    const ChunkDesc dl = a.chunks[l == 0 ? ce - 1 : cs];
+    uint32_t p1 = dl.start + dl.count;
+    if (p1 - p0 > 256u) p1 = p0 + 256u;
     float best = INFINITY;
-    const uint32_t n = d.count < 8u ? d.count : 8u;
-    for (uint32_t t = 0; t < n; ++t) {
-      const float4 p = a.pts[d.start + t];
-      const float dd = dist2(q.x - p.x, q.y - p.y, q.z - p.z);
-      if (dd < best) { best = dd; bi = (int)(d.start + t); bp = p; }
+    for (uint32_t t = p0; t < p1; t += 4) {  // pts is padded: running a few points past p1 is harmless
+      const float4 c0 = a.pts[t], c1 = a.pts[t + 1], c2 = a.pts[t + 2], c3 = a.pts[t + 3];
+      const float d0 = dist2(q.x - c0.x, q.y - c0.y, q.z - c0.z), d1 = dist2(q.x - c1.x, q.y - c1.y, q.z - c1.z);
+      const float d2 = dist2(q.x - c2.x, q.y - c2.y, q.z - c2.z), d3 = dist2(q.x - c3.x, q.y - c3.y, q.z - c3.z);
+      if (d0 < best) { best = d0; bi = (int)t; bp = c0; }
+      if (d1 < best) { best = d1; bi = (int)t + 1; bp = c1; }
+      if (d2 < best) { best = d2; bi = (int)t + 2; bp = c2; }
+      if (d3 < best) { best = d3; bi = (int)t + 3; bp = c3; }
     }
     break;
   }
@@ -291,7 +304,14 @@ __global__ __launch_bounds__(256) void k_knn_tile(KnnArgs a) {
   // same reference chunks and hash entries, share one L2.
   const uint32_t wpb = blockDim.x >> 6;
   uint32_t blk = blockIdx.x;
-  if (a.xcd_swizzle) {
+  if (a.xcd_swizzle > 1) {
+    // XCD x takes runs of `xcd_swizzle` consecutive blocks: run index = (i / S) * 8 + x.  Neighbouring
+    // tiles share an L2 inside a run, while every XCD still gets an even mix of the whole scan.
+    const uint32_t S = (uint32_t)a.xcd_swizzle, nb = gridDim.x, x = blk & 7u, i = blk >> 3;
+    const uint32_t cand = ((i / S) * 8u + x) * S + (i % S);
+    const uint32_t full = (nb / (8u * S)) * (8u * S);  // blocks beyond the last complete round keep their id
+    if (blk < full) blk = cand;
+  } else if (a.xcd_swizzle == 1) {
     const uint32_t nb = gridDim.x, q = nb >> 3, r = nb & 7u, x = blk & 7u, i = blk >> 3;
     blk = (x < r ? x * (q + 1u) : r * (q + 1u) + (x - r) * q) + i;  // bijective for any grid size
   }
@@ -307,8 +327,10 @@ __global__ __launch_bounds__(256) void k_knn_tile(KnnArgs a) {
   float qx = 0.f, qy = 0.f, qz = 0.f, best = 0.f;
   int bi = -1, grp = -1;
   float4 mp = make_float4(0.f, 0.f, 0.f, 0.f);  // the current match (point + index)
+  float4 rraw = mp;
   if (act) {
     const float4 r = a.rdq[j];
+    rraw = r;
     const float3 q = xform(T, r.x, r.y, r.z);
     qx = q.x; qy = q.y; qz = q.z;
     mp = a.prev[j];  // coalesced: no dependent gather of pts[prev]
@@ -320,10 +342,23 @@ __global__ __launch_bounds__(256) void k_knn_tile(KnnArgs a) {
   const long long t_loaded = clock64();
   long long t_red = t_loaded, t_look = t_loaded;
 #endif
+  // lower bound carried over from the previous iteration, reduced by this query's displacement
+  float lbn = 0.f;
+  bool farskip = false;
+  if (act && a.lb && a.st && a.use_state_cap) {
+    Mat34 To;
+#pragma unroll
+    for (int i = 0; i < 12; ++i) To.m[i] = a.st->T_rows_prev[i];
+    const float3 qo = xform(To, rraw.x, rraw.y, rraw.z);
+    const float ddx = qx - qo.x, ddy = qy - qo.y, ddz = qz - qo.z;
+    const float delta = sqrtf(ddx * ddx + ddy * ddy + ddz * ddz) * (1.0f + 1e-5f) + 1e-7f;
+    lbn = fmaxf(a.lb[j] * (1.0f - 1e-6f) - delta, 0.f);
+    farskip = lbn * lbn > cap2 * (1.0f + 1e-5f);  // provably beyond the cap: weight 0 whatever it is
+  }
   // only neighbours closer than min(best, cap2) can matter
   const float R = sqrtf(fminf(best, cap2)) * (1.0f + 1e-5f) + 1e-7f;
-  const bool straggler = act && !(R <= a.r_cap);
-  const bool ing = act && !straggler;
+  const bool straggler = act && !farskip && !(R <= a.r_cap);
+  const bool ing = act && !straggler && !farskip;
 #ifdef LSGPU_KNN_STATS
   if (__ballot(ing) && !(a.dbg_flags & 4)) {
 #else
@@ -422,6 +457,13 @@ __global__ __launch_bounds__(256) void k_knn_tile(KnnArgs a) {
     a.ids[j] = __float_as_int(mp.w);
     a.d2[j] = best;
     a.prev[j] = mp;
+    if (a.lb) {
+      float nb;
+      if (farskip) nb = lbn;
+      else if (best <= cap2) nb = sqrtf(best) * (1.0f - 1e-6f);               // exact neighbour
+      else nb = fmaxf(lbn, sqrtf(cap2) * (1.0f - 1e-5f));                     // nothing inside the cap
+      a.lb[j] = nb;  // (stragglers: overwritten by the fallback)
+    }
     if (straggler) a.strag[atomicAdd(a.strag_count, 1u)] = (uint32_t)j;
   }
 #ifdef LSGPU_KNN_STATS
@@ -455,6 +497,7 @@ __global__ __launch_bounds__(256) void k_knn_lane(KnnArgs a) {
   a.ids[j] = bi;
   a.d2[j] = best;
   a.prev[j] = mp;
+  if (a.lb) a.lb[j] = best <= cap2 ? sqrtf(best) * (1.0f - 1e-6f) : sqrtf(cap2) * (1.0f - 1e-5f);
 }
 
 // ---------------------------------------------------------------- exact fallback, one wave per query
@@ -535,6 +578,7 @@ __global__ __launch_bounds__(256) void k_knn_fallback(KnnArgs a) {
       a.ids[j] = id;
       a.d2[j] = __uint_as_float((uint32_t)(bestp >> 32));
       a.prev[j] = make_float4(p.x, p.y, p.z, __int_as_float(id));
+      if (a.lb) a.lb[j] = sqrtf(__uint_as_float((uint32_t)(bestp >> 32))) * (1.0f - 1e-6f);
     }
   }
 }

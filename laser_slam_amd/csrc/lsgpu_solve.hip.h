@@ -302,6 +302,8 @@ __global__ __launch_bounds__(1024) void k_ne_final(const double* __restrict__ pa
   }
 }
 
+constexpr float kCapFactor = 1.1f;  // next search cap = this x the current trim limit (verified each iteration)
+
 // ---------------------------------------------------------------- per-iteration update (device side)
 // One lane: 6x6 float LLT solve, AngleAxis update, T_iter <- dT * T_iter, Counter + Differential
 // checkers, trace record, next cap.  Same code as the host (lsgpu_host_math.h).
@@ -328,6 +330,7 @@ __global__ __launch_bounds__(64) void k_icp_update(IcpState* __restrict__ st,
   hostmath::delta_from_x(x, dT);
   hostmath::mul4(dT, st->T_iter, Tn);
   for (int i = 0; i < 16; ++i) st->T_iter[i] = Tn[i];
+  for (int i = 0; i < 12; ++i) st->T_rows_prev[i] = st->T_rows[i];
   for (int r = 0; r < 3; ++r)
     for (int c = 0; c < 4; ++c) st->T_rows[r * 4 + c] = Tn[c * 4 + r];
   const int it = st->iter;
@@ -340,7 +343,7 @@ __global__ __launch_bounds__(64) void k_icp_update(IcpState* __restrict__ st,
     tr.knn_main_us = 0.f; tr.knn_fallback_us = 0.f; tr.stragglers = (uint32_t)nstrag; tr.reserved = 0;
   }
   st->prev_limit = limit;
-  st->cap2 = st->cap_enabled ? limit * 2.0f : INFINITY;
+  st->cap2 = st->cap_enabled ? limit * kCapFactor : INFINITY;
   st->iter = it + 1;
   hostmath::CheckerState cs{st->counter, st->n_hist};
   bool iterate = true, by_diff = false;
