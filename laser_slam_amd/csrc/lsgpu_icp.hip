@@ -102,6 +102,10 @@ struct lsgpu_icp {
   uint32_t nchunks = 0;
   DevBuf<uint4> knn_dbg_wave;
   DevBuf<unsigned long long> knn_dbg;  // LSGPU_KNN_STATS builds: 8 counters
+  DevBuf<uint2> cell_cache;  // ntiles x 64
+  DevBuf<ulonglong2> cell_tags;
+  uint32_t cache_gen = 1;
+  int dbg_launch_no = 0;     // kNN launches since the last prepare_queries (stats build ablations)
   DevBuf<float> lb;          // per-query lower bound on the NN distance
   DevBuf<IcpState> state;    // loop state of the running align (device)
   DevBuf<float> chk_hist;    // checker history: 8 floats x (max_iterations + 2)
@@ -204,7 +208,7 @@ void lsgpu_icp_destroy(lsgpu_icp* h) {
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   h->ref_in.release(); h->nrm_in.release(); h->keys.release(); h->keys_alt.release();
   h->vals.release(); h->vals_alt.release(); h->sort_tmp.release(); h->pts.release();
-  h->nrm.release(); h->ref_inv.release(); h->tables.release(); h->flags.release(); h->cidx.release(); h->bounds.release(); h->chunks.release(); h->prev.release(); h->state.release(); h->lb.release(); h->chk_hist.release(); h->trace_dev.release(); h->knn_dbg.release(); h->knn_dbg_wave.release(); h->stat_partials.release();
+  h->nrm.release(); h->ref_inv.release(); h->tables.release(); h->flags.release(); h->cidx.release(); h->bounds.release(); h->chunks.release(); h->prev.release(); h->state.release(); h->lb.release(); h->cell_cache.release(); h->cell_tags.release(); h->chk_hist.release(); h->trace_dev.release(); h->knn_dbg.release(); h->knn_dbg_wave.release(); h->stat_partials.release();
   h->counters.release(); h->q_in.release(); h->rdq.release(); h->ids.release(); h->d2.release();
   h->ids_io.release(); h->d2_io.release(); h->strag.release(); h->hist.release();
   h->sel.release(); h->ne_partials.release(); h->ne_out.release(); h->limit_dev.release();
@@ -273,6 +277,15 @@ static int prepare_queries(lsgpu_icp* h, const float* q_xyz1, int64_t nq, const 
                      h->vals_alt.p, T, h->rdq.p);
   HIPC(hipGetLastError());
   h->nq = nq;
+  {  // per-tile probe cache: new generation, tags cleared when (re)allocated
+    const size_t nt = (size_t)((nq + 63) / 64);
+    const bool grow = nt > h->cell_tags.cap;
+    HIPC(h->cell_cache.reserve(nt * 64));
+    HIPC(h->cell_tags.reserve(nt));
+    if (grow) HIPC(hipMemsetAsync(h->cell_tags.p, 0, h->cell_tags.cap * sizeof(ulonglong2), h->stream));
+    if (++h->cache_gen == 0) h->cache_gen = 1;
+  }
+  h->dbg_launch_no = 0;
   return ensure_loop_buffers(h, nq);
 }
 
@@ -282,11 +295,12 @@ static KnnArgs knn_args(lsgpu_icp* h, const Mat34& T) {
   a.chunks = h->chunks.p; a.ids = h->ids.p; a.d2 = h->d2.p; a.prev = h->prev.p;
   a.strag = h->strag.p; a.strag_count = h->counters.p + 32;
   a.r_cap = 1.0f; a.group_r = 0.75f; a.cap2 = INFINITY; a.st = nullptr; a.use_state_cap = 0; a.lb = nullptr;
-  a.ntiles = (int)((h->nq + 63) / 64); a.xcd_swizzle = 0;
+  a.ntiles = (int)((h->nq + 63) / 64); a.xcd_swizzle = 0; a.pad_index = (int)h->nr;
+  a.cell_cache = h->cell_cache.p; a.cell_tags = h->cell_tags.p; a.cache_gen = h->cache_gen;
   a.dbg = h->knn_dbg.p;
   a.dbg_wave = h->knn_dbg_wave.p;
   { const char* e = getenv("LSGPU_KNN_DBG"); a.dbg_flags = e ? atoi(e) : 0;
-    if ((a.dbg_flags & (64 | 128 | 256)) && h->trace.size() < 6) a.dbg_flags = 0; }  // early-exit ablations from launch 6 on
+    if ((a.dbg_flags & (64 | 128 | 256 | 512)) && h->dbg_launch_no < 6) a.dbg_flags = 0; }  // early-exit ablations from launch 6 on
   return a;
 }
 
@@ -300,6 +314,7 @@ static KnnArgs knn_args(lsgpu_icp* h, const Mat34& T) {
 static int run_knn(lsgpu_icp* h, const Mat34& T, const IcpState* st, bool seed, bool capped, bool timed) {
   const int nq = (int)h->nq;
   KnnArgs a = knn_args(h, T);
+  h->dbg_launch_no++;
   a.st = st;
   a.lb = st ? h->lb.p : nullptr;
   a.use_state_cap = capped ? 1 : 0;
@@ -321,11 +336,11 @@ static int run_knn(lsgpu_icp* h, const Mat34& T, const IcpState* st, bool seed, 
     hipLaunchKernelGGL(k_knn_lane, dim3(nblk(nq)), dim3(256), 0, h->stream, a);
     if (timed) { HIPC(hipEventRecord(ev->b, h->stream)); HIPC(hipEventRecord(ev->c, h->stream)); }
   } else {
-    static const int tile_threads = getenv("LSGPU_TILE_THREADS") ? atoi(getenv("LSGPU_TILE_THREADS")) : 64;
+    const int tile_threads = 64;
     static const int swz = getenv("LSGPU_XCD_SWIZZLE") ? atoi(getenv("LSGPU_XCD_SWIZZLE")) : 0;
     a.xcd_swizzle = swz;
     const int waves_per_block = tile_threads / 64;
-    hipLaunchKernelGGL(k_knn_tile, dim3((a.ntiles + waves_per_block - 1) / waves_per_block), dim3(tile_threads), 0, h->stream, a);
+    hipLaunchKernelGGL(k_knn_tile<1>, dim3((a.ntiles + waves_per_block - 1) / waves_per_block), dim3(tile_threads), 0, h->stream, a);
     if (timed) HIPC(hipEventRecord(ev->b, h->stream));
     // stragglers (balls > r_cap) only exist in uncapped launches
     if (!capped) hipLaunchKernelGGL(k_knn_fallback, dim3(kFallbackBlocks), dim3(256), 0, h->stream, a);

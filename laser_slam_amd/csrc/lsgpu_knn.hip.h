@@ -54,6 +54,10 @@ struct KnnArgs {
   unsigned long long* dbg;  // optional counters (LSGPU_KNN_STATS builds only)
   uint4* dbg_wave;          // optional per-wave {cycles, chunk evals, proxy survivors, groups<<8|level}
   int ntiles;               // number of 64-query tiles
+  int pad_index;            // index of the first far pad point behind pts (= Nr)
+  uint2* cell_cache;        // per tile: the 64 (chunk_start, chunk_end) probe results of its cell block
+  ulonglong2* cell_tags;    // per tile: which block (generation, level, origin, extent) the cache holds
+  uint32_t cache_gen;       // bumped by every set_reference / align: older entries never match
   int xcd_swizzle;          // 1: block b -> XCD (b % 8) gets a contiguous eighth of the tiles
   int dbg_flags;            // LSGPU_KNN_STATS builds: ablation switches (1 no eval, 2 no refine, 4 no search)
 };
@@ -165,11 +169,11 @@ __device__ __forceinline__ void lane_ball_search(const KnnArgs& a, float cap2, f
 }
 
 // ---------------------------------------------------------------- tile search
-constexpr int kListCap = 256;        // chunk ids queued per wave (LDS)
+constexpr int kListCap = 128;        // chunk ids queued per wave (LDS)
 constexpr uint32_t kChunkBudget = 1024;  // a whole-wave group is accepted up to this many chunks
 
 struct TileLds {
-  float cx[64], cy[64], cz[64];  // staged points of the chunk being evaluated (SoA: pairs feed v_pk_*)
+  float4 slot[4][64];            // 4 chunks in flight: filled by LDS-DMA (global_load_lds, 16 B per lane)
   uint32_t list[kListCap];       // flattened chunk ids of the region's cells
 };
 
@@ -184,9 +188,25 @@ __device__ __forceinline__ f32x2 dist2_pair(f32x2 qx, f32x2 qy, f32x2 qz, f32x2 
   return d;
 }
 
-// Cull 64 queued chunks (one per lane) against the group's query box, then walk the survivors:
-// per-lane box test against the lane's own best, stage + broadcast the chunk if any lane needs it.
-// The next survivor's points are loaded while the current one is evaluated.
+// Broadcast-evaluate one staged chunk: 4 candidates per step -- 12 packed-pair ops for the distances,
+// min3 + min, then ONE compare/select pair that records the group of 4 holding the new best; the exact
+// index is resolved once at the end of the kernel (tile_resolve_match).
+__device__ __forceinline__ void tile_eval_slot(const float4* __restrict__ slot, uint32_t st, uint32_t cnt,
+                                               float qx, float qy, float qz, float& best, int& grp) {
+  const uint32_t cnt4 = (cnt + 3u) & ~3u;
+  const f32x2 q2x = {qx, qx}, q2y = {qy, qy}, q2z = {qz, qz};
+  for (uint32_t t = 0; t < cnt4; t += 4) {
+    const float4 c0 = slot[t], c1 = slot[t + 1], c2 = slot[t + 2], c3 = slot[t + 3];
+    const f32x2 d0 = dist2_pair(q2x, q2y, q2z, f32x2{c0.x, c1.x}, f32x2{c0.y, c1.y}, f32x2{c0.z, c1.z});
+    const f32x2 d1 = dist2_pair(q2x, q2y, q2z, f32x2{c2.x, c3.x}, f32x2{c2.y, c3.y}, f32x2{c2.z, c3.z});
+    const float m4 = fminf(fminf(fminf(d0.x, d0.y), d1.x), d1.y);
+    if (m4 < best) { best = m4; grp = (int)(st + t); }
+  }
+}
+
+// Cull 64 queued chunks (one per lane) against the group's query box, test the survivors per lane
+// against each lane's own bound, then fetch the needed chunks FOUR AT A TIME with LDS-DMA (one memory
+// latency per four chunks, no staging registers) and broadcast-evaluate them.
 __device__ __forceinline__ void tile_process_batch(const KnnArgs& a, float cap2, TileLds& lds, int lane, bool valid,
                                                    uint32_t ch, bool ing, float qx, float qy, float qz,
                                                    float tlx, float tly, float tlz, float thx, float thy,
@@ -207,11 +227,7 @@ __device__ __forceinline__ void tile_process_batch(const KnnArgs& a, float cap2,
 #ifdef LSGPU_KNN_STATS
   if (a.dbg_flags & 128) { n_surv += __popcll(m); return; }
 #endif
-#ifdef LSGPU_KNN_STATS
-  if (__popcll(m) > ((a.dbg_flags & 2) ? 64 : 8)) {
-#else
-  if (__popcll(m) > 8) {
-#endif
+  if (__popcll(m) > 48) {
     // Many boxes passed the group-level test: refine lane-parallel (lane = chunk) against every
     // query's own bound before the serial walk, which costs a broadcast + branch per chunk.
     bool needed = false;
@@ -227,53 +243,46 @@ __device__ __forceinline__ void tile_process_batch(const KnnArgs& a, float cap2,
     if (!m) return;
   }
   n_surv += __popcll(m);
-  int k = __ffsll((long long)m) - 1;
-  uint32_t st_n = rl_u(__float_as_uint(b0.w), k), cnt_n = rl_u(__float_as_uint(b1.w), k);
-  float4 p_n = make_float4(kPadCoord, kPadCoord, kPadCoord, 0.f);
-  if ((uint32_t)lane < cnt_n) p_n = a.pts[st_n + lane];
-  while (m) {
-    const int kc = k;
-    const uint32_t st = st_n, cnt = cnt_n;
-    const float4 p = p_n;
-    m &= m - 1;
-    if (m) {  // prefetch the next survivor's points
-      k = __ffsll((long long)m) - 1;
-      st_n = rl_u(__float_as_uint(b0.w), k); cnt_n = rl_u(__float_as_uint(b1.w), k);
-      p_n = make_float4(kPadCoord, kPadCoord, kPadCoord, 0.f);
-      if ((uint32_t)lane < cnt_n) p_n = a.pts[st_n + lane];
+  // ---- which survivors does any lane need (bounds as of now; they only tighten later)
+  unsigned long long needm = 0;
+  {
+    const float lim = fminf(best, cap2);
+    unsigned long long mm = m;
+    while (mm) {
+      const int k = __ffsll((long long)mm) - 1;
+      mm &= mm - 1;
+      const float lx = rl_f(b0.x, k), ly = rl_f(b0.y, k), lz = rl_f(b0.z, k);
+      const float hx = rl_f(b1.x, k), hy = rl_f(b1.y, k), hz = rl_f(b1.z, k);
+      const bool need = ing && box_dist2(lx, ly, lz, hx, hy, hz, qx, qy, qz) * kPruneShrink <= lim;
+      if (__ballot(need)) needm |= 1ull << k;
     }
-    const float lx = rl_f(b0.x, kc), ly = rl_f(b0.y, kc), lz = rl_f(b0.z, kc);
-    const float hx = rl_f(b1.x, kc), hy = rl_f(b1.y, kc), hz = rl_f(b1.z, kc);
-    bool need = ing && box_dist2(lx, ly, lz, hx, hy, hz, qx, qy, qz) * kPruneShrink <= fminf(best, cap2);
+  }
 #ifdef LSGPU_KNN_STATS
-    if (a.dbg_flags & 16) {
-      float lx2 = lx; asm volatile("" : "+v"(lx2));
-      need = need && (ing && box_dist2(lx2, ly, lz, hx, hy, hz, qx, qy, qz) * kPruneShrink <= fminf(best, cap2));
+  if (a.dbg_flags & (1 | 256)) { n_eval += __popcll(needm); return; }
+#endif
+  // ---- fetch + evaluate, four chunks per round
+  typedef __attribute__((address_space(1))) const void* gptr_t;
+  typedef __attribute__((address_space(3))) void* lptr_t;
+  while (needm) {
+    uint32_t st[4], cnt[4];
+    int ng = 0;
+#pragma unroll
+    for (int gslot = 0; gslot < 4; ++gslot) {
+      if (!needm) break;
+      const int k = __ffsll((long long)needm) - 1;
+      needm &= needm - 1;
+      st[gslot] = rl_u(__float_as_uint(b0.w), k);
+      cnt[gslot] = rl_u(__float_as_uint(b1.w), k);
+      // lanes past the chunk's end fetch a far pad point: the slot is always fully defined
+      const float4* src = a.pts + ((uint32_t)lane < cnt[gslot] ? st[gslot] + (uint32_t)lane : (uint32_t)a.pad_index);
+      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)&lds.slot[gslot][0], 16, 0, 0);
+      ng = gslot + 1;
     }
-#endif
-    if (!__ballot(need)) continue;
-    n_eval++;
-#ifdef LSGPU_KNN_STATS
-    if (a.dbg_flags & (1 | 256)) continue;
-#endif
-    lds.cx[lane] = p.x; lds.cy[lane] = p.y; lds.cz[lane] = p.z;
-    const uint32_t cnt4 = (cnt + 3u) & ~3u;
-    const f32x2 q2x = {qx, qx}, q2y = {qy, qy}, q2z = {qz, qz};
-    // 4 candidates per step: 12 packed-pair ops for the distances, min3 + min, then ONE compare/select
-    // pair that records the group of 4 holding the new best; the exact index is resolved once at
-    // the end of the kernel (tile_resolve_index).
-#ifdef LSGPU_KNN_STATS
-    for (int rep = (a.dbg_flags & 8) ? 2 : 1; rep > 0; --rep)
-#endif
-    for (uint32_t t = 0; t < cnt4; t += 4) {
-      const float4 X = *reinterpret_cast<const float4*>(&lds.cx[t]);
-      const float4 Y = *reinterpret_cast<const float4*>(&lds.cy[t]);
-      const float4 Z = *reinterpret_cast<const float4*>(&lds.cz[t]);
-      const f32x2 d0 = dist2_pair(q2x, q2y, q2z, f32x2{X.x, X.y}, f32x2{Y.x, Y.y}, f32x2{Z.x, Z.y});
-      const f32x2 d1 = dist2_pair(q2x, q2y, q2z, f32x2{X.z, X.w}, f32x2{Y.z, Y.w}, f32x2{Z.z, Z.w});
-      const float m4 = fminf(fminf(fminf(d0.x, d0.y), d1.x), d1.y);
-      if (m4 < best) { best = m4; grp = (int)(st + t); }
-    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    n_eval += ng;
+#pragma unroll
+    for (int gslot = 0; gslot < 4; ++gslot)
+      if (gslot < ng) tile_eval_slot(lds.slot[gslot], st[gslot], cnt[gslot], qx, qy, qz, best, grp);
   }
   maxbest = wave_max(ing ? fminf(best, cap2) : 0.f);
 }
@@ -292,8 +301,9 @@ __device__ __forceinline__ float4 tile_resolve_match(const KnnArgs& a, int grp, 
   return mp;
 }
 
-__global__ __launch_bounds__(256) void k_knn_tile(KnnArgs a) {
-  __shared__ TileLds lds_all[4];
+template <int WAVES>
+__global__ __launch_bounds__(WAVES * 64, 8) void k_knn_tile(KnnArgs a) {
+  __shared__ TileLds lds_all[WAVES];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   TileLds& lds = lds_all[w];
 #ifdef LSGPU_KNN_STATS
@@ -389,13 +399,35 @@ __global__ __launch_bounds__(256) void k_knn_tile(KnnArgs a) {
     sh = g.fine + l;
     const int x0 = flx >> sh, y0 = fly >> sh, z0 = flz >> sh;
     const int nx = (fhx >> sh) - x0 + 1, ny = (fhy >> sh) - y0 + 1, nz = (fhz >> sh) - z0 + 1;
-    // ---- one cell per lane
+#ifdef LSGPU_KNN_STATS
+    if (a.dbg_flags & 512) { if (lane == 0 && nx + ny + nz == -7) a.d2[0] = 0.f; return; }
+#endif
+    // ---- one cell per lane.  A tile's cell block rarely changes between iterations (the queries move
+    // by far less than a cell once ICP converges), so the 64 probe results are kept per tile, tagged
+    // with the block they belong to: a hit replaces up to 64 random table probes by one coalesced read.
     uint32_t cs = 0, ce = 0;
     {
-      const int cx = lane & 3, cy = (lane >> 2) & 3, cz = lane >> 4;
-      if (cx < nx && cy < ny && cz < nz) {
-        if (!grid_lookup(g, l, (uint32_t)(x0 + cx), (uint32_t)(y0 + cy), (uint32_t)(z0 + cz), cs, ce)) {
-          cs = 0; ce = 0;
+      const unsigned long long tag0 = ((unsigned long long)a.cache_gen << 32) | ((unsigned long long)l << 24) |
+                                      ((unsigned long long)nx << 16) | ((unsigned long long)ny << 8) | (unsigned long long)nz;
+      const unsigned long long tag1 = (unsigned long long)x0 | ((unsigned long long)y0 << 21) | ((unsigned long long)z0 << 42);
+      bool hit = false;
+      if (a.cell_cache) {
+        const ulonglong2 t = a.cell_tags[tile];
+        hit = (t.x == tag0) && (t.y == tag1);
+      }
+      if (hit) {
+        const uint2 c = a.cell_cache[(size_t)tile * 64 + lane];
+        cs = c.x; ce = c.y;
+      } else {
+        const int cx = lane & 3, cy = (lane >> 2) & 3, cz = lane >> 4;
+        if (cx < nx && cy < ny && cz < nz) {
+          if (!grid_lookup(g, l, (uint32_t)(x0 + cx), (uint32_t)(y0 + cy), (uint32_t)(z0 + cz), cs, ce)) {
+            cs = 0; ce = 0;
+          }
+        }
+        if (a.cell_cache) {
+          a.cell_cache[(size_t)tile * 64 + lane] = make_uint2(cs, ce);
+          if (lane == 0) a.cell_tags[tile] = make_ulonglong2(tag0, tag1);
         }
       }
     }
@@ -450,7 +482,7 @@ __global__ __launch_bounds__(256) void k_knn_tile(KnnArgs a) {
     }
   }
 #ifdef LSGPU_KNN_STATS
-  if (a.dbg_flags & (64 | 128 | 256)) return;
+  if (a.dbg_flags & (64 | 128 | 256 | 512)) return;
 #endif
   if (act) {
     mp = tile_resolve_match(a, grp, qx, qy, qz, best, mp);
