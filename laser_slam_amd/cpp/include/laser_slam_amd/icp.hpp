@@ -1,0 +1,267 @@
+// icp.hpp -- C++ host-side mirror of the ICP object the reference owns (SURVEY.md §8b seam B2).
+//
+// The reference's `PointMatcher::ICP icp_` (laser_slam/include/laser_slam/laser_track.hpp:217,
+// incremental_estimator.hpp:70) is used through three members only:
+//     icp_.loadFromYaml(std::istream&)      laser_slam/src/laser_track.cpp:17
+//     icp_.setDefault()                     laser_slam/src/laser_track.cpp:20
+//     icp_.compute(reading, reference, T)   laser_slam/src/laser_track.cpp:496,
+//                                           laser_slam/src/incremental_estimator.cpp:108
+// laser_slam_amd::ICP keeps those names, argument meaning and error behaviour (ConvergenceError)
+// over the C ABI of include/lsgpu_icp.h.  No libpointmatcher / Eigen / yaml-cpp dependency: clouds
+// are plain float vectors in PointMatcher's own memory layout.
+#pragma once
+#include <array>
+#include <cctype>
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <istream>
+#include <map>
+#include <sstream>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "lsgpu_icp.h"
+
+namespace laser_slam_amd {
+
+// PointMatcher<float>::DataPoints, reduced to what the path uses: features = (dim+1) x N column major
+// (x,y,z,1 per point), optional "normals" descriptor 3 x N (laser_slam/.../common.hpp:14-15).
+struct DataPoints {
+  std::vector<float> features;  // 4 * N
+  std::vector<float> normals;   // 3 * N or empty
+  int64_t getNbPoints() const { return (int64_t)(features.size() / 4); }
+  // DataPoints::concatenate (laser_track.cpp:485)
+  void concatenate(const DataPoints& o) {
+    const bool both = !normals.empty() && !o.normals.empty();
+    features.insert(features.end(), o.features.begin(), o.features.end());
+    if (both) normals.insert(normals.end(), o.normals.begin(), o.normals.end());
+    else normals.clear();
+  }
+};
+
+using TransformationParameters = std::array<float, 16>;  // 4x4 float, column major
+
+inline TransformationParameters identityTransformation() {
+  TransformationParameters T{};
+  T[0] = T[5] = T[10] = T[15] = 1.f;
+  return T;
+}
+
+// PointMatcher::ConvergenceError (caught at laser_track.cpp:499)
+struct ConvergenceError : std::runtime_error {
+  explicit ConvergenceError(const std::string& w) : std::runtime_error(w) {}
+};
+struct ConfigError : std::runtime_error {
+  explicit ConfigError(const std::string& w) : std::runtime_error(w) {}
+};
+struct DeviceError : std::runtime_error {
+  explicit DeviceError(const std::string& w) : std::runtime_error(w) {}
+};
+
+// RigidTransformation (laser_track.cpp:33): compute / checkParameters / correctParameters
+class RigidTransformation {
+ public:
+  static bool checkParameters(const TransformationParameters& T) { return lsgpu_check_rigid(T.data()) != 0; }
+  static TransformationParameters correctParameters(const TransformationParameters& T) {
+    TransformationParameters o;
+    lsgpu_correct_rigid(T.data(), o.data());
+    return o;
+  }
+  // features' = T * features; the "normals" descriptor is rotated.  Host arithmetic identical to the
+  // device kernel (fma chain), so clouds built on either side agree bit for bit.
+  static DataPoints compute(const DataPoints& in, const TransformationParameters& T) {
+    if (!checkParameters(T)) throw std::runtime_error("RigidTransformation: matrix is not rigid");
+    DataPoints out;
+    const int64_t n = in.getNbPoints();
+    out.features.resize((size_t)n * 4);
+    auto M = [&](int r, int c) { return T[c * 4 + r]; };
+    for (int64_t i = 0; i < n; ++i) {
+      const float x = in.features[4 * i], y = in.features[4 * i + 1], z = in.features[4 * i + 2];
+      for (int r = 0; r < 3; ++r)
+        out.features[4 * i + r] = std::fma(M(r, 2), z, std::fma(M(r, 1), y, std::fma(M(r, 0), x, M(r, 3))));
+      out.features[4 * i + 3] = in.features[4 * i + 3];
+    }
+    if (!in.normals.empty()) {
+      out.normals.resize((size_t)n * 3);
+      for (int64_t i = 0; i < n; ++i) {
+        const float x = in.normals[3 * i], y = in.normals[3 * i + 1], z = in.normals[3 * i + 2];
+        for (int r = 0; r < 3; ++r)
+          out.normals[3 * i + r] = std::fma(M(r, 2), z, std::fma(M(r, 1), y, M(r, 0) * x));
+      }
+    }
+    return out;
+  }
+};
+
+// correctTransformationMatrix (laser_slam/include/laser_slam/common.hpp:136-149)
+inline void correctTransformationMatrix(TransformationParameters* T) {
+  if (!RigidTransformation::checkParameters(*T)) *T = RigidTransformation::correctParameters(*T);
+}
+
+class ICP {
+ public:
+  ICP() { setDefault(); }
+  explicit ICP(int device) : device_(device) { setDefault(); }
+  ~ICP() { release(); }
+  ICP(const ICP&) = delete;
+  ICP& operator=(const ICP&) = delete;
+
+  // ICP::setDefault(): RandomSampling 0.75 / SamplingSurfaceNormal knn 7 / KDTree 1,0 / TrimmedDist 0.85 /
+  // PointToPlane / Counter 40 + Differential 1e-3, 1e-3, 3
+  void setDefault() {
+    lsgpu_icp_config_default(&cfg_);
+    prob_ = 0.75f; knn_ = 7; ratio_ = 0.5f;
+    release();
+  }
+
+  // Accepts the module chain of laser_slam/configurations/icp_default.yaml; any other module is a
+  // configuration error (PointMatcher's registrar throws on unknown names as well).
+  void loadFromYaml(std::istream& in) {
+    lsgpu_icp_config c;
+    lsgpu_icp_config_default(&c);
+    float prob = 0.75f, ratio = 0.5f;
+    int knn = 7;
+    const auto mods = parseYaml(in);
+    for (const auto& m : mods) {
+      const std::string& sec = m.section;
+      const std::string& name = m.name;
+      auto num = [&](const char* key, double def) {
+        auto it = m.params.find(key);
+        return it == m.params.end() ? def : std::stod(it->second);
+      };
+      if (sec == "readingDataPointsFilters" && name == "RandomSamplingDataPointsFilter") prob = (float)num("prob", 0.75);
+      else if (sec == "referenceDataPointsFilters" && name == "SamplingSurfaceNormalDataPointsFilter") {
+        knn = (int)num("knn", 7); ratio = (float)num("ratio", 0.5);
+        if ((int)num("samplingMethod", 0) != 0) throw ConfigError("samplingMethod != 0 is not implemented");
+      } else if (sec == "matcher" && name == "KDTreeMatcher") {
+        if ((int)num("knn", 1) != 1 || num("epsilon", 0) != 0.0) throw ConfigError("only knn 1 / epsilon 0");
+      } else if (sec == "outlierFilters" && name == "TrimmedDistOutlierFilter") c.trim_ratio = (float)num("ratio", 0.85);
+      else if (sec == "errorMinimizer" && name == "PointToPlaneErrorMinimizer") {}
+      else if (sec == "transformationCheckers" && name == "CounterTransformationChecker") c.max_iterations = (int)num("maxIterationCount", 40);
+      else if (sec == "transformationCheckers" && name == "DifferentialTransformationChecker") {
+        c.min_diff_rot = (float)num("minDiffRotErr", 0.001);
+        c.min_diff_trans = (float)num("minDiffTransErr", 0.001);
+        c.smooth_length = (int)num("smoothLength", 3);
+      } else if (sec == "inspector" || sec == "logger") {}  // debug output only (yaml:32-44)
+      else throw ConfigError(sec + ": module " + name + " is not implemented on the HIP path");
+    }
+    cfg_ = c; prob_ = prob; knn_ = knn; ratio_ = ratio;
+    release();
+  }
+
+  // T with p_reference = T * p_reading.  Throws ConvergenceError exactly where PointMatcher would.
+  TransformationParameters compute(const DataPoints& reading, const DataPoints& reference,
+                                   const TransformationParameters& T_init) {
+    ensureHandle();
+    const int64_t nr = reference.getNbPoints(), nq = reading.getNbPoints();
+    if (nr <= 0 || nq <= 0) throw ConvergenceError("empty cloud");
+    // referenceDataPointsFilters, then readingDataPointsFilters (ICP::compute steps 1 and 4)
+    std::vector<float> rf((size_t)nr * 4), rn((size_t)nr * 3);
+    const int64_t nrf = lsgpu_filter_sampling_surface_normal(reference.features.data(), nr, knn_, ratio_, -1,
+                                                             rf.data(), rn.data());
+    std::vector<int64_t> keep((size_t)nq);
+    const int64_t nqf = lsgpu_filter_random_sampling(nq, prob_, -1, keep.data());
+    if (nrf <= 0 || nqf <= 0) throw ConvergenceError("empty cloud after filtering");
+    std::vector<float> rd((size_t)nqf * 4);
+    for (int64_t i = 0; i < nqf; ++i) std::memcpy(&rd[4 * i], &reading.features[4 * keep[i]], 16);
+    return computeFiltered(rd.data(), nqf, rf.data(), rn.data(), nrf, T_init);
+  }
+
+  // Steps 2-7 on already filtered clouds (device or host pointers).
+  TransformationParameters computeFiltered(const float* reading_xyz1, int64_t nq, const float* ref_xyz1,
+                                           const float* ref_normals, int64_t nr,
+                                           const TransformationParameters& T_init) {
+    ensureHandle();
+    check(lsgpu_icp_set_reference(h_, ref_xyz1, ref_normals, nr), "lsgpu_icp_set_reference");
+    TransformationParameters T = T_init;
+    check(lsgpu_icp_align(h_, reading_xyz1, nq, T_init.data(), T.data(), &stats_), "lsgpu_icp_align");
+    return T;
+  }
+
+  const lsgpu_icp_stats& lastStats() const { return stats_; }
+  const lsgpu_icp_config& config() const { return cfg_; }
+  float readingSamplingProb() const { return prob_; }
+  int surfaceNormalKnn() const { return knn_; }
+
+ private:
+  struct Module { std::string section, name; std::map<std::string, std::string> params; };
+
+  static std::string trim(const std::string& s) {
+    size_t a = 0, b = s.size();
+    while (a < b && std::isspace((unsigned char)s[a])) ++a;
+    while (b > a && std::isspace((unsigned char)s[b - 1])) --b;
+    return s.substr(a, b - a);
+  }
+  static void parseInline(const std::string& body, std::map<std::string, std::string>* out) {  // {k: v, k: v}
+    std::stringstream ss(body);
+    std::string kv;
+    while (std::getline(ss, kv, ',')) {
+      const size_t c = kv.find(':');
+      if (c != std::string::npos) (*out)[trim(kv.substr(0, c))] = trim(kv.substr(c + 1));
+    }
+  }
+  // The YAML subset libpointmatcher configurations use: top-level `section:`, module either as a list
+  // item `- Name:` / `- Name` or as a mapping `Name:` / scalar `section: Name`, parameters as an
+  // indented `key: value` block or an inline `{...}` map; `#` comments.
+  static std::vector<Module> parseYaml(std::istream& in) {
+    std::vector<Module> mods;
+    std::string line, section;
+    int mod_indent = -1;
+    while (std::getline(in, line)) {
+      const size_t hash = line.find('#');
+      if (hash != std::string::npos) line = line.substr(0, hash);
+      if (trim(line).empty()) continue;
+      int indent = 0;
+      while (indent < (int)line.size() && line[indent] == ' ') ++indent;
+      std::string t = trim(line);
+      bool item = false;
+      if (t[0] == '-') { item = true; t = trim(t.substr(1)); }
+      const size_t c = t.find(':');
+      std::string key = trim(c == std::string::npos ? t : t.substr(0, c));
+      std::string val = c == std::string::npos ? "" : trim(t.substr(c + 1));
+      if (indent == 0 && !item) {  // section
+        section = key;
+        mod_indent = -1;
+        if (!val.empty() && val[0] != '{') { mods.push_back({section, val, {}}); }
+        continue;
+      }
+      if (section.empty()) throw ConfigError("yaml: content before the first section");
+      const bool is_param = mod_indent >= 0 && indent > mod_indent && !item;
+      if (is_param) {
+        mods.back().params[key] = val;
+      } else {  // a module
+        Module m{section, key, {}};
+        if (!val.empty() && val.front() == '{' && val.back() == '}') parseInline(val.substr(1, val.size() - 2), &m.params);
+        mods.push_back(m);
+        mod_indent = indent;
+      }
+    }
+    return mods;
+  }
+
+  void ensureHandle() {
+    if (h_) return;
+    const int rc = lsgpu_icp_create(&cfg_, device_, &h_);
+    if (rc == LSGPU_BAD_CONFIG) throw ConfigError("lsgpu_icp_create: bad configuration");
+    if (rc != LSGPU_OK) throw DeviceError("lsgpu_icp_create failed (no ROCm GPU visible?)");
+  }
+  void release() { if (h_) { lsgpu_icp_destroy(h_); h_ = nullptr; } }
+  void check(int rc, const char* what) {
+    if (rc == LSGPU_OK) return;
+    const std::string msg = std::string(what) + ": " + lsgpu_strerror(rc) + " [" + lsgpu_last_error(h_) + "]";
+    if (rc == LSGPU_NO_CONVERGENCE) throw ConvergenceError(msg);
+    if (rc == LSGPU_BAD_CONFIG) throw ConfigError(msg);
+    throw DeviceError(msg);
+  }
+
+  int device_ = 0;
+  lsgpu_icp_config cfg_{};
+  lsgpu_icp* h_ = nullptr;
+  lsgpu_icp_stats stats_{};
+  float prob_ = 0.75f, ratio_ = 0.5f;
+  int knn_ = 7;
+};
+
+}  // namespace laser_slam_amd

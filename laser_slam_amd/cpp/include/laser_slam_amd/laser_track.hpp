@@ -1,0 +1,325 @@
+// laser_track.hpp -- dependency-free C++ mirror of the part of laser_slam::LaserTrack that sits on
+// the ICP hot path (§8b seam B1).
+//
+// Reference: laser_slam/include/laser_slam/laser_track.hpp:17-236, laser_slam/src/laser_track.cpp.
+// Same method names, argument meaning and error behaviour for
+//   processPose / processLaserScan / processPoseAndLaserScan      laser_track.cpp:66-231
+//   computeICPTransformations / localScanToSubMap                 laser_track.cpp:460-519
+//   buildSubMapAroundTime                                         laser_track.cpp:602-651
+//   getLocalCloudInWorldFrame                                     laser_track.cpp:247-266
+//   getTrajectory / getCurrentPose / getMin/MaxTime / getNumScans / evaluate / getLaserScans
+// What differs, because GTSAM, mincurves and minkindr are not available:
+//   * gtsam::NonlinearFactorGraph / gtsam::Values become the plain-data FactorList / Values below
+//     (one record per ExpressionFactor<SE3> the reference would emit, laser_track.cpp:431-458);
+//   * curves::DiscreteSE3Curve becomes Trajectory (time-keyed SE3 nodes, interpolating evaluate);
+//   * glog CHECKs become std::logic_error.
+// The ICP itself runs on the GPU through laser_slam_amd::ICP (icp.hpp -> include/lsgpu_icp.h).
+#pragma once
+#include <algorithm>
+#include <chrono>
+#include <fstream>
+#include <map>
+#include <mutex>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "laser_slam_amd/icp.hpp"
+#include "laser_slam_amd/se3.hpp"
+
+namespace laser_slam_amd {
+
+using Time = int64_t;  // curves::Time, nanoseconds
+using Key = size_t;
+
+struct Pose {          // laser_slam/include/laser_slam/common.hpp:87-94
+  SE3 T_w;
+  Time time_ns = 0;
+  Key key = 0;
+};
+struct RelativePose {  // common.hpp:97-110
+  SE3 T_a_b;
+  Time time_a_ns = 0, time_b_ns = 0;
+  Key key_a = 0, key_b = 0;
+  unsigned int track_id_a = 0, track_id_b = 0;
+};
+struct LaserScan {     // common.hpp:113-120
+  DataPoints scan;
+  Time time_ns = 0;
+  Key key = 0;
+};
+
+struct LaserTrackParams {  // laser_slam/include/laser_slam/parameters.hpp:8-23
+  std::array<double, 6> odometry_noise_model{};
+  std::array<double, 6> icp_noise_model{};
+  bool add_m_estimator_on_odom = false;
+  bool add_m_estimator_on_icp = false;
+  std::string icp_configuration_file;
+  std::string icp_input_filters_file;   // input filter chain (K0): the file is not in the reference repo;
+                                        // empty = no input filters
+  bool use_icp_factors = true;
+  bool use_odom_factors = true;
+  int nscan_in_sub_map = 3;
+  bool save_icp_results = false;
+  bool force_priors = false;
+  int device = 0;                       // HIP device of this track's ICP handle
+};
+
+// One record per factor the reference pushes into the gtsam graph.
+struct Factor {
+  enum Type { PRIOR, ODOMETRY, ICP } type;
+  Key key_a = 0, key_b = 0;        // PRIOR uses key_b only
+  SE3 measurement;                 // T_w (prior) or T_a_b (between)
+  std::array<double, 6> sigmas{};  // diagonal noise model [translation; rotation]
+  bool cauchy = false;             // Cauchy(1) m-estimator (laser_track.cpp:47-54)
+};
+using FactorList = std::vector<Factor>;
+using Values = std::map<Key, SE3>;
+using TrajectoryMap = std::map<Time, SE3>;
+
+// curves::DiscreteSE3Curve stand-in
+class Trajectory {
+ public:
+  bool isEmpty() const { return nodes_.empty(); }
+  Key extend(Time t, const SE3& v) {
+    if (!nodes_.empty() && t <= nodes_.back().t) throw std::logic_error("trajectory times must increase");
+    nodes_.push_back({t, v, next_key_});
+    return next_key_++;
+  }
+  SE3 evaluate(Time t) const {
+    if (nodes_.empty()) throw std::logic_error("empty trajectory");
+    if (t <= nodes_.front().t) return nodes_.front().v;
+    if (t >= nodes_.back().t) return nodes_.back().v;
+    auto hi = std::lower_bound(nodes_.begin(), nodes_.end(), t, [](const Node& n, Time x) { return n.t < x; });
+    if (hi->t == t) return hi->v;
+    auto lo = hi - 1;
+    return SE3::interpolate(lo->v, hi->v, double(t - lo->t) / double(hi->t - lo->t));
+  }
+  Time getMinTime() const { return nodes_.empty() ? 0 : nodes_.front().t; }
+  Time getMaxTime() const { return nodes_.empty() ? 0 : nodes_.back().t; }
+  void getCurveTimes(std::vector<Time>* out) const { out->clear(); for (auto& n : nodes_) out->push_back(n.t); }
+  void update(const Values& v) { for (auto& n : nodes_) { auto it = v.find(n.key); if (it != v.end()) n.v = it->second; } }
+  void setFirstKey(Key k) { if (nodes_.empty()) next_key_ = k; }
+
+ private:
+  struct Node { Time t; SE3 v; Key key; };
+  std::vector<Node> nodes_;
+  Key next_key_ = 0;
+};
+
+class LaserTrack {
+ public:
+  explicit LaserTrack(const LaserTrackParams& parameters, unsigned int laser_track_id = 0u)
+      : params_(parameters), laser_track_id_(laser_track_id), icp_(parameters.device) {
+    // laser_track.cpp:14-21: YAML if readable, otherwise the default chain
+    std::ifstream ifs(params_.icp_configuration_file.c_str());
+    if (!params_.icp_configuration_file.empty() && ifs.good()) icp_.loadFromYaml(ifs);
+    else icp_.setDefault();
+    trajectory_.setFirstKey((Key)laser_track_id_ << 40);  // per-track key range
+  }
+
+  void processPose(const Pose& pose) {  // laser_track.cpp:66-72
+    std::lock_guard<std::recursive_mutex> lock(mutex_);
+    pose_measurements_.push_back(pose);
+  }
+
+  void processLaserScan(const LaserScan& in_scan) {  // laser_track.cpp:74-120
+    std::lock_guard<std::recursive_mutex> lock(mutex_);
+    LaserScan scan = in_scan;
+    registerScan(&scan, nullptr);
+  }
+
+  void processPoseAndLaserScan(const Pose& pose, const LaserScan& in_scan, FactorList* newFactors = nullptr,
+                               Values* newValues = nullptr, bool* is_prior = nullptr) {  // :122-231
+    std::lock_guard<std::recursive_mutex> lock(mutex_);
+    const auto t0 = std::chrono::steady_clock::now();
+    if (newFactors && !newFactors->empty()) throw std::logic_error("newFactors must be empty");
+    if (newValues) newValues->clear();
+    LaserScan scan = in_scan;
+    pose_measurements_.push_back(pose);
+    const bool first = trajectory_.isEmpty();
+    RelativePose odom;
+    registerScan(&scan, &odom);
+    if (first) {
+      if (newFactors) {
+        Pose prior = pose;
+        if (params_.force_priors)  // laser_track.cpp:166-170: priors 100 m apart along y, one per track
+          prior.T_w = SE3({1, 0, 0, 0}, {0.0, kDistanceBetweenPriorPoses_m * laser_track_id_, 0.0});
+        Factor f{Factor::PRIOR, 0, scan.key, prior.T_w, {}, false};
+        f.sigmas.fill(kPriorSigma);
+        newFactors->push_back(f);
+      }
+      if (is_prior) *is_prior = true;
+    } else {
+      scan_matching_times_[scan.time_ns] =
+          std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+      if (newFactors) {
+        if (params_.use_odom_factors)
+          newFactors->push_back({Factor::ODOMETRY, odom.key_a, odom.key_b, odom.T_a_b,
+                                 params_.odometry_noise_model, params_.add_m_estimator_on_odom});
+        if (params_.use_icp_factors && !icp_transformations_.empty()) {
+          const RelativePose& r = icp_transformations_.back();
+          newFactors->push_back({Factor::ICP, r.key_a, r.key_b, r.T_a_b, params_.icp_noise_model,
+                                 params_.add_m_estimator_on_icp});
+        }
+      }
+      if (is_prior) *is_prior = false;
+    }
+    if (newValues) (*newValues)[scan.key] = pose.T_w;
+  }
+
+  void getLocalCloudInWorldFrame(const Time& timestamp_ns, DataPoints* out) const {  // :247-266
+    std::lock_guard<std::recursive_mutex> lock(mutex_);
+    if (!out) throw std::logic_error("null output");
+    auto it = scanAtTime(timestamp_ns);
+    TransformationParameters T = trajectory_.evaluate(timestamp_ns).transformationMatrixF();
+    correctTransformationMatrix(&T);
+    *out = RigidTransformation::compute(it->scan, T);
+  }
+
+  const std::vector<LaserScan>& getLaserScans() const { return laser_scans_; }
+
+  void getTrajectory(TrajectoryMap* trajectory) const {  // :268-279
+    std::lock_guard<std::recursive_mutex> lock(mutex_);
+    trajectory->clear();
+    std::vector<Time> times;
+    trajectory_.getCurveTimes(&times);
+    for (Time t : times) trajectory->emplace(t, trajectory_.evaluate(t));
+  }
+
+  Pose getCurrentPose() const {  // :292-300
+    std::lock_guard<std::recursive_mutex> lock(mutex_);
+    Pose p;
+    if (!trajectory_.isEmpty()) { p.time_ns = trajectory_.getMaxTime(); p.T_w = trajectory_.evaluate(p.time_ns); }
+    return p;
+  }
+  Time getMinTime() const { std::lock_guard<std::recursive_mutex> l(mutex_); return trajectory_.getMinTime(); }
+  Time getMaxTime() const { std::lock_guard<std::recursive_mutex> l(mutex_); return trajectory_.getMaxTime(); }
+  size_t getNumScans() const { std::lock_guard<std::recursive_mutex> l(mutex_); return laser_scans_.size(); }
+  SE3 evaluate(const Time& t) const { std::lock_guard<std::recursive_mutex> l(mutex_); return trajectory_.evaluate(t); }
+  void updateFromValues(const Values& v) { std::lock_guard<std::recursive_mutex> l(mutex_); trajectory_.update(v); }
+  const std::map<Time, double>& getScanMatchingTimes() const { return scan_matching_times_; }
+  const std::vector<RelativePose>& getIcpTransformations() const { return icp_transformations_; }
+  const std::vector<RelativePose>& getOdometryMeasurements() const { return odometry_measurements_; }
+  const lsgpu_icp_stats& lastIcpStats() const { return icp_.lastStats(); }
+
+  // laser_track.cpp:602-651: the scan at time_ns plus up to `radius` scans on either side, in its frame
+  void buildSubMapAroundTime(const Time& time_ns, unsigned int sub_maps_radius, DataPoints* sub_map_out) const {
+    std::lock_guard<std::recursive_mutex> lock(mutex_);
+    if (!sub_map_out) throw std::logic_error("null output");
+    const SE3 T_w_a = trajectory_.evaluate(time_ns);
+    auto it = scanAtTime(time_ns);
+    DataPoints sub_map = it->scan;
+    auto add = [&](std::vector<LaserScan>::const_iterator s) {
+      TransformationParameters T = (T_w_a.inverse() * trajectory_.evaluate(s->time_ns)).transformationMatrixF();
+      correctTransformationMatrix(&T);
+      sub_map.concatenate(RigidTransformation::compute(s->scan, T));
+    };
+    auto before = it;
+    for (unsigned int i = 0; i < sub_maps_radius && before != laser_scans_.begin(); ++i) add(--before);
+    auto after = it;
+    for (unsigned int i = 0; i < sub_maps_radius; ++i) {
+      if (++after == laser_scans_.end()) break;
+      add(after);
+    }
+    *sub_map_out = sub_map;
+  }
+
+ private:
+  static constexpr double kDistanceBetweenPriorPoses_m = 100.0;  // laser_track.hpp:235
+  static constexpr double kPriorSigma = 1e-7;                    // laser_track.cpp:56-64
+
+  SE3 getPoseMeasurement(Time t) const {  // findPose (:521-555): exact time stamp required
+    for (auto it = pose_measurements_.rbegin(); it != pose_measurements_.rend(); ++it)
+      if (it->time_ns == t) return it->T_w;
+    throw std::logic_error("The requested time does not exist in the pose measurements.");
+  }
+  void setPoseKey(Time t, Key k) {
+    for (auto it = pose_measurements_.rbegin(); it != pose_measurements_.rend(); ++it)
+      if (it->time_ns == t) { it->key = k; return; }
+  }
+  Key getPoseKey(Time t) const {
+    for (auto it = pose_measurements_.rbegin(); it != pose_measurements_.rend(); ++it)
+      if (it->time_ns == t) return it->key;
+    throw std::logic_error("no pose key at the requested time");
+  }
+  std::vector<LaserScan>::const_iterator scanAtTime(Time t) const {  // :584-600
+    for (auto it = laser_scans_.begin(); it != laser_scans_.end(); ++it)
+      if (it->time_ns == t) return it;
+    throw std::logic_error("Could not find the scan.");
+  }
+
+  // shared tail of processLaserScan / processPoseAndLaserScan (:154-206)
+  void registerScan(LaserScan* scan, RelativePose* odom_out) {
+    if (trajectory_.isEmpty()) {
+      scan->key = trajectory_.extend(scan->time_ns, getPoseMeasurement(scan->time_ns));
+      setPoseKey(scan->time_ns, scan->key);
+      laser_scans_.push_back(*scan);
+      return;
+    }
+    const Time t_last = trajectory_.getMaxTime();
+    RelativePose rel;
+    rel.T_a_b = getPoseMeasurement(t_last).inverse() * getPoseMeasurement(scan->time_ns);
+    rel.time_a_ns = t_last;
+    rel.key_a = getPoseKey(t_last);
+    rel.time_b_ns = scan->time_ns;
+    scan->key = trajectory_.extend(scan->time_ns, trajectory_.evaluate(t_last) * rel.T_a_b);
+    setPoseKey(scan->time_ns, scan->key);
+    laser_scans_.push_back(*scan);
+    rel.key_b = scan->key;
+    rel.track_id_a = rel.track_id_b = laser_track_id_;
+    odometry_measurements_.push_back(rel);
+    if (params_.use_icp_factors) computeICPTransformations();
+    if (odom_out) *odom_out = rel;
+  }
+
+  void computeICPTransformations() {  // :460-464
+    if (laser_scans_.size() > 1u) localScanToSubMap();
+  }
+
+  // laser_track.cpp:466-519
+  void localScanToSubMap() {
+    const size_t n = laser_scans_.size();
+    const LaserScan& last_scan = laser_scans_.back();
+    RelativePose icp;
+    icp.time_b_ns = last_scan.time_ns;
+    icp.time_a_ns = laser_scans_[n - 2].time_ns;
+    // sub-map = scan n-2 plus the (nscan_in_sub_map - 1) scans before it, in the frame of scan n-2
+    const SE3 T_w_a = trajectory_.evaluate(icp.time_a_ns);
+    DataPoints sub_map = laser_scans_[n - 2].scan;
+    const size_t extra = std::min(n - 2, size_t(std::max(params_.nscan_in_sub_map, 1) - 1));
+    for (size_t i = 0; i < extra; ++i) {
+      const LaserScan& prev = laser_scans_[n - 3 - i];
+      TransformationParameters T = (T_w_a.inverse() * trajectory_.evaluate(prev.time_ns)).transformationMatrixF();
+      correctTransformationMatrix(&T);
+      sub_map.concatenate(RigidTransformation::compute(prev.scan, T));
+    }
+    // initial guess from the (odometry-extended) trajectory
+    const SE3 guess = trajectory_.evaluate(icp.time_a_ns).inverse() * trajectory_.evaluate(icp.time_b_ns);
+    const TransformationParameters T_init = guess.transformationMatrixF();
+    TransformationParameters solution = T_init;
+    try {
+      solution = icp_.compute(last_scan.scan, sub_map, T_init);
+    } catch (const ConvergenceError&) {
+      // keep the initial guess (laser_track.cpp:499-502)
+    }
+    icp.T_a_b = SE3::fromTransformationMatrix(solution.data());  // convertTransformationMatrixToSE3
+    icp.key_a = getPoseKey(icp.time_a_ns);
+    icp.key_b = getPoseKey(icp.time_b_ns);
+    icp.track_id_a = icp.track_id_b = laser_track_id_;
+    icp_transformations_.push_back(icp);
+  }
+
+  LaserTrackParams params_;
+  unsigned int laser_track_id_;
+  ICP icp_;
+  Trajectory trajectory_;
+  std::vector<Pose> pose_measurements_;
+  std::vector<RelativePose> odometry_measurements_;
+  std::vector<RelativePose> icp_transformations_;
+  std::vector<LaserScan> laser_scans_;
+  std::map<Time, double> scan_matching_times_;
+  mutable std::recursive_mutex mutex_;
+};
+
+}  // namespace laser_slam_amd
