@@ -7,7 +7,7 @@ from laser_slam_amd._lib import IcpConfig, lib
 n_az = int(sys.argv[1]) if len(sys.argv) > 1 else 16384
 ref, rd, Tt, Ti = synth.scan_pair(n_az)
 rf, rn = icp.sampling_surface_normal(ref, 10, 1.0, 0)
-cfg = IcpConfig(); lib().lsgpu_icp_config_yaml(C.byref(cfg)); cfg.min_diff_rot, cfg.min_diff_trans = 1e-5, 1e-4; cfg.profile_kernels = 1
+cfg = IcpConfig(); lib().lsgpu_icp_config_yaml(C.byref(cfg)); cfg.min_diff_rot, cfg.min_diff_trans = 1e-5, 1e-4; cfg.profile_kernels = 1; cfg.cell_size = float(os.environ.get("CELL", "0"))
 h = icp.IcpHandle(cfg)
 dref, dn, drd = torch.from_numpy(rf).cuda(), torch.from_numpy(rn).cuda(), torch.from_numpy(rd).cuda()
 for rep in range(2):

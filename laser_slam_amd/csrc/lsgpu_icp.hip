@@ -422,10 +422,13 @@ int lsgpu_icp_set_reference(lsgpu_icp* h, const float* ref_xyz1, const float* re
   }
   // ---- grid geometry: level-0 cells of h0 (2^bits per axis), keys quantised at hf = h0 / 2^fine
   const float ext = std::max(std::max(mx[0] - mn[0], mx[1] - mn[1]), mx[2] - mn[2]);
-  const int bits = 11, fine = 5;
+  // 16 key bits per axis in total: `bits` of them address level-0 cells, `fine` order points inside
+  // a cell.  Start from the requested level-0 edge and trade fine bits for cell bits until the
+  // bounding box fits (bits <= 13); beyond that the cells grow.
+  int bits = 11, fine = 5;
   float h0 = h->cfg.cell_size > 0.f ? h->cfg.cell_size : 0.125f;
-  const float need = ext * 1.0001f / (float)((1 << bits) - 1);
-  while (h0 < need) h0 *= 2.f;
+  while (bits < 13 && h0 * (float)((1 << bits) - 1) < ext * 1.0001f) { ++bits; --fine; }
+  while (h0 * (float)((1 << bits) - 1) < ext * 1.0001f) h0 *= 2.f;
   GridDev g;
   std::memset(&g, 0, sizeof(g));
   g.ox = mn[0]; g.oy = mn[1]; g.oz = mn[2];

@@ -15,31 +15,39 @@ struct SelState {
   uint32_t k;       // rank still to find inside the selected bin
 };
 
-// Whole block (256 threads): find bin b with cum(b) <= k < cum(b)+hist[b].
+// Whole block (256 threads): find bin b with cum(b) <= k < cum(b)+hist[b] -- parallel: each thread
+// owns nbins/256 consecutive bins, block-wide inclusive scan of the per-thread sums, the one thread
+// whose range contains rank k walks its own bins.
 __device__ void find_bin(const uint32_t* __restrict__ hist, int nbins, uint32_t k, uint32_t* bin,
                          uint32_t* krem, uint32_t* sh /* >= 260 words */) {
-  const int t = threadIdx.x;
-  const int per = nbins / 256;  // nbins is a multiple of 256
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+  const int per = nbins / 256;  // nbins is a multiple of 256, per <= 8
+  uint32_t c[8];
   uint32_t loc = 0;
-  for (int i = 0; i < per; ++i) loc += hist[t * per + i];
-  sh[t] = loc;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) { c[i] = i < per ? hist[t * per + i] : 0u; loc += c[i]; }
+  uint32_t incl = loc;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const uint32_t v = __shfl_up(incl, o, 64);
+    if (lane >= o) incl += v;
+  }
+  if (lane == 63) sh[w] = incl;
+  if (t == 0) { sh[256] = (uint32_t)(nbins - 1); sh[257] = 0u; }  // k beyond the total: last bin
   __syncthreads();
-  if (t == 0) {
-    uint32_t cum = 0;
-    int sel = 255;
-    for (int i = 0; i < 256; ++i) {
-      if (k < cum + sh[i]) { sel = i; break; }
-      cum += sh[i];
+  uint32_t base = 0;
+  for (int i = 0; i < w; ++i) base += sh[i];
+  incl += base;
+  const uint32_t excl = incl - loc;
+  if (excl <= k && k < incl) {
+    uint32_t cum = excl;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      if (i < per) {
+        if (k < cum + c[i]) { sh[256] = (uint32_t)(t * per + i); sh[257] = k - cum; break; }
+        cum += c[i];
+      }
     }
-    uint32_t b = sel * per;
-    for (int i = 0; i < per; ++i) {
-      const uint32_t c = hist[sel * per + i];
-      b = sel * per + i;
-      if (k < cum + c) break;
-      if (i + 1 < per) cum += c;
-    }
-    sh[256] = b;
-    sh[257] = k - cum;
   }
   __syncthreads();
   *bin = sh[256];
