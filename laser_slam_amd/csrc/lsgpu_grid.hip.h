@@ -209,10 +209,16 @@ __global__ __launch_bounds__(256) void k_cells_count(const uint64_t* __restrict_
   if (threadIdx.x < kMaxLevels) sh[threadIdx.x] = 0;
   __syncthreads();
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  int lv = -1;
   if (i < n) {
-    int lv = (i == 0) ? bits : boundary_level(keys[i], keys[i - 1], fine);
+    lv = (i == 0) ? bits : boundary_level(keys[i], keys[i - 1], fine);
     if (lv > bits) lv = bits;
-    for (int l = 0; l <= lv; ++l) atomicAdd(&sh[l], 1u);
+  }
+  // per level: one ballot + one LDS add per wave (boundaries are rare: ~6 % of the points at level 0)
+  for (int l = 0; l <= bits; ++l) {
+    const unsigned long long m = __ballot(lv >= l);
+    if (!m) break;
+    if ((threadIdx.x & 63) == 0) atomicAdd(&sh[l], (uint32_t)__popcll(m));
   }
   __syncthreads();
   if (threadIdx.x <= bits && sh[threadIdx.x]) atomicAdd(&counts[threadIdx.x], sh[threadIdx.x]);
@@ -242,28 +248,30 @@ __device__ __forceinline__ HashEntry* cell_of_key(const TableSet& ts, int l, uin
   return table_slot(ts.tab[l], ts.mask[l], compact3(c), compact3(c >> 1), compact3(c >> 2));
 }
 
-// entries hold CHUNK ranges: the chunk that starts at point i is cidx[i]-1
+// Entries hold CHUNK ranges.  Every cell boundary (any level) is also a chunk boundary, so one thread
+// per CHUNK looks at the key step in front of its first point: chunk c opens the cells of the levels
+// that change there and closes the previous point's cells.
 __global__ __launch_bounds__(256) void k_cells_fill(const uint64_t* __restrict__ keys,
-                                                    const uint32_t* __restrict__ cidx, int64_t n,
-                                                    int fine, int bits, TableSet ts) {
-  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (i >= n) return;
+                                                    const uint32_t* __restrict__ bounds,
+                                                    uint32_t nchunks, int fine, int bits, TableSet ts) {
+  const uint32_t c = blockIdx.x * 256u + threadIdx.x;
+  if (c >= nchunks) return;
+  const uint32_t i = bounds[c];
   const uint64_t k = keys[i];
-  if (i == 0) {
+  if (c == 0) {
     for (int l = 0; l <= bits; ++l) cell_of_key(ts, l, k, fine)->start = 0;
   } else {
     const uint64_t kp = keys[i - 1];
     int lv = boundary_level(k, kp, fine);
     if (lv > bits) lv = bits;
-    const uint32_t ch = cidx[i] - 1;
     for (int l = 0; l <= lv; ++l) {
-      cell_of_key(ts, l, k, fine)->start = ch;
-      cell_of_key(ts, l, kp, fine)->end = ch;
+      cell_of_key(ts, l, k, fine)->start = c;
+      cell_of_key(ts, l, kp, fine)->end = c;
     }
   }
-  if (i == n - 1) {
-    const uint32_t nch = cidx[i];
-    for (int l = 0; l <= bits; ++l) cell_of_key(ts, l, k, fine)->end = nch;
+  if (c == nchunks - 1) {
+    const uint64_t kl = keys[bounds[nchunks] - 1];
+    for (int l = 0; l <= bits; ++l) cell_of_key(ts, l, kl, fine)->end = nchunks;
   }
 }
 

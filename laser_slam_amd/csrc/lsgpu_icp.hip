@@ -356,8 +356,8 @@ static int run_select(lsgpu_icp* h, const float* d2, int n, uint32_t k, bool zer
   if (zero_hist) HIPC(hipMemsetAsync(h->hist.p, 0, 3 * kHistBins * sizeof(uint32_t), h->stream));
   if (zero_hist) {  // sel[0] = {0, k}: constant during an align, uploaded once
     SelState s0{0u, k};
-    std::memcpy(h->h_pinned + 48, &s0, sizeof(s0));
-    HIPC(hipMemcpyAsync(h->sel.p, h->h_pinned + 48, sizeof(SelState), hipMemcpyHostToDevice, h->stream));
+    std::memcpy(h->h_pinned + 56, &s0, sizeof(s0));
+    HIPC(hipMemcpyAsync(h->sel.p, h->h_pinned + 56, sizeof(SelState), hipMemcpyHostToDevice, h->stream));
   }
   const int nb = std::min(kHistBlocks, nblk(n));
   hipLaunchKernelGGL(k_hist1, dim3(nb), dim3(256), 0, h->stream, d2, n, h->hist.p, st);
@@ -488,10 +488,9 @@ int lsgpu_icp_set_reference(lsgpu_icp* h, const float* ref_xyz1, const float* re
     ts.tab[l] = h->tables.p + off[l]; ts.mask[l] = cap[l] - 1;
     g.tab[l] = ts.tab[l]; g.mask[l] = ts.mask[l];
   }
-  hipLaunchKernelGGL(k_cells_fill, dim3(nblk(nr)), dim3(256), 0, h->stream, h->keys_alt.p, h->cidx.p,
-                     nr, fine, bits, ts);
-  HIPC(hipGetLastError());
-  HIPC(hipStreamSynchronize(h->stream));
+  hipLaunchKernelGGL(k_cells_fill, dim3((nchunks + 255) / 256), dim3(256), 0, h->stream, h->keys_alt.p,
+                     h->bounds.p, nchunks, fine, bits, ts);
+  HIPC(hipGetLastError());  // (no sync: align / knn follow on the same stream)
   h->grid = g;
   h->nr = nr;
   h->nchunks = nchunks;
@@ -659,7 +658,7 @@ int lsgpu_icp_align(lsgpu_icp* h, const float* reading_xyz1, int64_t nq, const f
   HIPC(h->state.reserve(1));
   HIPC(h->chk_hist.reserve((size_t)8 * (max_it + 2)));
   HIPC(h->trace_dev.reserve((size_t)max_it));
-  IcpState* hst = reinterpret_cast<IcpState*>(h->h_pinned + 64);  // pinned staging (<= 512 B)
+  IcpState* hst = reinterpret_cast<IcpState*>(h->h_pinned + 64);  // pinned staging (<= 512 B); [0..47] D2H, [48..63] H2D
   static_assert(sizeof(IcpState) <= 64 * sizeof(double), "IcpState staging");
   std::memset(hst, 0, sizeof(IcpState));
   hostmath::identity4(hst->T_iter);
@@ -678,7 +677,6 @@ int lsgpu_icp_align(lsgpu_icp* h, const float* reading_xyz1, int64_t nq, const f
   }
   HIPC(hipMemcpyAsync(h->state.p, hst, sizeof(IcpState), hipMemcpyHostToDevice, h->stream));
   HIPC(hipMemsetAsync(h->counters.p + 32, 0, 2 * sizeof(uint32_t), h->stream));  // stragglers, NE ticket
-  HIPC(hipStreamSynchronize(h->stream));  // the staging area is reused below
 
   const uint32_t k = trim_rank(nq, h->cfg.trim_ratio);
   const int nb = std::min(kNeBlocks, nblk(nq));
