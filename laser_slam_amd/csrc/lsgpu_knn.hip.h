@@ -31,6 +31,7 @@
 namespace lsgpu {
 
 constexpr float kPruneShrink = 1.0f - 2e-6f;  // a box is skipped only if mind2 * this > best
+constexpr float kCapSearchMargin2 = 1.05f * 1.05f;  // (search radius / cap radius)^2 in capped launches
 constexpr float kPadCoord = 3e18f;            // LDS pad point: squared distance ~2.7e37, never best
 
 struct KnnArgs {
@@ -55,6 +56,7 @@ struct KnnArgs {
   uint4* dbg_wave;          // optional per-wave {cycles, chunk evals, proxy survivors, groups<<8|level}
   int ntiles;               // number of 64-query tiles
   int pad_index;            // index of the first far pad point behind pts (= Nr)
+  int chunk_budget;         // a wide wave whose region holds more chunks than this searches per lane
   uint2* cell_cache;        // per tile: the 64 (chunk_start, chunk_end) probe results of its cell block
   ulonglong2* cell_tags;    // per tile: which block (generation, level, origin, extent) the cache holds
   uint32_t cache_gen;       // bumped by every set_reference / align: older entries never match
@@ -140,32 +142,51 @@ __device__ __forceinline__ void lane_ball_search(const KnnArgs& a, float cap2, f
   sh = g.fine + l;
   const int x0 = flx >> sh, y0 = fly >> sh, z0 = flz >> sh;
   const int x1 = fhx >> sh, y1 = fhy >> sh, z1 = fhz >> sh;
-  for (int cz = z0; cz <= z1; ++cz)
-    for (int cy = y0; cy <= y1; ++cy)
-      for (int cx = x0; cx <= x1; ++cx) {
-        uint32_t cs, ce;
-        if (!grid_lookup(g, l, (uint32_t)cx, (uint32_t)cy, (uint32_t)cz, cs, ce)) continue;
-        for (uint32_t ch = cs; ch < ce; ++ch) {
-          const float4* cd = reinterpret_cast<const float4*>(a.chunks + ch);
-          const float4 b0 = cd[0], b1 = cd[1];
-          if (!(box_dist2(b0.x, b0.y, b0.z, b1.x, b1.y, b1.z, qx, qy, qz) * kPruneShrink <= prune))
-            continue;
-          const uint32_t st = __float_as_uint(b0.w), cnt = __float_as_uint(b1.w);
-          for (uint32_t t = 0; t < cnt; t += 4) {
-            const float4 p0 = a.pts[st + t], p1 = a.pts[st + t + 1], p2 = a.pts[st + t + 2],
-                         p3 = a.pts[st + t + 3];
-            const float d0 = dist2(qx - p0.x, qy - p0.y, qz - p0.z);
-            const float d1 = dist2(qx - p1.x, qy - p1.y, qz - p1.z);
-            const float d2 = dist2(qx - p2.x, qy - p2.y, qz - p2.z);
-            const float d3 = dist2(qx - p3.x, qy - p3.y, qz - p3.z);
-            if (d0 < best) { best = d0; bi = (int)(st + t); }
-            if (d1 < best) { best = d1; bi = (int)(st + t + 1); }
-            if (d2 < best) { best = d2; bi = (int)(st + t + 2); }
-            if (d3 < best) { best = d3; bi = (int)(st + t + 3); }
-          }
-          prune = fminf(best, cap2);
-        }
+  // all (up to 8) first probes in flight together: one table latency instead of eight
+  const uint32_t mask = g.mask[l];
+  const uint4* tab = reinterpret_cast<const uint4*>(g.tab[l]);
+  uint4 en[8];
+  uint32_t slot[8];
+  bool want[8];
+#pragma unroll
+  for (int c = 0; c < 8; ++c) {
+    const int cx = x0 + (c & 1), cy = y0 + ((c >> 1) & 1), cz = z0 + (c >> 2);
+    want[c] = cx <= x1 && cy <= y1 && cz <= z1;
+    slot[c] = cell_hash((uint32_t)cx, (uint32_t)cy, (uint32_t)cz) & mask;
+    en[c] = make_uint4(kEmpty, 0u, 0u, 0u);
+    if (want[c]) en[c] = tab[slot[c]];
+  }
+#pragma unroll
+  for (int c = 0; c < 8; ++c) {
+    if (!want[c]) continue;
+    const uint32_t cx = (uint32_t)(x0 + (c & 1)), cy = (uint32_t)(y0 + ((c >> 1) & 1)), cz = (uint32_t)(z0 + (c >> 2));
+    const uint32_t xy = cx | (cy << 16);
+    uint4 e = en[c];
+    uint32_t sl = slot[c];
+    while (!(((e.x ^ xy) | (e.y ^ cz)) == 0u) && e.x != kEmpty) {  // collision chain (rare)
+      sl = (sl + 1) & mask;
+      e = tab[sl];
+    }
+    if (e.x == kEmpty) continue;
+    for (uint32_t ch = e.z; ch < e.w; ++ch) {
+      const float4* cd = reinterpret_cast<const float4*>(a.chunks + ch);
+      const float4 b0 = cd[0], b1 = cd[1];
+      if (!(box_dist2(b0.x, b0.y, b0.z, b1.x, b1.y, b1.z, qx, qy, qz) * kPruneShrink <= prune)) continue;
+      const uint32_t st = __float_as_uint(b0.w), cnt = __float_as_uint(b1.w);
+      for (uint32_t t = 0; t < cnt; t += 4) {
+        const float4 p0 = a.pts[st + t], p1 = a.pts[st + t + 1], p2 = a.pts[st + t + 2], p3 = a.pts[st + t + 3];
+        const float d0 = dist2(qx - p0.x, qy - p0.y, qz - p0.z);
+        const float d1 = dist2(qx - p1.x, qy - p1.y, qz - p1.z);
+        const float d2 = dist2(qx - p2.x, qy - p2.y, qz - p2.z);
+        const float d3 = dist2(qx - p3.x, qy - p3.y, qz - p3.z);
+        if (d0 < best) { best = d0; bi = (int)(st + t); }
+        if (d1 < best) { best = d1; bi = (int)(st + t + 1); }
+        if (d2 < best) { best = d2; bi = (int)(st + t + 2); }
+        if (d3 < best) { best = d3; bi = (int)(st + t + 3); }
       }
+      prune = fminf(best, cap2);
+    }
+  }
 }
 
 // ---------------------------------------------------------------- tile search
@@ -329,6 +350,9 @@ __global__ __launch_bounds__(WAVES * 64, 8) void k_knn_tile(KnnArgs a) {
   if (tile >= (uint32_t)a.ntiles) return;
   Mat34 T; float cap2;
   if (!iter_params(a.st, a.T, a.cap2, a.use_state_cap, T, cap2)) return;
+  // Search / verification radius 5 % beyond the cap: a lane verified to have nothing inside keeps a
+  // lower bound ABOVE the next iterations' caps, so it is skipped (farskip) instead of re-verified.
+  const float cap2s = cap2 * kCapSearchMargin2;
   const int j = (int)(tile * 64u) + lane;
   const bool act = j < a.nq;
   const GridDev& g = a.g;
@@ -365,8 +389,8 @@ __global__ __launch_bounds__(WAVES * 64, 8) void k_knn_tile(KnnArgs a) {
     lbn = fmaxf(a.lb[j] * (1.0f - 1e-6f) - delta, 0.f);
     farskip = lbn * lbn > cap2 * (1.0f + 1e-5f);  // provably beyond the cap: weight 0 whatever it is
   }
-  // only neighbours closer than min(best, cap2) can matter
-  const float R = sqrtf(fminf(best, cap2)) * (1.0f + 1e-5f) + 1e-7f;
+  // only neighbours closer than min(best, cap2s) can matter
+  const float R = sqrtf(fminf(best, cap2s)) * (1.0f + 1e-5f) + 1e-7f;
   const bool straggler = act && !farskip && !(R <= a.r_cap);
   const bool ing = act && !straggler && !farskip;
 #ifdef LSGPU_KNN_STATS
@@ -379,7 +403,7 @@ __global__ __launch_bounds__(WAVES * 64, 8) void k_knn_tile(KnnArgs a) {
     const float tly = wave_min(ing ? qy : INFINITY), thy = wave_max(ing ? qy : -INFINITY);
     const float tlz = wave_min(ing ? qz : INFINITY), thz = wave_max(ing ? qz : -INFINITY);
     const float Rmax = wave_max(ing ? R : 0.f);
-    float maxbest = wave_max(ing ? fminf(best, cap2) : 0.f);
+    float maxbest = wave_max(ing ? fminf(best, cap2s) : 0.f);
     const int lim = (1 << (g.bits + g.fine)) - 1;
     // fine-key box of the region (every lane's ball lies inside), widened by the rounding slack
     const float pad = Rmax + kFineSlack * g.hf;
@@ -438,14 +462,14 @@ __global__ __launch_bounds__(WAVES * 64, 8) void k_knn_tile(KnnArgs a) {
     // A wave whose queries are spread far wider than their balls (sparse far field, Morton jumps)
     // shares no candidates: its lanes search on their own.
     const float ext = fmaxf(fmaxf(thx - tlx, thy - tly), thz - tlz);
-    const bool spread = ext > fmaxf(a.group_r, 4.f * Rmax) && wave_sum_u32(ce - cs) > kChunkBudget;
+    const bool spread = ext > fmaxf(a.group_r, 4.f * Rmax) && wave_sum_u32(ce - cs) > (uint32_t)a.chunk_budget;
 #ifdef LSGPU_KNN_STATS
     if (spread && (a.dbg_flags & 32)) { /* ablation: drop spread waves */ } else
 #endif
     if (spread) {
       if (ing) {  // tracks the exact index itself
         const int before = bi;
-        lane_ball_search(a, cap2, qx, qy, qz, best, bi);
+        lane_ball_search(a, cap2s, qx, qy, qz, best, bi);
         if (bi != before) { const float4 p = a.pts[bi]; mp = make_float4(p.x, p.y, p.z, __int_as_float(bi)); }
       }
       n_grp = 64;
@@ -468,7 +492,7 @@ __global__ __launch_bounds__(WAVES * 64, 8) void k_knn_tile(KnnArgs a) {
           while (fill >= 64u) {  // a full batch is ready
             fill -= 64u;
             const uint32_t ch = lds.list[fill + lane];
-            tile_process_batch(a, cap2, lds, lane, true, ch, ing, qx, qy, qz, tlx, tly, tlz, thx, thy, thz,
+            tile_process_batch(a, cap2s, lds, lane, true, ch, ing, qx, qy, qz, tlx, tly, tlz, thx, thy, thz,
                                maxbest, best, grp, n_eval, n_surv);
           }
         }
@@ -476,7 +500,7 @@ __global__ __launch_bounds__(WAVES * 64, 8) void k_knn_tile(KnnArgs a) {
       if (fill) {
         const bool v = (uint32_t)lane < fill;
         const uint32_t ch = v ? lds.list[lane] : 0u;
-        tile_process_batch(a, cap2, lds, lane, v, ch, ing, qx, qy, qz, tlx, tly, tlz, thx, thy, thz,
+        tile_process_batch(a, cap2s, lds, lane, v, ch, ing, qx, qy, qz, tlx, tly, tlz, thx, thy, thz,
                            maxbest, best, grp, n_eval, n_surv);
       }
     }
@@ -492,8 +516,8 @@ __global__ __launch_bounds__(WAVES * 64, 8) void k_knn_tile(KnnArgs a) {
     if (a.lb) {
       float nb;
       if (farskip) nb = lbn;
-      else if (best <= cap2) nb = sqrtf(best) * (1.0f - 1e-6f);               // exact neighbour
-      else nb = fmaxf(lbn, sqrtf(cap2) * (1.0f - 1e-5f));                     // nothing inside the cap
+      else if (best <= cap2s) nb = sqrtf(best) * (1.0f - 1e-6f);              // exact neighbour
+      else nb = fmaxf(lbn, sqrtf(cap2s) * (1.0f - 1e-5f));                    // nothing inside the search cap
       a.lb[j] = nb;  // (stragglers: overwritten by the fallback)
     }
     if (straggler) a.strag[atomicAdd(a.strag_count, 1u)] = (uint32_t)j;
