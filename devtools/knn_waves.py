@@ -29,13 +29,5 @@ print("sum cycles / (1024 SIMD) = %.0f cycles; max single wave = %.0f" % (cyc.su
 top = np.argsort(-cyc)[:8]
 for t in top: print("wave", t, "cycles", cyc[t], "evals", ev[t], "surv", sv[t], "groups", grp[t], "lvl", lvl[t])
 print("corr cycles~evals", np.corrcoef(cyc, ev)[0, 1], "cycles per eval (fit)", np.polyfit(ev, cyc, 1))
-# timeline (column 2 now holds the low 32 bits of the start time)
-st0 = buf[:, 2].astype(np.int64); st0 = (st0 - st0.min()) & 0xFFFFFFFF
-en = st0 + cyc
-print("timeline: last start %.0f, last end %.0f (cycles after first start)" % (st0.max(), en.max()))
-for frac in (0.5, 0.9, 0.99, 0.999):
-    print("  %.1f%% of waves ended by %.0f" % (100*frac, np.percentile(en, 100*frac)))
-order = np.argsort(st0)
-print("  start time of wave #k in start order: k=1000 %.0f, 4000 %.0f, 8000 %.0f, 12000 %.0f, 16000 %.0f" % tuple(st0[order][[1000,4000,8000,12000,16000]]))
-conc = [( (st0 <= t) & (en > t) ).sum() for t in np.linspace(0, en.max(), 21)]
-print("  concurrent waves at 21 instants:", conc)
+# which tiles are the slow ones: dump query extents of the top waves
+rdq = rd  # original order unknown here; only stats

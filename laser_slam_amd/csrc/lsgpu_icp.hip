@@ -301,7 +301,7 @@ static KnnArgs knn_args(lsgpu_icp* h, const Mat34& T) {
   a.dbg = h->knn_dbg.p;
   a.dbg_wave = h->knn_dbg_wave.p;
   { const char* e = getenv("LSGPU_KNN_DBG"); a.dbg_flags = e ? atoi(e) : 0;
-    if ((a.dbg_flags & (64 | 128 | 256 | 512)) && h->dbg_launch_no < 6) a.dbg_flags = 0; }  // early-exit ablations from launch 6 on
+    if ((a.dbg_flags & (64 | 128 | 256 | 512 | 1024 | 2048)) && h->dbg_launch_no < 6) a.dbg_flags = 0; }  // early-exit ablations from launch 6 on
   return a;
 }
 
@@ -775,6 +775,28 @@ int lsgpu_icp_align(lsgpu_icp* h, const float* reading_xyz1, int64_t nq, const f
   st.t_total_ms = wall_ms() - t0;
   if (stats) *stats = st;
   return rc;
+}
+
+// dev only (LSGPU_KNN_STATS build): per-wave records of the last k_knn_tile launch / global counters
+int lsgpu_dev_knn_wave_stats(lsgpu_icp* h, unsigned int* out, int nwaves) {
+  if (!h) return LSGPU_BAD_ARG;
+  if (!out) { HIPC(h->knn_dbg_wave.reserve((size_t)nwaves)); HIPC(hipMemset(h->knn_dbg_wave.p, 0, (size_t)nwaves * 16)); return LSGPU_OK; }
+  HIPC(hipStreamSynchronize(h->stream));
+  HIPC(hipMemcpy(out, h->knn_dbg_wave.p, (size_t)nwaves * 16, hipMemcpyDeviceToHost));
+  return LSGPU_OK;
+}
+int lsgpu_dev_knn_counters(lsgpu_icp* h, unsigned long long out[8]) {
+  if (!h) return LSGPU_BAD_ARG;
+  if (!h->knn_dbg.p) {
+    HIPC(h->knn_dbg.reserve(8));
+    HIPC(hipMemset(h->knn_dbg.p, 0, 64));
+    std::memset(out, 0, 64);
+    return LSGPU_OK;
+  }
+  HIPC(hipStreamSynchronize(h->stream));
+  HIPC(hipMemcpy(out, h->knn_dbg.p, 64, hipMemcpyDeviceToHost));
+  HIPC(hipMemset(h->knn_dbg.p, 0, 64));
+  return LSGPU_OK;
 }
 
 int lsgpu_icp_get_trace(lsgpu_icp* h, lsgpu_iter_trace* out, int cap) {

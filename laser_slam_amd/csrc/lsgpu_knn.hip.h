@@ -353,6 +353,10 @@ __global__ __launch_bounds__(WAVES * 64, 8) void k_knn_tile(KnnArgs a) {
   // Search / verification radius 5 % beyond the cap: a lane verified to have nothing inside keeps a
   // lower bound ABOVE the next iterations' caps, so it is skipped (farskip) instead of re-verified.
   const float cap2s = cap2 * kCapSearchMargin2;
+#ifdef LSGPU_KNN_STATS
+  if ((a.dbg_flags & 1024) && (tile & 1u)) return;
+  if ((a.dbg_flags & 2048) && (tile & 3u)) return;
+#endif
   const int j = (int)(tile * 64u) + lane;
   const bool act = j < a.nq;
   const GridDev& g = a.g;
