@@ -208,17 +208,20 @@ __global__ __launch_bounds__(256) void k_cells_count(const uint64_t* __restrict_
   __shared__ uint32_t sh[kMaxLevels];
   if (threadIdx.x < kMaxLevels) sh[threadIdx.x] = 0;
   __syncthreads();
-  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  int lv = -1;
-  if (i < n) {
-    lv = (i == 0) ? bits : boundary_level(keys[i], keys[i - 1], fine);
-    if (lv > bits) lv = bits;
-  }
-  // per level: one ballot + one LDS add per wave (boundaries are rare: ~6 % of the points at level 0)
-  for (int l = 0; l <= bits; ++l) {
-    const unsigned long long m = __ballot(lv >= l);
-    if (!m) break;
-    if ((threadIdx.x & 63) == 0) atomicAdd(&sh[l], (uint32_t)__popcll(m));
+  // grid-stride: few blocks, so that the final global adds (same 12 addresses for every block) stay cheap
+  for (int64_t i0 = (int64_t)blockIdx.x * 256; i0 < n; i0 += (int64_t)gridDim.x * 256) {
+    const int64_t i = i0 + threadIdx.x;
+    int lv = -1;
+    if (i < n) {
+      lv = (i == 0) ? bits : boundary_level(keys[i], keys[i - 1], fine);
+      if (lv > bits) lv = bits;
+    }
+    // per level: one ballot + one LDS add per wave (boundaries are rare: ~6 % of the points at level 0)
+    for (int l = 0; l <= bits; ++l) {
+      const unsigned long long m = __ballot(lv >= l);
+      if (!m) break;
+      if ((threadIdx.x & 63) == 0) atomicAdd(&sh[l], (uint32_t)__popcll(m));
+    }
   }
   __syncthreads();
   if (threadIdx.x <= bits && sh[threadIdx.x]) atomicAdd(&counts[threadIdx.x], sh[threadIdx.x]);
@@ -254,24 +257,27 @@ __device__ __forceinline__ HashEntry* cell_of_key(const TableSet& ts, int l, uin
 __global__ __launch_bounds__(256) void k_cells_fill(const uint64_t* __restrict__ keys,
                                                     const uint32_t* __restrict__ bounds,
                                                     uint32_t nchunks, int fine, int bits, TableSet ts) {
+  // one thread per (chunk, level): the inserts are device-scope CAS round trips, so the levels of one
+  // chunk must not queue up behind each other in a single thread
   const uint32_t c = blockIdx.x * 256u + threadIdx.x;
+  const int l = (int)blockIdx.y;
   if (c >= nchunks) return;
   const uint32_t i = bounds[c];
   const uint64_t k = keys[i];
   if (c == 0) {
-    for (int l = 0; l <= bits; ++l) cell_of_key(ts, l, k, fine)->start = 0;
+    cell_of_key(ts, l, k, fine)->start = 0;
   } else {
     const uint64_t kp = keys[i - 1];
     int lv = boundary_level(k, kp, fine);
     if (lv > bits) lv = bits;
-    for (int l = 0; l <= lv; ++l) {
+    if (l <= lv) {
       cell_of_key(ts, l, k, fine)->start = c;
       cell_of_key(ts, l, kp, fine)->end = c;
     }
   }
   if (c == nchunks - 1) {
     const uint64_t kl = keys[bounds[nchunks] - 1];
-    for (int l = 0; l <= bits; ++l) cell_of_key(ts, l, kl, fine)->end = nchunks;
+    cell_of_key(ts, l, kl, fine)->end = nchunks;
   }
 }
 

@@ -460,7 +460,7 @@ int lsgpu_icp_set_reference(lsgpu_icp* h, const float* ref_xyz1, const float* re
   // ---- cell counts per level (+ chunk count) -> host, to size the tables
   HIPC(h->counters.reserve(64));
   HIPC(hipMemsetAsync(h->counters.p, 0, 64 * sizeof(uint32_t), h->stream));
-  hipLaunchKernelGGL(k_cells_count, dim3(nblk(nr)), dim3(256), 0, h->stream, h->keys_alt.p, nr, fine,
+  hipLaunchKernelGGL(k_cells_count, dim3(std::min(512, nblk(nr))), dim3(256), 0, h->stream, h->keys_alt.p, nr, fine,
                      bits, h->counters.p);
   uint32_t* hc = reinterpret_cast<uint32_t*>(h->h_pinned);
   HIPC(hipMemcpyAsync(hc, h->counters.p, kMaxLevels * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
@@ -489,7 +489,7 @@ int lsgpu_icp_set_reference(lsgpu_icp* h, const float* ref_xyz1, const float* re
     ts.tab[l] = h->tables.p + off[l]; ts.mask[l] = cap[l] - 1;
     g.tab[l] = ts.tab[l]; g.mask[l] = ts.mask[l];
   }
-  hipLaunchKernelGGL(k_cells_fill, dim3((nchunks + 255) / 256), dim3(256), 0, h->stream, h->keys_alt.p,
+  hipLaunchKernelGGL(k_cells_fill, dim3((nchunks + 255) / 256, bits + 1), dim3(256), 0, h->stream, h->keys_alt.p,
                      h->bounds.p, nchunks, fine, bits, ts);
   HIPC(hipGetLastError());  // (no sync: align / knn follow on the same stream)
   h->grid = g;
