@@ -1,0 +1,32 @@
+"""dev helper: BASELINE config 4 shape on one GPU -- 8 aggregated scans (8M-pt sub-map) vs one 1M-pt scan."""
+import ctypes as C, sys, os, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np, torch
+from laser_slam_amd import synth, icp
+from laser_slam_amd._lib import IcpConfig, lib
+n_az = int(sys.argv[1]) if len(sys.argv) > 1 else 16384
+scene = synth.Scene(1234)
+poses = [synth.se3(0.8 * i, 0.05 * i, synth.SENSOR_HEIGHT, yaw=np.deg2rad(2.0 * i)) for i in range(9)]
+t = time.time()
+parts = []
+T_ref = poses[7]
+for i in range(8):
+    s = synth.hdl64_scan(scene, poses[i], n_az, 20 + i)
+    Trel = np.linalg.inv(T_ref) @ poses[i]
+    p = s.copy(); p[:, :3] = (s[:, :3].astype(np.float64) @ Trel[:3, :3].T + Trel[:3, 3]).astype(np.float32)
+    parts.append(p)
+ref = np.concatenate(parts)
+rd = synth.hdl64_scan(scene, poses[8], n_az, 40)
+T_true = np.linalg.inv(T_ref) @ poses[8]
+T_init = synth.se3(0.25, -0.1, 0.05, yaw=np.deg2rad(1.2)) @ T_true
+print("gen", time.time() - t, ref.shape, rd.shape)
+t = time.time(); rf, rn = icp.sampling_surface_normal(ref, 10, 1.0, 0); print("normals (host)", time.time() - t)
+cfg = IcpConfig(); lib().lsgpu_icp_config_yaml(C.byref(cfg)); cfg.min_diff_rot, cfg.min_diff_trans = 1e-5, 1e-4; cfg.profile_kernels = 1
+h = icp.IcpHandle(cfg)
+dref, dn, drd = torch.from_numpy(rf).cuda(), torch.from_numpy(rn).cuda(), torch.from_numpy(rd).cuda()
+for rep in range(2):
+    t = time.perf_counter(); h.set_reference(dref, dn); torch.cuda.synchronize(); t1 = time.perf_counter()
+    T, st = h.align(drd, T_init); t2 = time.perf_counter()
+print("set_reference ms %.2f align ms %.2f iters %d knn avg us %.1f cap_retries %d" % ((t1 - t) * 1e3, (t2 - t1) * 1e3, st.iterations, st.t_knn_ms / max(st.knn_launches, 1) * 1e3, st.cap_retries))
+print("err vs truth", synth.pose_error(T.astype(np.float64), T_true), "info chunks", h.info().n_chunks, list(h.info().cells)[:6])

@@ -98,6 +98,17 @@ int lsgpu_icp_set_reference(lsgpu_icp* h, const float* ref_xyz1, const float* re
 int lsgpu_icp_align(lsgpu_icp* h, const float* reading_xyz1, int64_t nq, const float T_init[16],
                     float T_out[16], lsgpu_icp_stats* stats);
 
+/* ---- one scan pair split over several GPUs (BASELINE config 4) -------------------------
+ * Every rank holds the whole reference (set_reference with the same cloud) and ITS shard of the reading.
+ * After lsgpu_icp_comm_init, lsgpu_icp_align treats its `reading_xyz1` as the local shard: per iteration
+ * the three select histograms (3 x 2048 u32) and the 29 normal-equation sums are all-reduced over RCCL on
+ * the handle's stream, so every rank computes the same limit, the same 6x6 system and the same T.
+ * The unique id comes from rank 0 (lsgpu_comm_get_unique_id) and travels to the other ranks by any
+ * means (torch.distributed broadcast in laser_slam_amd/sharding.py).  Every rank needs >= 1 point. */
+#define LSGPU_COMM_ID_BYTES 128
+int lsgpu_comm_get_unique_id(void* id /* LSGPU_COMM_ID_BYTES */);
+int lsgpu_icp_comm_init(lsgpu_icp* h, int rank, int nranks, const void* id);
+
 /* Per-iteration records of the last align; returns the number written. */
 int lsgpu_icp_get_trace(lsgpu_icp* h, lsgpu_iter_trace* out, int cap);
 

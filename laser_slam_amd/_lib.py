@@ -18,7 +18,7 @@ OK, NO_CONVERGENCE, BAD_CONFIG, HIP_ERROR, BAD_ARG = 0, 1, 2, 3, 4
 ABI_SYMBOLS = [
     "lsgpu_icp_config_yaml", "lsgpu_icp_config_default", "lsgpu_icp_create", "lsgpu_icp_destroy",
     "lsgpu_icp_set_reference", "lsgpu_icp_align", "lsgpu_icp_get_trace",
-    "lsgpu_icp_get_reference_mean", "lsgpu_icp_get_info", "lsgpu_knn", "lsgpu_trim_limit", "lsgpu_normal_eq",
+    "lsgpu_icp_get_reference_mean", "lsgpu_icp_get_info", "lsgpu_comm_get_unique_id", "lsgpu_icp_comm_init", "lsgpu_knn", "lsgpu_trim_limit", "lsgpu_normal_eq",
     "lsgpu_transform_points", "lsgpu_filter_random_sampling",
     "lsgpu_filter_sampling_surface_normal", "lsgpu_check_rigid", "lsgpu_correct_rigid",
     "lsgpu_strerror", "lsgpu_last_error", "lsgpu_abi_version",
@@ -119,6 +119,8 @@ def lib() -> C.CDLL:
     L.lsgpu_icp_get_trace.argtypes = [vp, C.POINTER(IterTrace), C.c_int]
     L.lsgpu_icp_get_reference_mean.argtypes = [vp, C.POINTER(C.c_float)]
     L.lsgpu_icp_get_info.argtypes = [vp, C.POINTER(IcpInfo)]
+    L.lsgpu_comm_get_unique_id.argtypes = [C.c_char_p]
+    L.lsgpu_icp_comm_init.argtypes = [vp, C.c_int, C.c_int, C.c_char_p]
     L.lsgpu_knn.argtypes = [vp, fp, i64, C.POINTER(C.c_float), fp, fp]
     L.lsgpu_trim_limit.argtypes = [vp, fp, i64, C.c_float, C.POINTER(C.c_float)]
     L.lsgpu_normal_eq.argtypes = [vp, fp, i64, C.POINTER(C.c_float), fp, fp, C.c_float,

@@ -13,7 +13,10 @@
 #include <vector>
 #include <chrono>
 
+#include <dlfcn.h>
+
 #include <hip/hip_runtime.h>
+#include <rccl/rccl.h>  // types only: the library is opened lazily (dlopen) by lsgpu_icp_comm_init
 #include <rocprim/device/device_radix_sort.hpp>
 #include <rocprim/device/device_scan.hpp>
 
@@ -39,6 +42,36 @@ using namespace lsgpu;
   } while (0)
 
 namespace {
+
+// RCCL entry points, resolved at run time so that liblsgpu_icp.so itself has no RCCL dependency.
+struct RcclApi {
+  void* lib = nullptr;
+  ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+  ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+  ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  const char* (*GetErrorString)(ncclResult_t) = nullptr;
+};
+RcclApi* rccl_api() {
+  static RcclApi api;
+  static bool tried = false;
+  if (!tried) {
+    tried = true;
+    for (const char* name : {"librccl.so.1", "/opt/rocm/lib/librccl.so.1", "librccl.so"}) {
+      api.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+      if (api.lib) break;
+    }
+    if (api.lib) {
+      api.GetUniqueId = reinterpret_cast<decltype(api.GetUniqueId)>(dlsym(api.lib, "ncclGetUniqueId"));
+      api.CommInitRank = reinterpret_cast<decltype(api.CommInitRank)>(dlsym(api.lib, "ncclCommInitRank"));
+      api.AllReduce = reinterpret_cast<decltype(api.AllReduce)>(dlsym(api.lib, "ncclAllReduce"));
+      api.CommDestroy = reinterpret_cast<decltype(api.CommDestroy)>(dlsym(api.lib, "ncclCommDestroy"));
+      api.GetErrorString = reinterpret_cast<decltype(api.GetErrorString)>(dlsym(api.lib, "ncclGetErrorString"));
+      if (!api.GetUniqueId || !api.CommInitRank || !api.AllReduce || !api.CommDestroy) api.lib = nullptr;
+    }
+  }
+  return api.lib ? &api : nullptr;
+}
 
 template <class T>
 struct DevBuf {
@@ -105,6 +138,9 @@ struct lsgpu_icp {
   DevBuf<uint2> cell_cache;  // ntiles x 64
   DevBuf<ulonglong2> cell_tags;
   uint32_t cache_gen = 1;
+  ncclComm_t comm = nullptr;  // split-scan mode (lsgpu_icp_comm_init)
+  int comm_rank = 0, comm_size = 1;
+  DevBuf<long long> comm_tmp;
   int dbg_launch_no = 0;     // kNN launches since the last prepare_queries (stats build ablations)
   DevBuf<float> lb;          // per-query lower bound on the NN distance
   DevBuf<IcpState> state;    // loop state of the running align (device)
@@ -206,6 +242,8 @@ void lsgpu_icp_destroy(lsgpu_icp* h) {
   if (!h) return;
   (void)hipSetDevice(h->device);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
+  if (h->comm && rccl_api()) (void)rccl_api()->CommDestroy(h->comm);
+  h->comm_tmp.release();
   h->ref_in.release(); h->nrm_in.release(); h->keys.release(); h->keys_alt.release();
   h->vals.release(); h->vals_alt.release(); h->sort_tmp.release(); h->pts.release();
   h->nrm.release(); h->ref_inv.release(); h->tables.release(); h->flags.release(); h->cidx.release(); h->bounds.release(); h->chunks.release(); h->prev.release(); h->state.release(); h->lb.release(); h->cell_cache.release(); h->cell_tags.release(); h->chk_hist.release(); h->trace_dev.release(); h->knn_dbg.release(); h->knn_dbg_wave.release(); h->stat_partials.release();
@@ -351,9 +389,18 @@ static int run_knn(lsgpu_icp* h, const Mat34& T, const IcpState* st, bool seed, 
   return LSGPU_OK;
 }
 
+#define RCCLC(expr)                                                                     \
+  do {                                                                                  \
+    ncclResult_t r__ = (expr);                                                          \
+    if (r__ != ncclSuccess) {                                                           \
+      h->err = std::string("RCCL: ") + (rccl_api()->GetErrorString ? rccl_api()->GetErrorString(r__) : "error"); \
+      return LSGPU_HIP_ERROR;                                                           \
+    }                                                                                   \
+  } while (0)
+
 // TrimmedDist order statistic of d2[0..n) -> rank k; leaves hist3 + sel[2] for select_limit().
 static int run_select(lsgpu_icp* h, const float* d2, int n, uint32_t k, bool zero_hist = true,
-                      const IcpState* st = nullptr) {
+                      const IcpState* st = nullptr, bool use_comm = false) {
   if (zero_hist) HIPC(hipMemsetAsync(h->hist.p, 0, 3 * kHistBins * sizeof(uint32_t), h->stream));
   if (zero_hist) {  // sel[0] = {0, k}: constant during an align, uploaded once
     SelState s0{0u, k};
@@ -362,10 +409,13 @@ static int run_select(lsgpu_icp* h, const float* d2, int n, uint32_t k, bool zer
   }
   const int nb = std::min(kHistBlocks, nblk(n));
   hipLaunchKernelGGL(k_hist1, dim3(nb), dim3(256), 0, h->stream, d2, n, h->hist.p, st);
+  if (use_comm && h->comm) RCCLC(rccl_api()->AllReduce(h->hist.p, h->hist.p, kHistBins, ncclUint32, ncclSum, h->comm, h->stream));
   hipLaunchKernelGGL(k_hist_refine<2>, dim3(nb), dim3(256), 0, h->stream, d2, n, h->hist.p,
                      h->sel.p, h->sel.p + 1, h->hist.p + kHistBins, st);
+  if (use_comm && h->comm) RCCLC(rccl_api()->AllReduce(h->hist.p + kHistBins, h->hist.p + kHistBins, kHistBins, ncclUint32, ncclSum, h->comm, h->stream));
   hipLaunchKernelGGL(k_hist_refine<3>, dim3(nb), dim3(256), 0, h->stream, d2, n,
                      h->hist.p + kHistBins, h->sel.p + 1, h->sel.p + 2, h->hist.p + 2 * kHistBins, st);
+  if (use_comm && h->comm) RCCLC(rccl_api()->AllReduce(h->hist.p + 2 * kHistBins, h->hist.p + 2 * kHistBins, kHistBins, ncclUint32, ncclSum, h->comm, h->stream));
   HIPC(hipGetLastError());
   return LSGPU_OK;
 }
@@ -503,6 +553,31 @@ int lsgpu_icp_set_reference(lsgpu_icp* h, const float* ref_xyz1, const float* re
   h->info.n_chunks = nchunks;
   for (int l = 0; l <= bits; ++l) h->info.cells[l] = ncell[l];
   h->info.table_bytes = total * sizeof(HashEntry);
+  return LSGPU_OK;
+}
+
+int lsgpu_comm_get_unique_id(void* id) {
+  if (!id) return LSGPU_BAD_ARG;
+  RcclApi* api = rccl_api();
+  if (!api) return LSGPU_HIP_ERROR;
+  ncclUniqueId u;
+  if (api->GetUniqueId(&u) != ncclSuccess) return LSGPU_HIP_ERROR;
+  static_assert(sizeof(u) == LSGPU_COMM_ID_BYTES, "unique id size");
+  std::memcpy(id, &u, sizeof(u));
+  return LSGPU_OK;
+}
+
+int lsgpu_icp_comm_init(lsgpu_icp* h, int rank, int nranks, const void* id) {
+  if (!h || !id || nranks < 1 || rank < 0 || rank >= nranks) return LSGPU_BAD_ARG;
+  h->err.clear();
+  RcclApi* api = rccl_api();
+  if (!api) { h->err = "librccl.so.1 could not be loaded"; return LSGPU_HIP_ERROR; }
+  HIPC(hipSetDevice(h->device));
+  if (h->comm) { (void)api->CommDestroy(h->comm); h->comm = nullptr; }
+  ncclUniqueId u;
+  std::memcpy(&u, id, sizeof(u));
+  RCCLC(api->CommInitRank(&h->comm, nranks, u, rank));
+  h->comm_rank = rank; h->comm_size = nranks;
   return LSGPU_OK;
 }
 
@@ -679,7 +754,18 @@ int lsgpu_icp_align(lsgpu_icp* h, const float* reading_xyz1, int64_t nq, const f
   HIPC(hipMemcpyAsync(h->state.p, hst, sizeof(IcpState), hipMemcpyHostToDevice, h->stream));
   HIPC(hipMemsetAsync(h->counters.p + 32, 0, 2 * sizeof(uint32_t), h->stream));  // stragglers, NE ticket
 
-  const uint32_t k = trim_rank(nq, h->cfg.trim_ratio);
+  int64_t nq_total = nq;
+  if (h->comm) {  // TrimmedDist ranks over ALL matches: the rank uses the global count
+    HIPC(h->comm_tmp.reserve(2));
+    long long* hn = reinterpret_cast<long long*>(h->h_pinned + 60);
+    *hn = (long long)nq;
+    HIPC(hipMemcpyAsync(h->comm_tmp.p, hn, sizeof(long long), hipMemcpyHostToDevice, h->stream));
+    RCCLC(rccl_api()->AllReduce(h->comm_tmp.p, h->comm_tmp.p + 1, 1, ncclInt64, ncclSum, h->comm, h->stream));
+    HIPC(hipMemcpyAsync(hn, h->comm_tmp.p + 1, sizeof(long long), hipMemcpyDeviceToHost, h->stream));
+    HIPC(hipStreamSynchronize(h->stream));
+    nq_total = (int64_t)*hn;
+  }
+  const uint32_t k = trim_rank(nq_total, h->cfg.trim_ratio);
   const int nb = std::min(kNeBlocks, nblk(nq));
   const bool timed = h->cfg.profile_kernels != 0;
   const Mat34 Tdummy = to_mat34(hst->T_iter);
@@ -689,12 +775,17 @@ int lsgpu_icp_align(lsgpu_icp* h, const float* reading_xyz1, int64_t nq, const f
     int r = run_knn(h, Tdummy, h->state.p, seed, capped, timed);                         // 6a+6b
     if (r) return r;
     ev_of_launch.push_back(h->knn_events_used ? h->knn_events_used - 1 : 0);
-    r = run_select(h, h->d2.p, (int)nq, k, first_select, h->state.p);                    // 6c
+    r = run_select(h, h->d2.p, (int)nq, k, first_select, h->state.p, true);                    // 6c
     first_select = false;
     if (r) return r;
     hipLaunchKernelGGL(k_normal_eq_loop, dim3(nb), dim3(256), 0, h->stream, h->rdq.p, (int)nq,
                        h->state.p, h->prev.p, h->d2.p, h->nrm.p, h->hist.p, h->sel.p + 2,
                        h->counters.p + 32, h->counters.p + 33, h->ne_partials.p, h->ne_out.p);  // 6d
+    if (h->comm &&   // split scan: every rank gets the sums over all shards (the limit, slot 29, is already global)
+        rccl_api()->AllReduce(h->ne_out.p, h->ne_out.p, kNe, ncclDouble, ncclSum, h->comm, h->stream) != ncclSuccess) {
+      h->err = "RCCL all-reduce of the normal equations failed";
+      return LSGPU_HIP_ERROR;
+    }
     hipLaunchKernelGGL(k_icp_update, dim3(1), dim3(64), 0, h->stream, h->state.p, h->ne_out.p,
                        h->chk_hist.p, h->trace_dev.p, max_it, capped ? 1 : 0);             // 6d+6e
     return hipGetLastError() == hipSuccess ? LSGPU_OK : LSGPU_HIP_ERROR;

@@ -116,6 +116,15 @@ class IcpHandle:
             _raise(rc, "lsgpu_icp_get_reference_mean", self._h)
         return m
 
+    def comm_init(self, rank: int, nranks: int, unique_id: bytes):
+        """Split-scan mode: this handle's align() now takes the LOCAL shard of the reading and
+        all-reduces the select histograms and normal-equation sums over RCCL (include/lsgpu_icp.h)."""
+        if len(unique_id) != 128:
+            raise ValueError("unique id must be 128 bytes")
+        rc = _lib.lib().lsgpu_icp_comm_init(self._h, rank, nranks, unique_id)
+        if rc != _lib.OK:
+            _raise(rc, "lsgpu_icp_comm_init", self._h)
+
     def info(self) -> "_lib.IcpInfo":
         out = _lib.IcpInfo()
         rc = _lib.lib().lsgpu_icp_get_info(self._h, C.byref(out))
@@ -196,6 +205,15 @@ class IcpHandle:
         if rc != _lib.OK:
             _raise(rc, "lsgpu_transform_points", self._h)
         return out
+
+
+def comm_unique_id() -> bytes:
+    """RCCL unique id (call on rank 0, ship to the other ranks)."""
+    buf = C.create_string_buffer(128)
+    rc = _lib.lib().lsgpu_comm_get_unique_id(buf)
+    if rc != _lib.OK:
+        _raise(rc, "lsgpu_comm_get_unique_id")
+    return buf.raw
 
 
 # ---------------------------------------------------------------------------------------------

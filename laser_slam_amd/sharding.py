@@ -44,3 +44,26 @@ def gather_results(local: List[Tuple[int, object]]):
     dist.all_gather_object(out, local)
     merged = [kv for part in out for kv in part]
     return sorted(merged, key=lambda kv: kv[0])
+
+
+def split_shard(n_points: int, rank: int, world: int):
+    """Contiguous query shard of rank `rank` for the split-scan mode (BASELINE config 4): slice object."""
+    per = (n_points + world - 1) // world
+    return slice(min(rank * per, n_points), min((rank + 1) * per, n_points))
+
+
+def init_split_comm(handle, device=None):
+    """Give `handle` (laser_slam_amd.icp.IcpHandle) an RCCL communicator spanning the default
+    torch.distributed group: rank 0 creates the unique id, everybody receives it by broadcast."""
+    import torch
+    import torch.distributed as dist
+    from . import icp
+    rank = dist.get_rank() if dist.is_initialized() else 0
+    world = dist.get_world_size() if dist.is_initialized() else 1
+    uid = icp.comm_unique_id() if rank == 0 else bytes(128)
+    if world > 1:
+        t = torch.tensor(list(uid), dtype=torch.uint8, device=device)
+        dist.broadcast(t, src=0)
+        uid = bytes(t.cpu().tolist())
+    handle.comm_init(rank, world, uid)
+    return rank, world

@@ -340,3 +340,17 @@ def test_full_size_properties(icp_mod):
         Tg, st = h.align(rd, T_init)
     et, er = synth.pose_error(Tg.astype(np.float64), T_true)
     assert et < 0.02 and er < 1e-3 and st.iterations < 40
+
+
+def test_split_scan_world1_equals_plain(icp_mod, pair64k):
+    """Split-scan mode with a one-rank RCCL communicator: identical result, exercises every collective."""
+    rf, rn = _filtered(icp_mod, pair64k)
+    with icp_mod.IcpHandle() as h:
+        h.set_reference(rf, rn)
+        T0, st0 = h.align(pair64k["rd"], pair64k["T_init"])
+        tr0 = [(t["limit"], t["n_used"]) for t in h.trace()]
+        h.comm_init(0, 1, icp_mod.comm_unique_id())
+        T1, st1 = h.align(pair64k["rd"], pair64k["T_init"])
+        tr1 = [(t["limit"], t["n_used"]) for t in h.trace()]
+    assert st0.iterations == st1.iterations and tr0 == tr1
+    assert np.array_equal(T0, T1)

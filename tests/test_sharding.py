@@ -81,3 +81,74 @@ def test_two_rank_gloo_run_matches_single_process():
         rc1, T1, st1, _ = O.icp_compute(O.config_yaml(accum_double=1), rd, rf, rn, synth.colmajor(T_init), 0)
         assert rc == rc1 == 0 and iters == st1.iterations
         assert np.array_equal(np.array(T, np.float32), T1)
+
+
+def _split_worker(rank, world, port, q):
+    """One ICP iteration of the split-scan scheme on CPU: queries sharded, reference replicated, the
+    three select histograms and the 29 normal-equation sums all-reduced (gloo) -- the arithmetic the
+    HIP path performs with RCCL (include/lsgpu_icp.h, lsgpu_icp_comm_init)."""
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch
+    import torch.distributed as dist
+    from laser_slam_amd import sharding, synth
+    from oracle import oracle_py as O
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    ref, rd, T_true, T_init = synth.scan_pair(64)
+    rf, rn = O.sampling_surface_normal(ref, 10, 1.0, 0)
+    q_all = O.transform_points(synth.colmajor(T_init), rd)
+    sl = sharding.split_shard(q_all.shape[0], rank, world)
+    qs = q_all[sl]
+    ids, d2 = O.KdTree(rf).nn(qs)
+    n_total = torch.tensor([qs.shape[0]], dtype=torch.int64)
+    dist.all_reduce(n_total)
+    k = min(int(np.float32(int(n_total)) * np.float32(0.75)), int(n_total) - 1)
+    # exact radix select on float bits, 12 + 11 + 9, histograms all-reduced after every pass
+    bits = d2.view(np.uint32).astype(np.int64)
+    prefix, shift_hi = 0, 32
+    for nb, shift in ((12, 20), (11, 9), (9, 0)):
+        sel = bits >> shift_hi == prefix if shift_hi < 32 else np.ones(bits.shape, bool)
+        h = torch.from_numpy(np.bincount((bits[sel] >> shift) & ((1 << nb) - 1), minlength=1 << nb).astype(np.int64))
+        dist.all_reduce(h)
+        c = np.cumsum(h.numpy())
+        b = int(np.searchsorted(c, k, side="right"))
+        k -= int(c[b - 1]) if b > 0 else 0
+        prefix = (prefix << nb) | b
+        shift_hi = shift
+    limit = np.array([prefix], np.uint32).view(np.float32)[0]
+    rc, A, b_, x, dT, used = O.point_to_plane(qs, rf, rn, ids, d2, float(limit), 1)
+    t = torch.from_numpy(np.concatenate([A.ravel(), b_, [float(used)]]))
+    dist.all_reduce(t)
+    if rank == 0:
+        q.put((float(limit), t.numpy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_split_scan_allreduce_scheme_matches_unsharded():
+    import torch.multiprocessing as mp
+    sys.path.insert(0, ROOT)
+    from laser_slam_amd import sharding, synth
+    from oracle import oracle_py as O
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_split_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    limit, t = q.get(timeout=240)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    ref, rd, T_true, T_init = synth.scan_pair(64)
+    rf, rn = O.sampling_surface_normal(ref, 10, 1.0, 0)
+    qa = O.transform_points(synth.colmajor(T_init), rd)
+    ids, d2 = O.KdTree(rf).nn(qa)
+    rc, want = O.trim_limit(d2, 0.75)
+    assert np.float32(limit) == np.float32(want)                     # global order statistic, exact
+    rc, A, b_, x, dT, used = O.point_to_plane(qa, rf, rn, ids, d2, want, 1)
+    assert int(t[-1]) == used
+    assert np.allclose(t[:36].reshape(6, 6), A, rtol=1e-12) and np.allclose(t[36:42], b_, rtol=1e-11)
+    parts = [sharding.split_shard(10, r, 3) for r in range(3)]
+    assert [(s.start, s.stop) for s in parts] == [(0, 4), (4, 8), (8, 10)]
