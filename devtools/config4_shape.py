@@ -30,3 +30,13 @@ for rep in range(2):
     T, st = h.align(drd, T_init); t2 = time.perf_counter()
 print("set_reference ms %.2f align ms %.2f iters %d knn avg us %.1f cap_retries %d" % ((t1 - t) * 1e3, (t2 - t1) * 1e3, st.iterations, st.t_knn_ms / max(st.knn_launches, 1) * 1e3, st.cap_retries))
 print("err vs truth", synth.pose_error(T.astype(np.float64), T_true), "info chunks", h.info().n_chunks, list(h.info().cells)[:6])
+if len(sys.argv) > 2 and sys.argv[2] == "oracle":
+    from oracle import oracle_py as O
+    ocfg = O.config_yaml(accum_double=1, min_diff_rot=1e-5, min_diff_trans=1e-4, num_threads=32)
+    t = time.time()
+    rc, To, sto, tro = O.icp_compute(ocfg, rd, rf, rn, synth.colmajor(T_init), 40)
+    print("oracle rc", rc, "iters", sto.iterations, "time", time.time() - t, "err vs truth", synth.pose_error(synth.from_colmajor(To), T_true))
+    print("GPU vs oracle", synth.pose_error(synth.from_colmajor(To), T.astype(np.float64)))
+    trg = h.trace()
+    print("limits equal:", [np.float32(a["limit"]) == np.float32(b["limit"]) for a, b in zip(trg, tro)].count(True), "of", len(tro),
+          "| n_used equal:", [a["n_used"] == b["n_used"] for a, b in zip(trg, tro)].count(True))

@@ -354,3 +354,33 @@ def test_split_scan_world1_equals_plain(icp_mod, pair64k):
         tr1 = [(t["limit"], t["n_used"]) for t in h.trace()]
     assert st0.iterations == st1.iterations and tr0 == tr1
     assert np.array_equal(T0, T1)
+
+
+def test_submap_vs_scan_matches_oracle(icp_mod, oracle):
+    """BASELINE config 4 shape at reduced size: an aggregated 8-scan sub-map (the reference of
+    localScanToSubMap with nscan_in_sub_map = 8, laser_track.cpp:474-486) against one scan."""
+    scene = synth.Scene(1234)
+    poses = [synth.se3(0.8 * i, 0.05 * i, synth.SENSOR_HEIGHT, yaw=np.deg2rad(2.0 * i)) for i in range(9)]
+    parts = []
+    for i in range(8):
+        s = synth.hdl64_scan(scene, poses[i], 1024, 20 + i)
+        Trel = np.linalg.inv(poses[7]) @ poses[i]
+        p = s.copy()
+        p[:, :3] = (s[:, :3].astype(np.float64) @ Trel[:3, :3].T + Trel[:3, 3]).astype(np.float32)
+        parts.append(p)
+    ref = np.concatenate(parts)
+    rd = synth.hdl64_scan(scene, poses[8], 1024, 40)
+    T_true = np.linalg.inv(poses[7]) @ poses[8]
+    T_init = synth.se3(0.25, -0.1, 0.05, yaw=np.deg2rad(1.2)) @ T_true
+    rf, rn = icp_mod.sampling_surface_normal(ref, 10, 1.0, 0)
+    assert rf.shape[0] > 500000
+    with icp_mod.IcpHandle() as h:
+        h.set_reference(rf, rn)
+        Tg, stg = h.align(rd, T_init)
+        trg = h.trace()
+    rc, To, sto, tro = oracle.icp_compute(oracle.config_yaml(accum_double=1, num_threads=8), rd, rf, rn,
+                                          synth.colmajor(T_init), 40)
+    assert rc == 0 and stg.iterations == sto.iterations
+    assert [t["n_used"] for t in trg] == [t["n_used"] for t in tro]
+    dt, dr = synth.pose_error(synth.from_colmajor(To), Tg.astype(np.float64))
+    assert dt <= TOL_T and dr <= TOL_R, (dt, dr)
