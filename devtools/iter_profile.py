@@ -2,6 +2,8 @@
 import ctypes as C, sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
+from laser_slam_amd import _lib as _l
+if os.environ.get("LSGPU_SO"): _l.SO_PATH = os.environ["LSGPU_SO"]
 from laser_slam_amd import synth, icp
 from laser_slam_amd._lib import IcpConfig, lib
 n_az = int(sys.argv[1]) if len(sys.argv) > 1 else 16384

@@ -22,6 +22,10 @@ namespace lsgpu {
 constexpr int kMaxLevels = 17;       // bits per axis <= 16
 constexpr uint32_t kEmpty = 0xFFFFFFFFu;
 constexpr int kHistBins = 2048;
+#ifndef LSGPU_CHUNK_MAX
+#define LSGPU_CHUNK_MAX 64
+#endif
+constexpr int kChunkMax = LSGPU_CHUNK_MAX;  // points per chunk (power of two, <= 64)
 
 struct HashEntry {  // 16 B: one dwordx4 per probe
   uint32_t xy;      // cell x | y << 16
@@ -54,6 +58,12 @@ struct GridDev {
 
 // slack (in fine-key units) that covers float rounding of (c - o) * inv_hf at 16-bit magnitudes
 constexpr float kFineSlack = 0.0625f;
+
+// tile kNN: batches with more surviving boxes than this get the lane-parallel per-query refinement
+#ifndef LSGPU_REFINE_MIN
+#define LSGPU_REFINE_MIN 48
+#endif
+constexpr int kRefineMin = LSGPU_REFINE_MIN;
 
 __device__ __forceinline__ int fine_coord(float c, float o, float inv_hf, int lim) {
   const float t = floorf((c - o) * inv_hf);

@@ -154,7 +154,7 @@ __global__ __launch_bounds__(256) void k_chunk_flags(const uint64_t* __restrict_
                                                      int fine, uint32_t* __restrict__ flags) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
-  uint32_t f = ((i & 63) == 0);
+  uint32_t f = ((i & (kChunkMax - 1)) == 0);
   if (i > 0 && ((keys[i] ^ keys[i - 1]) >> (3 * fine)) != 0) f = 1;
   flags[i] = f;
 }

@@ -248,7 +248,8 @@ __device__ __forceinline__ void tile_process_batch(const KnnArgs& a, float cap2,
 #ifdef LSGPU_KNN_STATS
   if (a.dbg_flags & 128) { n_surv += __popcll(m); return; }
 #endif
-  if (__popcll(m) > 48) {
+  bool refined = false;
+  if (__popcll(m) > kRefineMin) {
     // Many boxes passed the group-level test: refine lane-parallel (lane = chunk) against every
     // query's own bound before the serial walk, which costs a broadcast + branch per chunk.
     bool needed = false;
@@ -262,11 +263,12 @@ __device__ __forceinline__ void tile_process_batch(const KnnArgs& a, float cap2,
     }
     m &= __ballot(pass && needed);
     if (!m) return;
+    refined = true;
   }
   n_surv += __popcll(m);
   // ---- which survivors does any lane need (bounds as of now; they only tighten later)
-  unsigned long long needm = 0;
-  {
+  unsigned long long needm = refined ? m : 0;
+  if (!refined) {
     const float lim = fminf(best, cap2);
     unsigned long long mm = m;
     while (mm) {
@@ -281,29 +283,44 @@ __device__ __forceinline__ void tile_process_batch(const KnnArgs& a, float cap2,
 #ifdef LSGPU_KNN_STATS
   if (a.dbg_flags & (1 | 256)) { n_eval += __popcll(needm); return; }
 #endif
-  // ---- fetch + evaluate, four chunks per round
+  // ---- fetch + evaluate: two chunks per round, double buffered -- the LDS-DMA of the next pair is in
+  // flight while the current pair is evaluated (slots 0,1 <-> 2,3)
   typedef __attribute__((address_space(1))) const void* gptr_t;
   typedef __attribute__((address_space(3))) void* lptr_t;
-  while (needm) {
-    uint32_t st[4], cnt[4];
-    int ng = 0;
-#pragma unroll
-    for (int gslot = 0; gslot < 4; ++gslot) {
-      if (!needm) break;
-      const int k = __ffsll((long long)needm) - 1;
-      needm &= needm - 1;
-      st[gslot] = rl_u(__float_as_uint(b0.w), k);
-      cnt[gslot] = rl_u(__float_as_uint(b1.w), k);
-      // lanes past the chunk's end fetch a far pad point: the slot is always fully defined
-      const float4* src = a.pts + ((uint32_t)lane < cnt[gslot] ? st[gslot] + (uint32_t)lane : (uint32_t)a.pad_index);
-      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)&lds.slot[gslot][0], 16, 0, 0);
-      ng = gslot + 1;
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    n_eval += ng;
-#pragma unroll
-    for (int gslot = 0; gslot < 4; ++gslot)
-      if (gslot < ng) tile_eval_slot(lds.slot[gslot], st[gslot], cnt[gslot], qx, qy, qz, best, grp);
+  uint32_t sa0 = 0, sa1 = 0, ca0 = 0, ca1 = 0, sb0 = 0, sb1 = 0, cb0 = 0, cb1 = 0;
+  auto issue = [&](int slot, uint32_t& st, uint32_t& cnt) -> int {
+    if (!needm) return 0;
+    const int k = __ffsll((long long)needm) - 1;
+    needm &= needm - 1;
+    st = rl_u(__float_as_uint(b0.w), k);
+    cnt = rl_u(__float_as_uint(b1.w), k);
+    // lanes past the chunk's end fetch a far pad point: the slot is always fully defined
+    const float4* src = a.pts + ((uint32_t)lane < cnt ? st + (uint32_t)lane : (uint32_t)a.pad_index);
+    __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)&lds.slot[slot][0], 16, 0, 0);
+    return 1;
+  };
+  int na = issue(0, sa0, ca0);
+  na += issue(1, sa1, ca1);
+  while (na) {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // slots 2,3 are no longer being read
+    int nb = issue(2, sb0, cb0);
+    nb += issue(3, sb1, cb1);
+    if (nb == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    else if (nb == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    n_eval += na;
+    tile_eval_slot(lds.slot[0], sa0, ca0, qx, qy, qz, best, grp);
+    if (na > 1) tile_eval_slot(lds.slot[1], sa1, ca1, qx, qy, qz, best, grp);
+    if (!nb) break;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // slots 0,1 are no longer being read
+    na = issue(0, sa0, ca0);
+    na += issue(1, sa1, ca1);
+    if (na == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    else if (na == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    n_eval += nb;
+    tile_eval_slot(lds.slot[2], sb0, cb0, qx, qy, qz, best, grp);
+    if (nb > 1) tile_eval_slot(lds.slot[3], sb1, cb1, qx, qy, qz, best, grp);
   }
   maxbest = wave_max(ing ? fminf(best, cap2) : 0.f);
 }
