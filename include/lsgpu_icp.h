@@ -98,6 +98,21 @@ int lsgpu_icp_set_reference(lsgpu_icp* h, const float* ref_xyz1, const float* re
 int lsgpu_icp_align(lsgpu_icp* h, const float* reading_xyz1, int64_t nq, const float T_init[16],
                     float T_out[16], lsgpu_icp_stats* stats);
 
+/* ---- many independent scan pairs on one GPU (BASELINE config 3) --------------------
+ * Replaces a loop of `icp_.compute` calls over independent pairs (laser_slam/src/laser_track.cpp:496 has
+ * no state across calls).  Pair i runs {set_reference, align} on handles[i % n_handles]; the handles work
+ * concurrently, each on its own HIP stream driven by its own host thread, so that small clouds (200 k
+ * points do not fill 256 CUs) overlap on the device.  Results do not depend on n_handles.  All handles
+ * must live on the same device.  rc[i] receives pair i's return code (LSGPU_NO_CONVERGENCE leaves
+ * T_out[i] = T_init[i], like lsgpu_icp_align); the function returns the first non-OK, non-NO_CONVERGENCE
+ * code, else LSGPU_NO_CONVERGENCE if any pair failed to converge, else LSGPU_OK.
+ * T_init / T_out: 16 floats per pair, column major.  stats and rc may be NULL. */
+int lsgpu_icp_align_batch(lsgpu_icp* const* handles, int n_handles, int64_t n_pairs,
+                          const float* const* reference_xyz1, const float* const* reference_normals,
+                          const int64_t* n_reference, const float* const* reading_xyz1,
+                          const int64_t* n_reading, const float* T_init, float* T_out,
+                          lsgpu_icp_stats* stats, int* rc);
+
 /* ---- one scan pair split over several GPUs (BASELINE config 4) -------------------------
  * Every rank holds the whole reference (set_reference with the same cloud) and ITS shard of the reading.
  * After lsgpu_icp_comm_init, lsgpu_icp_align treats its `reading_xyz1` as the local shard: per iteration

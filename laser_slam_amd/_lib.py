@@ -17,7 +17,7 @@ OK, NO_CONVERGENCE, BAD_CONFIG, HIP_ERROR, BAD_ARG = 0, 1, 2, 3, 4
 # every symbol include/lsgpu_icp.h declares (tests/test_abi.py checks the export table against this)
 ABI_SYMBOLS = [
     "lsgpu_icp_config_yaml", "lsgpu_icp_config_default", "lsgpu_icp_create", "lsgpu_icp_destroy",
-    "lsgpu_icp_set_reference", "lsgpu_icp_align", "lsgpu_icp_get_trace",
+    "lsgpu_icp_set_reference", "lsgpu_icp_align", "lsgpu_icp_align_batch", "lsgpu_icp_get_trace",
     "lsgpu_icp_get_reference_mean", "lsgpu_icp_get_info", "lsgpu_comm_get_unique_id", "lsgpu_icp_comm_init", "lsgpu_knn", "lsgpu_trim_limit", "lsgpu_normal_eq",
     "lsgpu_transform_points", "lsgpu_filter_random_sampling",
     "lsgpu_filter_sampling_surface_normal", "lsgpu_check_rigid", "lsgpu_correct_rigid",
@@ -116,6 +116,10 @@ def lib() -> C.CDLL:
     L.lsgpu_icp_set_reference.argtypes = [vp, fp, fp, i64]
     L.lsgpu_icp_align.argtypes = [vp, fp, i64, C.POINTER(C.c_float), C.POINTER(C.c_float),
                                   C.POINTER(IcpStats)]
+    L.lsgpu_icp_align_batch.argtypes = [C.POINTER(vp), C.c_int, i64, C.POINTER(fp), C.POINTER(fp),
+                                        C.POINTER(i64), C.POINTER(fp), C.POINTER(i64),
+                                        C.POINTER(C.c_float), C.POINTER(C.c_float),
+                                        C.POINTER(IcpStats), C.POINTER(C.c_int)]
     L.lsgpu_icp_get_trace.argtypes = [vp, C.POINTER(IterTrace), C.c_int]
     L.lsgpu_icp_get_reference_mean.argtypes = [vp, C.POINTER(C.c_float)]
     L.lsgpu_icp_get_info.argtypes = [vp, C.POINTER(IcpInfo)]

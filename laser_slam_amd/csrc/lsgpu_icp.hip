@@ -12,6 +12,7 @@
 #include <string>
 #include <vector>
 #include <chrono>
+#include <thread>
 
 #include <dlfcn.h>
 
@@ -869,6 +870,47 @@ int lsgpu_icp_align(lsgpu_icp* h, const float* reading_xyz1, int64_t nq, const f
 }
 
 // dev only (LSGPU_KNN_STATS build): per-wave records of the last k_knn_tile launch / global counters
+int lsgpu_icp_align_batch(lsgpu_icp* const* handles, int n_handles, int64_t n_pairs,
+                          const float* const* reference_xyz1, const float* const* reference_normals,
+                          const int64_t* n_reference, const float* const* reading_xyz1,
+                          const int64_t* n_reading, const float* T_init, float* T_out,
+                          lsgpu_icp_stats* stats, int* rc) {
+  if (!handles || n_handles < 1 || n_pairs < 0) return LSGPU_BAD_ARG;
+  if (n_pairs == 0) return LSGPU_OK;
+  if (!reference_xyz1 || !reference_normals || !n_reference || !reading_xyz1 || !n_reading || !T_init || !T_out)
+    return LSGPU_BAD_ARG;
+  for (int k = 0; k < n_handles; ++k)
+    if (!handles[k] || handles[k]->device != handles[0]->device || handles[k]->comm) return LSGPU_BAD_ARG;
+  std::vector<int> codes((size_t)n_pairs, LSGPU_OK);
+  // handle k owns pairs k, k + n_handles, ...: a static assignment, each pair is one independent,
+  // deterministic {set_reference, align} on that handle's stream
+  auto worker = [&](int k) {
+    lsgpu_icp* h = handles[k];
+    for (int64_t i = k; i < n_pairs; i += n_handles) {
+      float* To = T_out + 16 * i;
+      const float* Ti = T_init + 16 * i;
+      std::memcpy(To, Ti, 16 * sizeof(float));
+      if (stats) std::memset(&stats[i], 0, sizeof(lsgpu_icp_stats));
+      int c = lsgpu_icp_set_reference(h, reference_xyz1[i], reference_normals[i], n_reference[i]);
+      if (c == LSGPU_OK) c = lsgpu_icp_align(h, reading_xyz1[i], n_reading[i], Ti, To, stats ? &stats[i] : nullptr);
+      codes[(size_t)i] = c;
+    }
+  };
+  const int nt = (int)std::min<int64_t>(n_handles, n_pairs);
+  std::vector<std::thread> pool;
+  for (int k = 1; k < nt; ++k) pool.emplace_back(worker, k);
+  worker(0);
+  for (auto& t : pool) t.join();
+  int ret = LSGPU_OK;
+  for (int64_t i = 0; i < n_pairs; ++i) {
+    const int c = codes[(size_t)i];
+    if (rc) rc[i] = c;
+    if (c != LSGPU_OK && c != LSGPU_NO_CONVERGENCE) { if (ret == LSGPU_OK || ret == LSGPU_NO_CONVERGENCE) ret = c; }
+    else if (c == LSGPU_NO_CONVERGENCE && ret == LSGPU_OK) ret = c;
+  }
+  return ret;
+}
+
 int lsgpu_dev_knn_wave_stats(lsgpu_icp* h, unsigned int* out, int nwaves) {
   if (!h) return LSGPU_BAD_ARG;
   if (!out) { HIPC(h->knn_dbg_wave.reserve((size_t)nwaves)); HIPC(hipMemset(h->knn_dbg_wave.p, 0, (size_t)nwaves * 16)); return LSGPU_OK; }

@@ -207,6 +207,39 @@ class IcpHandle:
         return out
 
 
+def align_batch(handles, references, normals, readings, T_inits):
+    """BASELINE config 3: many independent pairs on one GPU (``lsgpu_icp_align_batch``).
+
+    ``handles``: IcpHandle pool on one device (pair i -> handles[i % len]); every cloud may be a host
+    array or a CUDA tensor.  -> (T [B,4,4] float32, [IcpStats], rc int array); non-converged pairs keep
+    T_init and have rc == 1, any other failure raises."""
+    B = len(readings)
+    if not (len(references) == len(normals) == len(T_inits) == B):
+        raise ValueError("one reference, normals, reading and T_init per pair")
+    keep, rp, npn, qp = [], (C.c_void_p * B)(), (C.c_void_p * B)(), (C.c_void_p * B)()
+    nr, nq = (C.c_int64 * B)(), (C.c_int64 * B)()
+    for i in range(B):
+        p, k1, n = _as_f32(references[i], 4)
+        q, k2, m = _as_f32(normals[i], 3)
+        r, k3, l = _as_f32(readings[i], 4)
+        if m != n:
+            raise ValueError("normals must have one row per reference point")
+        keep += [k1, k2, k3]
+        rp[i], npn[i], qp[i], nr[i], nq[i] = p, q, r, n, l
+    ti = np.concatenate([_t16(T) for T in T_inits]) if B else np.zeros(0, np.float32)
+    to = np.empty(16 * B, np.float32)
+    st = (IcpStats * max(B, 1))()
+    rc = (C.c_int * max(B, 1))()
+    hs = (C.c_void_p * len(handles))(*[h._h for h in handles])
+    code = _lib.lib().lsgpu_icp_align_batch(hs, len(handles), B, rp, npn, nr, qp, nq, _fp(ti), _fp(to), st, rc)
+    if code not in (_lib.OK, _lib.NO_CONVERGENCE):
+        bad = next((i for i in range(B) if rc[i] not in (_lib.OK, _lib.NO_CONVERGENCE)), None)
+        _raise(code, "lsgpu_icp_align_batch" + (f" (pair {bad})" if bad is not None else ""),
+               handles[bad % len(handles)]._h if bad is not None else None)
+    T = to.reshape(B, 4, 4).transpose(0, 2, 1).copy()
+    return T, [st[i] for i in range(B)], np.array(rc[:B], np.int32)
+
+
 def comm_unique_id() -> bytes:
     """RCCL unique id (call on rank 0, ship to the other ranks)."""
     buf = C.create_string_buffer(128)

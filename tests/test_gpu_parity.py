@@ -384,3 +384,40 @@ def test_submap_vs_scan_matches_oracle(icp_mod, oracle):
     assert [t["n_used"] for t in trg] == [t["n_used"] for t in tro]
     dt, dr = synth.pose_error(synth.from_colmajor(To), Tg.astype(np.float64))
     assert dt <= TOL_T and dr <= TOL_R, (dt, dr)
+
+
+def test_align_batch_matches_sequential(icp_mod, oracle):
+    """BASELINE config 3 (many independent pairs, several streams on one GPU): the batch entry point gives,
+    for every pair, exactly what {set_reference, align} on a single handle gives, whatever the pool
+    size; pairs differ in size, one has an empty reading (rc 1, T_out = T_init), and the first pair is
+    checked against the oracle."""
+    from laser_slam_amd import synth
+    pairs = []
+    for i, n_az in enumerate([96, 160, 64, 128, 200, 80, 112]):
+        ref, rd, _Tt, Ti = synth.scan_pair(n_az, noise_seeds=(1000 + i, 2000 + i), guess_seed=1000 + i)
+        rf, rn = icp_mod.sampling_surface_normal(ref, 10, 1.0, 0)
+        pairs.append((rf, rn, rd, Ti))
+    pairs.insert(3, (pairs[0][0], pairs[0][1], np.zeros((0, 4), np.float32), pairs[0][3]))
+    refs, nrms, rds, Tis = map(list, zip(*pairs))
+    seq = []
+    with icp_mod.IcpHandle() as h:
+        for rf, rn, rd, Ti in pairs:
+            if len(rd) == 0:
+                seq.append(np.asarray(Ti, np.float32))
+                continue
+            h.set_reference(rf, rn)
+            seq.append(h.align(rd, Ti)[0])
+    for pool in (1, 3, 8):
+        hs = [icp_mod.IcpHandle() for _ in range(pool)]
+        T, st, rc = icp_mod.align_batch(hs, refs, nrms, rds, Tis)
+        for h in hs:
+            h.close()
+        assert list(rc) == [0, 0, 0, 1, 0, 0, 0, 0]
+        for i in range(len(pairs)):
+            assert np.array_equal(T[i], seq[i]), (pool, i)
+        assert st[0].iterations > 0 and st[3].iterations == 0
+    rco, To, _sto, _tr = oracle.icp_compute(oracle.config_yaml(accum_double=1), rds[0], refs[0], nrms[0],
+                                            synth.colmajor(Tis[0]))
+    assert rco == 0
+    dt, dr = synth.pose_error(T[0], synth.from_colmajor(To))
+    assert dt <= TOL_T and dr <= TOL_R, (dt, dr)
