@@ -21,7 +21,11 @@ T, st = h.align(rd, Ti)
 buf = np.zeros((nw, 4), np.uint32)
 lib().lsgpu_dev_knn_wave_stats(h._h, buf.ctypes.data_as(C.POINTER(C.c_uint)), nw)
 cyc, ev, sv, gl = buf[:, 0].astype(np.float64), buf[:, 1], buf[:, 2], buf[:, 3]
-grp, lvl = gl >> 8, gl & 255
+grp, lvl, nact = (gl >> 8) & 255, gl & 255, gl >> 16
+print('active lanes per tile: mean %.1f' % nact.mean(), 'hist(0,1-4,5-8,9-16,17-32,33-64):', [int(((nact >= a) & (nact <= b)).sum()) for a, b in ((0, 0), (1, 4), (5, 8), (9, 16), (17, 32), (33, 64))])
+for a, b in ((0, 0), (1, 4), (5, 8), (9, 16), (17, 32), (33, 64)):
+    m = (nact >= a) & (nact <= b)
+    if m.any(): print('  tiles with', a, '-', b, 'active: mean cycles %.0f evals %.1f' % (cyc[m].mean(), ev[m].mean()))
 print("waves", nw, "last-iteration per-wave stats")
 for name, a in (("cycles", cyc), ("chunk evals", ev), ("proxy survivors", sv), ("groups", grp), ("level", lvl)):
     print("%-16s mean %.1f p50 %.0f p90 %.0f p99 %.0f p99.9 %.0f max %.0f" % ((name, a.mean()) + tuple(np.percentile(a, [50, 90, 99, 99.9, 100]))))

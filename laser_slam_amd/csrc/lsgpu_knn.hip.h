@@ -49,7 +49,8 @@ struct KnnArgs {
   float r_cap;              // lanes with a larger ball go to the fallback
   float group_r;            // half extent of one search group inside a wave
   float cap2;               // only neighbours with d2 <= cap2 must be exact (INF: all)
-  float* lb;                // per-query lower bound on the NN distance (nullable; capped loop only)
+  float* lb;                // per-query lower bound on the distance to every point OTHER than prev (nullable)
+  float gap;                // capped launches search `gap` metres beyond the current best (keep-match bound)
   const IcpState* st;       // loop state (nullable): overrides T (and cap2 if use_state_cap)
   int use_state_cap;
   unsigned long long* dbg;  // optional counters (LSGPU_KNN_STATS builds only)
@@ -212,8 +213,14 @@ __device__ __forceinline__ f32x2 dist2_pair(f32x2 qx, f32x2 qy, f32x2 qz, f32x2 
 // Broadcast-evaluate one staged chunk: 4 candidates per step -- 12 packed-pair ops for the distances,
 // min3 + min, then ONE compare/select pair that records the group of 4 holding the new best; the exact
 // index is resolved once at the end of the kernel (tile_resolve_match).
+// Squared search radius of a lane: `gap` beyond its current bound b (so that the search also proves
+// that no OTHER point lies within sqrt(b) + gap), never beyond the cap.  gap == 0: min(b, cap2).
+__device__ __forceinline__ float prune_lim(float b, float gap, float cap2) {
+  return fminf(__fmaf_rn(2.f * gap, __builtin_amdgcn_sqrtf(b), b) + gap * gap, cap2);
+}
+
 __device__ __forceinline__ void tile_eval_slot(const float4* __restrict__ slot, uint32_t st, uint32_t cnt,
-                                               float qx, float qy, float qz, float& best, int& grp) {
+                                               float qx, float qy, float qz, float& best, float& sec, int& grp) {
   const uint32_t cnt4 = (cnt + 3u) & ~3u;
   const f32x2 q2x = {qx, qx}, q2y = {qy, qy}, q2z = {qz, qz};
   for (uint32_t t = 0; t < cnt4; t += 4) {
@@ -221,6 +228,7 @@ __device__ __forceinline__ void tile_eval_slot(const float4* __restrict__ slot, 
     const f32x2 d0 = dist2_pair(q2x, q2y, q2z, f32x2{c0.x, c1.x}, f32x2{c0.y, c1.y}, f32x2{c0.z, c1.z});
     const f32x2 d1 = dist2_pair(q2x, q2y, q2z, f32x2{c2.x, c3.x}, f32x2{c2.y, c3.y}, f32x2{c2.z, c3.z});
     const float m4 = fminf(fminf(fminf(d0.x, d0.y), d1.x), d1.y);
+    sec = __builtin_amdgcn_fmed3f(best, m4, sec);  // second smallest group minimum (best <= sec always)
     if (m4 < best) { best = m4; grp = (int)(st + t); }
   }
 }
@@ -231,8 +239,8 @@ __device__ __forceinline__ void tile_eval_slot(const float4* __restrict__ slot, 
 __device__ __forceinline__ void tile_process_batch(const KnnArgs& a, float cap2, TileLds& lds, int lane, bool valid,
                                                    uint32_t ch, bool ing, float qx, float qy, float qz,
                                                    float tlx, float tly, float tlz, float thx, float thy,
-                                                   float thz, float& maxbest, float& best, int& grp,
-                                                   uint32_t& n_eval, uint32_t& n_surv) {
+                                                   float thz, float& maxbest, float ub, float gap, float& best,
+                                                   float& sec, int& grp, uint32_t& n_eval, uint32_t& n_surv) {
   float4 b0 = make_float4(0.f, 0.f, 0.f, 0.f), b1 = b0;
   bool pass = false;
   if (valid) {
@@ -248,6 +256,7 @@ __device__ __forceinline__ void tile_process_batch(const KnnArgs& a, float cap2,
 #ifdef LSGPU_KNN_STATS
   if (a.dbg_flags & 128) { n_surv += __popcll(m); return; }
 #endif
+  const float lim = ing ? prune_lim(fminf(best, ub), gap, cap2) : 0.f;  // bounds as of now; they only tighten
   bool refined = false;
   if (__popcll(m) > kRefineMin) {
     // Many boxes passed the group-level test: refine lane-parallel (lane = chunk) against every
@@ -258,7 +267,7 @@ __device__ __forceinline__ void tile_process_batch(const KnnArgs& a, float cap2,
       const int u = __ffsll((long long)qm) - 1;
       qm &= qm - 1;
       const float ux = rl_f(qx, u), uy = rl_f(qy, u), uz = rl_f(qz, u);
-      const float ul = rl_f(fminf(best, cap2), u);
+      const float ul = rl_f(lim, u);
       needed = needed || (box_dist2(b0.x, b0.y, b0.z, b1.x, b1.y, b1.z, ux, uy, uz) * kPruneShrink <= ul);
     }
     m &= __ballot(pass && needed);
@@ -269,7 +278,6 @@ __device__ __forceinline__ void tile_process_batch(const KnnArgs& a, float cap2,
   // ---- which survivors does any lane need (bounds as of now; they only tighten later)
   unsigned long long needm = refined ? m : 0;
   if (!refined) {
-    const float lim = fminf(best, cap2);
     unsigned long long mm = m;
     while (mm) {
       const int k = __ffsll((long long)mm) - 1;
@@ -309,8 +317,8 @@ __device__ __forceinline__ void tile_process_batch(const KnnArgs& a, float cap2,
     else if (nb == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     n_eval += na;
-    tile_eval_slot(lds.slot[0], sa0, ca0, qx, qy, qz, best, grp);
-    if (na > 1) tile_eval_slot(lds.slot[1], sa1, ca1, qx, qy, qz, best, grp);
+    tile_eval_slot(lds.slot[0], sa0, ca0, qx, qy, qz, best, sec, grp);
+    if (na > 1) tile_eval_slot(lds.slot[1], sa1, ca1, qx, qy, qz, best, sec, grp);
     if (!nb) break;
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // slots 0,1 are no longer being read
     na = issue(0, sa0, ca0);
@@ -319,22 +327,27 @@ __device__ __forceinline__ void tile_process_batch(const KnnArgs& a, float cap2,
     else if (na == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     n_eval += nb;
-    tile_eval_slot(lds.slot[2], sb0, cb0, qx, qy, qz, best, grp);
-    if (nb > 1) tile_eval_slot(lds.slot[3], sb1, cb1, qx, qy, qz, best, grp);
+    tile_eval_slot(lds.slot[2], sb0, cb0, qx, qy, qz, best, sec, grp);
+    if (nb > 1) tile_eval_slot(lds.slot[3], sb1, cb1, qx, qy, qz, best, sec, grp);
   }
-  maxbest = wave_max(ing ? fminf(best, cap2) : 0.f);
+  maxbest = wave_max(ing ? prune_lim(fminf(best, ub), gap, cap2) : 0.f);
 }
 
 // Which point of the recorded group of 4 is at distance `best` (first one; pts is padded, and a point
 // of the following chunk at exactly the same distance would be an equally valid nearest neighbour).
+// `s4` receives the second smallest distance inside that group (points of the following chunk that the
+// group may run into are real reference points too, so the value stays a valid bound on "every other point").
 __device__ __forceinline__ float4 tile_resolve_match(const KnnArgs& a, int grp, float qx, float qy, float qz,
-                                                     float best, float4 mp) {
+                                                     float best, float4 mp, float& s4) {
   if (grp >= 0) {
     const float4 p0 = a.pts[grp], p1 = a.pts[grp + 1], p2 = a.pts[grp + 2], p3 = a.pts[grp + 3];
-    if (dist2(qx - p3.x, qy - p3.y, qz - p3.z) == best) mp = make_float4(p3.x, p3.y, p3.z, __int_as_float(grp + 3));
-    if (dist2(qx - p2.x, qy - p2.y, qz - p2.z) == best) mp = make_float4(p2.x, p2.y, p2.z, __int_as_float(grp + 2));
-    if (dist2(qx - p1.x, qy - p1.y, qz - p1.z) == best) mp = make_float4(p1.x, p1.y, p1.z, __int_as_float(grp + 1));
-    if (dist2(qx - p0.x, qy - p0.y, qz - p0.z) == best) mp = make_float4(p0.x, p0.y, p0.z, __int_as_float(grp));
+    const float e0 = dist2(qx - p0.x, qy - p0.y, qz - p0.z), e1 = dist2(qx - p1.x, qy - p1.y, qz - p1.z);
+    const float e2 = dist2(qx - p2.x, qy - p2.y, qz - p2.z), e3 = dist2(qx - p3.x, qy - p3.y, qz - p3.z);
+    if (e3 == best) mp = make_float4(p3.x, p3.y, p3.z, __int_as_float(grp + 3));
+    if (e2 == best) mp = make_float4(p2.x, p2.y, p2.z, __int_as_float(grp + 2));
+    if (e1 == best) mp = make_float4(p1.x, p1.y, p1.z, __int_as_float(grp + 1));
+    if (e0 == best) mp = make_float4(p0.x, p0.y, p0.z, __int_as_float(grp));
+    s4 = fminf(fmaxf(fminf(e0, e1), fminf(e2, e3)), fminf(fmaxf(e0, e1), fmaxf(e2, e3)));
   }
   return mp;
 }
@@ -379,7 +392,9 @@ __global__ __launch_bounds__(WAVES * 64, 8) void k_knn_tile(KnnArgs a) {
   const GridDev& g = a.g;
   uint32_t n_eval = 0, n_surv = 0, n_grp = 0, lvl_max = 0;
 
-  float qx = 0.f, qy = 0.f, qz = 0.f, best = 0.f;
+  // ub: distance to the warm-start point (prev match); best / sec: smallest and second smallest distance
+  // among the points this search evaluates (the warm-start point is one of them whenever its chunk is)
+  float qx = 0.f, qy = 0.f, qz = 0.f, ub = 0.f, best = INFINITY, sec = INFINITY;
   int bi = -1, grp = -1;
   float4 mp = make_float4(0.f, 0.f, 0.f, 0.f);  // the current match (point + index)
   float4 rraw = mp;
@@ -390,16 +405,20 @@ __global__ __launch_bounds__(WAVES * 64, 8) void k_knn_tile(KnnArgs a) {
     qx = q.x; qy = q.y; qz = q.z;
     mp = a.prev[j];  // coalesced: no dependent gather of pts[prev]
     bi = __float_as_int(mp.w);
-    best = dist2(qx - mp.x, qy - mp.y, qz - mp.z);
+    ub = dist2(qx - mp.x, qy - mp.y, qz - mp.z);
   }
 #ifdef LSGPU_KNN_STATS
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   const long long t_loaded = clock64();
   long long t_red = t_loaded, t_look = t_loaded;
 #endif
-  // lower bound carried over from the previous iteration, reduced by this query's displacement
+  // lb = lower bound on the distance to every reference point other than the warm-start point, carried
+  // over from the previous iteration and reduced by this query's displacement (triangle inequality).
+  //   keep: the warm-start point is provably still the unique nearest neighbour -> no search
+  //   far : every point, the warm-start one included, is provably beyond the cap -> weight 0, no search
   float lbn = 0.f;
-  bool farskip = false;
+  bool skip = false;
+  const float gap = a.use_state_cap ? a.gap : 0.f;
   if (act && a.lb && a.st && a.use_state_cap) {
     Mat34 To;
 #pragma unroll
@@ -408,12 +427,15 @@ __global__ __launch_bounds__(WAVES * 64, 8) void k_knn_tile(KnnArgs a) {
     const float ddx = qx - qo.x, ddy = qy - qo.y, ddz = qz - qo.z;
     const float delta = sqrtf(ddx * ddx + ddy * ddy + ddz * ddz) * (1.0f + 1e-5f) + 1e-7f;
     lbn = fmaxf(a.lb[j] * (1.0f - 1e-6f) - delta, 0.f);
-    farskip = lbn * lbn > cap2 * (1.0f + 1e-5f);  // provably beyond the cap: weight 0 whatever it is
+    const float lb2 = lbn * lbn;
+    const bool keep = ub * (1.0f + 1e-5f) < lb2;
+    const bool far = fminf(ub, lb2) > cap2 * (1.0f + 1e-5f);
+    skip = keep || far;
   }
-  // only neighbours closer than min(best, cap2s) can matter
-  const float R = sqrtf(fminf(best, cap2s)) * (1.0f + 1e-5f) + 1e-7f;
-  const bool straggler = act && !farskip && !(R <= a.r_cap);
-  const bool ing = act && !straggler && !farskip;
+  // only neighbours closer than the lane's search radius can matter
+  const float R = sqrtf(prune_lim(ub, gap, cap2s)) * (1.0f + 1e-5f) + 1e-7f;
+  const bool straggler = act && !skip && !(R <= a.r_cap);
+  const bool ing = act && !straggler && !skip;
 #ifdef LSGPU_KNN_STATS
   if (__ballot(ing) && !(a.dbg_flags & 4)) {
 #else
@@ -424,7 +446,7 @@ __global__ __launch_bounds__(WAVES * 64, 8) void k_knn_tile(KnnArgs a) {
     const float tly = wave_min(ing ? qy : INFINITY), thy = wave_max(ing ? qy : -INFINITY);
     const float tlz = wave_min(ing ? qz : INFINITY), thz = wave_max(ing ? qz : -INFINITY);
     const float Rmax = wave_max(ing ? R : 0.f);
-    float maxbest = wave_max(ing ? fminf(best, cap2s) : 0.f);
+    float maxbest = wave_max(ing ? prune_lim(ub, gap, cap2s) : 0.f);
     const int lim = (1 << (g.bits + g.fine)) - 1;
     // fine-key box of the region (every lane's ball lies inside), widened by the rounding slack
     const float pad = Rmax + kFineSlack * g.hf;
@@ -490,6 +512,7 @@ __global__ __launch_bounds__(WAVES * 64, 8) void k_knn_tile(KnnArgs a) {
     if (spread) {
       if (ing) {  // tracks the exact index itself
         const int before = bi;
+        best = ub;
         lane_ball_search(a, cap2s, qx, qy, qz, best, bi);
         if (bi != before) { const float4 p = a.pts[bi]; mp = make_float4(p.x, p.y, p.z, __int_as_float(bi)); }
       }
@@ -514,7 +537,7 @@ __global__ __launch_bounds__(WAVES * 64, 8) void k_knn_tile(KnnArgs a) {
             fill -= 64u;
             const uint32_t ch = lds.list[fill + lane];
             tile_process_batch(a, cap2s, lds, lane, true, ch, ing, qx, qy, qz, tlx, tly, tlz, thx, thy, thz,
-                               maxbest, best, grp, n_eval, n_surv);
+                               maxbest, ub, gap, best, sec, grp, n_eval, n_surv);
           }
         }
       }
@@ -522,7 +545,7 @@ __global__ __launch_bounds__(WAVES * 64, 8) void k_knn_tile(KnnArgs a) {
         const bool v = (uint32_t)lane < fill;
         const uint32_t ch = v ? lds.list[lane] : 0u;
         tile_process_batch(a, cap2s, lds, lane, v, ch, ing, qx, qy, qz, tlx, tly, tlz, thx, thy, thz,
-                           maxbest, best, grp, n_eval, n_surv);
+                           maxbest, ub, gap, best, sec, grp, n_eval, n_surv);
       }
     }
   }
@@ -530,20 +553,36 @@ __global__ __launch_bounds__(WAVES * 64, 8) void k_knn_tile(KnnArgs a) {
   if (a.dbg_flags & (64 | 128 | 256 | 512)) return;
 #endif
   if (act) {
-    mp = tile_resolve_match(a, grp, qx, qy, qz, best, mp);
+    float nb;  // new lower bound on the distance to every point other than the (new) match
+    if (n_grp == 64 && ing) {
+      // per-lane search: exact neighbour inside the cap, or nothing there (match unchanged)
+      nb = best <= cap2s ? sqrtf(best) * (1.0f - 1e-6f) : fmaxf(lbn, sqrtf(cap2s) * (1.0f - 1e-5f));
+    } else if (!ing) {
+      best = ub;   // keep / far / straggler (the fallback overwrites a straggler's result)
+      nb = lbn;
+    } else {
+      const float lim_f = prune_lim(fminf(best, ub), gap, cap2s);  // every unevaluated point is beyond this
+      if (best <= ub) {  // the evaluated minimum (the warm-start point itself unless something beat it)
+        float s4 = INFINITY;
+        mp = tile_resolve_match(a, grp, qx, qy, qz, best, mp, s4);
+        float others = fminf(fminf(sec, s4), lim_f);
+        const bool same = __float_as_int(mp.w) == bi;
+        if (!same) others = fminf(others, ub);  // (covers a warm-start point whose chunk was not needed)
+        nb = sqrtf(others) * (1.0f - 1e-5f);
+        if (same) nb = fmaxf(nb, lbn);
+      } else {  // the warm-start point's chunk was beyond the cap and nothing closer exists
+        nb = fmaxf(sqrtf(fminf(best, lim_f)) * (1.0f - 1e-5f), lbn);
+        best = ub;
+      }
+    }
     a.ids[j] = __float_as_int(mp.w);
     a.d2[j] = best;
     a.prev[j] = mp;
-    if (a.lb) {
-      float nb;
-      if (farskip) nb = lbn;
-      else if (best <= cap2s) nb = sqrtf(best) * (1.0f - 1e-6f);              // exact neighbour
-      else nb = fmaxf(lbn, sqrtf(cap2s) * (1.0f - 1e-5f));                    // nothing inside the search cap
-      a.lb[j] = nb;  // (stragglers: overwritten by the fallback)
-    }
+    if (a.lb) a.lb[j] = nb;
     if (straggler) a.strag[atomicAdd(a.strag_count, 1u)] = (uint32_t)j;
   }
 #ifdef LSGPU_KNN_STATS
+  const uint32_t n_act = (uint32_t)__popcll(__ballot(ing));
   if (lane == 0 && a.dbg) {
     atomicAdd(&a.dbg[1], (unsigned long long)(t_loaded - t_begin)); atomicAdd(&a.dbg[2], (unsigned long long)(t_red - t_loaded));
     atomicAdd(&a.dbg[5], (unsigned long long)(t_look - t_red)); atomicAdd(&a.dbg[6], (unsigned long long)(clock64() - t_look));
@@ -551,7 +590,7 @@ __global__ __launch_bounds__(WAVES * 64, 8) void k_knn_tile(KnnArgs a) {
     atomicAdd(&a.dbg[4], (unsigned long long)n_eval);
   }
   if (lane == 0 && a.dbg_wave)
-    a.dbg_wave[tile] = make_uint4((uint32_t)(clock64() - t_begin), n_eval, n_surv, (n_grp << 8) | lvl_max);
+    a.dbg_wave[tile] = make_uint4((uint32_t)(clock64() - t_begin), n_eval, n_surv, (n_act << 16) | (n_grp << 8) | lvl_max);
 #else
   (void)n_grp; (void)lvl_max;
 #endif
