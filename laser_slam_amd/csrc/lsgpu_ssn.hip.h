@@ -1,0 +1,182 @@
+// lsgpu_ssn.hip.h -- SamplingSurfaceNormalDataPointsFilter on the device:
+// the reference filter of laser_slam/configurations/icp_default.yaml:5-7 (knn 10, ratio 0.5), which
+// PointMatcher::ICP::compute applies to the reference cloud on the CPU at every call
+// (laser_slam/src/laser_track.cpp:496).
+//
+// The filter splits the cloud recursively at the median of the widest box axis until a box holds
+// <= knn points, gives every point of a box the box's PCA normal and keeps a random `ratio` of them.
+// Every split is an exact halving (left = count - count / 2), so the tree's SHAPE depends only on n
+// and knn: level L has at most 2^L segments with static sizes, and all levels are processed
+// breadth-first, one stable radix sort per level with key = (segment, cut coordinate).  Stable =
+// equal coordinates keep their order, the same rule the oracle and the host filter follow, so the
+// three build identical boxes in identical order.  The per-box arithmetic is lsgpu_box_normal.h.
+#pragma once
+#include "lsgpu_common.hip.h"
+#include "lsgpu_box_normal.h"
+
+namespace lsgpu {
+
+struct SsnSeg {
+  uint32_t start, count;
+  float lo[3], hi[3];
+};
+constexpr int kSsnMaxKnn = 32;  // box points are staged in registers / scratch
+
+// float -> uint32 with the same order; -0 and +0 share a key (they compare equal on the host too)
+__device__ __forceinline__ uint32_t float_order_key(float f) {
+  uint32_t u = __float_as_uint(f);
+  if (u == 0x80000000u) u = 0u;
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float float_from_order_key(uint32_t k) {
+  return __uint_as_float((k & 0x80000000u) ? (k & 0x7FFFFFFFu) : ~k);
+}
+
+__device__ __forceinline__ float coord_of(const float4& p, int d) { return d == 0 ? p.x : (d == 1 ? p.y : p.z); }
+
+__device__ __forceinline__ int ssn_cut_axis(const SsnSeg& s) {
+  int cut = 0;
+  float ext = s.hi[0] - s.lo[0];
+  if (s.hi[1] - s.lo[1] > ext) { ext = s.hi[1] - s.lo[1]; cut = 1; }
+  if (s.hi[2] - s.lo[2] > ext) { cut = 2; }
+  return cut;
+}
+
+// bounding box of the cloud -> ordered-uint min/max (bb[0..2] = lo, bb[3..5] = hi; preset to ~0 / 0)
+__global__ __launch_bounds__(256) void k_ssn_bounds(const float4* __restrict__ p, int n, uint32_t* __restrict__ bb) {
+  uint32_t lo[3] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu}, hi[3] = {0u, 0u, 0u};
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+    const float4 v = p[i];
+    const uint32_t k[3] = {float_order_key(v.x), float_order_key(v.y), float_order_key(v.z)};
+#pragma unroll
+    for (int d = 0; d < 3; ++d) { lo[d] = min(lo[d], k[d]); hi[d] = max(hi[d], k[d]); }
+  }
+#pragma unroll
+  for (int d = 0; d < 3; ++d) {
+    for (int o = 32; o; o >>= 1) {
+      lo[d] = min(lo[d], (uint32_t)__shfl_xor((int)lo[d], o));
+      hi[d] = max(hi[d], (uint32_t)__shfl_xor((int)hi[d], o));
+    }
+    if ((threadIdx.x & 63) == 0) { atomicMin(&bb[d], lo[d]); atomicMax(&bb[3 + d], hi[d]); }
+  }
+}
+
+__global__ void k_ssn_root(const uint32_t* __restrict__ bb, int n, SsnSeg* __restrict__ seg,
+                           uint32_t* __restrict__ seg_of_fill /*unused*/) {
+  SsnSeg s;
+  s.start = 0; s.count = (uint32_t)n;
+  for (int d = 0; d < 3; ++d) { s.lo[d] = float_from_order_key(bb[d]); s.hi[d] = float_from_order_key(bb[3 + d]); }
+  seg[0] = s;
+}
+
+// level keys: (segment << 32) | ordered cut coordinate for segments that still split, (segment << 32) |
+// rank for finished ones (they keep their order).  idx_in == nullptr: identity (level 0).
+__global__ __launch_bounds__(256) void k_ssn_keys(const float4* __restrict__ p, int n,
+                                                  const uint32_t* __restrict__ idx_in,
+                                                  const uint32_t* __restrict__ seg_of,
+                                                  const SsnSeg* __restrict__ segs, int knn,
+                                                  uint64_t* __restrict__ keys, uint32_t* __restrict__ vals) {
+  const int pos = blockIdx.x * 256 + threadIdx.x;
+  if (pos >= n) return;
+  const uint32_t s = seg_of ? seg_of[pos] : 0u;
+  const SsnSeg sg = segs[s];
+  const uint32_t i = idx_in ? idx_in[pos] : (uint32_t)pos;
+  uint32_t low;
+  if (sg.count > (uint32_t)knn) low = float_order_key(coord_of(p[i], ssn_cut_axis(sg)));
+  else low = (uint32_t)pos - sg.start;
+  keys[pos] = ((uint64_t)s << 32) | low;
+  vals[pos] = i;
+}
+
+// children of every segment of this level (2s, 2s+1); a finished segment carries over as child 2s
+__global__ __launch_bounds__(256) void k_ssn_split(const float4* __restrict__ p, const uint32_t* __restrict__ idx,
+                                                   const SsnSeg* __restrict__ segs, int nseg, int knn,
+                                                   SsnSeg* __restrict__ out) {
+  const int s = blockIdx.x * 256 + threadIdx.x;
+  if (s >= nseg) return;
+  const SsnSeg sg = segs[s];
+  SsnSeg a = sg, b = sg;
+  if (sg.count > (uint32_t)knn) {
+    const int cut = ssn_cut_axis(sg);
+    const uint32_t right = sg.count / 2, left = sg.count - right;
+    const float cutval = coord_of(p[idx[sg.start + left]], cut);
+    a.count = left; a.hi[cut] = cutval;
+    b.start = sg.start + left; b.count = right; b.lo[cut] = cutval;
+  } else {
+    b.start = sg.start + sg.count; b.count = 0;
+  }
+  out[2 * s] = a;
+  out[2 * s + 1] = b;
+}
+
+__global__ __launch_bounds__(256) void k_ssn_assign(int n, const SsnSeg* __restrict__ parents, int knn,
+                                                    uint32_t* __restrict__ seg_of, int first_level) {
+  const int pos = blockIdx.x * 256 + threadIdx.x;
+  if (pos >= n) return;
+  const uint32_t s = first_level ? 0u : seg_of[pos];
+  const SsnSeg sg = parents[s];
+  uint32_t c = 2u * s;
+  if (sg.count > (uint32_t)knn) {
+    const uint32_t left = sg.count - sg.count / 2;
+    c += ((uint32_t)pos - sg.start) >= left ? 1u : 0u;
+  }
+  seg_of[pos] = c;
+}
+
+// one thread per box: normal (or "dropped"); box_pts = number of points that draw a random number
+__global__ __launch_bounds__(128) void k_ssn_boxes(const float4* __restrict__ p, const uint32_t* __restrict__ idx,
+                                                   const SsnSeg* __restrict__ segs, int nseg,
+                                                   float* __restrict__ box_normal, uint32_t* __restrict__ box_pts) {
+  const int s = blockIdx.x * 128 + threadIdx.x;
+  if (s >= nseg) return;
+  const SsnSeg sg = segs[s];
+  uint32_t kept = 0;
+  if (sg.count > 0) {
+    float n[3];
+    const uint32_t* bi = idx + sg.start;
+    if (boxnormal::box_normal((int)sg.count, [&](int i, int d) { return coord_of(p[bi[i]], d); }, n)) {
+      kept = sg.count;
+      box_normal[3 * (size_t)s + 0] = n[0];
+      box_normal[3 * (size_t)s + 1] = n[1];
+      box_normal[3 * (size_t)s + 2] = n[2];
+    }
+  }
+  box_pts[s] = kept;
+}
+
+// per position: does the point survive?  r = the rand() draw of this point = draws[box_base + rank]
+// (dropped boxes draw nothing, exactly like the sequential filter).
+__global__ __launch_bounds__(256) void k_ssn_select(int n, const uint32_t* __restrict__ seg_of,
+                                                    const SsnSeg* __restrict__ segs,
+                                                    const uint32_t* __restrict__ box_pts,
+                                                    const uint32_t* __restrict__ box_base,
+                                                    const float* __restrict__ draws, float ratio,
+                                                    uint32_t* __restrict__ keep) {
+  const int pos = blockIdx.x * 256 + threadIdx.x;
+  if (pos >= n) return;
+  const uint32_t s = seg_of[pos];
+  uint32_t k = 0;
+  if (box_pts[s]) {
+    const float r = draws[box_base[s] + ((uint32_t)pos - segs[s].start)];
+    k = r < ratio ? 1u : 0u;
+  }
+  keep[pos] = k;
+}
+
+__global__ __launch_bounds__(256) void k_ssn_emit(const float4* __restrict__ p, int n,
+                                                  const uint32_t* __restrict__ idx,
+                                                  const uint32_t* __restrict__ seg_of,
+                                                  const float* __restrict__ box_normal,
+                                                  const uint32_t* __restrict__ keep,
+                                                  const uint32_t* __restrict__ out_pos,
+                                                  float4* __restrict__ out_xyz1, float* __restrict__ out_nrm) {
+  const int pos = blockIdx.x * 256 + threadIdx.x;
+  if (pos >= n || !keep[pos]) return;
+  const uint32_t o = out_pos[pos], s = seg_of[pos];
+  out_xyz1[o] = p[idx[pos]];
+  out_nrm[3 * (size_t)o + 0] = box_normal[3 * (size_t)s + 0];
+  out_nrm[3 * (size_t)o + 1] = box_normal[3 * (size_t)s + 1];
+  out_nrm[3 * (size_t)o + 2] = box_normal[3 * (size_t)s + 2];
+}
+
+}  // namespace lsgpu

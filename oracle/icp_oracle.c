@@ -192,9 +192,40 @@ static void nth_element_idx(int32_t* idx, int64_t lo, int64_t hi, int64_t nth, c
 
 /* ------------------------------------------------------------------ K2 SamplingSurfaceNormal */
 
+/* Stable merge sort of idx[lo,hi) by coordinate `dim` (equal coordinates keep their order; -0 == +0).
+ * std::nth_element leaves the order among equal keys and inside each half unspecified; the restatement
+ * fixes it as "stable sort, split at the median" so that every implementation of the chain (this one,
+ * the device filter) builds bit-identical boxes, box orders and rand() consumption orders. */
+static void stable_sort_idx(int32_t* idx, int32_t* tmp, int64_t lo, int64_t hi, const float* xyz1, int dim) {
+  const int64_t n = hi - lo;
+  if (n < 2) return;
+  if (n <= 16) { /* insertion sort */
+    for (int64_t i = lo + 1; i < hi; ++i) {
+      const int32_t v = idx[i];
+      const float kv = xyz1[4 * (int64_t)v + dim];
+      int64_t j = i;
+      while (j > lo && xyz1[4 * (int64_t)idx[j - 1] + dim] > kv) { idx[j] = idx[j - 1]; --j; }
+      idx[j] = v;
+    }
+    return;
+  }
+  const int64_t mid = lo + n / 2;
+  stable_sort_idx(idx, tmp, lo, mid, xyz1, dim);
+  stable_sort_idx(idx, tmp, mid, hi, xyz1, dim);
+  int64_t a = lo, b = mid, o = lo;
+  while (a < mid && b < hi) {
+    if (xyz1[4 * (int64_t)idx[b] + dim] < xyz1[4 * (int64_t)idx[a] + dim]) tmp[o++] = idx[b++];
+    else tmp[o++] = idx[a++];
+  }
+  while (a < mid) tmp[o++] = idx[a++];
+  while (b < hi) tmp[o++] = idx[b++];
+  memcpy(idx + lo, tmp + lo, sizeof(int32_t) * (size_t)n);
+}
+
 typedef struct ssn_ctx {
   const float* xyz1;
   int32_t* idx;
+  int32_t* tmp;
   int knn;
   float ratio;
   float* out_xyz1;
@@ -309,7 +340,7 @@ static void ssn_build(ssn_ctx* s, int64_t first, int64_t last, const float* minb
   for (int d = 1; d < 3; ++d)
     if (maxb[d] - minb[d] > ext) { ext = maxb[d] - minb[d]; cut = d; }
   const int64_t right = count / 2, left = count - right;
-  nth_element_idx(s->idx, first, last, first + left, s->xyz1, cut);
+  stable_sort_idx(s->idx, s->tmp, first, last, s->xyz1, cut);
   const float cutval = s->xyz1[4 * (int64_t)s->idx[first + left] + cut];
   float lmax[3] = {maxb[0], maxb[1], maxb[2]}, rmin[3] = {minb[0], minb[1], minb[2]};
   lmax[cut] = cutval;
@@ -326,6 +357,7 @@ int64_t lso_sampling_surface_normal(const float* xyz1, int64_t n, int knn, float
   s.xyz1 = xyz1; s.knn = knn; s.ratio = ratio;
   s.out_xyz1 = out_xyz1; s.out_nrm = out_normals; s.n_out = 0;
   s.idx = (int32_t*)malloc(sizeof(int32_t) * (size_t)n);
+  s.tmp = (int32_t*)malloc(sizeof(int32_t) * (size_t)n);
   float minb[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, maxb[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
   for (int64_t i = 0; i < n; ++i) {
     s.idx[i] = (int32_t)i;
@@ -337,6 +369,7 @@ int64_t lso_sampling_surface_normal(const float* xyz1, int64_t n, int knn, float
   }
   ssn_build(&s, 0, n, minb, maxb);
   free(s.idx);
+  free(s.tmp);
   return s.n_out;
 }
 
