@@ -157,9 +157,39 @@ int lsgpu_normal_eq(lsgpu_icp* h, const float* query_xyz1, int64_t nq, const flo
 /* RigidTransformation::compute on features (laser_track.cpp:265,485): out = T * xyz1. */
 int lsgpu_transform_points(lsgpu_icp* h, const float T[16], const float* xyz1, int64_t n, float* out);
 
-/* ---- host-side modules of the chain (run on the CPU; the reference runs them there too) ---- */
+/* ---- the whole of ICP::compute on the device ----------------------------------
+ * The sampling filters of icp_default.yaml:1-7 as device kernels, and the complete call
+ * `icp_.compute(reading, reference, T_init)` (laser_slam/src/laser_track.cpp:496,
+ * incremental_estimator.cpp:108) = reference filter, set_reference, reading filter, align, without the
+ * clouds leaving the GPU.  Draws: the library's own stream with the std::srand/std::rand sequence of
+ * glibc (csrc/lsgpu_rand.h); seed >= 0 reseeds it, seed < 0 continues it.  The device filters, the host
+ * filters below and the oracle produce the same points, in the same order, with the same normals. */
+typedef struct lsgpu_chain_config {
+  float   reading_prob;     /* RandomSamplingDataPointsFilter.prob            yaml:2-3 (0.5)  */
+  int     ssn_knn;          /* SamplingSurfaceNormalDataPointsFilter.knn      yaml:6-7 (10)   */
+  float   ssn_ratio;        /* SamplingSurfaceNormalDataPointsFilter.ratio    yaml:6-7 (0.5)  */
+  int     pad_;
+  int64_t seed;             /* >= 0: reseed before the reference filter; < 0: continue        */
+} lsgpu_chain_config;
+void lsgpu_chain_config_yaml(lsgpu_chain_config* c);     /* icp_default.yaml values           */
+void lsgpu_chain_config_default(lsgpu_chain_config* c);  /* ICP::setDefault(): 0.75, 7, 0.5   */
 
-/* RandomSamplingDataPointsFilter (yaml:1-3): keep i iff rand()/RAND_MAX < prob; seed >= 0 -> srand. */
+/* SamplingSurfaceNormalDataPointsFilter on the device.  3 <= knn <= 32.  out_xyz1 (4 floats/pt) and
+ * out_normals (3 floats/pt) need room for n points; host or device pointers. */
+int lsgpu_icp_filter_reference(lsgpu_icp* h, const float* xyz1, int64_t n, int knn, float ratio,
+                               int64_t seed, float* out_xyz1, float* out_normals, int64_t* n_out);
+/* RandomSamplingDataPointsFilter on the device: keeps point i iff draw_i < prob, order preserved. */
+int lsgpu_icp_filter_reading(lsgpu_icp* h, const float* xyz1, int64_t n, float prob, int64_t seed,
+                             float* out_xyz1, int64_t* n_out);
+/* ICP::compute.  Returns like lsgpu_icp_align (LSGPU_NO_CONVERGENCE also when a filter leaves no
+ * point); stats->t_reserved[0] = milliseconds spent in the two filters + set_reference. */
+int lsgpu_icp_compute(lsgpu_icp* h, const float* reading_xyz1, int64_t nq, const float* reference_xyz1,
+                      int64_t nr, const float T_init[16], const lsgpu_chain_config* chain,
+                      float T_out[16], lsgpu_icp_stats* stats);
+
+/* ---- host-side versions of the two filters (same output as the device filters) and O(1) helpers ---- */
+
+/* RandomSamplingDataPointsFilter (yaml:1-3): keep i iff draw_i < prob; seed as above. */
 int64_t lsgpu_filter_random_sampling(int64_t n, float prob, int64_t seed, int64_t* keep_idx);
 /* SamplingSurfaceNormalDataPointsFilter (yaml:5-7), samplingMethod 0, keepNormals 1. */
 int64_t lsgpu_filter_sampling_surface_normal(const float* xyz1, int64_t n, int knn, float ratio,

@@ -18,11 +18,23 @@ OK, NO_CONVERGENCE, BAD_CONFIG, HIP_ERROR, BAD_ARG = 0, 1, 2, 3, 4
 ABI_SYMBOLS = [
     "lsgpu_icp_config_yaml", "lsgpu_icp_config_default", "lsgpu_icp_create", "lsgpu_icp_destroy",
     "lsgpu_icp_set_reference", "lsgpu_icp_align", "lsgpu_icp_align_batch", "lsgpu_icp_get_trace",
+    "lsgpu_chain_config_yaml", "lsgpu_chain_config_default", "lsgpu_icp_filter_reference",
+    "lsgpu_icp_filter_reading", "lsgpu_icp_compute",
     "lsgpu_icp_get_reference_mean", "lsgpu_icp_get_info", "lsgpu_comm_get_unique_id", "lsgpu_icp_comm_init", "lsgpu_knn", "lsgpu_trim_limit", "lsgpu_normal_eq",
     "lsgpu_transform_points", "lsgpu_filter_random_sampling",
     "lsgpu_filter_sampling_surface_normal", "lsgpu_check_rigid", "lsgpu_correct_rigid",
     "lsgpu_strerror", "lsgpu_last_error", "lsgpu_abi_version",
 ]
+
+
+class ChainCfg(C.Structure):
+    _fields_ = [
+        ("reading_prob", C.c_float),
+        ("ssn_knn", C.c_int),
+        ("ssn_ratio", C.c_float),
+        ("pad_", C.c_int),
+        ("seed", C.c_int64),
+    ]
 
 
 class IcpConfig(C.Structure):
@@ -120,6 +132,14 @@ def lib() -> C.CDLL:
                                         C.POINTER(i64), C.POINTER(fp), C.POINTER(i64),
                                         C.POINTER(C.c_float), C.POINTER(C.c_float),
                                         C.POINTER(IcpStats), C.POINTER(C.c_int)]
+    L.lsgpu_chain_config_yaml.argtypes = [C.POINTER(ChainCfg)]
+    L.lsgpu_chain_config_yaml.restype = None
+    L.lsgpu_chain_config_default.argtypes = [C.POINTER(ChainCfg)]
+    L.lsgpu_chain_config_default.restype = None
+    L.lsgpu_icp_filter_reference.argtypes = [vp, fp, i64, C.c_int, C.c_float, i64, fp, fp, C.POINTER(i64)]
+    L.lsgpu_icp_filter_reading.argtypes = [vp, fp, i64, C.c_float, i64, fp, C.POINTER(i64)]
+    L.lsgpu_icp_compute.argtypes = [vp, fp, i64, fp, i64, C.POINTER(C.c_float), C.POINTER(ChainCfg),
+                                    C.POINTER(C.c_float), C.POINTER(IcpStats)]
     L.lsgpu_icp_get_trace.argtypes = [vp, C.POINTER(IterTrace), C.c_int]
     L.lsgpu_icp_get_reference_mean.argtypes = [vp, C.POINTER(C.c_float)]
     L.lsgpu_icp_get_info.argtypes = [vp, C.POINTER(IcpInfo)]

@@ -26,6 +26,8 @@
 #include "lsgpu_knn.hip.h"
 #include "lsgpu_solve.hip.h"
 #include "lsgpu_host_math.h"
+#include "lsgpu_ssn.hip.h"
+#include "lsgpu_rand.h"
 
 using namespace lsgpu;
 
@@ -151,6 +153,15 @@ struct lsgpu_icp {
   DevBuf<RefStats> stat_partials;
   DevBuf<uint32_t> counters;  // [0..16] cell counts, [32] straggler count
 
+  // device filters (lsgpu_ssn.hip.h)
+  DevBuf<SsnSeg> ssn_seg_a, ssn_seg_b;
+  DevBuf<uint32_t> ssn_seg_of, ssn_box_pts, ssn_box_base, ssn_keep, ssn_out_pos, ssn_bb;
+  DevBuf<float> ssn_box_normal, ssn_draws;
+  DevBuf<float4> flt_in, flt_ref, flt_rd;
+  DevBuf<float> flt_nrm;
+  float* draws_pinned = nullptr;  // host staging of the filter draws (pinned: async H2D)
+  size_t draws_pinned_cap = 0;
+
   // reading
   int64_t nq = 0;
   DevBuf<float4> q_in, rdq;
@@ -195,6 +206,16 @@ void lsgpu_icp_config_default(lsgpu_icp_config* c) {  // ICP::setDefault(), lase
   c->min_diff_trans = 0.001f;
   c->smooth_length = 3;
   c->cell_size = 0.f;
+}
+
+void lsgpu_chain_config_yaml(lsgpu_chain_config* c) {  // icp_default.yaml:1-7
+  std::memset(c, 0, sizeof(*c));
+  c->reading_prob = 0.5f; c->ssn_knn = 10; c->ssn_ratio = 0.5f; c->seed = -1;
+}
+
+void lsgpu_chain_config_default(lsgpu_chain_config* c) {  // ICP::setDefault(), laser_track.cpp:20
+  std::memset(c, 0, sizeof(*c));
+  c->reading_prob = 0.75f; c->ssn_knn = 7; c->ssn_ratio = 0.5f; c->seed = -1;
 }
 
 int lsgpu_abi_version(void) { return LSGPU_ABI_VERSION; }
@@ -247,7 +268,7 @@ void lsgpu_icp_destroy(lsgpu_icp* h) {
   h->comm_tmp.release();
   h->ref_in.release(); h->nrm_in.release(); h->keys.release(); h->keys_alt.release();
   h->vals.release(); h->vals_alt.release(); h->sort_tmp.release(); h->pts.release();
-  h->nrm.release(); h->ref_inv.release(); h->tables.release(); h->flags.release(); h->cidx.release(); h->bounds.release(); h->chunks.release(); h->prev.release(); h->state.release(); h->lb.release(); h->cell_cache.release(); h->cell_tags.release(); h->chk_hist.release(); h->trace_dev.release(); h->knn_dbg.release(); h->knn_dbg_wave.release(); h->stat_partials.release();
+  h->nrm.release(); h->ref_inv.release(); h->tables.release(); h->flags.release(); h->cidx.release(); h->bounds.release(); h->chunks.release(); h->prev.release(); h->state.release(); h->lb.release(); h->cell_cache.release(); h->cell_tags.release(); h->ssn_seg_a.release(); h->ssn_seg_b.release(); h->ssn_seg_of.release(); h->ssn_box_pts.release(); h->ssn_box_base.release(); h->ssn_keep.release(); h->ssn_out_pos.release(); h->ssn_bb.release(); h->ssn_box_normal.release(); h->ssn_draws.release(); h->flt_in.release(); h->flt_ref.release(); h->flt_rd.release(); h->flt_nrm.release(); h->chk_hist.release(); h->trace_dev.release(); h->knn_dbg.release(); h->knn_dbg_wave.release(); h->stat_partials.release();
   h->counters.release(); h->q_in.release(); h->rdq.release(); h->ids.release(); h->d2.release();
   h->ids_io.release(); h->d2_io.release(); h->strag.release(); h->hist.release();
   h->sel.release(); h->ne_partials.release(); h->ne_out.release(); h->limit_dev.release();
@@ -255,6 +276,7 @@ void lsgpu_icp_destroy(lsgpu_icp* h) {
   if (h->ev0) (void)hipEventDestroy(h->ev0);
   if (h->ev1) (void)hipEventDestroy(h->ev1);
   if (h->h_pinned) (void)hipHostFree(h->h_pinned);
+  if (h->draws_pinned) (void)hipHostFree(h->draws_pinned);
   if (h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
 }
@@ -702,6 +724,234 @@ int lsgpu_transform_points(lsgpu_icp* h, const float T[16], const float* xyz1, i
   if (!dev_out) HIPC(hipMemcpyAsync(out, dst, (size_t)n * 16, hipMemcpyDeviceToHost, h->stream));
   HIPC(hipStreamSynchronize(h->stream));
   return LSGPU_OK;
+}
+
+}  // extern "C"
+
+// exclusive prefix sum of n uint32 on the handle's stream
+static int scan_u32(lsgpu_icp* h, const uint32_t* in, uint32_t* out, size_t n) {
+  size_t bytes = 0;
+  HIPC(rocprim::exclusive_scan(nullptr, bytes, in, out, 0u, n, rocprim::plus<uint32_t>(), h->stream));
+  HIPC(h->sort_tmp.reserve(bytes));
+  bytes = h->sort_tmp.cap;
+  HIPC(rocprim::exclusive_scan((void*)h->sort_tmp.p, bytes, in, out, 0u, n, rocprim::plus<uint32_t>(), h->stream));
+  return LSGPU_OK;
+}
+
+// Up to `kmax` draws of the library stream -> h->ssn_draws, speculatively: the stream stays locked until
+// the caller commits the number the sequential filter would have consumed (DrawStream::commit).
+static int upload_draws_begin(lsgpu_icp* h, int64_t seed, size_t kmax) {
+  if (kmax + 1 > h->draws_pinned_cap) {
+    if (h->draws_pinned) (void)hipHostFree(h->draws_pinned);
+    h->draws_pinned = nullptr; h->draws_pinned_cap = 0;
+    HIPC(hipHostMalloc((void**)&h->draws_pinned, (kmax + 1) * sizeof(float), hipHostMallocDefault));
+    h->draws_pinned_cap = kmax + 1;
+  }
+  HIPC(h->ssn_draws.reserve(kmax + 1));
+  DrawStream::global().begin(seed, kmax, h->draws_pinned);
+  if (kmax) {
+    const hipError_t e = hipMemcpyAsync(h->ssn_draws.p, h->draws_pinned, kmax * sizeof(float), hipMemcpyHostToDevice, h->stream);
+    if (e != hipSuccess) { DrawStream::global().commit(0); HIPC(e); }
+  }
+  return LSGPU_OK;
+}
+
+// totals of two exclusive scans (last scanned value + last input) in one D2H, synchronises the stream
+static int scan_totals(lsgpu_icp* h, const uint32_t* in_a, const uint32_t* sc_a, size_t na,
+                       const uint32_t* in_b, const uint32_t* sc_b, size_t nb, uint32_t* tot_a, uint32_t* tot_b) {
+  uint32_t* hp = reinterpret_cast<uint32_t*>(h->h_pinned + 100);
+  hp[0] = hp[1] = hp[2] = hp[3] = 0;
+  hipError_t e = hipSuccess;
+  if (in_a) {
+    e = hipMemcpyAsync(hp, in_a + (na - 1), 4, hipMemcpyDeviceToHost, h->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(hp + 1, sc_a + (na - 1), 4, hipMemcpyDeviceToHost, h->stream);
+  }
+  if (e == hipSuccess) e = hipMemcpyAsync(hp + 2, in_b + (nb - 1), 4, hipMemcpyDeviceToHost, h->stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(hp + 3, sc_b + (nb - 1), 4, hipMemcpyDeviceToHost, h->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+  *tot_a = hp[0] + hp[1];
+  *tot_b = hp[2] + hp[3];
+  if (e != hipSuccess) HIPC(e);
+  return LSGPU_OK;
+}
+
+// SamplingSurfaceNormal on device memory: src (n points) -> out_xyz1 / out_nrm (device, room for n)
+static int ssn_device(lsgpu_icp* h, const float4* src, int64_t n, int knn, float ratio, int64_t seed,
+                      float4* out_xyz1, float* out_nrm, int64_t* n_out) {
+  *n_out = 0;
+  int levels = 0;
+  for (int64_t c = n; c > knn; c -= c / 2) ++levels;  // the largest child keeps count - count / 2 points
+  const size_t nseg = (size_t)1 << levels;
+  HIPC(h->ssn_seg_a.reserve(nseg));
+  HIPC(h->ssn_seg_b.reserve(nseg));
+  HIPC(h->ssn_seg_of.reserve(n));
+  HIPC(h->ssn_box_pts.reserve(nseg));
+  HIPC(h->ssn_box_base.reserve(nseg));
+  HIPC(h->ssn_box_normal.reserve(3 * nseg));
+  HIPC(h->ssn_keep.reserve(n));
+  HIPC(h->ssn_out_pos.reserve(n));
+  HIPC(h->ssn_bb.reserve(8));
+  HIPC(h->keys.reserve(n));
+  HIPC(h->vals.reserve(n));
+  HIPC(hipMemsetAsync(h->ssn_bb.p, 0xFF, 12, h->stream));
+  HIPC(hipMemsetAsync(h->ssn_bb.p + 3, 0, 12, h->stream));
+  hipLaunchKernelGGL(k_ssn_bounds, dim3(std::min(nblk(n), 256)), dim3(256), 0, h->stream, src, (int)n, h->ssn_bb.p);
+  hipLaunchKernelGGL(k_ssn_root, dim3(1), dim3(1), 0, h->stream, h->ssn_bb.p, (int)n, h->ssn_seg_a.p, (uint32_t*)nullptr);
+  SsnSeg* cur = h->ssn_seg_a.p;
+  SsnSeg* nxt = h->ssn_seg_b.p;
+  const uint32_t* idx = nullptr;
+  for (int L = 0; L < levels; ++L) {
+    hipLaunchKernelGGL(k_ssn_keys, dim3(nblk(n)), dim3(256), 0, h->stream, src, (int)n, idx,
+                       L ? h->ssn_seg_of.p : (const uint32_t*)nullptr, cur, knn, h->keys.p, h->vals.p);
+    int rc = sort_pairs(h, n, 32 + L);
+    if (rc) return rc;
+    idx = h->vals_alt.p;
+    const int ns = 1 << L;
+    hipLaunchKernelGGL(k_ssn_split, dim3(nblk(ns)), dim3(256), 0, h->stream, src, idx, cur, ns, knn, nxt);
+    hipLaunchKernelGGL(k_ssn_assign, dim3(nblk(n)), dim3(256), 0, h->stream, (int)n, cur, knn, h->ssn_seg_of.p, L == 0 ? 1 : 0);
+    std::swap(cur, nxt);
+  }
+  if (levels == 0) {  // a single box: identity order
+    hipLaunchKernelGGL(k_ssn_keys, dim3(nblk(n)), dim3(256), 0, h->stream, src, (int)n, (const uint32_t*)nullptr,
+                       (const uint32_t*)nullptr, cur, knn, h->keys.p, h->vals.p);
+    HIPC(hipMemsetAsync(h->ssn_seg_of.p, 0, (size_t)n * 4, h->stream));
+    idx = h->vals.p;
+  }
+  hipLaunchKernelGGL(k_ssn_boxes, dim3((int)((nseg + 127) / 128)), dim3(128), 0, h->stream, src, idx, cur, (int)nseg,
+                     h->ssn_box_normal.p, h->ssn_box_pts.p);
+  HIPC(hipGetLastError());
+  int rc = scan_u32(h, h->ssn_box_pts.p, h->ssn_box_base.p, nseg);
+  if (rc) return rc;
+  // the draws: at most one per point; produced on the host while the kernels above run
+  rc = upload_draws_begin(h, seed, (size_t)n);
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_ssn_select, dim3(nblk(n)), dim3(256), 0, h->stream, (int)n, h->ssn_seg_of.p, cur,
+                     h->ssn_box_pts.p, h->ssn_box_base.p, h->ssn_draws.p, ratio, h->ssn_keep.p);
+  rc = scan_u32(h, h->ssn_keep.p, h->ssn_out_pos.p, (size_t)n);
+  if (rc == LSGPU_OK) {
+    hipLaunchKernelGGL(k_ssn_emit, dim3(nblk(n)), dim3(256), 0, h->stream, src, (int)n, idx, h->ssn_seg_of.p,
+                       h->ssn_box_normal.p, h->ssn_keep.p, h->ssn_out_pos.p, out_xyz1, out_nrm);
+  }
+  uint32_t n_draws = 0, kept = 0;
+  if (rc == LSGPU_OK)
+    rc = scan_totals(h, h->ssn_box_pts.p, h->ssn_box_base.p, nseg, h->ssn_keep.p, h->ssn_out_pos.p, (size_t)n, &n_draws, &kept);
+  DrawStream::global().commit(rc == LSGPU_OK ? (size_t)n_draws : 0);  // dropped boxes drew nothing
+  if (rc) return rc;
+  HIPC(hipGetLastError());
+  *n_out = kept;
+  return LSGPU_OK;
+}
+
+// RandomSampling on device memory (order preserved)
+static int random_sampling_device(lsgpu_icp* h, const float4* src, int64_t n, float prob, int64_t seed,
+                                  float4* out_xyz1, int64_t* n_out) {
+  *n_out = 0;
+  HIPC(h->ssn_keep.reserve(n));
+  HIPC(h->ssn_out_pos.reserve(n));
+  int rc = upload_draws_begin(h, seed, (size_t)n);
+  if (rc) return rc;
+  DrawStream::global().commit((size_t)n);  // one draw per point, whatever happens next
+  hipLaunchKernelGGL(k_draw_select, dim3(nblk(n)), dim3(256), 0, h->stream, (int)n, h->ssn_draws.p, prob, h->ssn_keep.p);
+  rc = scan_u32(h, h->ssn_keep.p, h->ssn_out_pos.p, (size_t)n);
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_compact_points, dim3(nblk(n)), dim3(256), 0, h->stream, src, (int)n, h->ssn_keep.p,
+                     h->ssn_out_pos.p, out_xyz1);
+  HIPC(hipGetLastError());
+  uint32_t unused = 0, kept = 0;
+  rc = scan_totals(h, nullptr, nullptr, 0, h->ssn_keep.p, h->ssn_out_pos.p, (size_t)n, &unused, &kept);
+  if (rc) return rc;
+  *n_out = kept;
+  return LSGPU_OK;
+}
+
+extern "C" {
+
+int lsgpu_icp_filter_reference(lsgpu_icp* h, const float* xyz1, int64_t n, int knn, float ratio,
+                               int64_t seed, float* out_xyz1, float* out_normals, int64_t* n_out) {
+  if (!h || !n_out || !out_xyz1 || !out_normals) return LSGPU_BAD_ARG;
+  h->err.clear();
+  *n_out = 0;
+  if (knn < 3 || knn > kSsnMaxKnn) { h->err = "filter_reference: knn must be in [3, 32]"; return LSGPU_BAD_ARG; }
+  if (seed >= 0) DrawStream::global().take(seed, 0, nullptr);
+  if (n <= 0 || !xyz1) return LSGPU_OK;
+  if (n > 0x7FFFFFF0ll) return LSGPU_BAD_ARG;
+  HIPC(hipSetDevice(h->device));
+  const float4* src = nullptr;
+  int rc = stage_points(h, xyz1, n, h->flt_in, &src);
+  if (rc) return rc;
+  const bool dev_x = is_device_ptr(out_xyz1), dev_n = is_device_ptr(out_normals);
+  float4* ox = reinterpret_cast<float4*>(out_xyz1);
+  float* on = out_normals;
+  if (!dev_x) { HIPC(h->flt_ref.reserve(n)); ox = h->flt_ref.p; }
+  if (!dev_n) { HIPC(h->flt_nrm.reserve(3 * n)); on = h->flt_nrm.p; }
+  rc = ssn_device(h, src, n, knn, ratio, -1, ox, on, n_out);
+  if (rc) return rc;
+  if (!dev_x && *n_out) HIPC(hipMemcpyAsync(out_xyz1, ox, (size_t)*n_out * 16, hipMemcpyDeviceToHost, h->stream));
+  if (!dev_n && *n_out) HIPC(hipMemcpyAsync(out_normals, on, (size_t)*n_out * 12, hipMemcpyDeviceToHost, h->stream));
+  HIPC(hipStreamSynchronize(h->stream));
+  return LSGPU_OK;
+}
+
+int lsgpu_icp_filter_reading(lsgpu_icp* h, const float* xyz1, int64_t n, float prob, int64_t seed,
+                             float* out_xyz1, int64_t* n_out) {
+  if (!h || !n_out || !out_xyz1) return LSGPU_BAD_ARG;
+  h->err.clear();
+  *n_out = 0;
+  if (seed >= 0) DrawStream::global().take(seed, 0, nullptr);
+  if (n <= 0 || !xyz1) return LSGPU_OK;
+  if (n > 0x7FFFFFF0ll) return LSGPU_BAD_ARG;
+  HIPC(hipSetDevice(h->device));
+  const float4* src = nullptr;
+  int rc = stage_points(h, xyz1, n, h->flt_in, &src);
+  if (rc) return rc;
+  const bool dev_x = is_device_ptr(out_xyz1);
+  float4* ox = reinterpret_cast<float4*>(out_xyz1);
+  if (!dev_x) { HIPC(h->flt_rd.reserve(n)); ox = h->flt_rd.p; }
+  rc = random_sampling_device(h, src, n, prob, -1, ox, n_out);
+  if (rc) return rc;
+  if (!dev_x && *n_out) HIPC(hipMemcpyAsync(out_xyz1, ox, (size_t)*n_out * 16, hipMemcpyDeviceToHost, h->stream));
+  HIPC(hipStreamSynchronize(h->stream));
+  return LSGPU_OK;
+}
+
+int lsgpu_icp_compute(lsgpu_icp* h, const float* reading_xyz1, int64_t nq, const float* reference_xyz1,
+                      int64_t nr, const float T_init[16], const lsgpu_chain_config* chain,
+                      float T_out[16], lsgpu_icp_stats* stats) {
+  if (!h || !T_init || !T_out || !chain) return LSGPU_BAD_ARG;
+  h->err.clear();
+  std::memcpy(T_out, T_init, 16 * sizeof(float));
+  if (stats) std::memset(stats, 0, sizeof(*stats));
+  if (chain->ssn_knn < 3 || chain->ssn_knn > kSsnMaxKnn) { h->err = "compute: ssn_knn must be in [3, 32]"; return LSGPU_BAD_CONFIG; }
+  if (chain->seed >= 0) DrawStream::global().take(chain->seed, 0, nullptr);
+  if (nq <= 0 || nr <= 0 || !reading_xyz1 || !reference_xyz1) { h->err = "compute: empty cloud"; return LSGPU_NO_CONVERGENCE; }
+  if (nq > 0x7FFFFFF0ll || nr > 0x7FFFFFF0ll) return LSGPU_BAD_ARG;
+  HIPC(hipSetDevice(h->device));
+  const double t0 = wall_ms();
+  // step 1: reference filter (yaml:5-7)
+  const float4* src = nullptr;
+  int rc = stage_points(h, reference_xyz1, nr, h->flt_in, &src);
+  if (rc) return rc;
+  HIPC(h->flt_ref.reserve(nr));
+  HIPC(h->flt_nrm.reserve(3 * nr));
+  int64_t nrf = 0, nqf = 0;
+  rc = ssn_device(h, src, nr, chain->ssn_knn, chain->ssn_ratio, -1, h->flt_ref.p, h->flt_nrm.p, &nrf);
+  if (rc) return rc;
+  if (nrf <= 0) { h->err = "compute: the reference filter left no point"; h->nr = 0; return LSGPU_NO_CONVERGENCE; }
+  // steps 2-3
+  rc = lsgpu_icp_set_reference(h, reinterpret_cast<const float*>(h->flt_ref.p), h->flt_nrm.p, nrf);
+  if (rc) return rc;
+  // step 4: reading filter (yaml:1-3)
+  rc = stage_points(h, reading_xyz1, nq, h->flt_in, &src);
+  if (rc) return rc;
+  HIPC(h->flt_rd.reserve(nq));
+  rc = random_sampling_device(h, src, nq, chain->reading_prob, -1, h->flt_rd.p, &nqf);
+  if (rc) return rc;
+  const double t_filters = wall_ms() - t0;
+  if (nqf <= 0) { h->err = "compute: the reading filter left no point"; return LSGPU_NO_CONVERGENCE; }
+  // steps 5-7
+  rc = lsgpu_icp_align(h, reinterpret_cast<const float*>(h->flt_rd.p), nqf, T_init, T_out, stats);
+  if (stats) stats->t_reserved[0] = t_filters;
+  return rc;
 }
 
 int lsgpu_icp_align(lsgpu_icp* h, const float* reading_xyz1, int64_t nq, const float T_init[16],

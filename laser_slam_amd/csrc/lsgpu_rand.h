@@ -26,7 +26,22 @@ class DrawStream {
   void take(int64_t seed, size_t k, float* out) {
     std::lock_guard<std::mutex> g(mu_);
     if (seed >= 0) reseed_locked((unsigned)seed);
-    for (size_t i = 0; i < k; ++i) out[i] = (float)next_locked() / 2147483648.0f;  // (float)RAND_MAX == 2^31
+    generate_locked(k, out);
+    commit_locked(k);
+  }
+
+  // Speculative use: begin() locks the stream and produces up to kmax draws WITHOUT consuming them,
+  // commit(k) consumes the first k <= kmax of them and unlocks.  (The device filters learn how many
+  // draws the sequential filter would have made only after their kernels ran; the draws themselves are
+  // produced while those kernels run.)
+  void begin(int64_t seed, size_t kmax, float* out) {
+    mu_.lock();
+    if (seed >= 0) reseed_locked((unsigned)seed);
+    generate_locked(kmax, out);
+  }
+  void commit(size_t k) {
+    commit_locked(k);
+    mu_.unlock();
   }
 
   static DrawStream& global() {
@@ -37,26 +52,38 @@ class DrawStream {
  private:
   void reseed_locked(unsigned seed) {
     int32_t word = seed ? (int32_t)seed : 1;
-    r_[0] = word;
+    uint32_t r[31 + 310];
+    r[0] = (uint32_t)word;
     for (int i = 1; i < 31; ++i) {
       const int32_t hi = word / 127773, lo = word % 127773;
       word = 16807 * lo - 2836 * hi;
       if (word < 0) word += 2147483647;
-      r_[i] = word;
+      r[i] = (uint32_t)word;
     }
-    f_ = 3; b_ = 0;
-    for (int i = 0; i < 310; ++i) (void)next_locked();
+    // glibc starts with the front pointer 3 words ahead of the rear one: in history order (oldest
+    // first) the table reads r[3], r[4], ..., r[30], r[0], r[1], r[2]; then 310 outputs are discarded
+    uint32_t w[31 + 310];
+    for (int i = 0; i < 31; ++i) w[i] = r[(i + 3) % 31];
+    // the first three sums use the seed table's r[0..2] as the "3 steps ago" values
+    for (int i = 0; i < 310; ++i) w[i + 31] = w[i] + w[i + 28];
+    for (int i = 0; i < 31; ++i) hist_[i] = w[310 + i];
+    raw_.clear();
   }
-  uint32_t next_locked() {
-    const uint32_t v = (uint32_t)r_[f_] + (uint32_t)r_[b_];
-    r_[f_] = (int32_t)v;
-    f_ = f_ + 1 == 31 ? 0 : f_ + 1;
-    b_ = b_ + 1 == 31 ? 0 : b_ + 1;
-    return v >> 1;
+  // raw_[0..31) = the last 31 raw words (oldest first), raw_[31 + i] = the i-th not yet consumed word
+  void generate_locked(size_t k, float* out) {
+    raw_.resize(31 + k);
+    uint32_t* w = raw_.data();
+    for (int i = 0; i < 31; ++i) w[i] = hist_[i];
+    for (size_t i = 0; i < k; ++i) w[i + 31] = w[i] + w[i + 28];
+    if (out)
+      for (size_t i = 0; i < k; ++i) out[i] = (float)(w[i + 31] >> 1) / 2147483648.0f;  // (float)RAND_MAX == 2^31
+  }
+  void commit_locked(size_t k) {
+    for (int i = 0; i < 31; ++i) hist_[i] = raw_[k + i];
   }
   std::mutex mu_;
-  int32_t r_[31];
-  int f_ = 3, b_ = 0;
+  uint32_t hist_[31];
+  std::vector<uint32_t> raw_;
 };
 
 }  // namespace lsgpu

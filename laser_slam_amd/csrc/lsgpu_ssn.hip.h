@@ -51,13 +51,20 @@ __global__ __launch_bounds__(256) void k_ssn_bounds(const float4* __restrict__ p
 #pragma unroll
     for (int d = 0; d < 3; ++d) { lo[d] = min(lo[d], k[d]); hi[d] = max(hi[d], k[d]); }
   }
+  __shared__ uint32_t red[4][6];
 #pragma unroll
   for (int d = 0; d < 3; ++d) {
     for (int o = 32; o; o >>= 1) {
       lo[d] = min(lo[d], (uint32_t)__shfl_xor((int)lo[d], o));
       hi[d] = max(hi[d], (uint32_t)__shfl_xor((int)hi[d], o));
     }
-    if ((threadIdx.x & 63) == 0) { atomicMin(&bb[d], lo[d]); atomicMax(&bb[3 + d], hi[d]); }
+    if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6][d] = lo[d]; red[threadIdx.x >> 6][3 + d] = hi[d]; }
+  }
+  __syncthreads();
+  if (threadIdx.x < 3) {  // one atomic per block and bound (same-address device atomics cost ~12 ns each)
+    const int d = threadIdx.x;
+    atomicMin(&bb[d], min(min(red[0][d], red[1][d]), min(red[2][d], red[3][d])));
+    atomicMax(&bb[3 + d], max(max(red[0][3 + d], red[1][3 + d]), max(red[2][3 + d], red[3][3 + d])));
   }
 }
 
@@ -177,6 +184,21 @@ __global__ __launch_bounds__(256) void k_ssn_emit(const float4* __restrict__ p, 
   out_nrm[3 * (size_t)o + 0] = box_normal[3 * (size_t)s + 0];
   out_nrm[3 * (size_t)o + 1] = box_normal[3 * (size_t)s + 1];
   out_nrm[3 * (size_t)o + 2] = box_normal[3 * (size_t)s + 2];
+}
+
+// RandomSamplingDataPointsFilter (yaml:1-3): keep point i iff its draw < prob
+__global__ __launch_bounds__(256) void k_draw_select(int n, const float* __restrict__ draws, float prob,
+                                                     uint32_t* __restrict__ keep) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n) keep[i] = draws[i] < prob ? 1u : 0u;
+}
+
+__global__ __launch_bounds__(256) void k_compact_points(const float4* __restrict__ p, int n,
+                                                        const uint32_t* __restrict__ keep,
+                                                        const uint32_t* __restrict__ out_pos,
+                                                        float4* __restrict__ out) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n && keep[i]) out[out_pos[i]] = p[i];
 }
 
 }  // namespace lsgpu

@@ -144,6 +144,57 @@ class IcpHandle:
             _raise(rc, "lsgpu_icp_align", self._h)
         return to.reshape(4, 4).T.copy(), st
 
+    # ---- the sampling filters on the device, and the whole of ICP::compute
+    def filter_reference(self, xyz1, knn: int = 10, ratio: float = 0.5, seed: int = -1):
+        """SamplingSurfaceNormalDataPointsFilter (icp_default.yaml:5-7) on the GPU -> (xyz1', normals);
+        torch CUDA input gives torch CUDA output, anything else numpy."""
+        p, _k, n = _as_f32(xyz1, 4)
+        m = C.c_int64(0)
+        if _is_torch(xyz1) and xyz1.is_cuda:
+            o = torch.empty((max(n, 1), 4), dtype=torch.float32, device=xyz1.device)
+            nr = torch.empty((max(n, 1), 3), dtype=torch.float32, device=xyz1.device)
+            torch.cuda.synchronize()
+            po, pn = o.data_ptr(), nr.data_ptr()
+        else:
+            o = np.empty((max(n, 1), 4), np.float32)
+            nr = np.empty((max(n, 1), 3), np.float32)
+            po, pn = o.ctypes.data, nr.ctypes.data
+        rc = _lib.lib().lsgpu_icp_filter_reference(self._h, p, n, knn, ratio, seed, po, pn, C.byref(m))
+        if rc != _lib.OK:
+            _raise(rc, "lsgpu_icp_filter_reference", self._h)
+        return o[:m.value], nr[:m.value]
+
+    def filter_reading(self, xyz1, prob: float = 0.5, seed: int = -1):
+        """RandomSamplingDataPointsFilter (icp_default.yaml:1-3) on the GPU -> xyz1'."""
+        p, _k, n = _as_f32(xyz1, 4)
+        m = C.c_int64(0)
+        if _is_torch(xyz1) and xyz1.is_cuda:
+            o = torch.empty((max(n, 1), 4), dtype=torch.float32, device=xyz1.device)
+            torch.cuda.synchronize()
+            po = o.data_ptr()
+        else:
+            o = np.empty((max(n, 1), 4), np.float32)
+            po = o.ctypes.data
+        rc = _lib.lib().lsgpu_icp_filter_reading(self._h, p, n, prob, seed, po, C.byref(m))
+        if rc != _lib.OK:
+            _raise(rc, "lsgpu_icp_filter_reading", self._h)
+        return o[:m.value]
+
+    def compute(self, reading_xyz1, reference_xyz1, T_init, reading_prob: float = 0.5, ssn_knn: int = 10,
+                ssn_ratio: float = 0.5, seed: int = -1):
+        """``icp_.compute(reading, reference, T_init)`` entirely on the device: reference filter,
+        set_reference, reading filter, align.  -> (T 4x4, IcpStats); raises ConvergenceError."""
+        q, _k1, nq = _as_f32(reading_xyz1, 4)
+        r, _k2, nr = _as_f32(reference_xyz1, 4)
+        ch = _lib.ChainCfg(reading_prob, ssn_knn, ssn_ratio, 0, seed)
+        ti = _t16(T_init)
+        to = np.empty(16, np.float32)
+        st = IcpStats()
+        rc = _lib.lib().lsgpu_icp_compute(self._h, q, nq, r, nr, _fp(ti), C.byref(ch), _fp(to), C.byref(st))
+        if rc != _lib.OK:
+            _raise(rc, "lsgpu_icp_compute", self._h)
+        return to.reshape(4, 4).T.copy(), st
+
     def trace(self, cap: int = 64):
         buf = (IterTrace * cap)()
         n = _lib.lib().lsgpu_icp_get_trace(self._h, buf, cap)
@@ -403,15 +454,7 @@ class ICP:
         """T (4x4 float32) with p_reference = T p_reading.  Raises ConvergenceError."""
         h = self._ensure_handle()
         ch = self.chain
-        ref = np.ascontiguousarray(reference_xyz1, np.float32)
-        rd = np.ascontiguousarray(reading_xyz1, np.float32)
-        if ch.seed >= 0:
-            random_sampling(0, 0.0, ch.seed)  # srand once, reference filters then reading filters
-        rf, rn = sampling_surface_normal(ref, ch.surface_normal_knn, ch.surface_normal_ratio, -1)
-        if rf.shape[0] == 0 or rd.shape[0] == 0:
-            raise ConvergenceError(_lib.NO_CONVERGENCE, "compute", "empty cloud after filtering")
-        h.set_reference(rf, rn)
-        keep = random_sampling(rd.shape[0], ch.reading_sampling_prob, -1)
-        T, st = h.align(rd[keep], T_init)
+        T, st = h.compute(reading_xyz1, reference_xyz1, T_init, ch.reading_sampling_prob,
+                          ch.surface_normal_knn, ch.surface_normal_ratio, ch.seed)
         self.last_stats = st
         return T

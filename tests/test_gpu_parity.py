@@ -421,3 +421,71 @@ def test_align_batch_matches_sequential(icp_mod, oracle):
     assert rco == 0
     dt, dr = synth.pose_error(T[0], synth.from_colmajor(To))
     assert dt <= TOL_T and dr <= TOL_R, (dt, dr)
+
+
+# ---- the sampling filters and the whole of ICP::compute on the device
+
+@pytest.mark.parametrize("n_az,knn,ratio,seed", [(64, 10, 0.5, 3), (256, 10, 1.0, 0), (1024, 7, 0.5, 11),
+                                                 (64, 32, 0.3, 5)])
+def test_device_reference_filter_is_bit_identical(icp_mod, oracle, n_az, knn, ratio, seed):
+    """SamplingSurfaceNormal on the GPU == oracle == host filter: same points, same order, same normals."""
+    ref = synth.scan_pair(n_az)[0]
+    of, on = oracle.sampling_surface_normal(ref, knn, ratio, seed)
+    hf, hn = icp_mod.sampling_surface_normal(ref, knn, ratio, seed)
+    with icp_mod.IcpHandle() as h:
+        gf, gn = h.filter_reference(ref, knn, ratio, seed)
+        import torch
+        tf, tn = h.filter_reference(torch.from_numpy(ref).cuda(), knn, ratio, seed)
+    assert len(of) > 0.2 * ratio * len(ref)
+    assert np.array_equal(gf, of) and np.array_equal(gn, on)
+    assert np.array_equal(hf, of) and np.array_equal(hn, on)
+    assert np.array_equal(tf.cpu().numpy(), of) and np.array_equal(tn.cpu().numpy(), on)
+
+
+def test_device_reference_filter_edge_cases(icp_mod, oracle):
+    from laser_slam_amd._lib import LsgpuError
+    rng = np.random.default_rng(5)
+    with icp_mod.IcpHandle() as h:
+        # fewer points than one box; duplicate coordinates (ties at the split); a degenerate (collinear) cloud
+        tiny = np.concatenate([rng.normal(size=(7, 3)), np.ones((7, 1))], 1).astype(np.float32)
+        dup = np.repeat(np.concatenate([rng.integers(0, 6, size=(400, 3)), np.ones((400, 1))], 1), 3, 0).astype(np.float32)
+        line = np.zeros((500, 4), np.float32); line[:, 0] = np.arange(500); line[:, 3] = 1
+        for cloud in (tiny, dup, line):
+            of, on = oracle.sampling_surface_normal(cloud, 10, 1.0, 2)
+            gf, gn = h.filter_reference(cloud, 10, 1.0, 2)
+            assert np.array_equal(gf, of) and np.array_equal(gn, on), len(cloud)
+        assert len(h.filter_reference(line, 10, 1.0, 2)[0]) == 0      # every box is rank deficient: all dropped
+        assert len(h.filter_reference(np.zeros((0, 4), np.float32), 10, 1.0, 2)[0]) == 0
+        with pytest.raises(LsgpuError):
+            h.filter_reference(tiny, 2, 1.0, 0)
+
+
+def test_device_reading_filter_and_stream_continuation(icp_mod, oracle):
+    """RandomSampling on the GPU keeps the points the oracle keeps; seed -1 continues the stream the way
+    consecutive rand() calls do (reference filter first, then reading filter: ICP::compute's order)."""
+    ref, rd = synth.scan_pair(256)[:2]
+    of, on = oracle.sampling_surface_normal(ref, 10, 0.5, 9)
+    ok = oracle.random_sampling(len(rd), 0.5, -1)
+    with icp_mod.IcpHandle() as h:
+        gf, gn = h.filter_reference(ref, 10, 0.5, 9)
+        gr = h.filter_reading(rd, 0.5, -1)
+    assert np.array_equal(gf, of) and np.array_equal(gr, rd[ok])
+    assert 0.4 * len(rd) < len(gr) < 0.6 * len(rd)
+
+
+def test_device_compute_matches_oracle_full_chain(icp_mod, oracle, pair64k):
+    """lsgpu_icp_compute (filters + ICP on the device) vs the oracle's whole ICP::compute with the yaml
+    chain: identical filtered clouds, same iteration count, transform within tolerance."""
+    rc, To, sto = oracle.icp_compute_full(oracle.config_yaml(accum_double=1), pair64k["rd"], pair64k["ref"],
+                                          synth.colmajor(pair64k["T_init"]), seed=4)
+    assert rc == 0
+    with icp_mod.IcpHandle() as h:
+        T, st = h.compute(pair64k["rd"], pair64k["ref"], pair64k["T_init"], 0.5, 10, 0.5, seed=4)
+        info = h.info()
+    assert st.iterations == sto.iterations and st.final_n_used == sto.final_n_used
+    assert st.final_limit == sto.final_limit or abs(st.final_limit - sto.final_limit) < 1e-6 * sto.final_limit
+    assert 0.3 * len(pair64k["ref"]) < info.n_reference < 0.6 * len(pair64k["ref"])
+    dt, dr = synth.pose_error(T, synth.from_colmajor(To))
+    assert dt <= TOL_T and dr <= TOL_R, (dt, dr)
+    dt, dr = synth.pose_error(T, pair64k["T_true"])
+    assert dt < 0.05 and dr < 0.005
