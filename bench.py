@@ -65,9 +65,11 @@ def main():
     data_rank = 0 if args.split else rank   # split: every rank works on the SAME pair
     ref, rd, T_true, T_init = synth.scan_pair(args.n_az, noise_seeds=(1 + 2 * data_rank, 2 + 2 * data_rank),
                                               guess_seed=7 + data_rank)
-    rf, rn = icp.sampling_surface_normal(ref, 10, 1.0, 0)   # chain (F): ratio 1.0, knn 10
-    d_ref = torch.from_numpy(rf).cuda()
-    d_nrm = torch.from_numpy(rn).cuda()
+    raw_ref, raw_rd = ref, rd
+    with icp.IcpHandle(None, local_rank) as hf:               # chain (F): ratio 1.0, knn 10; the device filter
+        d_ref, d_nrm = hf.filter_reference(torch.from_numpy(ref).cuda(), 10, 1.0, 0)  # == host filter == oracle
+    d_ref, d_nrm = d_ref.contiguous().clone(), d_nrm.contiguous().clone()
+    rf, rn = d_ref.cpu().numpy(), d_nrm.cpu().numpy()
     if args.split:
         from laser_slam_amd import sharding
         rd = rd[sharding.split_shard(rd.shape[0], rank, world)]
@@ -131,6 +133,24 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    # ---- the whole ICP::compute (both filters + set_reference + align) on the raw clouds, SURVEY.md §8d
+    # variants P (icp_default.yaml chain: prob 0.5 / ratio 0.5) and F (full density): reported, not `value`
+    end_to_end = None
+    if not args.split:
+        d_raw_ref, d_raw_rd = torch.from_numpy(raw_ref).cuda(), torch.from_numpy(raw_rd).cuda()
+        torch.cuda.synchronize()
+        end_to_end = {}
+        for name, prob, ratio in (("P_yaml_chain", 0.5, 0.5), ("F_full_density", 1.0, 1.0)):
+            ts = []
+            for rep in range(4):
+                tc0 = time.perf_counter()
+                Te, ste = h.compute(d_raw_rd, d_raw_ref, T_init, prob, 10, ratio, seed=0)
+                ts.append((time.perf_counter() - tc0) * 1e3)
+            end_to_end[name] = {"ms_per_compute": float(np.median(ts[1:])), "filters_and_grid_ms": ste.t_reserved[0],
+                                "iterations": ste.iterations, "n_reference_after_filter": int(h.info().n_reference),
+                                "trans_err_m": synth.pose_error(Te.astype(np.float64), T_true)[0]}
+        h.set_reference(d_ref, d_nrm)
+
     info = h.info()
     ncell = int(info.cells[0])
     # algorithmic bytes of one kNN launch: 24 Nq + 16 Nr + 8 Ncell
@@ -180,6 +200,8 @@ def main():
                      "stragglers_per_launch": strag / max(knn_launches, 1)},
         "final_error_vs_truth": {"trans_m": et, "rot_rad": er},
     }
+    if end_to_end is not None:
+        out["compute_with_filters"] = end_to_end
 
     # ---- CPU baseline: the oracle (port) on this box's host cores, same workload, rank 0, N=1 only
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

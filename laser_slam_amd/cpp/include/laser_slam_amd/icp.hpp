@@ -157,17 +157,19 @@ class ICP {
     ensureHandle();
     const int64_t nr = reference.getNbPoints(), nq = reading.getNbPoints();
     if (nr <= 0 || nq <= 0) throw ConvergenceError("empty cloud");
-    // referenceDataPointsFilters, then readingDataPointsFilters (ICP::compute steps 1 and 4)
-    std::vector<float> rf((size_t)nr * 4), rn((size_t)nr * 3);
-    const int64_t nrf = lsgpu_filter_sampling_surface_normal(reference.features.data(), nr, knn_, ratio_, -1,
-                                                             rf.data(), rn.data());
-    std::vector<int64_t> keep((size_t)nq);
-    const int64_t nqf = lsgpu_filter_random_sampling(nq, prob_, -1, keep.data());
-    if (nrf <= 0 || nqf <= 0) throw ConvergenceError("empty cloud after filtering");
-    std::vector<float> rd((size_t)nqf * 4);
-    for (int64_t i = 0; i < nqf; ++i) std::memcpy(&rd[4 * i], &reading.features[4 * keep[i]], 16);
-    return computeFiltered(rd.data(), nqf, rf.data(), rn.data(), nrf, T_init);
+    // ICP::compute steps 1-7 on the device: referenceDataPointsFilters, centring + grid,
+    // readingDataPointsFilters, the loop (lsgpu_icp_compute)
+    lsgpu_chain_config chain;
+    lsgpu_chain_config_default(&chain);
+    chain.reading_prob = prob_; chain.ssn_knn = knn_; chain.ssn_ratio = ratio_; chain.seed = seed_;
+    TransformationParameters T = T_init;
+    check(lsgpu_icp_compute(h_, reading.features.data(), nq, reference.features.data(), nr, T_init.data(),
+                            &chain, T.data(), &stats_), "lsgpu_icp_compute");
+    return T;
   }
+
+  // >= 0: reseed the filters' draw stream at every compute() (reproducible runs); < 0: continue it
+  void setSeed(int64_t seed) { seed_ = seed; }
 
   // Steps 2-7 on already filtered clouds (device or host pointers).
   TransformationParameters computeFiltered(const float* reading_xyz1, int64_t nq, const float* ref_xyz1,
@@ -262,6 +264,7 @@ class ICP {
   lsgpu_icp_stats stats_{};
   float prob_ = 0.75f, ratio_ = 0.5f;
   int knn_ = 7;
+  int64_t seed_ = -1;
 };
 
 }  // namespace laser_slam_amd
