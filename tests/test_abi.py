@@ -139,3 +139,24 @@ def test_synthetic_scan_generator_is_seeded_and_sane():
     assert r.min() > 1.0 and r.max() < synth.MAX_RANGE + 1
     dt, dr = synth.pose_error(T_init, T_true)
     assert abs(dt - 0.3) < 0.05 and abs(np.rad2deg(dr) - 1.5) < 0.2
+
+
+def test_draw_stream_is_the_glibc_rand_sequence():
+    """The filters' draws come from the library's own generator (csrc/lsgpu_rand.h); it must reproduce
+    std::srand(seed) + std::rand() of glibc, which is what the reference's filters consume, including the
+    continuation of the stream across calls (seed < 0)."""
+    import ctypes as C
+    import numpy as np
+    from laser_slam_amd import icp
+    libc = C.CDLL("libc.so.6")
+    libc.rand.restype = C.c_int
+
+    def libc_keep(n, prob):
+        r = np.array([libc.rand() for _ in range(n)], np.int64)
+        draws = r.astype(np.float32) / np.float32(2147483648.0)   # (float)rand() / (float)RAND_MAX
+        return np.nonzero(draws < np.float32(prob))[0]
+
+    for seed in (0, 1, 7, 123456, 2 ** 32 - 1):
+        libc.srand(C.c_uint(seed))
+        assert np.array_equal(icp.random_sampling(4000, 0.37, seed), libc_keep(4000, 0.37)), seed
+        assert np.array_equal(icp.random_sampling(1500, 0.5, -1), libc_keep(1500, 0.5)), seed   # continues
