@@ -26,11 +26,11 @@
 
 #include "laser_slam_amd/icp.hpp"
 #include "laser_slam_amd/se3.hpp"
+#include "laser_slam_amd/pose_graph.hpp"
 
 namespace laser_slam_amd {
 
 using Time = int64_t;  // curves::Time, nanoseconds
-using Key = size_t;
 
 struct Pose {          // laser_slam/include/laser_slam/common.hpp:87-94
   SE3 T_w;
@@ -65,16 +65,7 @@ struct LaserTrackParams {  // laser_slam/include/laser_slam/parameters.hpp:8-23
   int device = 0;                       // HIP device of this track's ICP handle
 };
 
-// One record per factor the reference pushes into the gtsam graph.
-struct Factor {
-  enum Type { PRIOR, ODOMETRY, ICP } type;
-  Key key_a = 0, key_b = 0;        // PRIOR uses key_b only
-  SE3 measurement;                 // T_w (prior) or T_a_b (between)
-  std::array<double, 6> sigmas{};  // diagonal noise model [translation; rotation]
-  bool cauchy = false;             // Cauchy(1) m-estimator (laser_track.cpp:47-54)
-};
-using FactorList = std::vector<Factor>;
-using Values = std::map<Key, SE3>;
+// Factor / FactorList / Values: pose_graph.hpp
 using TrajectoryMap = std::map<Time, SE3>;
 
 // curves::DiscreteSE3Curve stand-in
@@ -100,6 +91,12 @@ class Trajectory {
   void getCurveTimes(std::vector<Time>* out) const { out->clear(); for (auto& n : nodes_) out->push_back(n.t); }
   void update(const Values& v) { for (auto& n : nodes_) { auto it = v.find(n.key); if (it != v.end()) n.v = it->second; } }
   void setFirstKey(Key k) { if (nodes_.empty()) next_key_ = k; }
+  // key of the node at exactly time t (DiscreteSE3Curve::getValueExpression needs an existing node)
+  Key keyAt(Time t) const {
+    auto it = std::lower_bound(nodes_.begin(), nodes_.end(), t, [](const Node& n, Time x) { return n.t < x; });
+    if (it == nodes_.end() || it->t != t) throw std::logic_error("no trajectory node at the requested time");
+    return it->key;
+  }
 
  private:
   struct Node { Time t; SE3 v; Key key; };
@@ -197,6 +194,9 @@ class LaserTrack {
   Time getMaxTime() const { std::lock_guard<std::recursive_mutex> l(mutex_); return trajectory_.getMaxTime(); }
   size_t getNumScans() const { std::lock_guard<std::recursive_mutex> l(mutex_); return laser_scans_.size(); }
   SE3 evaluate(const Time& t) const { std::lock_guard<std::recursive_mutex> l(mutex_); return trajectory_.evaluate(t); }
+  // key of the trajectory node at time t: what getValueExpression(t) binds a factor to (laser_track.cpp:435)
+  Key getValueKey(const Time& t) const { std::lock_guard<std::recursive_mutex> l(mutex_); return trajectory_.keyAt(t); }
+  unsigned int getId() const { return laser_track_id_; }
   void updateFromValues(const Values& v) { std::lock_guard<std::recursive_mutex> l(mutex_); trajectory_.update(v); }
   const std::map<Time, double>& getScanMatchingTimes() const { return scan_matching_times_; }
   const std::vector<RelativePose>& getIcpTransformations() const { return icp_transformations_; }

@@ -90,6 +90,34 @@ class SE3 {
     return t;
   }
 
+  // ---- minimal manifold operations for the pose graph (pose_graph.hpp): minkindr's decoupled
+  // [translation; rotation vector] chart
+  // this (+) d = this * SE3(exp(d[3..5]), d[0..2])
+  SE3 retract(const double d[6]) const {
+    const double th = std::sqrt(d[3] * d[3] + d[4] * d[4] + d[5] * d[5]);
+    SE3 e;
+    if (th < 1e-12) {
+      e.q_ = {1.0, 0.5 * d[3], 0.5 * d[4], 0.5 * d[5]};
+    } else {
+      const double s = std::sin(0.5 * th) / th;
+      e.q_ = {std::cos(0.5 * th), s * d[3], s * d[4], s * d[5]};
+    }
+    e.p_ = {d[0], d[1], d[2]};
+    e.normalize();
+    return (*this) * e;
+  }
+  // d with this (+) d == other: [position; rotation vector] of this^-1 * other
+  void localCoordinates(const SE3& other, double d[6]) const {
+    const SE3 e = inverse() * other;
+    std::array<double, 4> q = e.q_;
+    if (q[0] < 0) for (auto& v : q) v = -v;
+    const double vn = std::sqrt(q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+    double k = 2.0;  // angle / |v| for small angles
+    if (vn > 1e-12) k = 2.0 * std::atan2(vn, q[0]) / vn;
+    d[0] = e.p_[0]; d[1] = e.p_[1]; d[2] = e.p_[2];
+    d[3] = k * q[1]; d[4] = k * q[2]; d[5] = k * q[3];
+  }
+
   const std::array<double, 4>& quaternion() const { return q_; }
   const std::array<double, 3>& position() const { return p_; }
 

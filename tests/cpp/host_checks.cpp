@@ -5,6 +5,7 @@
 #include <cstdio>
 #include <sstream>
 
+#include "laser_slam_amd/incremental_estimator.hpp"
 #include "laser_slam_amd/laser_track.hpp"
 
 using namespace laser_slam_amd;
@@ -105,6 +106,133 @@ int main(int argc, char** argv) {
     TrajectoryMap tm;
     track.getTrajectory(&tm);
     CHECK(tm.size() == 3);
+  }
+  // --- SE3 chart: retract / localCoordinates are inverse of each other
+  {
+    SE3 a({0.9, 0.1, -0.2, 0.3}, {1, 2, 3});
+    const double d[6] = {0.3, -0.2, 0.1, 0.4, -0.5, 0.6};
+    double back[6];
+    a.localCoordinates(a.retract(d), back);
+    for (int i = 0; i < 6; ++i) CHECK(std::fabs(back[i] - d[i]) < 1e-12);
+    const double z[6] = {0, 0, 0, 0, 0, 0};
+    a.localCoordinates(a.retract(z), back);
+    for (int i = 0; i < 6; ++i) CHECK(std::fabs(back[i]) < 1e-15);
+  }
+  // --- pose graph: a drifting square loop closed by one loop-closure factor
+  {
+    auto yaw = [](double a) { return std::array<double, 4>{std::cos(a / 2), 0, 0, std::sin(a / 2)}; };
+    const int per_side = 6, n = 4 * per_side;
+    std::vector<SE3> truth;
+    SE3 cur;  // identity
+    for (int i = 0; i < n; ++i) {
+      truth.push_back(cur);
+      const bool corner = (i + 1) % per_side == 0;
+      cur = cur * SE3(yaw(corner ? M_PI / 2 : 0.0), {1.0, 0, 0});
+    }
+    // odometry: every step is off by 2 cm along x and 0.4 deg in yaw (a consistent drift)
+    const SE3 bias(yaw(0.4 * M_PI / 180), {0.02, 0.0, 0.0});
+    PoseGraph g;
+    Values init;
+    init[0] = truth[0];
+    g.insert(init);
+    Factor prior;
+    prior.type = Factor::PRIOR; prior.key_b = 0; prior.measurement = truth[0]; prior.sigmas.fill(1e-7);
+    g.addFactor(prior);
+    SE3 dead = truth[0];
+    for (int i = 1; i < n; ++i) {
+      const SE3 odo = truth[i - 1].inverse() * truth[i] * bias;
+      dead = dead * odo;
+      Values v; v[(Key)i] = dead; g.insert(v);
+      Factor f;
+      f.type = Factor::ODOMETRY; f.key_a = (Key)i - 1; f.key_b = (Key)i; f.measurement = odo;
+      f.sigmas = {0.05, 0.05, 0.05, 0.01, 0.01, 0.01};
+      g.addFactor(f);
+    }
+    g.optimize(3);
+    auto endErr = [&](const PoseGraph& gr) {
+      double d[6]; truth[n - 1].localCoordinates(gr.values().at((Key)n - 1), d);
+      return std::sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+    };
+    const double before = endErr(g);
+    CHECK(before > 0.5);             // dead reckoning drifted
+    CHECK(g.error() < 1e-12);        // ...but the chain alone is perfectly consistent
+    Factor lc;
+    lc.type = Factor::LOOP_CLOSURE; lc.key_a = 0; lc.key_b = (Key)n - 1;
+    lc.measurement = truth[0].inverse() * truth[n - 1];
+    lc.sigmas = {0.005, 0.005, 0.005, 0.001, 0.001, 0.001};
+    const size_t lc_index = g.addFactor(lc);
+    const double last = g.optimize(10);
+    CHECK(last < 1e-9);              // Gauss-Newton converged
+    CHECK(endErr(g) < 0.02 && endErr(g) < before / 25);
+    // the closed loop spreads the correction: mid-loop error shrinks as well
+    double dm[6]; truth[n / 2].localCoordinates(g.values().at((Key)n / 2), dm);
+    CHECK(std::sqrt(dm[0] * dm[0] + dm[1] * dm[1]) < 0.6 * before);
+    // a wrong loop closure with the Cauchy m-estimator barely moves the solution; without it, it does
+    PoseGraph robust = g, plain = g;
+    Factor bad = lc;
+    bad.measurement = lc.measurement * SE3(yaw(0.3), {3.0, -2.0, 0.0});
+    bad.cauchy = true;
+    robust.addFactor(bad); robust.optimize(10);
+    bad.cauchy = false;
+    plain.addFactor(bad); plain.optimize(10);
+    CHECK(endErr(robust) < 0.05);
+    CHECK(endErr(plain) > 0.5);
+    // removing a factor restores the previous optimum
+    g.removeFactor(lc_index);
+    g.optimize(10);
+    CHECK(g.error() < 1e-10 && g.numFactors() == (size_t)n);
+    bool threw = false;
+    try { g.removeFactor(lc_index); } catch (const std::out_of_range&) { threw = true; }
+    CHECK(threw);
+  }
+  // --- IncrementalEstimator bookkeeping (no ICP: use_icp_factors off, loop closure without ICP step):
+  // two robots, priors 100 m apart (force_priors), linked by a loop closure -> robot 1's prior is removed,
+  // the first-association noise model is used, and both trajectories end up in one frame
+  {
+    EstimatorParams ep;
+    ep.laser_track_params.use_icp_factors = false;
+    ep.laser_track_params.force_priors = true;
+    ep.laser_track_params.odometry_noise_model = {0.05, 0.05, 0.05, 0.01, 0.01, 0.01};
+    ep.loop_closure_noise_model = {0.005, 0.005, 0.005, 0.001, 0.001, 0.001};
+    ep.add_m_estimator_on_loop_closures = true;
+    IncrementalEstimator est(ep, 2u);
+    DataPoints dummy; dummy.features.assign(4 * 8, 1.f);
+    auto drive = [&](unsigned int id, double y0) {
+      auto track = est.getLaserTrack(id);
+      for (int i = 0; i < 5; ++i) {
+        Pose pose; pose.time_ns = 1000 * (i + 1); pose.T_w = SE3({1, 0, 0, 0}, {1.0 * i, y0, 0.0});
+        LaserScan scan; scan.time_ns = pose.time_ns; scan.scan = dummy;
+        FactorList f; Values v; bool is_prior = false;
+        track->processPoseAndLaserScan(pose, scan, &f, &v, &is_prior);
+        const Values result = is_prior ? est.registerPrior(f, v, id) : est.estimate(f, v, pose.time_ns);
+        for (auto& t : est.getAllLaserTracks()) t->updateFromValues(result);
+      }
+    };
+    drive(0, 0.0);
+    drive(1, 7.0);   // robot 1 really drives 7 m beside robot 0, but its forced prior puts it at y = 100
+    CHECK(std::fabs(est.getCurrentPose(1).T_w.position()[1] - 100.0) < 1e-6);
+    CHECK(est.linkedWorkers().size() == 2 && est.graph().numFactors() == 2 + 2 * 4);
+    RelativePose lc;  // robot 1's pose 2 seen from robot 0's pose 2: 7 m to the left; given in the WORLD frame
+    lc.track_id_a = 0; lc.track_id_b = 1; lc.time_a_ns = 3000; lc.time_b_ns = 3000;
+    const SE3 T_w_a = est.getLaserTrack(0)->evaluate(3000), T_w_b = est.getLaserTrack(1)->evaluate(3000);
+    const SE3 a_T_a_b({1, 0, 0, 0}, {0.0, 7.0, 0.0});
+    lc.T_a_b = T_w_a * a_T_a_b * T_w_b.inverse();   // processLoopClosure converts it back (:83-89)
+    est.processLoopClosure(lc);
+    CHECK(est.linkedWorkers().size() == 1 && est.linkedWorkers()[0].size() == 2);
+    CHECK(est.graph().numFactors() == 2 + 2 * 4);   // one prior removed, one association factor added
+    CHECK(std::fabs(est.getCurrentPose(1).T_w.position()[1] - 7.0) < 1e-3);
+    CHECK(std::fabs(est.getCurrentPose(1).T_w.position()[0] - 4.0) < 1e-3);
+    CHECK(std::fabs(est.getCurrentPose(0).T_w.position()[1]) < 1e-6);
+    CHECK(std::fabs(est.lastLoopClosure().T_a_b.position()[1] - 7.0) < 1e-9);
+    // a second closure between the (now linked) robots adds the regular loop-closure factor, removes nothing
+    lc.time_a_ns = 5000; lc.time_b_ns = 5000;
+    lc.T_a_b = est.getLaserTrack(0)->evaluate(5000) * a_T_a_b * est.getLaserTrack(1)->evaluate(5000).inverse();
+    est.processLoopClosure(lc);
+    CHECK(est.graph().numFactors() == 3 + 2 * 4);
+    bool threw = false;
+    lc.time_a_ns = 99999;
+    try { est.processLoopClosure(lc); } catch (const std::logic_error&) { threw = true; }
+    CHECK(threw);
   }
   // --- no GPU => loud error (only checked when asked, i.e. on the CPU-only container)
   if (argc > 1 && std::string(argv[1]) == "--expect-no-gpu") {

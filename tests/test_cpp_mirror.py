@@ -82,3 +82,72 @@ def test_cpp_laser_track_registers_scans(tmp_path):
     assert len(its) == n - 1 and all(2 <= k <= 40 for k in its)
     last = lines[-1].split()
     assert last[0] == "world_cloud" and int(last[1]) > 10000 and int(last[3]) > 30000
+
+
+def _pose_line(t_ns, T):
+    R = T[:3, :3]
+    qw = np.sqrt(max(0.0, 1 + R[0, 0] + R[1, 1] + R[2, 2])) / 2
+    q = [qw, (R[2, 1] - R[1, 2]) / (4 * qw), (R[0, 2] - R[2, 0]) / (4 * qw), (R[1, 0] - R[0, 1]) / (4 * qw)]
+    return "%d %s\n" % (t_ns, " ".join(repr(float(v)) for v in [*q, *T[:3, 3]]))
+
+
+def _parse_poses(lines):
+    out = []
+    for l in lines:
+        v = [float(x) for x in l.split()[2:]]
+        w, x, y, z = v[:4]
+        T = np.eye(4)
+        T[:3, :3] = [[1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y)],
+                     [2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x)],
+                     [2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)]]
+        T[:3, 3] = v[4:]
+        out.append(T)
+    return out
+
+
+@pytest.mark.gpu
+def test_cpp_incremental_estimator_closes_a_loop(tmp_path):
+    """BASELINE config 5 in miniature: a closed drive, odometry with a steady drift,
+    ICP factors from the device, pose graph on the host, then one loop closure whose relative pose comes from
+    the sub-map vs sub-map ICP (the second icp_.compute call site).  The estimate must beat dead reckoning by
+    a wide margin, and the loop closure must pull the end of the trajectory onto its start."""
+    exe = _build(tmp_path, "slam_driver.cpp", "slam_driver")
+    scene = synth.Scene(1234)
+    n, radius = 18, 4.0
+    truth = []
+    for i in range(n):                       # one lap of a circle, ending where it started (overlapping views)
+        a = 2 * np.pi * i / (n - 1)
+        truth.append(synth.se3(radius * np.sin(a), radius * (1 - np.cos(a)), synth.SENSOR_HEIGHT, yaw=a))
+    bias = synth.se3(0.04, 0.01, 0.0, yaw=np.deg2rad(0.8))   # per-step odometry error
+    odom = [truth[0]]
+    for i in range(1, n):
+        odom.append(odom[-1] @ np.linalg.inv(truth[i - 1]) @ truth[i] @ bias)
+    with open(tmp_path / "poses.txt", "w") as f:
+        for i in range(n):
+            synth.hdl64_scan(scene, truth[i], 256, 50 + i).tofile(tmp_path / f"scan{i}.bin")
+            f.write(_pose_line(100000000 * (i + 1), odom[i]))
+    yaml = os.path.join(ROOT, "tests", "golden", "icp_chain.yaml")
+    r = subprocess.run([exe, str(tmp_path), str(n), yaml, "3", "0", str(n - 1), "1"], capture_output=True,
+                       text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    lines = r.stdout.strip().splitlines()
+    ib, ia = lines.index("before_lc"), lines.index("after_lc")
+    before = _parse_poses(lines[ib + 1:ib + 1 + n])
+    after = _parse_poses(lines[ia + 1:ia + 1 + n])
+
+    def rmse(est):
+        return float(np.sqrt(np.mean([np.sum((e[:3, 3] - t[:3, 3]) ** 2) for e, t in zip(est, truth)])))
+
+    dead = rmse(odom)
+    assert dead > 0.5                                         # the odometry alone drifts by more than half a metre
+    assert rmse(before) < 0.1 and rmse(before) < dead / 8     # ICP factors hold the trajectory together
+    assert rmse(after) <= rmse(before) + 0.01
+    end_gap_before = np.linalg.norm(before[-1][:3, 3] - truth[-1][:3, 3])
+    end_gap_after = np.linalg.norm(after[-1][:3, 3] - truth[-1][:3, 3])
+    assert end_gap_after < 0.03 and end_gap_after <= end_gap_before + 0.005
+    lc = [l for l in lines if l.startswith("loop_closure ")][0].split()
+    assert 1 <= int(lc[2]) <= 40
+    m = _parse_poses(["x x " + " ".join([l for l in lines if l.startswith("lc_measurement ")][0].split()[1:])])[0]
+    want = np.linalg.inv(truth[0]) @ truth[-1]                # ~identity: the lap ends where it began
+    et, er = synth.pose_error(m, want)
+    assert et < 0.03 and er < 3e-3, (et, er)
