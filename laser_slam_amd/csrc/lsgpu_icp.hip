@@ -356,6 +356,7 @@ static KnnArgs knn_args(lsgpu_icp* h, const Mat34& T) {
   a.chunks = h->chunks.p; a.ids = h->ids.p; a.d2 = h->d2.p; a.prev = h->prev.p;
   a.strag = h->strag.p; a.strag_count = h->counters.p + 32;
   a.r_cap = 1.0f; a.group_r = 0.75f; a.cap2 = INFINITY; a.st = nullptr; a.use_state_cap = 0; a.lb = nullptr;
+  a.spread_route_r = 0.f;
   { static const float gap = getenv("LSGPU_GAP") ? (float)atof(getenv("LSGPU_GAP")) : 0.002f; a.gap = gap; }
   a.ntiles = (int)((h->nq + 63) / 64); a.xcd_swizzle = 0; a.pad_index = (int)h->nr;
   { static const int budget = getenv("LSGPU_BUDGET") ? atoi(getenv("LSGPU_BUDGET")) : 128; a.chunk_budget = budget; }
@@ -374,14 +375,19 @@ static KnnArgs knn_args(lsgpu_icp* h, const Mat34& T) {
 //   seed     : the queries have no warm start yet (first iteration, kernel-level API)
 //   capped   : search cap from the loop state (exact below cap, see lsgpu_knn.hip.h); otherwise uncapped,
 //              followed by the straggler fallback
-static int run_knn(lsgpu_icp* h, const Mat34& T, const IcpState* st, bool seed, bool capped, bool timed) {
+static int run_knn(lsgpu_icp* h, const Mat34& T, const IcpState* st, bool seed, bool capped, bool timed,
+                   bool wide = true) {
   const int nq = (int)h->nq;
   KnnArgs a = knn_args(h, T);
   h->dbg_launch_no++;
   a.st = st;
   a.lb = st ? h->lb.p : nullptr;
   a.use_state_cap = capped ? 1 : 0;
-  if (capped) a.r_cap = INFINITY;  // no fallback pass follows a capped launch: the tile kernel takes every lane
+  if (capped) a.r_cap = INFINITY;  // capped balls are never larger than the cap: no straggler by radius
+  // `wide`: the balls may still be large (first iterations of an align, retries, kernel-level API): spread
+  // waves with wide balls go to the wave-per-query pass, which is launched after the tile kernel
+  static const float route_r = getenv("LSGPU_ROUTE_R") ? (float)atof(getenv("LSGPU_ROUTE_R")) : 0.02f;
+  a.spread_route_r = wide ? route_r : 0.f;
   if (seed) HIPC(hipMemsetAsync(a.strag_count, 0, sizeof(uint32_t), h->stream));  // later: re-armed by k_normal_eq_loop
   if (seed) hipLaunchKernelGGL(k_knn_seed, dim3(nblk(nq)), dim3(256), 0, h->stream, a);
   lsgpu_icp::KnnEv* ev = nullptr;
@@ -406,7 +412,7 @@ static int run_knn(lsgpu_icp* h, const Mat34& T, const IcpState* st, bool seed, 
     hipLaunchKernelGGL(k_knn_tile<1>, dim3((a.ntiles + waves_per_block - 1) / waves_per_block), dim3(tile_threads), 0, h->stream, a);
     if (timed) HIPC(hipEventRecord(ev->b, h->stream));
     // stragglers (balls > r_cap) only exist in uncapped launches
-    if (!capped) hipLaunchKernelGGL(k_knn_fallback, dim3(kFallbackBlocks), dim3(256), 0, h->stream, a);
+    if (!capped || a.spread_route_r > 0.f) hipLaunchKernelGGL(k_knn_fallback, dim3(kFallbackBlocks), dim3(256), 0, h->stream, a);
     if (timed) HIPC(hipEventRecord(ev->c, h->stream));
   }
   HIPC(hipGetLastError());
@@ -1023,8 +1029,8 @@ int lsgpu_icp_align(lsgpu_icp* h, const float* reading_xyz1, int64_t nq, const f
   const Mat34 Tdummy = to_mat34(hst->T_iter);
   bool first_select = true;
   std::vector<size_t> ev_of_launch;  // event index of every enqueued iteration
-  auto enqueue_iteration = [&](bool seed, bool capped) -> int {
-    int r = run_knn(h, Tdummy, h->state.p, seed, capped, timed);                         // 6a+6b
+  auto enqueue_iteration = [&](bool seed, bool capped, bool wide) -> int {
+    int r = run_knn(h, Tdummy, h->state.p, seed, capped, timed, wide);                         // 6a+6b
     if (r) return r;
     ev_of_launch.push_back(h->knn_events_used ? h->knn_events_used - 1 : 0);
     r = run_select(h, h->d2.p, (int)nq, k, first_select, h->state.p, true);                    // 6c
@@ -1048,14 +1054,16 @@ int lsgpu_icp_align(lsgpu_icp* h, const float* reading_xyz1, int64_t nq, const f
     return LSGPU_OK;
   };
 
-  rc = enqueue_iteration(true, false);  // iteration 0: seeded, uncapped
+  // the first launches still have wide balls: their spread waves go to the wave-per-query pass
+  static const int wide_iters = getenv("LSGPU_WIDE_ITERS") ? atoi(getenv("LSGPU_WIDE_ITERS")) : 3;
+  rc = enqueue_iteration(true, false, true);  // iteration 0: seeded, uncapped
   if (rc) return rc;
   int enq = 1, since_check = 1;
   std::vector<std::pair<int, size_t>> launch_of_iter;  // (enqueue ordinal -> event) bookkeeping below
   const int group = 6;
   for (;;) {
     if (enq < max_it + st.cap_retries && since_check < group) {
-      rc = enqueue_iteration(false, true);
+      rc = enqueue_iteration(false, true, enq < wide_iters);
       if (rc) return rc;
       ++enq; ++since_check;
       continue;
@@ -1069,7 +1077,7 @@ int lsgpu_icp_align(lsgpu_icp* h, const float* reading_xyz1, int64_t nq, const f
       hst->done = 0; hst->status = 0;
       HIPC(hipMemcpyAsync(h->state.p, hst, sizeof(IcpState), hipMemcpyHostToDevice, h->stream));
       HIPC(hipStreamSynchronize(h->stream));
-      rc = enqueue_iteration(false, false);
+      rc = enqueue_iteration(false, false, true);
       if (rc) return rc;
       ++enq; since_check = 1;
       continue;

@@ -51,6 +51,7 @@ struct KnnArgs {
   float cap2;               // only neighbours with d2 <= cap2 must be exact (INF: all)
   float* lb;                // per-query lower bound on the distance to every point OTHER than prev (nullable)
   float gap;                // capped launches search `gap` metres beyond the current best (keep-match bound)
+  float spread_route_r;     // > 0: a spread wave whose largest ball exceeds this hands its lanes to k_knn_fallback
   const IcpState* st;       // loop state (nullable): overrides T (and cap2 if use_state_cap)
   int use_state_cap;
   unsigned long long* dbg;  // optional counters (LSGPU_KNN_STATS builds only)
@@ -436,6 +437,7 @@ __global__ __launch_bounds__(WAVES * 64, 8) void k_knn_tile(KnnArgs a) {
   const float R = sqrtf(prune_lim(ub, gap, cap2s)) * (1.0f + 1e-5f) + 1e-7f;
   const bool straggler = act && !skip && !(R <= a.r_cap);
   const bool ing = act && !straggler && !skip;
+  bool routed = false;
 #ifdef LSGPU_KNN_STATS
   if (__ballot(ing) && !(a.dbg_flags & 4)) {
 #else
@@ -509,7 +511,11 @@ __global__ __launch_bounds__(WAVES * 64, 8) void k_knn_tile(KnnArgs a) {
 #ifdef LSGPU_KNN_STATS
     if (spread && (a.dbg_flags & 32)) { /* ablation: drop spread waves */ } else
 #endif
-    if (spread) {
+    if (spread && a.spread_route_r > 0.f && Rmax > a.spread_route_r) {
+      // wide balls and no shared candidates: 64 divergent per-lane searches would hold this wave for up
+      // to a millisecond (the tail of the first launches); one wave per query (k_knn_fallback) instead
+      routed = ing;
+    } else if (spread) {
       if (ing) {  // tracks the exact index itself
         const int before = bi;
         best = ub;
@@ -554,7 +560,10 @@ __global__ __launch_bounds__(WAVES * 64, 8) void k_knn_tile(KnnArgs a) {
 #endif
   if (act) {
     float nb;  // new lower bound on the distance to every point other than the (new) match
-    if (n_grp == 64 && ing) {
+    if (routed) {
+      best = ub;   // the wave-per-query pass starts from the warm-start point and overwrites this result
+      nb = lbn;
+    } else if (n_grp == 64 && ing) {
       // per-lane search: exact neighbour inside the cap, or nothing there (match unchanged)
       nb = best <= cap2s ? sqrtf(best) * (1.0f - 1e-6f) : fmaxf(lbn, sqrtf(cap2s) * (1.0f - 1e-5f));
     } else if (!ing) {
@@ -579,7 +588,7 @@ __global__ __launch_bounds__(WAVES * 64, 8) void k_knn_tile(KnnArgs a) {
     a.d2[j] = best;
     a.prev[j] = mp;
     if (a.lb) a.lb[j] = nb;
-    if (straggler) a.strag[atomicAdd(a.strag_count, 1u)] = (uint32_t)j;
+    if (straggler || routed) a.strag[atomicAdd(a.strag_count, 1u)] = (uint32_t)j;
   }
 #ifdef LSGPU_KNN_STATS
   const uint32_t n_act = (uint32_t)__popcll(__ballot(ing));
@@ -620,8 +629,9 @@ __global__ __launch_bounds__(256) void k_knn_lane(KnnArgs a) {
 __global__ __launch_bounds__(256) void k_knn_fallback(KnnArgs a) {
   const int lane = threadIdx.x & 63;
   const uint32_t nw = gridDim.x * 4u;
-  Mat34 T; float cap2_unused;
-  if (!iter_params(a.st, a.T, a.cap2, 0, T, cap2_unused)) return;
+  Mat34 T; float cap2;
+  if (!iter_params(a.st, a.T, a.cap2, a.use_state_cap, T, cap2)) return;
+  const float cap2s = cap2 * kCapSearchMargin2;  // (INF in uncapped launches)
   const uint32_t count = *a.strag_count;
   const GridDev& g = a.g;
   const int lim = (1 << (g.bits + g.fine)) - 1;
@@ -629,9 +639,10 @@ __global__ __launch_bounds__(256) void k_knn_fallback(KnnArgs a) {
     const uint32_t j = a.strag[s];
     const float4 r = a.rdq[j];
     const float3 q = xform(T, r.x, r.y, r.z);
-    float best = a.d2[j];  // finite: distance to the warm-start point (possibly improved)
+    const float ub = a.d2[j];  // finite: distance to the warm-start point (possibly improved)
     unsigned long long bestp =
-        ((unsigned long long)__float_as_uint(best) << 32) | (uint32_t)a.ids[j];
+        ((unsigned long long)__float_as_uint(ub) << 32) | (uint32_t)a.ids[j];
+    float best = fminf(ub, cap2s);  // only neighbours inside the cap must be exact
     const float B = sqrtf(best) * (1.0f + 1e-5f) + 1e-7f + kFineSlack * g.hf;
     const int flx = fine_coord(q.x - B, g.ox, g.inv_hf, lim), fhx = fine_coord(q.x + B, g.ox, g.inv_hf, lim);
     const int fly = fine_coord(q.y - B, g.oy, g.inv_hf, lim), fhy = fine_coord(q.y + B, g.oy, g.inv_hf, lim);
@@ -694,7 +705,12 @@ __global__ __launch_bounds__(256) void k_knn_fallback(KnnArgs a) {
       a.ids[j] = id;
       a.d2[j] = __uint_as_float((uint32_t)(bestp >> 32));
       a.prev[j] = make_float4(p.x, p.y, p.z, __int_as_float(id));
-      if (a.lb) a.lb[j] = sqrtf(__uint_as_float((uint32_t)(bestp >> 32))) * (1.0f - 1e-6f);
+      if (a.lb) {
+        // every other point is at least as far as the neighbour found, or beyond the verified radius
+        // (nothing inside the cap: the match did not change, its old bound still holds)
+        const float fd = __uint_as_float((uint32_t)(bestp >> 32));
+        a.lb[j] = fd <= cap2s ? sqrtf(fd) * (1.0f - 1e-6f) : fmaxf(a.lb[j], sqrtf(cap2s) * (1.0f - 1e-5f));
+      }
     }
   }
 }
