@@ -806,7 +806,15 @@ static int ssn_device(lsgpu_icp* h, const float4* src, int64_t n, int knn, float
   SsnSeg* cur = h->ssn_seg_a.p;
   SsnSeg* nxt = h->ssn_seg_b.p;
   const uint32_t* idx = nullptr;
-  for (int L = 0; L < levels; ++L) {
+  // levels [0, glevels) with global sorts; the rest inside one workgroup per segment once a segment fits
+  // its LDS (<= kSsnLdsMax points, <= kSsnLdsLevels levels to go)
+  int glevels = 0;
+  {
+    static const bool lds_finish = getenv("LSGPU_SSN_GLOBAL") == nullptr;
+    int64_t c = n;
+    while (glevels < levels && !(lds_finish && c <= kSsnLdsMax && levels - glevels <= kSsnLdsLevels)) { c -= c / 2; ++glevels; }
+  }
+  for (int L = 0; L < glevels; ++L) {
     hipLaunchKernelGGL(k_ssn_keys, dim3(nblk(n)), dim3(256), 0, h->stream, src, (int)n, idx,
                        L ? h->ssn_seg_of.p : (const uint32_t*)nullptr, cur, knn, h->keys.p, h->vals.p);
     int rc = sort_pairs(h, n, 32 + L);
@@ -815,6 +823,16 @@ static int ssn_device(lsgpu_icp* h, const float4* src, int64_t n, int knn, float
     const int ns = 1 << L;
     hipLaunchKernelGGL(k_ssn_split, dim3(nblk(ns)), dim3(256), 0, h->stream, src, idx, cur, ns, knn, nxt);
     hipLaunchKernelGGL(k_ssn_assign, dim3(nblk(n)), dim3(256), 0, h->stream, (int)n, cur, knn, h->ssn_seg_of.p, L == 0 ? 1 : 0);
+    std::swap(cur, nxt);
+  }
+  if (glevels < levels) {
+    if (glevels == 0) {  // the whole cloud fits one workgroup: identity order to start from
+      hipLaunchKernelGGL(k_ssn_keys, dim3(nblk(n)), dim3(256), 0, h->stream, src, (int)n, (const uint32_t*)nullptr,
+                         (const uint32_t*)nullptr, cur, knn, h->keys.p, h->vals.p);
+      idx = h->vals.p;
+    }
+    hipLaunchKernelGGL(k_ssn_finish, dim3(1 << glevels), dim3(256), 0, h->stream, src, const_cast<uint32_t*>(idx), cur,
+                       knn, levels - glevels, h->ssn_seg_of.p, nxt);
     std::swap(cur, nxt);
   }
   if (levels == 0) {  // a single box: identity order

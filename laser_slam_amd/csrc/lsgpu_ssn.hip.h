@@ -130,6 +130,134 @@ __global__ __launch_bounds__(256) void k_ssn_assign(int n, const SsnSeg* __restr
   seg_of[pos] = c;
 }
 
+// ---- the last levels inside one workgroup.  Once a segment holds <= kSsnLdsMax points the remaining
+// levels need no global sort: one block per segment keeps the coordinates in LDS and, per level, sorts
+// 64-bit keys (local segment | ordered cut coordinate | current position) with a bitonic network -- the
+// position in the lowest bits makes the order stable, i.e. identical to the global stable radix sort --
+// then derives the children exactly like k_ssn_split / k_ssn_assign.
+constexpr int kSsnLdsMax = 2048;
+constexpr int kSsnLdsSegs = 256;  // local segments at the last in-block level (>= kSsnLdsMax / (knn / 2))
+
+constexpr int kSsnLdsLevels = 8;  // log2(kSsnLdsSegs)
+struct SsnLds {                   // 56 KB
+  float c[3][kSsnLdsMax];
+  unsigned long long key[kSsnLdsMax];
+  uint16_t perm[kSsnLdsMax];
+  uint16_t sof[kSsnLdsMax];
+  SsnSeg seg[kSsnLdsSegs];
+};
+
+__global__ __launch_bounds__(256) void k_ssn_finish(const float4* __restrict__ p, uint32_t* __restrict__ idx,
+                                                    const SsnSeg* __restrict__ segs, int knn, int rem,
+                                                    uint32_t* __restrict__ seg_of, SsnSeg* __restrict__ segs_out) {
+  __shared__ SsnLds L;
+  const int tid = threadIdx.x;
+  const SsnSeg root = segs[blockIdx.x];
+  const int cnt = (int)root.count;
+  int cap = 1;
+  while (cap < cnt) cap <<= 1;
+  for (int i = tid; i < cnt; i += 256) {
+    const uint32_t gi = idx[root.start + i];
+    const float4 v = p[gi];
+    L.c[0][i] = v.x; L.c[1][i] = v.y; L.c[2][i] = v.z;
+    L.perm[i] = (uint16_t)i;
+    L.sof[i] = 0;
+  }
+  if (tid == 0) { SsnSeg r = root; r.start = 0; L.seg[0] = r; }
+  __syncthreads();
+  for (int l = 0; l < rem; ++l) {
+    const int ns = 1 << l;
+    // keys
+    for (int i = tid; i < cap; i += 256) {
+      unsigned long long k = ~0ull;
+      if (i < cnt) {
+        const uint32_t s = L.sof[i];
+        const SsnSeg& sg = L.seg[s];
+        uint32_t low = 0;
+        if (sg.count > (uint32_t)knn) low = float_order_key(L.c[ssn_cut_axis(sg)][L.perm[i]]);
+        k = ((unsigned long long)s << 43) | ((unsigned long long)low << 11) | (unsigned long long)i;
+      }
+      L.key[i] = k;
+    }
+    __syncthreads();
+    // bitonic sort, ascending
+    for (int k = 2; k <= cap; k <<= 1) {
+      for (int j = k >> 1; j > 0; j >>= 1) {
+        for (int t = tid; t < (cap >> 1); t += 256) {
+          const int i = ((t / j) * 2 * j) + (t % j), x = i + j;
+          const unsigned long long a = L.key[i], b = L.key[x];
+          const bool asc = (i & k) == 0;
+          if ((a > b) == asc) { L.key[i] = b; L.key[x] = a; }
+        }
+        __syncthreads();
+      }
+    }
+    // apply the permutation (read everything, then write)
+    uint16_t np[kSsnLdsMax / 256];
+#pragma unroll
+    for (int r = 0; r < kSsnLdsMax / 256; ++r) {
+      const int i = tid + r * 256;
+      np[r] = i < cnt ? L.perm[(int)(L.key[i] & 2047ull)] : (uint16_t)0;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < kSsnLdsMax / 256; ++r) {
+      const int i = tid + r * 256;
+      if (i < cnt) L.perm[i] = np[r];
+    }
+    __syncthreads();
+    // children (computed from the parents, written once nobody reads the parents any more)
+    SsnSeg a, b;
+    if (tid < ns) {
+      const SsnSeg sg = L.seg[tid];
+      a = sg; b = sg;
+      if (sg.count > (uint32_t)knn) {
+        const int cut = ssn_cut_axis(sg);
+        const uint32_t right = sg.count / 2, left = sg.count - right;
+        const float cutval = L.c[cut][L.perm[sg.start + left]];
+        a.count = left; a.hi[cut] = cutval;
+        b.start = sg.start + left; b.count = right; b.lo[cut] = cutval;
+      } else {
+        b.start = sg.start + sg.count; b.count = 0;
+      }
+    }
+    for (int i = tid; i < cnt; i += 256) {
+      const uint32_t s = L.sof[i];
+      const SsnSeg& sg = L.seg[s];
+      uint32_t c = 2u * s;
+      if (sg.count > (uint32_t)knn) {
+        const uint32_t left = sg.count - sg.count / 2;
+        c += ((uint32_t)i - sg.start) >= left ? 1u : 0u;
+      }
+      L.sof[i] = (uint16_t)c;
+    }
+    __syncthreads();
+    if (tid < ns) { L.seg[2 * tid] = a; L.seg[2 * tid + 1] = b; }
+    __syncthreads();
+  }
+  const uint32_t base_seg = (uint32_t)blockIdx.x << rem;
+  uint32_t gi[kSsnLdsMax / 256];  // in place: read the block's whole index range before writing it
+#pragma unroll
+  for (int r = 0; r < kSsnLdsMax / 256; ++r) {
+    const int i = tid + r * 256;
+    gi[r] = i < cnt ? idx[root.start + L.perm[i]] : 0u;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < kSsnLdsMax / 256; ++r) {
+    const int i = tid + r * 256;
+    if (i < cnt) {
+      idx[root.start + i] = gi[r];
+      seg_of[root.start + i] = base_seg + L.sof[i];
+    }
+  }
+  for (int s = tid; s < (1 << rem); s += 256) {
+    SsnSeg sg = L.seg[s];
+    sg.start += root.start;
+    segs_out[base_seg + s] = sg;
+  }
+}
+
 // one thread per box: normal (or "dropped"); box_pts = number of points that draw a random number
 __global__ __launch_bounds__(128) void k_ssn_boxes(const float4* __restrict__ p, const uint32_t* __restrict__ idx,
                                                    const SsnSeg* __restrict__ segs, int nseg,
