@@ -1,0 +1,25 @@
+"""dev helper: profiles/knn_traffic.json from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) of bench.py.
+usage: knn_traffic.py <fetch_counter_collection.csv> <write_counter_collection.csv> <out.json> <tag>"""
+import csv, json, sys
+def mean_counter(path, name):
+    vals = {}
+    for r in csv.DictReader(open(path)):
+        k = r["Kernel_Name"]
+        if r["Counter_Name"] == name and ("k_knn_tile" in k or "k_knn_fallback" in k):
+            vals.setdefault("tile" if "k_knn_tile" in k else "fallback", []).append(float(r["Counter_Value"]))
+    tile = vals.get("tile", [])
+    fb = vals.get("fallback", [])
+    # per kNN launch = one k_knn_tile dispatch (+ the wave-per-query pass where one follows)
+    return (sum(tile) + sum(fb)) / max(len(tile), 1), len(tile), len(fb)
+f, nt, nf = mean_counter(sys.argv[1], "FETCH_SIZE")
+w, _, _ = mean_counter(sys.argv[2], "WRITE_SIZE")
+out = {"n_az": 16384, "kernel": "k_knn_tile (+ k_knn_fallback where it follows)",
+       "fetch_size_kb_per_launch": f, "write_size_kb_per_launch": w,
+       "hbm_bytes_per_launch": (2 * f + w) * 1024,
+       "dispatches": {"k_knn_tile": nt, "k_knn_fallback": nf},
+       "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes with --kernel-trace, mean over all "
+                 "kNN launches of `python bench.py --steps 2 --warmup 1 --no-cpu-baseline`; bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 "
+                 "(gfx950 FETCH_SIZE counts 128-B requests as 64 B: MI355X_MICROARCH.md HBM section; WRITE_SIZE uncalibrated)",
+       "source": ["profiles/%s_pmc_fetch.csv.gz" % sys.argv[4], "profiles/%s_pmc_write.csv.gz" % sys.argv[4]]}
+json.dump(out, open(sys.argv[3], "w"), indent=1)
+print(json.dumps(out))
