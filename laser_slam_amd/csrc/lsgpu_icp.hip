@@ -1056,14 +1056,16 @@ int lsgpu_icp_align(lsgpu_icp* h, const float* reading_xyz1, int64_t nq, const f
     if (r) return r;
     hipLaunchKernelGGL(k_normal_eq_loop, dim3(nb), dim3(256), 0, h->stream, h->rdq.p, (int)nq,
                        h->state.p, h->prev.p, h->d2.p, h->nrm.p, h->hist.p, h->sel.p + 2,
-                       h->counters.p + 32, h->counters.p + 33, h->ne_partials.p, h->ne_out.p);  // 6d
-    if (h->comm &&   // split scan: every rank gets the sums over all shards (the limit, slot 29, is already global)
-        rccl_api()->AllReduce(h->ne_out.p, h->ne_out.p, kNe, ncclDouble, ncclSum, h->comm, h->stream) != ncclSuccess) {
-      h->err = "RCCL all-reduce of the normal equations failed";
-      return LSGPU_HIP_ERROR;
+                       h->counters.p + 32, h->counters.p + 33, h->ne_partials.p, h->ne_out.p,
+                       h->chk_hist.p, h->trace_dev.p, max_it, capped ? 1 : 0, h->comm ? 0 : 1);  // 6d (+6e)
+    if (h->comm) {   // split scan: every rank gets the sums over all shards (the limit, slot 29, is already global)
+      if (rccl_api()->AllReduce(h->ne_out.p, h->ne_out.p, kNe, ncclDouble, ncclSum, h->comm, h->stream) != ncclSuccess) {
+        h->err = "RCCL all-reduce of the normal equations failed";
+        return LSGPU_HIP_ERROR;
+      }
+      hipLaunchKernelGGL(k_icp_update, dim3(1), dim3(64), 0, h->stream, h->state.p, h->ne_out.p,
+                         h->chk_hist.p, h->trace_dev.p, max_it, capped ? 1 : 0);           // 6d+6e
     }
-    hipLaunchKernelGGL(k_icp_update, dim3(1), dim3(64), 0, h->stream, h->state.p, h->ne_out.p,
-                       h->chk_hist.p, h->trace_dev.p, max_it, capped ? 1 : 0);             // 6d+6e
     return hipGetLastError() == hipSuccess ? LSGPU_OK : LSGPU_HIP_ERROR;
   };
   auto fetch_state = [&]() -> int {

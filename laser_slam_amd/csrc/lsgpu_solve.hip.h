@@ -182,13 +182,73 @@ __global__ __launch_bounds__(256) void k_normal_eq(const float4* __restrict__ rd
         ((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x];
 }
 
+constexpr float kCapFactor = 1.1f;  // next search cap = this x the current trim limit (verified each iteration)
+
+// ---------------------------------------------------------------- per-iteration update (device side)
+// One lane: 6x6 float LLT solve, AngleAxis update, T_iter <- dT * T_iter, Counter + Differential
+// checkers, trace record, next cap.  Same code as the host (lsgpu_host_math.h).
+__device__ inline void icp_update_lane(IcpState* st, const double* ne_out, float* chk_hist,
+                                       lsgpu_iter_trace* trace, int trace_cap, int capped_launch) {
+  if (st->done) return;
+  const float limit = (float)ne_out[29];
+  const unsigned long long nstrag = (unsigned long long)ne_out[30];
+  if (capped_launch && st->cap2 < INFINITY && !(limit <= st->cap2)) {
+    st->status = kStatusCapFailed;  // the order statistic is not among exact values: repeat uncapped
+    st->done = 1;
+    return;
+  }
+  st->stragglers += nstrag;
+  const long long used = (long long)ne_out[27];
+  if (used <= 0) { st->status = LSGPU_NO_CONVERGENCE; st->err_code = 1; st->done = 1; return; }
+  double A[36], b[6];
+  hostmath::unpack_normal_eq(ne_out, A, b);
+  float x[6], dT[16], Tn[16];
+  if (!hostmath::llt_solve6(A, b, x)) { st->status = LSGPU_NO_CONVERGENCE; st->err_code = 2; st->done = 1; return; }
+  hostmath::delta_from_x(x, dT);
+  hostmath::mul4(dT, st->T_iter, Tn);
+  for (int i = 0; i < 16; ++i) st->T_iter[i] = Tn[i];
+  for (int i = 0; i < 12; ++i) st->T_rows_prev[i] = st->T_rows[i];
+  for (int r = 0; r < 3; ++r)
+    for (int c = 0; c < 4; ++c) st->T_rows[r * 4 + c] = Tn[c * 4 + r];
+  const int it = st->iter;
+  if (it < trace_cap) {
+    lsgpu_iter_trace& tr = trace[it];
+    for (int i = 0; i < 16; ++i) tr.T_iter[i] = Tn[i];
+    tr.limit = limit; tr.n_used = used;
+    for (int i = 0; i < 36; ++i) tr.A[i] = A[i];
+    for (int i = 0; i < 6; ++i) { tr.b[i] = b[i]; tr.x[i] = x[i]; }
+    tr.knn_main_us = 0.f; tr.knn_fallback_us = 0.f; tr.stragglers = (uint32_t)nstrag; tr.reserved = 0;
+  }
+  st->prev_limit = limit;
+  st->cap2 = st->cap_enabled ? limit * kCapFactor : INFINITY;
+  st->iter = it + 1;
+  hostmath::CheckerState cs{st->counter, st->n_hist};
+  bool iterate = true, by_diff = false;
+  const bool ok = hostmath::checker_check(&cs, chk_hist, st->max_iter, st->smooth, st->lim_rot,
+                                          st->lim_trans, Tn, &iterate, &by_diff);
+  st->counter = cs.counter; st->n_hist = cs.n_hist;
+  if (!ok) { st->status = LSGPU_NO_CONVERGENCE; st->err_code = 3; st->done = 1; return; }
+  if (!iterate) { st->converged = by_diff ? 1 : 0; st->done = 1; }
+}
+
+// stand-alone launch: used when something sits between the normal equations and the update (the RCCL
+// all-reduce of the split-scan mode); otherwise the last block of k_normal_eq_loop runs the update itself
+__global__ __launch_bounds__(64) void k_icp_update(IcpState* __restrict__ st,
+                                                   const double* __restrict__ ne_out,
+                                                   float* __restrict__ chk_hist,
+                                                   lsgpu_iter_trace* __restrict__ trace, int trace_cap,
+                                                   int capped_launch) {
+  if (threadIdx.x == 0) icp_update_lane(st, ne_out, chk_hist, trace, trace_cap, capped_launch);
+}
+
+
 // The align loop's variant: the matched point comes coalesced from the warm-start array (xyz + sorted
 // index of every query's neighbour, written by the kNN kernels), only the normal is gathered.  The
 // LAST block to finish (agent-scope release / ticket / acquire, cdna guide G16) reduces the block
 // partials in a fixed order, publishes {29 sums, limit, straggler count} and re-arms the per-iteration
 // scratch (histograms, straggler counter, ticket) so the next iteration needs no memset launches.
 __global__ __launch_bounds__(256) void k_normal_eq_loop(const float4* __restrict__ rdq, int nq,
-                                                        const IcpState* __restrict__ ist,
+                                                        IcpState* __restrict__ ist,
                                                         const float4* __restrict__ match,
                                                         const float* __restrict__ d2,
                                                         const float4* __restrict__ nrm,
@@ -197,8 +257,12 @@ __global__ __launch_bounds__(256) void k_normal_eq_loop(const float4* __restrict
                                                         uint32_t* __restrict__ strag_count,
                                                         uint32_t* __restrict__ ticket,
                                                         double* __restrict__ partials,
-                                                        double* __restrict__ out /* 32 doubles */) {
+                                                        double* __restrict__ out /* 32 doubles */,
+                                                        float* __restrict__ chk_hist,
+                                                        lsgpu_iter_trace* __restrict__ trace, int trace_cap,
+                                                        int capped_launch, int fuse_update) {
   __shared__ uint32_t sc[260];
+  __shared__ double fin[32];
   __shared__ double red[8][33];
   __shared__ int is_last;
   if (ist->done) return;
@@ -282,14 +346,20 @@ __global__ __launch_bounds__(256) void k_normal_eq_loop(const float4* __restrict
     double t = 0.0;
     for (int r = 0; r < 8; ++r) t += red[r][threadIdx.x];
     out[threadIdx.x] = t;
+    fin[threadIdx.x] = t;
   }
   if (threadIdx.x == 32) {
-    out[29] = (double)limit;
-    out[30] = (double)__hip_atomic_load(strag_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const double ns = (double)__hip_atomic_load(strag_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    out[29] = (double)limit; fin[29] = (double)limit;
+    out[30] = ns; fin[30] = ns;
     __hip_atomic_store(strag_count, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   for (int i = threadIdx.x; i < 3 * kHistBins; i += 256) hist[i] = 0u;  // every block has read hist3 by now
+  if (fuse_update) {  // every other block has finished: the loop state is this block's to advance
+    __syncthreads();
+    if (threadIdx.x == 0) icp_update_lane(ist, fin, chk_hist, trace, trace_cap, capped_launch);
+  }
 }
 
 // 1024 threads = 32 groups of 32: group r sums rows r, r+32, ... of its column, then the 32 group
@@ -308,58 +378,6 @@ __global__ __launch_bounds__(1024) void k_ne_final(const double* __restrict__ pa
     for (int r = 0; r < 32; ++r) t += sh[r][threadIdx.x];
     out[threadIdx.x] = t;
   }
-}
-
-constexpr float kCapFactor = 1.1f;  // next search cap = this x the current trim limit (verified each iteration)
-
-// ---------------------------------------------------------------- per-iteration update (device side)
-// One lane: 6x6 float LLT solve, AngleAxis update, T_iter <- dT * T_iter, Counter + Differential
-// checkers, trace record, next cap.  Same code as the host (lsgpu_host_math.h).
-__global__ __launch_bounds__(64) void k_icp_update(IcpState* __restrict__ st,
-                                                   const double* __restrict__ ne_out,
-                                                   float* __restrict__ chk_hist,
-                                                   lsgpu_iter_trace* __restrict__ trace, int trace_cap,
-                                                   int capped_launch) {
-  if (threadIdx.x != 0 || st->done) return;
-  const float limit = (float)ne_out[29];
-  const unsigned long long nstrag = (unsigned long long)ne_out[30];
-  if (capped_launch && st->cap2 < INFINITY && !(limit <= st->cap2)) {
-    st->status = kStatusCapFailed;  // the order statistic is not among exact values: repeat uncapped
-    st->done = 1;
-    return;
-  }
-  st->stragglers += nstrag;
-  const long long used = (long long)ne_out[27];
-  if (used <= 0) { st->status = LSGPU_NO_CONVERGENCE; st->err_code = 1; st->done = 1; return; }
-  double A[36], b[6];
-  hostmath::unpack_normal_eq(ne_out, A, b);
-  float x[6], dT[16], Tn[16];
-  if (!hostmath::llt_solve6(A, b, x)) { st->status = LSGPU_NO_CONVERGENCE; st->err_code = 2; st->done = 1; return; }
-  hostmath::delta_from_x(x, dT);
-  hostmath::mul4(dT, st->T_iter, Tn);
-  for (int i = 0; i < 16; ++i) st->T_iter[i] = Tn[i];
-  for (int i = 0; i < 12; ++i) st->T_rows_prev[i] = st->T_rows[i];
-  for (int r = 0; r < 3; ++r)
-    for (int c = 0; c < 4; ++c) st->T_rows[r * 4 + c] = Tn[c * 4 + r];
-  const int it = st->iter;
-  if (it < trace_cap) {
-    lsgpu_iter_trace& tr = trace[it];
-    for (int i = 0; i < 16; ++i) tr.T_iter[i] = Tn[i];
-    tr.limit = limit; tr.n_used = used;
-    for (int i = 0; i < 36; ++i) tr.A[i] = A[i];
-    for (int i = 0; i < 6; ++i) { tr.b[i] = b[i]; tr.x[i] = x[i]; }
-    tr.knn_main_us = 0.f; tr.knn_fallback_us = 0.f; tr.stragglers = (uint32_t)nstrag; tr.reserved = 0;
-  }
-  st->prev_limit = limit;
-  st->cap2 = st->cap_enabled ? limit * kCapFactor : INFINITY;
-  st->iter = it + 1;
-  hostmath::CheckerState cs{st->counter, st->n_hist};
-  bool iterate = true, by_diff = false;
-  const bool ok = hostmath::checker_check(&cs, chk_hist, st->max_iter, st->smooth, st->lim_rot,
-                                          st->lim_trans, Tn, &iterate, &by_diff);
-  st->counter = cs.counter; st->n_hist = cs.n_hist;
-  if (!ok) { st->status = LSGPU_NO_CONVERGENCE; st->err_code = 3; st->done = 1; return; }
-  if (!iterate) { st->converged = by_diff ? 1 : 0; st->done = 1; }
 }
 
 }  // namespace lsgpu
