@@ -40,6 +40,9 @@ def main():
     ap.add_argument("--n-az", type=int, default=16384, help="azimuth steps (16384 -> 1 M rays)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=1)
+    ap.add_argument("--no-compute-e2e", action="store_true",
+                    help="skip the compute_with_filters section (used for the rocprofv3 run, so that the kernel\n"
+                         "averages of the profile cover the benchmark workload only)")
     ap.add_argument("--split", action="store_true",
                     help="BASELINE config 4 layout: ONE scan pair per step, its reading sharded over the ranks, "
                          "RCCL all-reduce of the select histograms + 6x6 sums (strong scaling)")
@@ -136,7 +139,7 @@ def main():
     # ---- the whole ICP::compute (both filters + set_reference + align) on the raw clouds, SURVEY.md §8d
     # variants P (icp_default.yaml chain: prob 0.5 / ratio 0.5) and F (full density): reported, not `value`
     end_to_end = None
-    if not args.split:
+    if not args.split and not args.no_compute_e2e:
         d_raw_ref, d_raw_rd = torch.from_numpy(raw_ref).cuda(), torch.from_numpy(raw_rd).cuda()
         torch.cuda.synchronize()
         end_to_end = {}
