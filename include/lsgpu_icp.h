@@ -187,6 +187,22 @@ int lsgpu_icp_compute(lsgpu_icp* h, const float* reading_xyz1, int64_t nq, const
                       int64_t nr, const float T_init[16], const lsgpu_chain_config* chain,
                       float T_out[16], lsgpu_icp_stats* stats);
 
+/* ---- clouds kept in HBM between calls (persistent sub-maps) ------------------------
+ * LaserTrack::localScanToSubMap (laser_slam/src/laser_track.cpp:466-519) rebuilds its sub-map at every scan
+ * from the last `nscan_in_sub_map` scans: a 4x4 * 4xN transform and a concatenate per extra scan, all on the
+ * host, then hands reading and sub-map to icp_.compute.  Here a scan is uploaded once into a numbered slot of
+ * the handle; lsgpu_icp_compute_clouds assembles the sub-map on the device (out_i = T_i * cloud_i with the
+ * arithmetic of lsgpu_transform_points, concatenated in the order given) and runs the whole ICP::compute on it.
+ * Slots are small non-negative integers chosen by the caller; uploading to a used slot replaces its cloud. */
+int lsgpu_cloud_upload(lsgpu_icp* h, int slot, const float* xyz1, int64_t n);
+int lsgpu_cloud_release(lsgpu_icp* h, int slot);
+int lsgpu_cloud_size(lsgpu_icp* h, int slot, int64_t* n);   /* n = -1: empty slot */
+/* reading = cloud `reading_slot`; reference = concat_i ( T_i * cloud ref_slots[i] ), ref_T = 16 floats per
+ * reference cloud, column major (NULL: all identity).  Otherwise exactly lsgpu_icp_compute. */
+int lsgpu_icp_compute_clouds(lsgpu_icp* h, int reading_slot, const int* ref_slots, const float* ref_T,
+                             int n_ref, const float T_init[16], const lsgpu_chain_config* chain,
+                             float T_out[16], lsgpu_icp_stats* stats);
+
 /* ---- host-side versions of the two filters (same output as the device filters) and O(1) helpers ---- */
 
 /* RandomSamplingDataPointsFilter (yaml:1-3): keep i iff draw_i < prob; seed as above. */

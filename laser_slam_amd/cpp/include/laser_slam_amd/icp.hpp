@@ -168,6 +168,38 @@ class ICP {
     return T;
   }
 
+  // ---- scans kept in HBM: upload once, match many times
+  // Slots live in the handle; loadFromYaml / setDefault drop them (generation() changes).
+  void uploadCloud(int slot, const DataPoints& cloud) {
+    ensureHandle();
+    check(lsgpu_cloud_upload(h_, slot, cloud.features.data(), cloud.getNbPoints()), "lsgpu_cloud_upload");
+  }
+  void releaseCloud(int slot) { if (h_) lsgpu_cloud_release(h_, slot); }
+  bool hasCloud(int slot) {
+    if (!h_) return false;
+    int64_t n = -1;
+    lsgpu_cloud_size(h_, slot, &n);
+    return n >= 0;
+  }
+  unsigned generation() const { return generation_; }
+  // compute() with reading = slot `reading` and reference = concat_i(T_i * slot refs[i]) assembled on the
+  // device: what localScanToSubMap builds on the host at laser_track.cpp:474-486
+  TransformationParameters computeClouds(int reading, const std::vector<int>& refs,
+                                         const std::vector<TransformationParameters>& ref_T,
+                                         const TransformationParameters& T_init) {
+    ensureHandle();
+    if (refs.size() != ref_T.size()) throw std::logic_error("one transform per reference cloud");
+    lsgpu_chain_config chain;
+    lsgpu_chain_config_default(&chain);
+    chain.reading_prob = prob_; chain.ssn_knn = knn_; chain.ssn_ratio = ratio_; chain.seed = seed_;
+    std::vector<float> flat(16 * refs.size());
+    for (size_t i = 0; i < refs.size(); ++i) std::memcpy(&flat[16 * i], ref_T[i].data(), 16 * sizeof(float));
+    TransformationParameters T = T_init;
+    check(lsgpu_icp_compute_clouds(h_, reading, refs.data(), flat.data(), (int)refs.size(), T_init.data(), &chain,
+                                   T.data(), &stats_), "lsgpu_icp_compute_clouds");
+    return T;
+  }
+
   // >= 0: reseed the filters' draw stream at every compute() (reproducible runs); < 0: continue it
   void setSeed(int64_t seed) { seed_ = seed; }
 
@@ -249,7 +281,7 @@ class ICP {
     if (rc == LSGPU_BAD_CONFIG) throw ConfigError("lsgpu_icp_create: bad configuration");
     if (rc != LSGPU_OK) throw DeviceError("lsgpu_icp_create failed (no ROCm GPU visible?)");
   }
-  void release() { if (h_) { lsgpu_icp_destroy(h_); h_ = nullptr; } }
+  void release() { if (h_) { lsgpu_icp_destroy(h_); h_ = nullptr; ++generation_; } }
   void check(int rc, const char* what) {
     if (rc == LSGPU_OK) return;
     const std::string msg = std::string(what) + ": " + lsgpu_strerror(rc) + " [" + lsgpu_last_error(h_) + "]";
@@ -265,6 +297,7 @@ class ICP {
   float prob_ = 0.75f, ratio_ = 0.5f;
   int knn_ = 7;
   int64_t seed_ = -1;
+  unsigned generation_ = 0;
 };
 
 }  // namespace laser_slam_amd

@@ -63,6 +63,7 @@ struct LaserTrackParams {  // laser_slam/include/laser_slam/parameters.hpp:8-23
   bool save_icp_results = false;
   bool force_priors = false;
   int device = 0;                       // HIP device of this track's ICP handle
+  int scans_on_device = 16;             // most recent scans kept in HBM for sub-map assembly (0: host assembly)
 };
 
 // Factor / FactorList / Values: pose_graph.hpp
@@ -286,20 +287,32 @@ class LaserTrack {
     icp.time_a_ns = laser_scans_[n - 2].time_ns;
     // sub-map = scan n-2 plus the (nscan_in_sub_map - 1) scans before it, in the frame of scan n-2
     const SE3 T_w_a = trajectory_.evaluate(icp.time_a_ns);
-    DataPoints sub_map = laser_scans_[n - 2].scan;
     const size_t extra = std::min(n - 2, size_t(std::max(params_.nscan_in_sub_map, 1) - 1));
+    std::vector<size_t> members{n - 2};
+    std::vector<TransformationParameters> member_T{identityTransformation()};
     for (size_t i = 0; i < extra; ++i) {
       const LaserScan& prev = laser_scans_[n - 3 - i];
       TransformationParameters T = (T_w_a.inverse() * trajectory_.evaluate(prev.time_ns)).transformationMatrixF();
       correctTransformationMatrix(&T);
-      sub_map.concatenate(RigidTransformation::compute(prev.scan, T));
+      members.push_back(n - 3 - i);
+      member_T.push_back(T);
     }
     // initial guess from the (odometry-extended) trajectory
     const SE3 guess = trajectory_.evaluate(icp.time_a_ns).inverse() * trajectory_.evaluate(icp.time_b_ns);
     const TransformationParameters T_init = guess.transformationMatrixF();
     TransformationParameters solution = T_init;
     try {
-      solution = icp_.compute(last_scan.scan, sub_map, T_init);
+      if (params_.scans_on_device > 0 && (int)members.size() + 1 <= params_.scans_on_device) {
+        // the scans stay in HBM; the sub-map is assembled there (same arithmetic as RigidTransformation::compute)
+        std::vector<int> slots;
+        for (size_t m : members) slots.push_back(deviceSlot(m));
+        solution = icp_.computeClouds(deviceSlot(n - 1), slots, member_T, T_init);
+      } else {
+        DataPoints sub_map = laser_scans_[members[0]].scan;
+        for (size_t i = 1; i < members.size(); ++i)
+          sub_map.concatenate(RigidTransformation::compute(laser_scans_[members[i]].scan, member_T[i]));
+        solution = icp_.compute(last_scan.scan, sub_map, T_init);
+      }
     } catch (const ConvergenceError&) {
       // keep the initial guess (laser_track.cpp:499-502)
     }
@@ -308,6 +321,20 @@ class LaserTrack {
     icp.key_b = getPoseKey(icp.time_b_ns);
     icp.track_id_a = icp.track_id_b = laser_track_id_;
     icp_transformations_.push_back(icp);
+  }
+
+  // Device slot of scan `index`: scan i lives in slot i % scans_on_device while it is among the most recent
+  // ones; anything else (or everything, after the ICP object was reconfigured) is uploaded on demand.
+  int deviceSlot(size_t index) {
+    const int slot = (int)(index % (size_t)params_.scans_on_device);
+    if (slot_generation_ != icp_.generation()) { slot_owner_.clear(); slot_generation_ = icp_.generation(); }
+    if ((int)slot_owner_.size() < params_.scans_on_device) slot_owner_.resize((size_t)params_.scans_on_device, (size_t)-1);
+    if (slot_owner_[(size_t)slot] != index || !icp_.hasCloud(slot)) {
+      icp_.uploadCloud(slot, laser_scans_[index].scan);
+      slot_owner_[(size_t)slot] = index;
+      slot_generation_ = icp_.generation();  // (uploadCloud may have created the handle)
+    }
+    return slot;
   }
 
   LaserTrackParams params_;
@@ -319,6 +346,8 @@ class LaserTrack {
   std::vector<RelativePose> icp_transformations_;
   std::vector<LaserScan> laser_scans_;
   std::map<Time, double> scan_matching_times_;
+  std::vector<size_t> slot_owner_;   // which scan each device slot holds
+  unsigned slot_generation_ = 0;
   mutable std::recursive_mutex mutex_;
 };
 

@@ -160,6 +160,9 @@ struct lsgpu_icp {
   DevBuf<float4> flt_in, flt_ref, flt_rd;
   DevBuf<float> flt_nrm;
   float* draws_pinned = nullptr;  // host staging of the filter draws (pinned: async H2D)
+  std::vector<DevBuf<float4>> clouds;  // lsgpu_cloud_upload slots
+  std::vector<int64_t> cloud_n;        // -1: empty
+  DevBuf<float4> submap;               // assembled reference of lsgpu_icp_compute_clouds
   size_t draws_pinned_cap = 0;
 
   // reading
@@ -266,6 +269,8 @@ void lsgpu_icp_destroy(lsgpu_icp* h) {
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   if (h->comm && rccl_api()) (void)rccl_api()->CommDestroy(h->comm);
   h->comm_tmp.release();
+  for (auto& c : h->clouds) c.release();
+  h->submap.release();
   h->ref_in.release(); h->nrm_in.release(); h->keys.release(); h->keys_alt.release();
   h->vals.release(); h->vals_alt.release(); h->sort_tmp.release(); h->pts.release();
   h->nrm.release(); h->ref_inv.release(); h->tables.release(); h->flags.release(); h->cidx.release(); h->bounds.release(); h->chunks.release(); h->prev.release(); h->state.release(); h->lb.release(); h->cell_cache.release(); h->cell_tags.release(); h->ssn_seg_a.release(); h->ssn_seg_b.release(); h->ssn_seg_of.release(); h->ssn_box_pts.release(); h->ssn_box_base.release(); h->ssn_keep.release(); h->ssn_out_pos.release(); h->ssn_bb.release(); h->ssn_box_normal.release(); h->ssn_draws.release(); h->flt_in.release(); h->flt_ref.release(); h->flt_rd.release(); h->flt_nrm.release(); h->chk_hist.release(); h->trace_dev.release(); h->knn_dbg.release(); h->knn_dbg_wave.release(); h->stat_partials.release();
@@ -976,6 +981,82 @@ int lsgpu_icp_compute(lsgpu_icp* h, const float* reading_xyz1, int64_t nq, const
   rc = lsgpu_icp_align(h, reinterpret_cast<const float*>(h->flt_rd.p), nqf, T_init, T_out, stats);
   if (stats) stats->t_reserved[0] = t_filters;
   return rc;
+}
+
+int lsgpu_cloud_upload(lsgpu_icp* h, int slot, const float* xyz1, int64_t n) {
+  if (!h || slot < 0 || slot >= (1 << 20) || n < 0 || n > 0x7FFFFFF0ll || (n > 0 && !xyz1)) return LSGPU_BAD_ARG;
+  h->err.clear();
+  HIPC(hipSetDevice(h->device));
+  if ((size_t)slot >= h->clouds.size()) { h->clouds.resize((size_t)slot + 1); h->cloud_n.resize((size_t)slot + 1, -1); }
+  HIPC(h->clouds[slot].reserve(n ? n : 1));
+  if (n) HIPC(hipMemcpyAsync(h->clouds[slot].p, xyz1, (size_t)n * 16, hipMemcpyDefault, h->stream));
+  HIPC(hipStreamSynchronize(h->stream));  // the caller's buffer is free again on return
+  h->cloud_n[slot] = n;
+  return LSGPU_OK;
+}
+
+int lsgpu_cloud_release(lsgpu_icp* h, int slot) {
+  if (!h || slot < 0) return LSGPU_BAD_ARG;
+  if ((size_t)slot >= h->clouds.size() || h->cloud_n[slot] < 0) return LSGPU_OK;
+  (void)hipSetDevice(h->device);
+  (void)hipStreamSynchronize(h->stream);
+  h->clouds[slot].release();
+  h->cloud_n[slot] = -1;
+  return LSGPU_OK;
+}
+
+int lsgpu_cloud_size(lsgpu_icp* h, int slot, int64_t* n) {
+  if (!h || !n || slot < 0) return LSGPU_BAD_ARG;
+  *n = (size_t)slot < h->clouds.size() ? h->cloud_n[slot] : -1;
+  return LSGPU_OK;
+}
+
+int lsgpu_icp_compute_clouds(lsgpu_icp* h, int reading_slot, const int* ref_slots, const float* ref_T,
+                             int n_ref, const float T_init[16], const lsgpu_chain_config* chain,
+                             float T_out[16], lsgpu_icp_stats* stats) {
+  if (!h || !T_init || !T_out || !chain || n_ref < 0 || (n_ref > 0 && !ref_slots)) return LSGPU_BAD_ARG;
+  h->err.clear();
+  std::memcpy(T_out, T_init, 16 * sizeof(float));
+  if (stats) std::memset(stats, 0, sizeof(*stats));
+  auto have = [&](int s) { return s >= 0 && (size_t)s < h->clouds.size() && h->cloud_n[s] >= 0; };
+  if (!have(reading_slot)) { h->err = "compute_clouds: empty reading slot"; return LSGPU_BAD_ARG; }
+  int64_t total = 0;
+  for (int i = 0; i < n_ref; ++i) {
+    if (!have(ref_slots[i])) { h->err = "compute_clouds: empty reference slot"; return LSGPU_BAD_ARG; }
+    total += h->cloud_n[ref_slots[i]];
+  }
+  if (total > 0x7FFFFFF0ll) return LSGPU_BAD_ARG;
+  if (total <= 0 || h->cloud_n[reading_slot] <= 0) {
+    if (chain->seed >= 0) DrawStream::global().take(chain->seed, 0, nullptr);
+    h->err = "compute: empty cloud";
+    return LSGPU_NO_CONVERGENCE;
+  }
+  HIPC(hipSetDevice(h->device));
+  // sub-map assembly (laser_track.cpp:474-486) on the device
+  HIPC(h->submap.reserve(total));
+  int64_t off = 0;
+  for (int i = 0; i < n_ref; ++i) {
+    const int64_t n = h->cloud_n[ref_slots[i]];
+    if (!n) continue;
+    const float* T = ref_T ? ref_T + 16 * i : nullptr;
+    bool identity = !T;
+    if (T) {
+      identity = true;
+      for (int k = 0; k < 16; ++k) identity = identity && T[k] == ((k % 5 == 0) ? 1.f : 0.f);
+    }
+    if (identity) {
+      HIPC(hipMemcpyAsync(h->submap.p + off, h->clouds[ref_slots[i]].p, (size_t)n * 16, hipMemcpyDeviceToDevice, h->stream));
+    } else {
+      if (!lsgpu_check_rigid(T)) { h->err = "compute_clouds: a sub-map transform is not rigid"; return LSGPU_BAD_ARG; }
+      hipLaunchKernelGGL(k_transform, dim3(nblk(n)), dim3(256), 0, h->stream, h->clouds[ref_slots[i]].p, n,
+                         to_mat34(T), h->submap.p + off);
+    }
+    off += n;
+  }
+  HIPC(hipGetLastError());
+  const int rc = lsgpu_icp_compute(h, reinterpret_cast<const float*>(h->clouds[reading_slot].p), h->cloud_n[reading_slot],
+                                   reinterpret_cast<const float*>(h->submap.p), total, T_init, chain, T_out, stats);
+  return rc;  // (the assembly is stream-ordered: its time is part of compute's filter time, stats->t_reserved[0])
 }
 
 int lsgpu_icp_align(lsgpu_icp* h, const float* reading_xyz1, int64_t nq, const float T_init[16],

@@ -195,6 +195,39 @@ class IcpHandle:
             _raise(rc, "lsgpu_icp_compute", self._h)
         return to.reshape(4, 4).T.copy(), st
 
+    # ---- clouds kept in HBM between calls; sub-map assembly on the device (laser_track.cpp:474-486)
+    def cloud_upload(self, slot: int, xyz1):
+        p, _k, n = _as_f32(xyz1, 4)
+        rc = _lib.lib().lsgpu_cloud_upload(self._h, slot, p, n)
+        if rc != _lib.OK:
+            _raise(rc, "lsgpu_cloud_upload", self._h)
+
+    def cloud_release(self, slot: int):
+        _lib.lib().lsgpu_cloud_release(self._h, slot)
+
+    def cloud_size(self, slot: int) -> int:
+        n = C.c_int64(-1)
+        _lib.lib().lsgpu_cloud_size(self._h, slot, C.byref(n))
+        return n.value
+
+    def compute_clouds(self, reading_slot: int, ref_slots, ref_T, T_init, reading_prob: float = 0.5,
+                       ssn_knn: int = 10, ssn_ratio: float = 0.5, seed: int = -1):
+        """ICP::compute with reading = cloud `reading_slot` and reference = concat(T_i * cloud ref_slots[i])."""
+        k = len(ref_slots)
+        slots = (C.c_int * max(k, 1))(*ref_slots)
+        Ts = None
+        if ref_T is not None:
+            Ts = np.concatenate([_t16(T) for T in ref_T]) if k else np.zeros(0, np.float32)
+        ch = _lib.ChainCfg(reading_prob, ssn_knn, ssn_ratio, 0, seed)
+        ti = _t16(T_init)
+        to = np.empty(16, np.float32)
+        st = IcpStats()
+        rc = _lib.lib().lsgpu_icp_compute_clouds(self._h, reading_slot, slots, _fp(Ts) if Ts is not None else None,
+                                                 k, _fp(ti), C.byref(ch), _fp(to), C.byref(st))
+        if rc != _lib.OK:
+            _raise(rc, "lsgpu_icp_compute_clouds", self._h)
+        return to.reshape(4, 4).T.copy(), st
+
     def trace(self, cap: int = 64):
         buf = (IterTrace * cap)()
         n = _lib.lib().lsgpu_icp_get_trace(self._h, buf, cap)

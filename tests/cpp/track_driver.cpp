@@ -1,6 +1,6 @@
 // track_driver.cpp -- drives laser_slam_amd::LaserTrack like LaserSlamWorker::scanCallback does
 // (laser_slam_ros/src/laser_slam_worker.cpp:133): one processPoseAndLaserScan per scan.
-//   usage: track_driver <dir> <n_scans> <icp_yaml> <nscan_in_sub_map>
+//   usage: track_driver <dir> <n_scans> <icp_yaml> <nscan_in_sub_map> [<scans_on_device>]
 // <dir>/scan<i>.bin = float32 N x 4 (x,y,z,1), <dir>/poses.txt = one "t_ns qw qx qy qz px py pz" per scan
 // (odometry pose measurements).  Prints one line per produced factor / ICP result.
 #include <cstdio>
@@ -32,6 +32,7 @@ int main(int argc, char** argv) {
   LaserTrackParams p;
   p.icp_configuration_file = argv[3];
   p.nscan_in_sub_map = std::atoi(argv[4]);
+  if (argc > 5) p.scans_on_device = std::atoi(argv[5]);
   p.odometry_noise_model = {0.05, 0.05, 0.05, 0.01, 0.01, 0.01};
   p.icp_noise_model = {0.005, 0.005, 0.005, 0.0015, 0.0015, 0.0015};
   std::srand(4);
@@ -60,8 +61,8 @@ int main(int argc, char** argv) {
         std::printf("factor %d keys %zu %zu q %.9f %.9f %.9f %.9f p %.9f %.9f %.9f\n", (int)f.type, f.key_a,
                     f.key_b, qq[0], qq[1], qq[2], qq[3], pp[0], pp[1], pp[2]);
       }
-      if (i > 0) std::printf("icp_iterations %d converged %d\n", track.lastIcpStats().iterations,
-                             track.lastIcpStats().converged);
+      if (i > 0) std::printf("icp_iterations %d converged %d scan_ms %.3f\n", track.lastIcpStats().iterations,
+                             track.lastIcpStats().converged, track.getScanMatchingTimes().at(scan.time_ns));
     }
     DataPoints world, submap;
     track.getLocalCloudInWorldFrame(track.getMaxTime(), &world);

@@ -151,3 +151,25 @@ def test_cpp_incremental_estimator_closes_a_loop(tmp_path):
     want = np.linalg.inv(truth[0]) @ truth[-1]                # ~identity: the lap ends where it began
     et, er = synth.pose_error(m, want)
     assert et < 0.03 and er < 3e-3, (et, er)
+
+
+@pytest.mark.gpu
+def test_cpp_submap_on_device_equals_host_assembly(tmp_path):
+    """LaserTrack with scans resident in HBM (sub-map assembled by lsgpu_icp_compute_clouds) must produce the
+    same ICP factors, bit for bit, as the host assembly of laser_track.cpp:474-486."""
+    exe = _build(tmp_path, "track_driver.cpp", "track_driver")
+    scene = synth.Scene(1234)
+    n = 5
+    with open(tmp_path / "poses.txt", "w") as f:
+        for i in range(n):
+            T = synth.se3(0.8 * i, 0.05 * i, synth.SENSOR_HEIGHT, yaw=np.deg2rad(2.0 * i))
+            synth.hdl64_scan(scene, T, 256, 10 + i).tofile(tmp_path / f"scan{i}.bin")
+            f.write(_pose_line(100000000 * i, T @ synth.se3(0.1 * i, -0.05 * i, 0, yaw=np.deg2rad(0.5 * i))))
+    yaml = os.path.join(ROOT, "tests", "golden", "icp_chain.yaml")
+    outs = []
+    for on_device in ("16", "0"):
+        r = subprocess.run([exe, str(tmp_path), str(n), yaml, "3", on_device], capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stdout + r.stderr
+        outs.append([l for l in r.stdout.splitlines() if l.startswith("factor ") or l.startswith("icp_iterations")])
+    strip = lambda ls: [" ".join(l.split()[:5]) if l.startswith("icp_iterations") else l for l in ls]
+    assert strip(outs[0]) == strip(outs[1]) and len(outs[0]) > 2 * (n - 1)

@@ -489,3 +489,36 @@ def test_device_compute_matches_oracle_full_chain(icp_mod, oracle, pair64k):
     assert dt <= TOL_T and dr <= TOL_R, (dt, dr)
     dt, dr = synth.pose_error(T, pair64k["T_true"])
     assert dt < 0.05 and dr < 0.005
+
+
+def test_compute_clouds_assembles_the_submap_on_the_device(icp_mod):
+    """lsgpu_icp_compute_clouds (scans resident in HBM, sub-map = concat(T_i * scan_i) built on the device)
+    must equal lsgpu_icp_compute on the sub-map assembled by the caller with lsgpu_transform_points."""
+    from laser_slam_amd._lib import LsgpuError
+    scene = synth.Scene(1234)
+    poses = [synth.se3(0.8 * i, 0.05 * i, synth.SENSOR_HEIGHT, yaw=np.deg2rad(2.0 * i)) for i in range(4)]
+    scans = [synth.hdl64_scan(scene, T, 256, 70 + i) for i, T in enumerate(poses)]
+    # reference frame = scan 2 (the scan before the reading), plus scans 1 and 0 moved into it
+    rel = [np.eye(4)] + [np.linalg.inv(poses[2]) @ poses[j] for j in (1, 0)]   # (an exact identity is copied, not applied)
+    T_init = (np.linalg.inv(poses[2]) @ poses[3] @ synth.se3(0.2, -0.1, 0.0, yaw=np.deg2rad(1.0))).astype(np.float32)
+    with icp_mod.IcpHandle() as h:
+        for s, sc in enumerate(scans):
+            h.cloud_upload(s, sc)
+        assert h.cloud_size(3) == len(scans[3]) and h.cloud_size(9) == -1
+        T_dev, st_dev = h.compute_clouds(3, [2, 1, 0], rel, T_init, 0.5, 10, 0.5, seed=6)
+        sub = np.concatenate([scans[2], h.transform_points(rel[1], scans[1]), h.transform_points(rel[2], scans[0])])
+        T_host, st_host = h.compute(scans[3], sub, T_init, 0.5, 10, 0.5, seed=6)
+        assert np.array_equal(T_dev, T_host) and st_dev.iterations == st_host.iterations
+        # identity transforms may be passed as NULL
+        T_a, _ = h.compute_clouds(3, [2], None, T_init, 0.5, 10, 0.5, seed=6)
+        T_b, _ = h.compute(scans[3], scans[2], T_init, 0.5, 10, 0.5, seed=6)
+        assert np.array_equal(T_a, T_b)
+        want = np.linalg.inv(poses[2]) @ poses[3]
+        et, er = synth.pose_error(T_dev, want)
+        assert et < 0.03 and er < 3e-3
+        h.cloud_release(1)
+        with pytest.raises(LsgpuError):
+            h.compute_clouds(3, [2, 1], None, T_init)
+        with pytest.raises(LsgpuError):
+            bad = np.eye(4); bad[0, 0] = 2.0
+            h.compute_clouds(3, [2], [bad], T_init)
