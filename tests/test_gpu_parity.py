@@ -522,3 +522,36 @@ def test_compute_clouds_assembles_the_submap_on_the_device(icp_mod):
         with pytest.raises(LsgpuError):
             bad = np.eye(4); bad[0, 0] = 2.0
             h.compute_clouds(3, [2], [bad], T_init)
+
+
+def test_align_degenerate_and_badly_initialised_cases_match_oracle(icp_mod, oracle, pair4k):
+    """(1) a single plane: the 6x6 system is singular -> ConvergenceError on both sides;
+    (2) a start 2 m / 10 deg off: whatever ICP does with it, the GPU does the same as the oracle."""
+    from laser_slam_amd._lib import ConvergenceError
+    rng = np.random.default_rng(8)
+    plane = np.ones((3000, 4), np.float32)
+    plane[:, :2] = rng.uniform(-5, 5, (3000, 2))
+    plane[:, 2] = 0.0
+    nrm = np.tile(np.float32([0, 0, 1]), (3000, 1))
+    rd = plane[::2].copy()
+    rd[:, 2] += 0.05
+    rc, To, sto, _ = oracle.icp_compute(oracle.config_yaml(accum_double=1), rd, plane, nrm, synth.colmajor(np.eye(4)), 0)
+    assert rc != 0
+    with icp_mod.IcpHandle() as h:
+        h.set_reference(plane, nrm)
+        with pytest.raises(ConvergenceError):
+            h.align(rd, np.eye(4))
+        # (2)
+        rf, rn = _filtered(icp_mod, pair4k)
+        T_bad = pair4k["T_true"] @ synth.se3(1.5, -1.2, 0.3, yaw=np.deg2rad(10.0))
+        rc, To, sto, _ = oracle.icp_compute(oracle.config_yaml(accum_double=1), pair4k["rd"], rf, rn,
+                                            synth.colmajor(T_bad), 0)
+        h.set_reference(rf, rn)
+        if rc == 0:
+            Tg, stg = h.align(pair4k["rd"], T_bad)
+            assert stg.iterations == sto.iterations
+            dt, dr = synth.pose_error(Tg, synth.from_colmajor(To))
+            assert dt <= 10 * TOL_T and dr <= 10 * TOL_R, (dt, dr)   # (40 iterations of float round-off apart)
+        else:
+            with pytest.raises(ConvergenceError):
+                h.align(pair4k["rd"], T_bad)
