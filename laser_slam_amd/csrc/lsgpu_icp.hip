@@ -187,7 +187,7 @@ struct lsgpu_icp {
 static constexpr int kNeBlocks = 512;
 static constexpr int kStatBlocks = 512;
 static constexpr int kHistBlocks = 256;
-static constexpr int kFallbackBlocks = 2048;
+static constexpr int kFallbackBlocks = 8192;  // x 4 waves: one query per wave for up to 32 k stragglers, round robin beyond
 
 extern "C" {
 
