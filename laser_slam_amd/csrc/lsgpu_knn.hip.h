@@ -52,6 +52,7 @@ struct KnnArgs {
   float* lb;                // per-query lower bound on the distance to every point OTHER than prev (nullable)
   float gap;                // capped launches search `gap` metres beyond the current best (keep-match bound)
   float spread_route_r;     // > 0: a spread wave whose largest ball exceeds this hands its lanes to k_knn_fallback
+  int route_chunks;         // (with spread_route_r > 0) so does any wave whose cell block holds more chunks than this
   const IcpState* st;       // loop state (nullable): overrides T (and cap2 if use_state_cap)
   int use_state_cap;
   unsigned long long* dbg;  // optional counters (LSGPU_KNN_STATS builds only)
@@ -511,7 +512,8 @@ __global__ __launch_bounds__(WAVES * 64, 8) void k_knn_tile(KnnArgs a) {
 #ifdef LSGPU_KNN_STATS
     if (spread && (a.dbg_flags & 32)) { /* ablation: drop spread waves */ } else
 #endif
-    if (spread && a.spread_route_r > 0.f && Rmax > a.spread_route_r) {
+    const uint32_t block_chunks = wave_sum_u32(ce - cs);
+    if (a.spread_route_r > 0.f && Rmax > a.spread_route_r && (spread || block_chunks > (uint32_t)a.route_chunks)) {
       // wide balls and no shared candidates: 64 divergent per-lane searches would hold this wave for up
       // to a millisecond (the tail of the first launches); one wave per query (k_knn_fallback) instead
       routed = ing;
