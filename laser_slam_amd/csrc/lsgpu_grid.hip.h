@@ -92,12 +92,76 @@ __global__ __launch_bounds__(256) void k_ref_keys(const float4* __restrict__ in,
 
 // Reading: fine Morton key in its own frame (2^-7 m steps, 21 bits per axis), only so that the 64
 // queries of a wave are neighbours.  Rigid motion keeps them neighbours in every iteration.
-__global__ __launch_bounds__(256) void k_query_keys(const float4* __restrict__ in, int64_t n,
-                                                    uint64_t* __restrict__ keys,
-                                                    uint32_t* __restrict__ vals) {
+// order == 1 (default): spherical cells seen from the cloud's own origin -- elevation bin (0.4 deg), azimuth
+// sector (0.35 deg), range bin (1 m) -- and azimuth inside a cell.  A spinning lidar's scan in its sensor frame is
+// a set of rings of constant elevation, and range noise moves a point along its ray, so this reproduces
+// (ring, azimuth) order whatever order the caller stored the points in: a wave's 64 queries are one short arc
+// instead of pieces of several rings inside a Morton block, and the reference points near them are about half
+// as many (measured on the benchmark scan: median 96 against 213 points in the dilated tile box; 214 against
+// 312 for a reading made of three merged scans, where the cells act as a plain spherical grid).  The order is
+// free: results are returned in caller order.  order == 0: Morton order at 2^-7 m, better when the rings are
+// sampled sparsely (k_query_order decides from the points per occupied angular cell).
+constexpr int kAngElev = 452, kAngSect = 1030;  // 0.4 deg x 0.35 deg cells over the sphere
+
+__device__ __forceinline__ void angular_cell(const float4& p, uint32_t& eb, uint32_t& sec, float& azim, float& range) {
+  const float rho = sqrtf(p.x * p.x + p.y * p.y);
+  const float elev = atan2f(p.z, rho);                                       // [-pi/2, pi/2]
+  azim = atan2f(p.y, p.x) + 3.1415927f;                                       // [0, 2 pi]
+  range = sqrtf(rho * rho + p.z * p.z);
+  eb = (uint32_t)fminf(fmaxf((elev + 1.5707964f) * 143.23945f, 0.f), (float)(kAngElev - 1));   // 0.4 deg
+  sec = (uint32_t)fminf(fmaxf(azim * 163.70223f, 0.f), (float)(kAngSect - 1));                 // 0.35 deg
+}
+
+// How densely are the rings sampled?  Points per occupied 1 deg x 1 deg angular cell: cells[kDecCells] counts;
+// cells[kDecCells + 0/1] = occupied cells / points, cells[kDecCells + 2] = the chosen order (k_query_order).
+constexpr int kDecElev = 181, kDecSect = 361, kDecCells = kDecElev * kDecSect;
+__global__ __launch_bounds__(256) void k_query_ang_hist(const float4* __restrict__ in, int64_t n,
+                                                        uint32_t* __restrict__ cells) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
   const float4 p = in[i];
+  const float elev = atan2f(p.z, sqrtf(p.x * p.x + p.y * p.y)), azim = atan2f(p.y, p.x) + 3.1415927f;
+  const uint32_t eb = (uint32_t)fminf(fmaxf((elev + 1.5707964f) * 57.29578f, 0.f), (float)(kDecElev - 1));
+  const uint32_t sec = (uint32_t)fminf(fmaxf(azim * 57.29578f, 0.f), (float)(kDecSect - 1));
+  atomicAdd(&cells[eb * kDecSect + sec], 1u);
+}
+
+// Spherical order pays when a ring is sampled densely compared with the ring spacing: 108 points per occupied
+// square degree on the 1 M-point benchmark scan, 54 on its random half, 21 on a 200 k-point scan.
+__global__ __launch_bounds__(1024) void k_query_order(uint32_t* __restrict__ cells, uint32_t min_per_cell,
+                                                      int forced) {
+  __shared__ uint32_t occ[16], tot[16];
+  uint32_t o = 0, t = 0;
+  if (forced < 0)
+    for (int i = threadIdx.x; i < kDecCells; i += 1024) { const uint32_t c = cells[i]; o += c ? 1u : 0u; t += c; }
+  o = wave_sum_u32(o); t = wave_sum_u32(t);
+  if ((threadIdx.x & 63) == 0) { occ[threadIdx.x >> 6] = o; tot[threadIdx.x >> 6] = t; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    o = 0; t = 0;
+    for (int w = 0; w < 16; ++w) { o += occ[w]; t += tot[w]; }
+    uint32_t* out = cells + kDecCells;
+    out[0] = o; out[1] = t;
+    out[2] = forced >= 0 ? (uint32_t)forced : ((unsigned long long)t >= (unsigned long long)o * min_per_cell ? 1u : 0u);
+  }
+}
+
+__global__ __launch_bounds__(256) void k_query_keys(const float4* __restrict__ in, int64_t n,
+                                                    uint64_t* __restrict__ keys,
+                                                    uint32_t* __restrict__ vals, const uint32_t* __restrict__ order_flag) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const float4 p = in[i];
+  if (*order_flag == 1u) {
+    uint32_t e32, s32; float azim, range;
+    angular_cell(p, e32, s32, azim, range);
+    const uint64_t eb = e32, sec = s32;
+    const uint64_t rb = (uint64_t)fminf(fmaxf(range, 0.f), 4095.f);                              // 1 m
+    const uint64_t fine = (uint64_t)fminf(fmaxf(azim * 166886.05f, 0.f), 1048575.f);             // 2 pi -> 2^20
+    keys[i] = (((eb * 2048ull + sec) * 4096ull + rb) << 20) | fine;
+    vals[i] = (uint32_t)i;
+    return;
+  }
   const float lim = 2097151.f, half = 1048576.f;
   const uint32_t ix = (uint32_t)fminf(fmaxf(floorf(p.x * 128.f) + half, 0.f), lim);
   const uint32_t iy = (uint32_t)fminf(fmaxf(floorf(p.y * 128.f) + half, 0.f), lim);

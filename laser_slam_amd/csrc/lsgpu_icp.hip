@@ -152,6 +152,7 @@ struct lsgpu_icp {
   DevBuf<float4> prev;       // warm start of every query: its current match {xyz, sorted index}
   DevBuf<RefStats> stat_partials;
   DevBuf<uint32_t> counters;  // [0..16] cell counts, [32] straggler count
+  DevBuf<uint32_t> ang_cells; // angular occupancy of the reading (query order decision)
 
   // device filters (lsgpu_ssn.hip.h)
   DevBuf<SsnSeg> ssn_seg_a, ssn_seg_b;
@@ -274,7 +275,7 @@ void lsgpu_icp_destroy(lsgpu_icp* h) {
   h->ref_in.release(); h->nrm_in.release(); h->keys.release(); h->keys_alt.release();
   h->vals.release(); h->vals_alt.release(); h->sort_tmp.release(); h->pts.release();
   h->nrm.release(); h->ref_inv.release(); h->tables.release(); h->flags.release(); h->cidx.release(); h->bounds.release(); h->chunks.release(); h->prev.release(); h->state.release(); h->lb.release(); h->cell_cache.release(); h->cell_tags.release(); h->ssn_seg_a.release(); h->ssn_seg_b.release(); h->ssn_seg_of.release(); h->ssn_box_pts.release(); h->ssn_box_base.release(); h->ssn_keep.release(); h->ssn_out_pos.release(); h->ssn_bb.release(); h->ssn_box_normal.release(); h->ssn_draws.release(); h->flt_in.release(); h->flt_ref.release(); h->flt_rd.release(); h->flt_nrm.release(); h->chk_hist.release(); h->trace_dev.release(); h->knn_dbg.release(); h->knn_dbg_wave.release(); h->stat_partials.release();
-  h->counters.release(); h->q_in.release(); h->rdq.release(); h->ids.release(); h->d2.release();
+  h->counters.release(); h->ang_cells.release(); h->q_in.release(); h->rdq.release(); h->ids.release(); h->d2.release();
   h->ids_io.release(); h->d2_io.release(); h->strag.release(); h->hist.release();
   h->sel.release(); h->ne_partials.release(); h->ne_out.release(); h->limit_dev.release();
   for (auto& e : h->knn_events) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); (void)hipEventDestroy(e.c); }
@@ -336,7 +337,17 @@ static int prepare_queries(lsgpu_icp* h, const float* q_xyz1, int64_t nq, const 
   HIPC(h->rdq.reserve(nq));
   HIPC(h->prev.reserve(nq));
   HIPC(h->lb.reserve(nq));
-  hipLaunchKernelGGL(k_query_keys, dim3(nblk(nq)), dim3(256), 0, h->stream, src, nq, h->keys.p, h->vals.p);
+  // order of the queries inside the waves: chosen on the device from the cloud's angular sampling density
+  static const int qorder = getenv("LSGPU_QUERY_ORDER") ? atoi(getenv("LSGPU_QUERY_ORDER")) : -1;   // -1: automatic
+  static const int qmin = getenv("LSGPU_QUERY_MIN_PER_CELL") ? atoi(getenv("LSGPU_QUERY_MIN_PER_CELL")) : 75;
+  HIPC(h->ang_cells.reserve(kDecCells + 4));
+  if (qorder < 0) {
+    HIPC(hipMemsetAsync(h->ang_cells.p, 0, (kDecCells + 4) * sizeof(uint32_t), h->stream));
+    hipLaunchKernelGGL(k_query_ang_hist, dim3(nblk(nq)), dim3(256), 0, h->stream, src, nq, h->ang_cells.p);
+  }
+  hipLaunchKernelGGL(k_query_order, dim3(1), dim3(1024), 0, h->stream, h->ang_cells.p, (uint32_t)qmin, qorder);
+  hipLaunchKernelGGL(k_query_keys, dim3(nblk(nq)), dim3(256), 0, h->stream, src, nq, h->keys.p, h->vals.p,
+                     h->ang_cells.p + kDecCells + 2);
   rc = sort_pairs(h, nq, 63);
   if (rc) return rc;
   hipLaunchKernelGGL(k_query_gather, dim3(nblk(nq)), dim3(256), 0, h->stream, src, nq,

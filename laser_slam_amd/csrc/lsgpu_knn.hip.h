@@ -508,11 +508,11 @@ __global__ __launch_bounds__(WAVES * 64, 8) void k_knn_tile(KnnArgs a) {
     // A wave whose queries are spread far wider than their balls (sparse far field, Morton jumps)
     // shares no candidates: its lanes search on their own.
     const float ext = fmaxf(fmaxf(thx - tlx, thy - tly), thz - tlz);
-    const bool spread = ext > fmaxf(a.group_r, 4.f * Rmax) && wave_sum_u32(ce - cs) > (uint32_t)a.chunk_budget;
+    const uint32_t block_chunks = wave_sum_u32(ce - cs);
+    const bool spread = ext > fmaxf(a.group_r, 4.f * Rmax) && block_chunks > (uint32_t)a.chunk_budget;
 #ifdef LSGPU_KNN_STATS
     if (spread && (a.dbg_flags & 32)) { /* ablation: drop spread waves */ } else
 #endif
-    const uint32_t block_chunks = wave_sum_u32(ce - cs);
     if (a.spread_route_r > 0.f && Rmax > a.spread_route_r && (spread || block_chunks > (uint32_t)a.route_chunks)) {
       // wide balls and no shared candidates: 64 divergent per-lane searches would hold this wave for up
       // to a millisecond (the tail of the first launches); one wave per query (k_knn_fallback) instead
