@@ -92,24 +92,24 @@ __global__ __launch_bounds__(256) void k_ref_keys(const float4* __restrict__ in,
 
 // Reading: fine Morton key in its own frame (2^-7 m steps, 21 bits per axis), only so that the 64
 // queries of a wave are neighbours.  Rigid motion keeps them neighbours in every iteration.
-// order == 1 (default): spherical cells seen from the cloud's own origin -- elevation bin (0.4 deg), azimuth
-// sector (0.35 deg), range bin (1 m) -- and azimuth inside a cell.  A spinning lidar's scan in its sensor frame is
+// order == 1 (default): spherical cells seen from the cloud's own origin -- elevation bin, azimuth sector (sized
+// by k_query_order: 0.57 x 0.25 deg on the benchmark scan), range bin (1 m) -- and azimuth inside a cell.  A spinning lidar's scan in its sensor frame is
 // a set of rings of constant elevation, and range noise moves a point along its ray, so this reproduces
 // (ring, azimuth) order whatever order the caller stored the points in: a wave's 64 queries are one short arc
 // instead of pieces of several rings inside a Morton block, and the reference points near them are about half
 // as many (measured on the benchmark scan: median 96 against 213 points in the dilated tile box; 214 against
 // 312 for a reading made of three merged scans, where the cells act as a plain spherical grid).  The order is
-// free: results are returned in caller order.  order == 0: Morton order at 2^-7 m, better when the rings are
-// sampled sparsely (k_query_order decides from the points per occupied angular cell).
-constexpr int kAngElev = 452, kAngSect = 1030;  // 0.4 deg x 0.35 deg cells over the sphere
+// free: results are returned in caller order.  order == 0 (LSGPU_QUERY_ORDER=0): Morton order at 2^-7 m.
+constexpr int kAngElev = 1024, kAngSect = 4096;  // key fields: elevation bins, azimuth sectors (cell sizes adapt)
 
-__device__ __forceinline__ void angular_cell(const float4& p, uint32_t& eb, uint32_t& sec, float& azim, float& range) {
+__device__ __forceinline__ void angular_cell(const float4& p, float inv_elev, float inv_sect, uint32_t& eb,
+                                             uint32_t& sec, float& azim, float& range) {
   const float rho = sqrtf(p.x * p.x + p.y * p.y);
   const float elev = atan2f(p.z, rho);                                       // [-pi/2, pi/2]
   azim = atan2f(p.y, p.x) + 3.1415927f;                                       // [0, 2 pi]
   range = sqrtf(rho * rho + p.z * p.z);
-  eb = (uint32_t)fminf(fmaxf((elev + 1.5707964f) * 143.23945f, 0.f), (float)(kAngElev - 1));   // 0.4 deg
-  sec = (uint32_t)fminf(fmaxf(azim * 163.70223f, 0.f), (float)(kAngSect - 1));                 // 0.35 deg
+  eb = (uint32_t)fminf(fmaxf((elev + 1.5707964f) * inv_elev, 0.f), (float)(kAngElev - 1));
+  sec = (uint32_t)fminf(fmaxf(azim * inv_sect, 0.f), (float)(kAngSect - 1));
 }
 
 // How densely are the rings sampled?  Points per occupied 1 deg x 1 deg angular cell: cells[kDecCells] counts;
@@ -126,14 +126,15 @@ __global__ __launch_bounds__(256) void k_query_ang_hist(const float4* __restrict
   atomicAdd(&cells[eb * kDecSect + sec], 1u);
 }
 
-// Spherical order pays when a ring is sampled densely compared with the ring spacing: 108 points per occupied
-// square degree on the 1 M-point benchmark scan, 54 on its random half, 21 on a 200 k-point scan.
-__global__ __launch_bounds__(1024) void k_query_order(uint32_t* __restrict__ cells, uint32_t min_per_cell,
-                                                      int forced) {
+// Cell size of the spherical order from the angular sampling density m = points per occupied square degree
+// (108 on the 1 M-point benchmark scan, 54 on its random half, 21 on a 200 k-point scan): about 15 points per
+// cell, elevation : azimuth = 0.8 : 0.35 (measured best on all three: a band of one to three rings, a sector of
+// a dozen points per ring).  cells[kDecCells + 2] = order, + 3 / + 4 = 1 / elevation bin, 1 / sector (radians).
+__global__ __launch_bounds__(1024) void k_query_order(uint32_t* __restrict__ cells, int forced, float elev_deg,
+                                                      float sect_deg) {
   __shared__ uint32_t occ[16], tot[16];
   uint32_t o = 0, t = 0;
-  if (forced < 0)
-    for (int i = threadIdx.x; i < kDecCells; i += 1024) { const uint32_t c = cells[i]; o += c ? 1u : 0u; t += c; }
+  for (int i = threadIdx.x; i < kDecCells; i += 1024) { const uint32_t c = cells[i]; o += c ? 1u : 0u; t += c; }
   o = wave_sum_u32(o); t = wave_sum_u32(t);
   if ((threadIdx.x & 63) == 0) { occ[threadIdx.x >> 6] = o; tot[threadIdx.x >> 6] = t; }
   __syncthreads();
@@ -142,7 +143,13 @@ __global__ __launch_bounds__(1024) void k_query_order(uint32_t* __restrict__ cel
     for (int w = 0; w < 16; ++w) { o += occ[w]; t += tot[w]; }
     uint32_t* out = cells + kDecCells;
     out[0] = o; out[1] = t;
-    out[2] = forced >= 0 ? (uint32_t)forced : ((unsigned long long)t >= (unsigned long long)o * min_per_cell ? 1u : 0u);
+    const float m = o ? (float)t / (float)o : 54.f;
+    const float f = sqrtf(54.f / fmaxf(m, 1.f));
+    const float e = elev_deg > 0.f ? elev_deg : fminf(fmaxf(0.8f * f, 0.2f), 4.f);
+    const float sc = sect_deg > 0.f ? sect_deg : fminf(fmaxf(0.35f * f, 0.1f), 2.f);
+    out[2] = forced >= 0 ? (uint32_t)forced : 1u;
+    out[3] = __float_as_uint(57.29578f / e);
+    out[4] = __float_as_uint(57.29578f / sc);
   }
 }
 
@@ -154,11 +161,11 @@ __global__ __launch_bounds__(256) void k_query_keys(const float4* __restrict__ i
   const float4 p = in[i];
   if (*order_flag == 1u) {
     uint32_t e32, s32; float azim, range;
-    angular_cell(p, e32, s32, azim, range);
+    angular_cell(p, __uint_as_float(order_flag[1]), __uint_as_float(order_flag[2]), e32, s32, azim, range);
     const uint64_t eb = e32, sec = s32;
     const uint64_t rb = (uint64_t)fminf(fmaxf(range, 0.f), 4095.f);                              // 1 m
     const uint64_t fine = (uint64_t)fminf(fmaxf(azim * 166886.05f, 0.f), 1048575.f);             // 2 pi -> 2^20
-    keys[i] = (((eb * 2048ull + sec) * 4096ull + rb) << 20) | fine;
+    keys[i] = (((eb * 4096ull + sec) * 4096ull + rb) << 20) | fine;
     vals[i] = (uint32_t)i;
     return;
   }

@@ -339,13 +339,12 @@ static int prepare_queries(lsgpu_icp* h, const float* q_xyz1, int64_t nq, const 
   HIPC(h->lb.reserve(nq));
   // order of the queries inside the waves: chosen on the device from the cloud's angular sampling density
   static const int qorder = getenv("LSGPU_QUERY_ORDER") ? atoi(getenv("LSGPU_QUERY_ORDER")) : -1;   // -1: automatic
-  static const int qmin = getenv("LSGPU_QUERY_MIN_PER_CELL") ? atoi(getenv("LSGPU_QUERY_MIN_PER_CELL")) : 75;
-  HIPC(h->ang_cells.reserve(kDecCells + 4));
-  if (qorder < 0) {
-    HIPC(hipMemsetAsync(h->ang_cells.p, 0, (kDecCells + 4) * sizeof(uint32_t), h->stream));
-    hipLaunchKernelGGL(k_query_ang_hist, dim3(nblk(nq)), dim3(256), 0, h->stream, src, nq, h->ang_cells.p);
-  }
-  hipLaunchKernelGGL(k_query_order, dim3(1), dim3(1024), 0, h->stream, h->ang_cells.p, (uint32_t)qmin, qorder);
+  static const float qelev = getenv("LSGPU_Q_ELEV") ? (float)atof(getenv("LSGPU_Q_ELEV")) : 0.f;   // 0: automatic
+  static const float qsect = getenv("LSGPU_Q_SECT") ? (float)atof(getenv("LSGPU_Q_SECT")) : 0.f;
+  HIPC(h->ang_cells.reserve(kDecCells + 8));
+  HIPC(hipMemsetAsync(h->ang_cells.p, 0, (kDecCells + 8) * sizeof(uint32_t), h->stream));
+  if (qorder != 0) hipLaunchKernelGGL(k_query_ang_hist, dim3(nblk(nq)), dim3(256), 0, h->stream, src, nq, h->ang_cells.p);
+  hipLaunchKernelGGL(k_query_order, dim3(1), dim3(1024), 0, h->stream, h->ang_cells.p, qorder, qelev, qsect);
   hipLaunchKernelGGL(k_query_keys, dim3(nblk(nq)), dim3(256), 0, h->stream, src, nq, h->keys.p, h->vals.p,
                      h->ang_cells.p + kDecCells + 2);
   rc = sort_pairs(h, nq, 63);
