@@ -273,15 +273,30 @@ __global__ __launch_bounds__(256) void k_normal_eq_loop(const float4* __restrict
   double acc[kNe];
 #pragma unroll
   for (int k = 0; k < kNe; ++k) acc[k] = 0.0;
-  for (int j = blockIdx.x * 256 + threadIdx.x; j < nq; j += gridDim.x * 256) {
-    const float d = d2[j];
-    if (!(d <= limit)) continue;
-    const float4 q = match[j];
-    const int id = __float_as_int(q.w);
-    if (id < 0) continue;
-    const float4 r = rdq[j];
+  // four points per step: their loads (distance, match, query, gathered normal) are issued together, the sums
+  // are still taken in index order, so the result does not depend on the unrolling
+  const int stride = gridDim.x * 256;
+  for (int j0 = blockIdx.x * 256 + threadIdx.x; j0 < nq; j0 += 4 * stride) {
+    float dd[4]; float4 qq[4], rr[4], nn[4]; bool use[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int j = j0 + u * stride;
+      use[u] = j < nq;
+      dd[u] = use[u] ? d2[j] : INFINITY;
+      use[u] = use[u] && dd[u] <= limit;
+      qq[u] = use[u] ? match[j] : make_float4(0.f, 0.f, 0.f, __int_as_float(-1));
+      rr[u] = use[u] ? rdq[j] : make_float4(0.f, 0.f, 0.f, 0.f);
+      use[u] = use[u] && __float_as_int(qq[u].w) >= 0;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) nn[u] = use[u] ? nrm[__float_as_int(qq[u].w)] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+    if (!use[u]) continue;
+    const float4 q = qq[u];
+    const float4 r = rr[u];
     const float3 p = xform(T, r.x, r.y, r.z);
-    const float4 n = nrm[id];
+    const float4 n = nn[u];
     float J[6];
     J[0] = p.y * n.z - p.z * n.y;
     J[1] = p.z * n.x - p.x * n.z;
@@ -298,6 +313,7 @@ __global__ __launch_bounds__(256) void k_normal_eq_loop(const float4* __restrict
     for (int a = 0; a < 6; ++a) acc[21 + a] -= (double)J[a] * (double)res;
     acc[27] += 1.0;
     acc[28] += (double)res * (double)res;
+    }
   }
 #pragma unroll
   for (int k = 0; k < kNe; ++k) acc[k] = wave_sum(acc[k]);
