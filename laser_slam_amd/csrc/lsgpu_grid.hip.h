@@ -147,7 +147,10 @@ __global__ __launch_bounds__(1024) void k_query_order(uint32_t* __restrict__ cel
     const float f = sqrtf(54.f / fmaxf(m, 1.f));
     const float e = elev_deg > 0.f ? elev_deg : fminf(fmaxf(0.8f * f, 0.2f), 4.f);
     const float sc = sect_deg > 0.f ? sect_deg : fminf(fmaxf(0.35f * f, 0.1f), 2.f);
-    out[2] = forced >= 0 ? (uint32_t)forced : 1u;
+    // a cloud seen under a small solid angle (its origin is far outside it, e.g. world coordinates) has no
+    // ring structure to exploit from here: Morton order
+    const uint32_t automatic = (o < 64u && t > 4096u) ? 0u : 1u;
+    out[2] = forced >= 0 ? (uint32_t)forced : automatic;
     out[3] = __float_as_uint(57.29578f / e);
     out[4] = __float_as_uint(57.29578f / sc);
   }
