@@ -203,6 +203,21 @@ int lsgpu_icp_compute_clouds(lsgpu_icp* h, int reading_slot, const int* ref_slot
                              int n_ref, const float T_init[16], const lsgpu_chain_config* chain,
                              float T_out[16], lsgpu_icp_stats* stats);
 
+/* ---- local-map maintenance on the device --------------------------------------------
+ * What the ROS worker does to its local map between scans (laser_slam_ros/src/laser_slam_worker.cpp:415-488,
+ * 522-540): cylindrical crop around the robot, voxel-grid down-sampling, rigid re-transform after a loop
+ * closure (= lsgpu_transform_points).  Inputs / outputs: host or device pointers, 4 floats per point. */
+/* applyCylindricalFilter (laser_slam_ros/include/laser_slam_ros/common.hpp:194-223): keeps the points with
+ * (x-cx)^2 + (y-cy)^2 <= r^2 and |z-cz| <= height/2 (remove_point_inside: the points with >= in either test).
+ * Order preserved.  out_xyz1 needs room for n points. */
+int lsgpu_filter_cylinder(lsgpu_icp* h, const float* xyz1, int64_t n, const float center[3], double radius_m,
+                          double height_m, int remove_point_inside, float* out_xyz1, int64_t* n_out);
+/* pcl::VoxelGrid<PointXYZ> (laser_slam_worker.cpp:70-72, 439-440): one centroid (float sums in input order,
+ * divided by the count) per voxel with >= min_points points, voxels in ascending index order.  LSGPU_BAD_ARG if
+ * the voxel index would overflow an int (PCL refuses such leaf sizes as well). */
+int lsgpu_filter_voxel_grid(lsgpu_icp* h, const float* xyz1, int64_t n, const float leaf[3], int min_points,
+                            float* out_xyz1, int64_t* n_out);
+
 /* ---- host-side versions of the two filters (same output as the device filters) and O(1) helpers ---- */
 
 /* RandomSamplingDataPointsFilter (yaml:1-3): keep i iff draw_i < prob; seed as above. */

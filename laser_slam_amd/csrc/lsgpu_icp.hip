@@ -994,6 +994,101 @@ int lsgpu_icp_compute(lsgpu_icp* h, const float* reading_xyz1, int64_t nq, const
   return rc;
 }
 
+int lsgpu_filter_cylinder(lsgpu_icp* h, const float* xyz1, int64_t n, const float center[3], double radius_m,
+                          double height_m, int remove_point_inside, float* out_xyz1, int64_t* n_out) {
+  if (!h || !n_out || !center || !out_xyz1) return LSGPU_BAD_ARG;
+  h->err.clear();
+  *n_out = 0;
+  if (n <= 0 || !xyz1) return LSGPU_OK;
+  if (n > 0x7FFFFFF0ll) return LSGPU_BAD_ARG;
+  HIPC(hipSetDevice(h->device));
+  const float4* src = nullptr;
+  int rc = stage_points(h, xyz1, n, h->flt_in, &src);
+  if (rc) return rc;
+  const bool dev_x = is_device_ptr(out_xyz1);
+  float4* ox = reinterpret_cast<float4*>(out_xyz1);
+  if (!dev_x) { HIPC(h->flt_rd.reserve(n)); ox = h->flt_rd.p; }
+  HIPC(h->ssn_keep.reserve(n));
+  HIPC(h->ssn_out_pos.reserve(n));
+  hipLaunchKernelGGL(k_cylinder_select, dim3(nblk(n)), dim3(256), 0, h->stream, src, (int)n, center[0], center[1],
+                     center[2], radius_m * radius_m, height_m / 2.0, remove_point_inside, h->ssn_keep.p);
+  rc = scan_u32(h, h->ssn_keep.p, h->ssn_out_pos.p, (size_t)n);
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_compact_points, dim3(nblk(n)), dim3(256), 0, h->stream, src, (int)n, h->ssn_keep.p,
+                     h->ssn_out_pos.p, ox);
+  HIPC(hipGetLastError());
+  uint32_t unused = 0, kept = 0;
+  rc = scan_totals(h, nullptr, nullptr, 0, h->ssn_keep.p, h->ssn_out_pos.p, (size_t)n, &unused, &kept);
+  if (rc) return rc;
+  *n_out = kept;
+  if (!dev_x && kept) HIPC(hipMemcpyAsync(out_xyz1, ox, (size_t)kept * 16, hipMemcpyDeviceToHost, h->stream));
+  HIPC(hipStreamSynchronize(h->stream));
+  return LSGPU_OK;
+}
+
+int lsgpu_filter_voxel_grid(lsgpu_icp* h, const float* xyz1, int64_t n, const float leaf[3], int min_points,
+                            float* out_xyz1, int64_t* n_out) {
+  if (!h || !n_out || !leaf || !out_xyz1) return LSGPU_BAD_ARG;
+  h->err.clear();
+  *n_out = 0;
+  if (!(leaf[0] > 0.f && leaf[1] > 0.f && leaf[2] > 0.f)) { h->err = "voxel_grid: leaf size must be positive"; return LSGPU_BAD_ARG; }
+  if (n <= 0 || !xyz1) return LSGPU_OK;
+  if (n > 0x7FFFFFF0ll) return LSGPU_BAD_ARG;
+  HIPC(hipSetDevice(h->device));
+  const float4* src = nullptr;
+  int rc = stage_points(h, xyz1, n, h->flt_in, &src);
+  if (rc) return rc;
+  // getMinMax3D
+  HIPC(h->ssn_bb.reserve(8));
+  HIPC(hipMemsetAsync(h->ssn_bb.p, 0xFF, 12, h->stream));
+  HIPC(hipMemsetAsync(h->ssn_bb.p + 3, 0, 12, h->stream));
+  hipLaunchKernelGGL(k_ssn_bounds, dim3(std::min(nblk(n), 256)), dim3(256), 0, h->stream, src, (int)n, h->ssn_bb.p);
+  uint32_t* hb = reinterpret_cast<uint32_t*>(h->h_pinned + 104);
+  HIPC(hipMemcpyAsync(hb, h->ssn_bb.p, 24, hipMemcpyDeviceToHost, h->stream));
+  HIPC(hipStreamSynchronize(h->stream));
+  auto from_key = [](uint32_t k) { const uint32_t u = (k & 0x80000000u) ? (k & 0x7FFFFFFFu) : ~k; float f; std::memcpy(&f, &u, 4); return f; };
+  float inv[3];
+  int minb[3], divb[3];
+  for (int d = 0; d < 3; ++d) {
+    inv[d] = 1.0f / leaf[d];
+    minb[d] = (int)std::floor(from_key(hb[d]) * inv[d]);
+    const int maxb = (int)std::floor(from_key(hb[3 + d]) * inv[d]);
+    divb[d] = maxb - minb[d] + 1;
+  }
+  if ((int64_t)divb[0] * (int64_t)divb[1] * (int64_t)divb[2] > 2147483647ll) {
+    h->err = "voxel_grid: leaf size too small for the cloud, the voxel index would overflow";
+    return LSGPU_BAD_ARG;
+  }
+  HIPC(h->keys.reserve(n));
+  HIPC(h->vals.reserve(n));
+  HIPC(h->ssn_keep.reserve(n));
+  HIPC(h->ssn_out_pos.reserve(n));
+  HIPC(h->ssn_seg_of.reserve(n));   // voxel head flags
+  HIPC(h->flt_ref.reserve(n));      // centroids by sorted position
+  hipLaunchKernelGGL(k_voxel_keys, dim3(nblk(n)), dim3(256), 0, h->stream, src, (int)n, inv[0], inv[1], inv[2],
+                     minb[0], minb[1], minb[2], divb[0], divb[0] * divb[1], h->keys.p, h->vals.p);
+  rc = sort_pairs(h, n, 31);  // stable: equal voxels keep input order
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_voxel_heads, dim3(nblk(n)), dim3(256), 0, h->stream, h->keys_alt.p, (int)n, h->ssn_seg_of.p);
+  hipLaunchKernelGGL(k_voxel_centroids, dim3(nblk(n)), dim3(256), 0, h->stream, src, h->keys_alt.p, h->vals_alt.p, (int)n,
+                     min_points, h->ssn_seg_of.p, h->flt_ref.p, h->ssn_keep.p);
+  rc = scan_u32(h, h->ssn_keep.p, h->ssn_out_pos.p, (size_t)n);
+  if (rc) return rc;
+  const bool dev_x = is_device_ptr(out_xyz1);
+  float4* ox = reinterpret_cast<float4*>(out_xyz1);
+  if (!dev_x) { HIPC(h->flt_rd.reserve(n)); ox = h->flt_rd.p; }
+  hipLaunchKernelGGL(k_compact_points, dim3(nblk(n)), dim3(256), 0, h->stream, h->flt_ref.p, (int)n, h->ssn_keep.p,
+                     h->ssn_out_pos.p, ox);
+  HIPC(hipGetLastError());
+  uint32_t unused = 0, kept = 0;
+  rc = scan_totals(h, nullptr, nullptr, 0, h->ssn_keep.p, h->ssn_out_pos.p, (size_t)n, &unused, &kept);
+  if (rc) return rc;
+  *n_out = kept;
+  if (!dev_x && kept) HIPC(hipMemcpyAsync(out_xyz1, ox, (size_t)kept * 16, hipMemcpyDeviceToHost, h->stream));
+  HIPC(hipStreamSynchronize(h->stream));
+  return LSGPU_OK;
+}
+
 int lsgpu_cloud_upload(lsgpu_icp* h, int slot, const float* xyz1, int64_t n) {
   if (!h || slot < 0 || slot >= (1 << 20) || n < 0 || n > 0x7FFFFFF0ll || (n > 0 && !xyz1)) return LSGPU_BAD_ARG;
   h->err.clear();

@@ -329,4 +329,65 @@ __global__ __launch_bounds__(256) void k_compact_points(const float4* __restrict
   if (i < n && keep[i]) out[out_pos[i]] = p[i];
 }
 
+// ---- local-map maintenance
+// applyCylindricalFilter (laser_slam_ros/include/laser_slam_ros/common.hpp:194-223)
+__global__ __launch_bounds__(256) void k_cylinder_select(const float4* __restrict__ p, int n, float cx, float cy,
+                                                         float cz, double radius_squared, double height_halved,
+                                                         int remove_point_inside, uint32_t* __restrict__ keep) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const float4 v = p[i];
+  const float dx = v.x - cx, dy = v.y - cy, dz = fabsf(v.z - cz);
+  const double r2 = (double)dx * (double)dx + (double)dy * (double)dy;
+  const bool inside = r2 <= radius_squared && (double)dz <= height_halved;
+  const bool outside = r2 >= radius_squared || (double)dz >= height_halved;
+  keep[i] = (remove_point_inside ? outside : inside) ? 1u : 0u;
+}
+
+// pcl::VoxelGrid: voxel index of every point (key), original index (value)
+__global__ __launch_bounds__(256) void k_voxel_keys(const float4* __restrict__ p, int n, float ix, float iy, float iz,
+                                                    int bx, int by, int bz, int mul1, int mul2,
+                                                    uint64_t* __restrict__ keys, uint32_t* __restrict__ vals) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const float4 v = p[i];
+  const int i0 = (int)(floorf(v.x * ix) - (float)bx);
+  const int i1 = (int)(floorf(v.y * iy) - (float)by);
+  const int i2 = (int)(floorf(v.z * iz) - (float)bz);
+  keys[i] = (uint64_t)(uint32_t)(i0 + i1 * mul1 + i2 * mul2);
+  vals[i] = (uint32_t)i;
+}
+
+// head flag of every voxel run in the sorted keys; flags[i] = 1 where a new voxel starts
+__global__ __launch_bounds__(256) void k_voxel_heads(const uint64_t* __restrict__ keys, int n, uint32_t* __restrict__ flags) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n) flags[i] = (i == 0 || keys[i] != keys[i - 1]) ? 1u : 0u;
+}
+
+// one thread per sorted position that starts a voxel: centroid of the run (float sums in input order, as the
+// stable sort left them), kept[i] = 1 if the voxel holds >= min_points points
+__global__ __launch_bounds__(256) void k_voxel_centroids(const float4* __restrict__ p, const uint64_t* __restrict__ keys,
+                                                         const uint32_t* __restrict__ idx, int n, int min_points,
+                                                         const uint32_t* __restrict__ flags, float4* __restrict__ cent,
+                                                         uint32_t* __restrict__ kept) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  uint32_t k = 0;
+  if (flags[i]) {
+    const uint64_t key = keys[i];
+    float sx = 0.f, sy = 0.f, sz = 0.f;
+    int j = i;
+    for (; j < n && keys[j] == key; ++j) {
+      const float4 v = p[idx[j]];
+      sx += v.x; sy += v.y; sz += v.z;
+    }
+    if (j - i >= min_points) {
+      const float c = (float)(j - i);
+      cent[i] = make_float4(sx / c, sy / c, sz / c, 1.0f);
+      k = 1;
+    }
+  }
+  kept[i] = k;
+}
+
 }  // namespace lsgpu

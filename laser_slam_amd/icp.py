@@ -195,6 +195,38 @@ class IcpHandle:
             _raise(rc, "lsgpu_icp_compute", self._h)
         return to.reshape(4, 4).T.copy(), st
 
+    # ---- local-map maintenance (laser_slam_ros worker): cylinder crop, voxel grid
+    def _filter_out(self, xyz1, n):
+        if _is_torch(xyz1) and xyz1.is_cuda:
+            o = torch.empty((max(n, 1), 4), dtype=torch.float32, device=xyz1.device)
+            torch.cuda.synchronize()
+            return o, o.data_ptr()
+        o = np.empty((max(n, 1), 4), np.float32)
+        return o, o.ctypes.data
+
+    def filter_cylinder(self, xyz1, center, radius_m: float, height_m: float, remove_point_inside: bool = False):
+        """applyCylindricalFilter (laser_slam_ros common.hpp:194-223) on the GPU, order preserved."""
+        p, _k, n = _as_f32(xyz1, 4)
+        c = np.ascontiguousarray(center, np.float32).reshape(3)
+        o, po = self._filter_out(xyz1, n)
+        m = C.c_int64(0)
+        rc = _lib.lib().lsgpu_filter_cylinder(self._h, p, n, _fp(c), radius_m, height_m, int(remove_point_inside),
+                                              po, C.byref(m))
+        if rc != _lib.OK:
+            _raise(rc, "lsgpu_filter_cylinder", self._h)
+        return o[:m.value]
+
+    def filter_voxel_grid(self, xyz1, leaf, min_points: int = 1):
+        """pcl::VoxelGrid (laser_slam_worker.cpp:70-72, 439-440) on the GPU: one centroid per occupied voxel."""
+        p, _k, n = _as_f32(xyz1, 4)
+        lf = np.ascontiguousarray(np.broadcast_to(np.asarray(leaf, np.float32), (3,)), np.float32)
+        o, po = self._filter_out(xyz1, n)
+        m = C.c_int64(0)
+        rc = _lib.lib().lsgpu_filter_voxel_grid(self._h, p, n, _fp(lf), int(min_points), po, C.byref(m))
+        if rc != _lib.OK:
+            _raise(rc, "lsgpu_filter_voxel_grid", self._h)
+        return o[:m.value]
+
     # ---- clouds kept in HBM between calls; sub-map assembly on the device (laser_track.cpp:474-486)
     def cloud_upload(self, slot: int, xyz1):
         p, _k, n = _as_f32(xyz1, 4)

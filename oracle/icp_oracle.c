@@ -870,3 +870,75 @@ int lso_icp_compute_full(const lso_config* cfg, const float* reading_xyz1, int64
   free(rf); free(rn); free(keep); free(qf);
   return rc;
 }
+
+/* ------------------------------------------------------------------ local-map maintenance (N4) */
+
+int64_t lso_cylinder_filter(const float* xyz1, int64_t n, const float center[3], double radius_m,
+                            double height_m, int remove_point_inside, float* out_xyz1) {
+  const double radius_squared = radius_m * radius_m; /* pow(radius_m, 2.0) */
+  const double height_halved_m = height_m / 2.0;
+  int64_t m = 0;
+  for (int64_t i = 0; i < n; ++i) {
+    const float dx = xyz1[4 * i] - center[0], dy = xyz1[4 * i + 1] - center[1];
+    const float dz = fabsf(xyz1[4 * i + 2] - center[2]);
+    const double r2 = (double)dx * (double)dx + (double)dy * (double)dy; /* pow(float, 2.0) promotes to double */
+    const int inside = r2 <= radius_squared && (double)dz <= height_halved_m;
+    const int outside = r2 >= radius_squared || (double)dz >= height_halved_m;
+    if (remove_point_inside ? outside : inside) memcpy(out_xyz1 + 4 * (m++), xyz1 + 4 * i, 16);
+  }
+  return m;
+}
+
+typedef struct { int32_t idx; int32_t pt; } lso_vox_pair;
+static int lso_vox_cmp(const void* a, const void* b) {
+  const lso_vox_pair* x = (const lso_vox_pair*)a; const lso_vox_pair* y = (const lso_vox_pair*)b;
+  if (x->idx != y->idx) return x->idx < y->idx ? -1 : 1;
+  return x->pt < y->pt ? -1 : (x->pt > y->pt); /* input order inside a voxel */
+}
+
+int64_t lso_voxel_grid(const float* xyz1, int64_t n, const float leaf[3], int min_points, float* out_xyz1) {
+  if (n <= 0) return 0;
+  float mn[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, mx[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+  for (int64_t i = 0; i < n; ++i)
+    for (int d = 0; d < 3; ++d) {
+      const float v = xyz1[4 * i + d];
+      if (v < mn[d]) mn[d] = v;
+      if (v > mx[d]) mx[d] = v;
+    }
+  float inv[3];
+  int minb[3], divb[3];
+  for (int d = 0; d < 3; ++d) {
+    inv[d] = 1.0f / leaf[d];
+    minb[d] = (int)floorf(mn[d] * inv[d]);
+    const int maxb = (int)floorf(mx[d] * inv[d]);
+    divb[d] = maxb - minb[d] + 1;
+  }
+  if ((int64_t)divb[0] * (int64_t)divb[1] * (int64_t)divb[2] > 2147483647ll) return -1;
+  const int mul1 = divb[0], mul2 = divb[0] * divb[1];
+  lso_vox_pair* pr = (lso_vox_pair*)malloc(sizeof(lso_vox_pair) * (size_t)n);
+  for (int64_t i = 0; i < n; ++i) {
+    const int i0 = (int)(floorf(xyz1[4 * i] * inv[0]) - (float)minb[0]);
+    const int i1 = (int)(floorf(xyz1[4 * i + 1] * inv[1]) - (float)minb[1]);
+    const int i2 = (int)(floorf(xyz1[4 * i + 2] * inv[2]) - (float)minb[2]);
+    pr[i].idx = i0 + i1 * mul1 + i2 * mul2;
+    pr[i].pt = (int32_t)i;
+  }
+  qsort(pr, (size_t)n, sizeof(lso_vox_pair), lso_vox_cmp);
+  int64_t m = 0;
+  for (int64_t a = 0; a < n;) {
+    int64_t b = a;
+    float sx = 0.f, sy = 0.f, sz = 0.f;
+    while (b < n && pr[b].idx == pr[a].idx) {
+      sx += xyz1[4 * (int64_t)pr[b].pt]; sy += xyz1[4 * (int64_t)pr[b].pt + 1]; sz += xyz1[4 * (int64_t)pr[b].pt + 2];
+      ++b;
+    }
+    if (b - a >= (int64_t)min_points) {
+      const float cnt = (float)(b - a);
+      out_xyz1[4 * m] = sx / cnt; out_xyz1[4 * m + 1] = sy / cnt; out_xyz1[4 * m + 2] = sz / cnt; out_xyz1[4 * m + 3] = 1.0f;
+      ++m;
+    }
+    a = b;
+  }
+  free(pr);
+  return m;
+}

@@ -114,6 +114,18 @@ int lso_icp_compute_full(const lso_config* cfg, const float* reading_xyz1, int64
                          const float* ref_xyz1, int64_t nr, const float T_init[16],
                          int64_t seed, float T_out[16], lso_stats* stats);
 
+/* ---- local-map maintenance of the ROS worker ------------------------------------
+ * applyCylindricalFilter, laser_slam_ros/include/laser_slam_ros/common.hpp:194-223: keep (or remove) the
+ * points inside the vertical cylinder |(x,y) - c| <= radius, |z - cz| <= height / 2.  Order preserved. */
+int64_t lso_cylinder_filter(const float* xyz1, int64_t n, const float center[3], double radius_m,
+                            double height_m, int remove_point_inside, float* out_xyz1);
+/* pcl::VoxelGrid<PointXYZ> as configured at laser_slam_ros/src/laser_slam_worker.cpp:70-72 and applied at
+ * :439-440: one centroid per voxel holding >= min_points points, voxels in ascending index order
+ * (index = i + j * div_x + k * div_x * div_y).  PCL sorts (index, point) pairs with an unstable sort, so the
+ * order of the float additions inside a voxel is unspecified upstream; here it is the input order.
+ * Returns the number of output points, or -1 if the index would overflow an int (PCL refuses as well). */
+int64_t lso_voxel_grid(const float* xyz1, int64_t n, const float leaf[3], int min_points, float* out_xyz1);
+
 #ifdef __cplusplus
 }
 #endif

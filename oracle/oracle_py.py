@@ -251,3 +251,28 @@ def icp_compute_full(cfg: Config, reading_xyz1, ref_xyz1, T_init16, seed=0):
     rc = lib().lso_icp_compute_full(C.byref(cfg), qp, q.shape[0], rp, r.shape[0], Tp, seed,
                                     out.ctypes.data_as(C.POINTER(C.c_float)), C.byref(st))
     return rc, out, st
+
+
+def cylinder_filter(xyz1, center, radius_m, height_m, remove_point_inside):
+    a, ap = _f(xyz1)
+    c = np.ascontiguousarray(center, np.float32)
+    out = np.empty((max(len(a), 1), 4), np.float32)
+    L = lib()
+    L.lso_cylinder_filter.restype = C.c_int64
+    L.lso_cylinder_filter.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_double, C.c_double, C.c_int, C.c_void_p]
+    m = L.lso_cylinder_filter(a.ctypes.data, len(a), c.ctypes.data, radius_m, height_m, int(remove_point_inside),
+                              out.ctypes.data)
+    return out[:m].copy()
+
+
+def voxel_grid(xyz1, leaf, min_points=1):
+    a, ap = _f(xyz1)
+    lf = np.ascontiguousarray(leaf, np.float32)
+    out = np.empty((max(len(a), 1), 4), np.float32)
+    L = lib()
+    L.lso_voxel_grid.restype = C.c_int64
+    L.lso_voxel_grid.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int, C.c_void_p]
+    m = L.lso_voxel_grid(a.ctypes.data, len(a), lf.ctypes.data, int(min_points), out.ctypes.data)
+    if m < 0:
+        raise OverflowError("voxel index overflows an int")
+    return out[:m].copy()

@@ -555,3 +555,40 @@ def test_align_degenerate_and_badly_initialised_cases_match_oracle(icp_mod, orac
         else:
             with pytest.raises(ConvergenceError):
                 h.align(pair4k["rd"], T_bad)
+
+
+def test_map_maintenance_filters_match_oracle(icp_mod, oracle):
+    """the worker's local-map filters on the device -- cylindrical crop (order preserved) and
+    pcl::VoxelGrid centroids (ascending voxel index) -- bit-identical with the oracle's restatement."""
+    import torch
+    from laser_slam_amd._lib import LsgpuError
+    rng = np.random.default_rng(11)
+    cloud = synth.scan_pair(512)[0]
+    rnd = np.ones((20000, 4), np.float32)
+    rnd[:, :3] = rng.uniform(-6, 6, (20000, 3))
+    with icp_mod.IcpHandle() as h:
+        for pts in (cloud, rnd):
+            for inside in (False, True):
+                want = oracle.cylinder_filter(pts, [1.0, -2.0, 0.5], 7.5, 3.0, inside)
+                got = h.filter_cylinder(pts, [1.0, -2.0, 0.5], 7.5, 3.0, inside)
+                assert np.array_equal(got, want) and 0 < len(got) < len(pts)
+            n_in = len(h.filter_cylinder(pts, [1.0, -2.0, 0.5], 7.5, 3.0, False))
+            n_out = len(h.filter_cylinder(pts, [1.0, -2.0, 0.5], 7.5, 3.0, True))
+            assert n_in + n_out >= len(pts)   # (points exactly on the boundary are in both)
+            for leaf, minpts in ((0.1, 1), (0.25, 2), ((0.5, 0.2, 1.0), 3)):
+                lf = np.broadcast_to(np.asarray(leaf, np.float32), (3,))
+                want = oracle.voxel_grid(pts, lf, minpts)
+                got = h.filter_voxel_grid(pts, leaf, minpts)
+                assert got.shape == want.shape and np.array_equal(got, want), (leaf, minpts)
+                assert 0 < len(got) < len(pts)
+        # device in, device out
+        d = torch.from_numpy(cloud).cuda()
+        assert np.array_equal(h.filter_voxel_grid(d, 0.1, 1).cpu().numpy(), oracle.voxel_grid(cloud, [0.1] * 3, 1))
+        assert np.array_equal(h.filter_cylinder(d, [0, 0, 0], 10.0, 40.0).cpu().numpy(),
+                              oracle.cylinder_filter(cloud, [0, 0, 0], 10.0, 40.0, False))
+        # empty input, overflow
+        assert len(h.filter_voxel_grid(np.zeros((0, 4), np.float32), 0.1)) == 0
+        with pytest.raises(LsgpuError):
+            h.filter_voxel_grid(cloud, 1e-4, 1)
+        with pytest.raises(OverflowError):
+            oracle.voxel_grid(cloud, [1e-4] * 3, 1)
