@@ -592,3 +592,20 @@ def test_map_maintenance_filters_match_oracle(icp_mod, oracle):
             h.filter_voxel_grid(cloud, 1e-4, 1)
         with pytest.raises(OverflowError):
             oracle.voxel_grid(cloud, [1e-4] * 3, 1)
+
+
+def test_device_filters_reproduce_golden_vectors(icp_mod):
+    """Committed fixture tests/golden/filters_4k.npz (oracle outputs): the DEVICE filters reproduce it bit for bit."""
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "filters_4k.npz"))
+    scan = g["scan"]
+    with icp_mod.IcpHandle() as h:
+        xyz, nrm = h.filter_reference(scan, 10, 0.5, 5)
+        kept = h.filter_reading(scan, 0.5, -1)
+        assert np.array_equal(xyz, g["ssn_xyz"]) and np.array_equal(nrm, g["ssn_nrm"])
+        assert np.array_equal(kept, scan[g["keep_after_ssn"]])
+        xyz, nrm = h.filter_reference(scan, 7, 1.0, 0)
+        assert np.array_equal(xyz, g["ssn_full_xyz"]) and np.array_equal(nrm, g["ssn_full_nrm"])
+        assert np.array_equal(h.filter_voxel_grid(scan, 0.5, 1), g["voxel_0p5"])
+        assert np.array_equal(h.filter_voxel_grid(scan, 1.0, 3), g["voxel_1p0_min3"])
+        assert np.array_equal(h.filter_cylinder(scan, [0.5, -0.5, 0.0], 10.0, 40.0, False), g["cyl_in"])
+        assert np.array_equal(h.filter_cylinder(scan, [0.5, -0.5, 0.0], 10.0, 40.0, True), g["cyl_out"])

@@ -192,3 +192,24 @@ def test_golden_vectors_reproduce(oracle):
             assert np.array_equal(np.array([t["limit"] for t in tr], np.float32), g[k + "_limits"])
             assert np.array_equal(np.array([t["n_used"] for t in tr]), g[k + "_used"])
             assert np.allclose(T, g[k + "_T"], atol=1e-6)
+
+
+def test_filter_golden_vectors_reproduce(oracle):
+    """tests/golden/filters_4k.npz (make_golden_filters.py): the oracle still produces the committed outputs,
+    and the product's HOST filters (same arithmetic, library-owned draw stream) produce them too."""
+    from laser_slam_amd import icp
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "filters_4k.npz"))
+    scan = g["scan"]
+    for impl in (oracle, icp):
+        xyz, nrm = impl.sampling_surface_normal(scan, 10, 0.5, 5)
+        keep = impl.random_sampling(len(scan), 0.5, -1)
+        assert np.array_equal(xyz, g["ssn_xyz"]) and np.array_equal(nrm, g["ssn_nrm"])
+        assert np.array_equal(keep, g["keep_after_ssn"])
+        xyz, nrm = impl.sampling_surface_normal(scan, 7, 1.0, 0)
+        assert np.array_equal(xyz, g["ssn_full_xyz"]) and np.array_equal(nrm, g["ssn_full_nrm"])
+        assert np.array_equal(impl.random_sampling(3000, 0.75, 7), g["keep_seed7"])
+    assert np.array_equal(oracle.voxel_grid(scan, [0.5] * 3, 1), g["voxel_0p5"])
+    assert np.array_equal(oracle.voxel_grid(scan, [1.0] * 3, 3), g["voxel_1p0_min3"])
+    assert np.array_equal(oracle.cylinder_filter(scan, [0.5, -0.5, 0.0], 10.0, 40.0, False), g["cyl_in"])
+    assert np.array_equal(oracle.cylinder_filter(scan, [0.5, -0.5, 0.0], 10.0, 40.0, True), g["cyl_out"])
+    assert len(g["cyl_in"]) + len(g["cyl_out"]) == len(scan) and 0 < len(g["voxel_1p0_min3"]) < len(g["voxel_0p5"])
