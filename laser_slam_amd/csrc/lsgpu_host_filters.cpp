@@ -11,6 +11,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <numeric>
+#include <utility>
 #include <vector>
 
 #include "../../include/lsgpu_icp.h"
@@ -22,6 +23,7 @@ namespace {
 struct SurfaceNormalBuilder {
   const float* xyz1;
   std::vector<int32_t> idx;
+  std::vector<std::pair<float, int32_t>> scratch;
   int knn;
   float ratio;
   float* out_xyz1;
@@ -59,8 +61,12 @@ struct SurfaceNormalBuilder {
     // std::nth_element leaves ties and the order inside each half unspecified; a stable sort fixes both,
     // so that this filter and the device filter (lsgpu_ssn.hip.h, stable radix sort) build the same boxes
     // in the same order and draw the same rand() numbers for the same points.
-    std::stable_sort(idx.begin() + first, idx.begin() + last,
-                     [&](int32_t a, int32_t b) { return coord(a, cut) < coord(b, cut); });
+    // (sorted as (coordinate, index) pairs: the comparisons then touch contiguous memory only)
+    scratch.resize((size_t)count);
+    for (int64_t i = 0; i < count; ++i) scratch[(size_t)i] = {coord(idx[first + i], cut), idx[first + i]};
+    std::stable_sort(scratch.begin(), scratch.end(),
+                     [](const std::pair<float, int32_t>& a, const std::pair<float, int32_t>& b) { return a.first < b.first; });
+    for (int64_t i = 0; i < count; ++i) idx[first + i] = scratch[(size_t)i].second;
     const float cutval = coord(idx[first + left], cut);
     float lmax[3] = {maxb[0], maxb[1], maxb[2]}, rmin[3] = {minb[0], minb[1], minb[2]};
     lmax[cut] = cutval; rmin[cut] = cutval;
