@@ -4,6 +4,8 @@ Bars (BASELINE.json north_star): ids / squared distances / trim limit / weights 
 distance are equivalent neighbours, libnabo's tie order is implementation defined); final transform
 within 1e-4 m / 1e-5 rad of the CPU path on identical filtered clouds.
 """
+import os
+
 import numpy as np
 import pytest
 
