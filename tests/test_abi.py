@@ -160,3 +160,18 @@ def test_draw_stream_is_the_glibc_rand_sequence():
         libc.srand(C.c_uint(seed))
         assert np.array_equal(icp.random_sampling(4000, 0.37, seed), libc_keep(4000, 0.37)), seed
         assert np.array_equal(icp.random_sampling(1500, 0.5, -1), libc_keep(1500, 0.5)), seed   # continues
+
+
+def test_header_is_c99_and_the_c_example_links(tmp_path):
+    """include/lsgpu_icp.h must stay a plain C header (the reference's maintainers would bind it from C++ or through
+    an FFI), and examples/compute_pair.c must build against it and the shared library."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-fsyntax-only", "-x", "c",
+                           os.path.join(root, "include", "lsgpu_icp.h")])
+    exe = str(tmp_path / "compute_pair")
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-I", os.path.join(root, "include"),
+                           os.path.join(root, "examples", "compute_pair.c"), "-o", exe,
+                           "-L", os.path.join(root, "laser_slam_amd"), "-llsgpu_icp",
+                           "-Wl,-rpath," + os.path.join(root, "laser_slam_amd")])
+    assert os.path.exists(exe)
