@@ -380,6 +380,16 @@ __global__ __launch_bounds__(WAVES * 64, 8) void k_knn_tile(KnnArgs a) {
   }
   const uint32_t tile = blk * wpb + w;
   if (tile >= (uint32_t)a.ntiles) return;
+  // the wave's three coalesced loads go out before anything waits on the loop state (scalar loads + early exit)
+  const int j = (int)(tile * 64u) + lane;
+  const bool act = j < a.nq;
+  float4 rraw = make_float4(0.f, 0.f, 0.f, 0.f), mp = rraw;  // query (own frame), current match (point + index)
+  float lb_in = 0.f;
+  if (act) {
+    rraw = a.rdq[j];
+    mp = a.prev[j];  // coalesced: no dependent gather of pts[prev]
+    if (a.lb) lb_in = a.lb[j];
+  }
   Mat34 T; float cap2;
   if (!iter_params(a.st, a.T, a.cap2, a.use_state_cap, T, cap2)) return;
   // Search / verification radius 5 % beyond the cap: a lane verified to have nothing inside keeps a
@@ -389,8 +399,6 @@ __global__ __launch_bounds__(WAVES * 64, 8) void k_knn_tile(KnnArgs a) {
   if ((a.dbg_flags & 1024) && (tile & 1u)) return;
   if ((a.dbg_flags & 2048) && (tile & 3u)) return;
 #endif
-  const int j = (int)(tile * 64u) + lane;
-  const bool act = j < a.nq;
   const GridDev& g = a.g;
   uint32_t n_eval = 0, n_surv = 0, n_grp = 0, lvl_max = 0;
 
@@ -398,14 +406,9 @@ __global__ __launch_bounds__(WAVES * 64, 8) void k_knn_tile(KnnArgs a) {
   // among the points this search evaluates (the warm-start point is one of them whenever its chunk is)
   float qx = 0.f, qy = 0.f, qz = 0.f, ub = 0.f, best = INFINITY, sec = INFINITY;
   int bi = -1, grp = -1;
-  float4 mp = make_float4(0.f, 0.f, 0.f, 0.f);  // the current match (point + index)
-  float4 rraw = mp;
   if (act) {
-    const float4 r = a.rdq[j];
-    rraw = r;
-    const float3 q = xform(T, r.x, r.y, r.z);
+    const float3 q = xform(T, rraw.x, rraw.y, rraw.z);
     qx = q.x; qy = q.y; qz = q.z;
-    mp = a.prev[j];  // coalesced: no dependent gather of pts[prev]
     bi = __float_as_int(mp.w);
     ub = dist2(qx - mp.x, qy - mp.y, qz - mp.z);
   }
@@ -428,7 +431,7 @@ __global__ __launch_bounds__(WAVES * 64, 8) void k_knn_tile(KnnArgs a) {
     const float3 qo = xform(To, rraw.x, rraw.y, rraw.z);
     const float ddx = qx - qo.x, ddy = qy - qo.y, ddz = qz - qo.z;
     const float delta = sqrtf(ddx * ddx + ddy * ddy + ddz * ddz) * (1.0f + 1e-5f) + 1e-7f;
-    lbn = fmaxf(a.lb[j] * (1.0f - 1e-6f) - delta, 0.f);
+    lbn = fmaxf(lb_in * (1.0f - 1e-6f) - delta, 0.f);
     const float lb2 = lbn * lbn;
     const bool keep = ub * (1.0f + 1e-5f) < lb2;
     const bool far = fminf(ub, lb2) > cap2 * (1.0f + 1e-5f);
