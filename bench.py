@@ -223,6 +223,15 @@ def main():
             "iterations": sto.iterations,
             "gpu_vs_cpu_transform": {"trans_m": dt, "rot_rad": dr},
         }
+        # second row of SURVEY.md §8d: the same oracle with OpenMP over the queries on all host cores (what a
+        # libnabo built with OpenMP does); reported next to the single-thread figure, never as the baseline value
+        nthr = min(os.cpu_count() or 1, 64)
+        if nthr > args.cpu_threads:
+            ocfg_mt = O.config_yaml(accum_double=0, min_diff_rot=1e-5, min_diff_trans=1e-4, num_threads=nthr)
+            tc = time.perf_counter()
+            rc_mt, _To, sto_mt, _ = O.icp_compute(ocfg_mt, rd, rf, rn, synth.colmajor(T_init), 0)
+            out["cpu_baseline"]["all_threads"] = {"value": 1.0 / (time.perf_counter() - tc), "unit": "scans/s", "cores": nthr,
+                                                  "iterations": sto_mt.iterations}
     if rank == 0:
         print(json.dumps(out))
     h.close()
