@@ -68,7 +68,7 @@ typedef struct lsgpu_icp_stats {
   double  t_knn_main_ms;     /* k_knn_main only                                         */
   double  t_knn_fallback_ms; /* k_knn_fallback only                                     */
   int     cap_retries;       /* iterations repeated because the radius-cap prediction failed */
-  int     pad_;
+  int     pad_;              /* iterations whose predicted select missed and was redone in full (info)  */
   double  t_reserved[1];
 } lsgpu_icp_stats;
 

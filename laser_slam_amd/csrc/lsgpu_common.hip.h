@@ -93,8 +93,17 @@ struct IcpState {
   int max_iter, smooth;
   float lim_rot, lim_trans;
   unsigned long long stragglers;
+  // predicted select: once the trim limit keeps its top 12 bits from one iteration to the next (sel_mode = 1) the
+  // kNN kernel itself counts the distances below that bin and histograms the ones inside it, which replaces the
+  // first two passes of the radix select; verified afterwards (k_hist_refine<3>), failure repeats the iteration
+  uint32_t sel_bin1;  // top 12 bits of the last limit
+  int sel_mode;
 };
+constexpr int kSelBelowSlots = 64;   // counters of "distance below the predicted bin", hashed by tile ...
+constexpr int kSelBelowStride = 32;  // ... one per 128-byte line (atomics on one line serialise in L2)
+constexpr int kSelFailFlag = kSelBelowSlots * kSelBelowStride;  // word index of the failure flag
 constexpr int kStatusCapFailed = 100;
+constexpr int kStatusSelFailed = 101;  // predicted select missed: the host repeats select + normal equations only
 
 // T and cap of this launch: from the kernel arguments, or from the loop state.  false => exit now.
 __device__ __forceinline__ bool iter_params(const IcpState* __restrict__ st, const Mat34& T_arg,

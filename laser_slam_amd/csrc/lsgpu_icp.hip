@@ -153,6 +153,7 @@ struct lsgpu_icp {
   DevBuf<RefStats> stat_partials;
   DevBuf<uint32_t> counters;  // [0..16] cell counts, [32] straggler count
   DevBuf<uint32_t> ang_cells; // angular occupancy of the reading (query order decision)
+  DevBuf<uint32_t> sel_aux;   // predicted select: kSelBelowSlots counters + failure flag
 
   // device filters (lsgpu_ssn.hip.h)
   DevBuf<SsnSeg> ssn_seg_a, ssn_seg_b;
@@ -275,7 +276,7 @@ void lsgpu_icp_destroy(lsgpu_icp* h) {
   h->ref_in.release(); h->nrm_in.release(); h->keys.release(); h->keys_alt.release();
   h->vals.release(); h->vals_alt.release(); h->sort_tmp.release(); h->pts.release();
   h->nrm.release(); h->ref_inv.release(); h->tables.release(); h->flags.release(); h->cidx.release(); h->bounds.release(); h->chunks.release(); h->prev.release(); h->state.release(); h->lb.release(); h->cell_cache.release(); h->cell_tags.release(); h->ssn_seg_a.release(); h->ssn_seg_b.release(); h->ssn_seg_of.release(); h->ssn_box_pts.release(); h->ssn_box_base.release(); h->ssn_keep.release(); h->ssn_out_pos.release(); h->ssn_bb.release(); h->ssn_box_normal.release(); h->ssn_draws.release(); h->flt_in.release(); h->flt_ref.release(); h->flt_rd.release(); h->flt_nrm.release(); h->chk_hist.release(); h->trace_dev.release(); h->knn_dbg.release(); h->knn_dbg_wave.release(); h->stat_partials.release();
-  h->counters.release(); h->ang_cells.release(); h->q_in.release(); h->rdq.release(); h->ids.release(); h->d2.release();
+  h->counters.release(); h->ang_cells.release(); h->sel_aux.release(); h->q_in.release(); h->rdq.release(); h->ids.release(); h->d2.release();
   h->ids_io.release(); h->d2_io.release(); h->strag.release(); h->hist.release();
   h->sel.release(); h->ne_partials.release(); h->ne_out.release(); h->limit_dev.release();
   for (auto& e : h->knn_events) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); (void)hipEventDestroy(e.c); }
@@ -371,7 +372,7 @@ static KnnArgs knn_args(lsgpu_icp* h, const Mat34& T) {
   a.chunks = h->chunks.p; a.ids = h->ids.p; a.d2 = h->d2.p; a.prev = h->prev.p;
   a.strag = h->strag.p; a.strag_count = h->counters.p + 32;
   a.r_cap = 1.0f; a.group_r = 0.75f; a.cap2 = INFINITY; a.st = nullptr; a.use_state_cap = 0; a.lb = nullptr;
-  a.spread_route_r = 0.f; a.route_chunks = 1 << 30;
+  a.spread_route_r = 0.f; a.route_chunks = 1 << 30; a.sel_hist2 = nullptr; a.sel_below = nullptr;
   { static const float gap = getenv("LSGPU_GAP") ? (float)atof(getenv("LSGPU_GAP")) : 0.002f; a.gap = gap; }
   a.ntiles = (int)((h->nq + 63) / 64); a.xcd_swizzle = 0; a.pad_index = (int)h->nr;
   { static const int budget = getenv("LSGPU_BUDGET") ? atoi(getenv("LSGPU_BUDGET")) : 128; a.chunk_budget = budget; }
@@ -391,7 +392,7 @@ static KnnArgs knn_args(lsgpu_icp* h, const Mat34& T) {
 //   capped   : search cap from the loop state (exact below cap, see lsgpu_knn.hip.h); otherwise uncapped,
 //              followed by the straggler fallback
 static int run_knn(lsgpu_icp* h, const Mat34& T, const IcpState* st, bool seed, bool capped, bool timed,
-                   bool wide = true) {
+                   bool wide = true, bool predicted = false) {
   const int nq = (int)h->nq;
   KnnArgs a = knn_args(h, T);
   h->dbg_launch_no++;
@@ -403,6 +404,7 @@ static int run_knn(lsgpu_icp* h, const Mat34& T, const IcpState* st, bool seed, 
   // waves with wide balls go to the wave-per-query pass, which is launched after the tile kernel
   static const float route_r = getenv("LSGPU_ROUTE_R") ? (float)atof(getenv("LSGPU_ROUTE_R")) : 0.02f;
   a.spread_route_r = wide ? route_r : 0.f;
+  if (predicted && !wide && capped && st) { a.sel_hist2 = h->hist.p + kHistBins; a.sel_below = h->sel_aux.p; }
   { static const int rc_ = getenv("LSGPU_ROUTE_CHUNKS") ? atoi(getenv("LSGPU_ROUTE_CHUNKS")) : 1024; a.route_chunks = rc_; }
   if (seed) HIPC(hipMemsetAsync(a.strag_count, 0, sizeof(uint32_t), h->stream));  // later: re-armed by k_normal_eq_loop
   if (seed) hipLaunchKernelGGL(k_knn_seed, dim3(nblk(nq)), dim3(256), 0, h->stream, a);
@@ -446,7 +448,7 @@ static int run_knn(lsgpu_icp* h, const Mat34& T, const IcpState* st, bool seed, 
 
 // TrimmedDist order statistic of d2[0..n) -> rank k; leaves hist3 + sel[2] for select_limit().
 static int run_select(lsgpu_icp* h, const float* d2, int n, uint32_t k, bool zero_hist = true,
-                      const IcpState* st = nullptr, bool use_comm = false) {
+                      const IcpState* st = nullptr, bool use_comm = false, bool predicted = false) {
   if (zero_hist) HIPC(hipMemsetAsync(h->hist.p, 0, 3 * kHistBins * sizeof(uint32_t), h->stream));
   if (zero_hist) {  // sel[0] = {0, k}: constant during an align, uploaded once
     SelState s0{0u, k};
@@ -454,13 +456,15 @@ static int run_select(lsgpu_icp* h, const float* d2, int n, uint32_t k, bool zer
     HIPC(hipMemcpyAsync(h->sel.p, h->h_pinned + 56, sizeof(SelState), hipMemcpyHostToDevice, h->stream));
   }
   const int nb = std::min(kHistBlocks, nblk(n));
-  hipLaunchKernelGGL(k_hist1, dim3(nb), dim3(256), 0, h->stream, d2, n, h->hist.p, st);
+  const int pr = predicted && st ? 1 : 0;
+  hipLaunchKernelGGL(k_hist1, dim3(nb), dim3(256), 0, h->stream, d2, n, h->hist.p, st, pr);
   if (use_comm && h->comm) RCCLC(rccl_api()->AllReduce(h->hist.p, h->hist.p, kHistBins, ncclUint32, ncclSum, h->comm, h->stream));
   hipLaunchKernelGGL(k_hist_refine<2>, dim3(nb), dim3(256), 0, h->stream, d2, n, h->hist.p,
-                     h->sel.p, h->sel.p + 1, h->hist.p + kHistBins, st);
+                     h->sel.p, h->sel.p + 1, h->hist.p + kHistBins, st, pr, h->sel_aux.p);
   if (use_comm && h->comm) RCCLC(rccl_api()->AllReduce(h->hist.p + kHistBins, h->hist.p + kHistBins, kHistBins, ncclUint32, ncclSum, h->comm, h->stream));
   hipLaunchKernelGGL(k_hist_refine<3>, dim3(nb), dim3(256), 0, h->stream, d2, n,
-                     h->hist.p + kHistBins, h->sel.p + 1, h->sel.p + 2, h->hist.p + 2 * kHistBins, st);
+                     h->hist.p + kHistBins, h->sel.p + 1, h->sel.p + 2, h->hist.p + 2 * kHistBins, st, pr,
+                     h->sel_aux.p);
   if (use_comm && h->comm) RCCLC(rccl_api()->AllReduce(h->hist.p + 2 * kHistBins, h->hist.p + 2 * kHistBins, kHistBins, ncclUint32, ncclSum, h->comm, h->stream));
   HIPC(hipGetLastError());
   return LSGPU_OK;
@@ -1216,6 +1220,8 @@ int lsgpu_icp_align(lsgpu_icp* h, const float* reading_xyz1, int64_t nq, const f
   }
   HIPC(hipMemcpyAsync(h->state.p, hst, sizeof(IcpState), hipMemcpyHostToDevice, h->stream));
   HIPC(hipMemsetAsync(h->counters.p + 32, 0, 2 * sizeof(uint32_t), h->stream));  // stragglers, NE ticket
+  HIPC(h->sel_aux.reserve(kSelFailFlag + 4));
+  HIPC(hipMemsetAsync(h->sel_aux.p, 0, (kSelFailFlag + 4) * sizeof(uint32_t), h->stream));
 
   int64_t nq_total = nq;
   if (h->comm) {  // TrimmedDist ranks over ALL matches: the rank uses the global count
@@ -1234,17 +1240,27 @@ int lsgpu_icp_align(lsgpu_icp* h, const float* reading_xyz1, int64_t nq, const f
   const Mat34 Tdummy = to_mat34(hst->T_iter);
   bool first_select = true;
   std::vector<size_t> ev_of_launch;  // event index of every enqueued iteration
-  auto enqueue_iteration = [&](bool seed, bool capped, bool wide) -> int {
-    int r = run_knn(h, Tdummy, h->state.p, seed, capped, timed, wide);                         // 6a+6b
-    if (r) return r;
-    ev_of_launch.push_back(h->knn_events_used ? h->knn_events_used - 1 : 0);
-    r = run_select(h, h->d2.p, (int)nq, k, first_select, h->state.p, true);                    // 6c
+  static const bool predict_select = getenv("LSGPU_NO_PREDICT") == nullptr;
+  auto enqueue_iteration = [&](bool seed, bool capped, bool wide, bool knn = true) -> int {
+    // capped launches without a wave-per-query pass may fold the first half of the select into the kNN kernel
+    // (the device decides per iteration, IcpState::sel_mode); not in the RCCL mode (the counts are per shard).
+    // knn == false: only select + normal equations + update on the distances already there (after a missed
+    // prediction)
+    const bool predicted = predict_select && knn && capped && !wide && !h->comm;
+    int r = LSGPU_OK;
+    if (knn) {
+      r = run_knn(h, Tdummy, h->state.p, seed, capped, timed, wide, predicted);                // 6a+6b
+      if (r) return r;
+      ev_of_launch.push_back(h->knn_events_used ? h->knn_events_used - 1 : 0);
+    }
+    r = run_select(h, h->d2.p, (int)nq, k, first_select, h->state.p, true, predicted);         // 6c
     first_select = false;
     if (r) return r;
     hipLaunchKernelGGL(k_normal_eq_loop, dim3(nb), dim3(256), 0, h->stream, h->rdq.p, (int)nq,
                        h->state.p, h->prev.p, h->d2.p, h->nrm.p, h->hist.p, h->sel.p + 2,
                        h->counters.p + 32, h->counters.p + 33, h->ne_partials.p, h->ne_out.p,
-                       h->chk_hist.p, h->trace_dev.p, max_it, capped ? 1 : 0, h->comm ? 0 : 1);  // 6d (+6e)
+                       h->chk_hist.p, h->trace_dev.p, max_it, capped ? 1 : 0, h->comm ? 0 : 1,
+                       h->comm ? (uint32_t*)nullptr : h->sel_aux.p);                            // 6d (+6e)
     if (h->comm) {   // split scan: every rank gets the sums over all shards (the limit, slot 29, is already global)
       if (rccl_api()->AllReduce(h->ne_out.p, h->ne_out.p, kNe, ncclDouble, ncclSum, h->comm, h->stream) != ncclSuccess) {
         h->err = "RCCL all-reduce of the normal equations failed";
@@ -1265,7 +1281,7 @@ int lsgpu_icp_align(lsgpu_icp* h, const float* reading_xyz1, int64_t nq, const f
   static const int wide_iters = getenv("LSGPU_WIDE_ITERS") ? atoi(getenv("LSGPU_WIDE_ITERS")) : 3;
   rc = enqueue_iteration(true, false, true);  // iteration 0: seeded, uncapped
   if (rc) return rc;
-  int enq = 1, since_check = 1;
+  int enq = 1, since_check = 1, sel_retries = 0;
   std::vector<std::pair<int, size_t>> launch_of_iter;  // (enqueue ordinal -> event) bookkeeping below
   const int group = 6;
   for (;;) {
@@ -1287,6 +1303,18 @@ int lsgpu_icp_align(lsgpu_icp* h, const float* reading_xyz1, int64_t nq, const f
       rc = enqueue_iteration(false, false, true);
       if (rc) return rc;
       ++enq; since_check = 1;
+      continue;
+    }
+    if (hst->done && hst->status == kStatusSelFailed) {
+      // the limit left the predicted 12-bit bin in iteration hst->iter: its distances stand, the full select
+      // and everything after it run again
+      sel_retries++;
+      hst->done = 0; hst->status = 0;
+      HIPC(hipMemcpyAsync(h->state.p, hst, sizeof(IcpState), hipMemcpyHostToDevice, h->stream));
+      HIPC(hipStreamSynchronize(h->stream));
+      rc = enqueue_iteration(false, true, false, /*knn*/ false);
+      if (rc) return rc;
+      since_check = 1;
       continue;
     }
     if (hst->done) break;
@@ -1325,11 +1353,13 @@ int lsgpu_icp_align(lsgpu_icp* h, const float* reading_xyz1, int64_t nq, const f
         (void)hipGetLastError();
         continue;
       }
-      if ((int)i >= it + st.cap_retries) break;  // exited immediately: not a real launch
+      if (st.knn_launches >= it + st.cap_retries) break;  // the rest exited immediately (enqueued past the end)
+      if (m1 < 0.02f) continue;  // exited immediately (enqueued behind an iteration that had to be repeated)
       st.t_knn_main_ms += m1; st.t_knn_fallback_ms += m2; st.t_knn_ms += m1 + m2; st.knn_launches++;
       if (t < h->trace.size()) { h->trace[t].knn_main_us = m1 * 1e3f; h->trace[t].knn_fallback_us = m2 * 1e3f; ++t; }
     }
   }
+  st.pad_ = sel_retries;  // (select predictions that missed; informational)
   st.t_total_ms = wall_ms() - t0;
   if (stats) *stats = st;
   return rc;

@@ -53,6 +53,8 @@ struct KnnArgs {
   float gap;                // capped launches search `gap` metres beyond the current best (keep-match bound)
   float spread_route_r;     // > 0: a spread wave whose largest ball exceeds this hands its lanes to k_knn_fallback
   int route_chunks;         // (with spread_route_r > 0) so does any wave whose cell block holds more chunks than this
+  uint32_t* sel_hist2;      // predicted select (IcpState::sel_mode): 2048-bin histogram of bits [19:9] inside the bin
+  uint32_t* sel_below;      //   kSelBelowSlots counters of distances below the bin (nullable: launch without prediction)
   const IcpState* st;       // loop state (nullable): overrides T (and cap2 if use_state_cap)
   int use_state_cap;
   unsigned long long* dbg;  // optional counters (LSGPU_KNN_STATS builds only)
@@ -594,6 +596,14 @@ __global__ __launch_bounds__(WAVES * 64, 8) void k_knn_tile(KnnArgs a) {
     a.prev[j] = mp;
     if (a.lb) a.lb[j] = nb;
     if (straggler || routed) a.strag[atomicAdd(a.strag_count, 1u)] = (uint32_t)j;
+  }
+  if (a.sel_below && a.st->sel_mode) {
+    // first two passes of the trimmed-distance select, folded into this kernel (every distance of the launch is
+    // final here: launches with a wave-per-query pass never predict)
+    const uint32_t bits = __float_as_uint(best), top = bits >> 20, b1 = a.st->sel_bin1;
+    const unsigned long long below = __ballot(act && top < b1);
+    if (act && top == b1) atomicAdd(&a.sel_hist2[(bits >> 9) & 0x7FFu], 1u);
+    if (lane == 0 && below) atomicAdd(&a.sel_below[(tile & (kSelBelowSlots - 1)) * kSelBelowStride], (uint32_t)__popcll(below));
   }
 #ifdef LSGPU_KNN_STATS
   const uint32_t n_act = (uint32_t)__popcll(__ballot(ing));

@@ -57,9 +57,10 @@ __device__ void find_bin(const uint32_t* __restrict__ hist, int nbins, uint32_t 
 
 __global__ __launch_bounds__(256) void k_hist1(const float* __restrict__ d2, int n,
                                                uint32_t* __restrict__ hist,
-                                               const IcpState* __restrict__ ist) {
+                                               const IcpState* __restrict__ ist, int predicted) {
   __shared__ uint32_t sh[kHistBins];
   if (ist && ist->done) return;
+  if (predicted && ist->sel_mode) return;  // the kNN kernel of this iteration did passes 1 and 2
   for (int i = threadIdx.x; i < kHistBins; i += 256) sh[i] = 0;
   __syncthreads();
   for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256)
@@ -76,11 +77,34 @@ __global__ __launch_bounds__(256) void k_hist_refine(const float* __restrict__ d
                                                      const SelState* __restrict__ st_in,
                                                      SelState* __restrict__ st_out,
                                                      uint32_t* __restrict__ hist,
-                                                     const IcpState* __restrict__ ist) {
+                                                     const IcpState* __restrict__ ist, int predicted,
+                                                     uint32_t* __restrict__ sel_aux) {
   __shared__ uint32_t sh[kHistBins];
   __shared__ uint32_t sc[260];
   if (ist && ist->done) return;
-  const SelState in = *st_in;
+  SelState in = *st_in;
+  if (predicted && ist->sel_mode) {
+    if (PASS == 2) return;  // done by the kNN kernel
+    // PASS 3 after a predicted first half: `parent` (the 11-bit histogram inside the predicted bin) and the
+    // counters of smaller distances come from the kNN kernel; st_in[-1] is the select's input {0, k}.  The rank must
+    // fall inside the bin, otherwise the prediction failed and the iteration is repeated with the full select.
+    in = st_in[-1];
+    uint32_t below = 0, inside = 0;
+    for (int i = threadIdx.x; i < kSelBelowSlots; i += 256) below += sel_aux[i * kSelBelowStride];
+    for (int i = threadIdx.x; i < kHistBins; i += 256) inside += parent[i];
+    below = wave_sum_u32(below); inside = wave_sum_u32(inside);
+    if ((threadIdx.x & 63) == 0) { sc[threadIdx.x >> 6] = below; sc[4 + (threadIdx.x >> 6)] = inside; }
+    __syncthreads();
+    below = sc[0] + sc[1] + sc[2] + sc[3];
+    inside = sc[4] + sc[5] + sc[6] + sc[7];
+    __syncthreads();
+    if (in.k < below || in.k - below >= inside) {
+      if (blockIdx.x == 0 && threadIdx.x == 0) sel_aux[kSelFailFlag] = 1u;
+      return;
+    }
+    in.prefix = ist->sel_bin1;
+    in.k -= below;
+  }
   uint32_t bin, krem;
   find_bin(parent, kHistBins, in.k, &bin, &krem, sc);
   const uint32_t prefix = (PASS == 2) ? bin : ((in.prefix << 11) | bin);
@@ -188,8 +212,17 @@ constexpr float kCapFactor = 1.1f;  // next search cap = this x the current trim
 // One lane: 6x6 float LLT solve, AngleAxis update, T_iter <- dT * T_iter, Counter + Differential
 // checkers, trace record, next cap.  Same code as the host (lsgpu_host_math.h).
 __device__ inline void icp_update_lane(IcpState* st, const double* ne_out, float* chk_hist,
-                                       lsgpu_iter_trace* trace, int trace_cap, int capped_launch) {
+                                       lsgpu_iter_trace* trace, int trace_cap, int capped_launch,
+                                       uint32_t* sel_aux) {
   if (st->done) return;
+  if (sel_aux && sel_aux[kSelFailFlag]) {
+    // the predicted select missed (the limit left its 12-bit bin): nothing of this iteration is usable
+    sel_aux[kSelFailFlag] = 0u;
+    st->sel_mode = 0;
+    st->status = kStatusSelFailed;  // the distances of this iteration stand: the host re-runs the full select on them
+    st->done = 1;
+    return;
+  }
   const float limit = (float)ne_out[29];
   const unsigned long long nstrag = (unsigned long long)ne_out[30];
   if (capped_launch && st->cap2 < INFINITY && !(limit <= st->cap2)) {
@@ -220,6 +253,11 @@ __device__ inline void icp_update_lane(IcpState* st, const double* ne_out, float
     tr.knn_main_us = 0.f; tr.knn_fallback_us = 0.f; tr.stragglers = (uint32_t)nstrag; tr.reserved = 0;
   }
   st->prev_limit = limit;
+  {
+    const uint32_t b1 = __float_as_uint(limit) >> 20;
+    st->sel_mode = (b1 == st->sel_bin1) ? 1 : 0;  // predict only a bin that has just been confirmed
+    st->sel_bin1 = b1;
+  }
   st->cap2 = st->cap_enabled ? limit * kCapFactor : INFINITY;
   st->iter = it + 1;
   hostmath::CheckerState cs{st->counter, st->n_hist};
@@ -238,7 +276,7 @@ __global__ __launch_bounds__(64) void k_icp_update(IcpState* __restrict__ st,
                                                    float* __restrict__ chk_hist,
                                                    lsgpu_iter_trace* __restrict__ trace, int trace_cap,
                                                    int capped_launch) {
-  if (threadIdx.x == 0) icp_update_lane(st, ne_out, chk_hist, trace, trace_cap, capped_launch);
+  if (threadIdx.x == 0) icp_update_lane(st, ne_out, chk_hist, trace, trace_cap, capped_launch, nullptr);
 }
 
 
@@ -260,7 +298,8 @@ __global__ __launch_bounds__(256) void k_normal_eq_loop(const float4* __restrict
                                                         double* __restrict__ out /* 32 doubles */,
                                                         float* __restrict__ chk_hist,
                                                         lsgpu_iter_trace* __restrict__ trace, int trace_cap,
-                                                        int capped_launch, int fuse_update) {
+                                                        int capped_launch, int fuse_update,
+                                                        uint32_t* __restrict__ sel_aux) {
   __shared__ uint32_t sc[260];
   __shared__ double fin[32];
   __shared__ double red[8][33];
@@ -372,9 +411,10 @@ __global__ __launch_bounds__(256) void k_normal_eq_loop(const float4* __restrict
     __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   for (int i = threadIdx.x; i < 3 * kHistBins; i += 256) hist[i] = 0u;  // every block has read hist3 by now
+  if (sel_aux && threadIdx.x < kSelBelowSlots) sel_aux[threadIdx.x * kSelBelowStride] = 0u;
   if (fuse_update) {  // every other block has finished: the loop state is this block's to advance
     __syncthreads();
-    if (threadIdx.x == 0) icp_update_lane(ist, fin, chk_hist, trace, trace_cap, capped_launch);
+    if (threadIdx.x == 0) icp_update_lane(ist, fin, chk_hist, trace, trace_cap, capped_launch, sel_aux);
   }
 }
 
