@@ -114,16 +114,30 @@ __device__ __forceinline__ void angular_cell(const float4& p, float inv_elev, fl
 
 // How densely are the rings sampled?  Points per occupied 1 deg x 1 deg angular cell: cells[kDecCells] counts;
 // cells[kDecCells + 0/1] = occupied cells / points, cells[kDecCells + 2] = the chosen order (k_query_order).
-constexpr int kDecElev = 181, kDecSect = 361, kDecCells = kDecElev * kDecSect;
+constexpr int kDecElev = 181, kDecSect = 361, kDecCells = 65536;  // 181 * 361 = 65341 cells, table of 2^16
 __global__ __launch_bounds__(256) void k_query_ang_hist(const float4* __restrict__ in, int64_t n,
                                                         uint32_t* __restrict__ cells) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (i >= n) return;
-  const float4 p = in[i];
-  const float elev = atan2f(p.z, sqrtf(p.x * p.x + p.y * p.y)), azim = atan2f(p.y, p.x) + 3.1415927f;
-  const uint32_t eb = (uint32_t)fminf(fmaxf((elev + 1.5707964f) * 57.29578f, 0.f), (float)(kDecElev - 1));
-  const uint32_t sec = (uint32_t)fminf(fmaxf(azim * 57.29578f, 0.f), (float)(kDecSect - 1));
-  atomicAdd(&cells[eb * kDecSect + sec], 1u);
+  uint32_t cell = 0xFFFFFFFFu;
+  if (i < n) {
+    const float4 p = in[i];
+    const float elev = atan2f(p.z, sqrtf(p.x * p.x + p.y * p.y)), azim = atan2f(p.y, p.x) + 3.1415927f;
+    const uint32_t eb = (uint32_t)fminf(fmaxf((elev + 1.5707964f) * 57.29578f, 0.f), (float)(kDecElev - 1));
+    const uint32_t sec = (uint32_t)fminf(fmaxf(azim * 57.29578f, 0.f), (float)(kDecSect - 1));
+    // (scattered over the table: neighbouring cells, hit by consecutive waves, would share cache lines)
+    cell = ((eb * kDecSect + sec) * 40503u) & 0xFFFFu;
+  }
+  // scans usually arrive ring by ring: neighbouring lanes fall into the same cell, and 64 atomics on one address
+  // serialise.  One atomic per run of equal cells inside the wave instead.
+  const int lane = threadIdx.x & 63;
+  const uint32_t prev = (uint32_t)__shfl_up((int)cell, 1, 64);
+  const bool head = lane == 0 || cell != prev;
+  const unsigned long long heads = __ballot(head);
+  if (head && cell != 0xFFFFFFFFu) {
+    const unsigned long long later = lane == 63 ? 0ull : (heads >> (lane + 1));
+    const int run = later ? __ffsll((long long)later) : 64 - lane;
+    atomicAdd(&cells[cell], (uint32_t)run);
+  }
 }
 
 // Cell size of the spherical order from the angular sampling density m = points per occupied square degree
