@@ -1284,8 +1284,13 @@ int lsgpu_icp_align(lsgpu_icp* h, const float* reading_xyz1, int64_t nq, const f
   int enq = 1, since_check = 1, sel_retries = 0;
   std::vector<std::pair<int, size_t>> launch_of_iter;  // (enqueue ordinal -> event) bookkeeping below
   const int group = 6;
+  // The device decides when the loop ends (CounterTransformationChecker raises `done` after max_iterations at the
+  // latest); the host keeps feeding groups of launches until it sees `done`.  Launches enqueued behind an
+  // iteration that had to be repeated exit at once, so the number of enqueues is NOT bounded by max_iterations;
+  // the cap below only guards against a device that never finishes.
+  const int enq_limit = 8 * max_it + 64;
   for (;;) {
-    if (enq < max_it + st.cap_retries && since_check < group) {
+    if (enq < enq_limit && since_check < group) {
       rc = enqueue_iteration(false, true, enq < wide_iters);
       if (rc) return rc;
       ++enq; ++since_check;
@@ -1318,7 +1323,10 @@ int lsgpu_icp_align(lsgpu_icp* h, const float* reading_xyz1, int64_t nq, const f
       continue;
     }
     if (hst->done) break;
-    if (enq >= max_it + st.cap_retries + 2) break;  // safety: cannot happen (the counter stops it)
+    if (enq >= enq_limit) {
+      h->err = "align: the device loop did not finish";
+      return LSGPU_HIP_ERROR;
+    }
   }
   const int it = hst->iter;
   rc = hst->status;

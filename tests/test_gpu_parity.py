@@ -611,3 +611,29 @@ def test_device_filters_reproduce_golden_vectors(icp_mod):
         assert np.array_equal(h.filter_voxel_grid(scan, 1.0, 3), g["voxel_1p0_min3"])
         assert np.array_equal(h.filter_cylinder(scan, [0.5, -0.5, 0.0], 10.0, 40.0, False), g["cyl_in"])
         assert np.array_equal(h.filter_cylinder(scan, [0.5, -0.5, 0.0], 10.0, 40.0, True), g["cyl_out"])
+
+
+@pytest.mark.timeout(120)
+def test_align_runs_to_the_iteration_cap_like_the_oracle(icp_mod, oracle, pair64k):
+    """No differential stop (thresholds 0): the loop must end on CounterTransformationChecker after exactly
+    max_iterations, however many launches the host had to enqueue around repeated iterations (a predicted select
+    that misses repeats its iteration and voids the launches queued behind it)."""
+    from laser_slam_amd._lib import IcpConfig, lib
+    import ctypes as C
+    rf, rn = _filtered(icp_mod, pair64k)
+    ocfg = oracle.config_yaml(accum_double=1, min_diff_rot=0.0, min_diff_trans=0.0, max_iterations=25)
+    rc, To, sto, _ = oracle.icp_compute(ocfg, pair64k["rd"], rf, rn, synth.colmajor(pair64k["T_init"]), 0)
+    cfg = IcpConfig()
+    lib().lsgpu_icp_config_yaml(C.byref(cfg))
+    cfg.min_diff_rot, cfg.min_diff_trans, cfg.max_iterations = 0.0, 0.0, 25
+    with icp_mod.IcpHandle(cfg) as h:
+        h.set_reference(rf, rn)
+        if rc != 0:  # the counter checker ends in "no convergence" upstream (it throws once the cap is exceeded)
+            from laser_slam_amd._lib import ConvergenceError
+            with pytest.raises(ConvergenceError):
+                h.align(pair64k["rd"], pair64k["T_init"])
+        else:
+            Tg, stg = h.align(pair64k["rd"], pair64k["T_init"])
+            assert stg.iterations == sto.iterations == 25
+            dt, dr = synth.pose_error(Tg, synth.from_colmajor(To))
+            assert dt <= TOL_T and dr <= TOL_R, (dt, dr)
