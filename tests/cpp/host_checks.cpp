@@ -234,6 +234,67 @@ int main(int argc, char** argv) {
     try { est.processLoopClosure(lc); } catch (const std::logic_error&) { threw = true; }
     CHECK(threw);
   }
+  // --- BASELINE config 5 in shape (host part only): 240 poses on a two-loop figure-eight, drifting odometry,
+  // accurate scan-matching factors, loop closures where the loops cross; driven through
+  // IncrementalEstimator::registerPrior / estimate / estimateAndRemove exactly like the worker does
+  {
+    EstimatorParams ep;
+    ep.laser_track_params.use_icp_factors = false;
+    IncrementalEstimator est(ep, 1u);
+    const int n = 240;
+    auto yawq = [](double a) { return std::array<double, 4>{std::cos(a / 2), 0, 0, std::sin(a / 2)}; };
+    std::vector<SE3> truth;
+    for (int i = 0; i < n; ++i) {  // lemniscate of Gerono, 0.8 m steps on average
+      const double t = 4 * M_PI * i / n, x = 15 * std::sin(t), y = 15 * std::sin(t) * std::cos(t);
+      const double dx = 15 * std::cos(t), dy = 15 * std::cos(2 * t);
+      truth.push_back(SE3(yawq(std::atan2(dy, dx)), {x, y, 0.0}));
+    }
+    unsigned rng = 12345u;
+    auto noise = [&](double s) { rng = rng * 1664525u + 1013904223u; return s * ((double)(rng >> 8) / 8388608.0 - 1.0); };
+    SE3 dead = truth[0];
+    std::vector<SE3> dead_reckoning{dead};
+    const std::array<double, 6> odo_sig = {0.05, 0.05, 0.05, 0.01, 0.01, 0.01}, icp_sig = {0.005, 0.005, 0.005, 0.001, 0.001, 0.001};
+    for (int i = 0; i < n; ++i) {
+      FactorList f;
+      Values v;
+      if (i == 0) {
+        Factor pr; pr.type = Factor::PRIOR; pr.key_b = 0; pr.measurement = truth[0]; pr.sigmas.fill(1e-7);
+        f.push_back(pr); v[0] = truth[0];
+        est.registerPrior(f, v, 0u);
+        continue;
+      }
+      const SE3 rel = truth[i - 1].inverse() * truth[i];
+      const SE3 odo = rel * SE3(yawq(0.002 + noise(0.002)), {0.02 + noise(0.01), noise(0.01), 0.0});   // biased
+      const SE3 icp = rel * SE3(yawq(noise(0.0005)), {noise(0.003), noise(0.003), 0.0});
+      dead = dead * odo;
+      dead_reckoning.push_back(dead);
+      Factor fo; fo.type = Factor::ODOMETRY; fo.key_a = (Key)i - 1; fo.key_b = (Key)i; fo.measurement = odo; fo.sigmas = odo_sig;
+      Factor fi = fo; fi.type = Factor::ICP; fi.measurement = icp; fi.sigmas = icp_sig;
+      f.push_back(fo); f.push_back(fi);
+      v[(Key)i] = est.graph().values().at((Key)i - 1) * odo;   // new node from the odometry, like the trajectory curve
+      est.estimate(f, v, i);
+      // the two lobes cross at the origin: poses n/2 and n-1 come back to pose 0's place
+      if (i == n / 2 || i == n - 1) {
+        Factor lc; lc.type = Factor::LOOP_CLOSURE; lc.key_a = 0; lc.key_b = (Key)i;
+        lc.measurement = truth[0].inverse() * truth[i] * SE3(yawq(noise(0.0005)), {noise(0.003), noise(0.003), 0.0});
+        lc.sigmas = icp_sig; lc.cauchy = true;
+        est.estimateAndRemove({lc}, {lc}, Values(), {0u, 0u}, i);
+      }
+    }
+    auto rmse = [&](auto&& pose_of) {
+      double s = 0;
+      for (int i = 0; i < n; ++i) {
+        const auto& p = pose_of(i).position(); const auto& q = truth[i].position();
+        s += (p[0] - q[0]) * (p[0] - q[0]) + (p[1] - q[1]) * (p[1] - q[1]);
+      }
+      return std::sqrt(s / n);
+    };
+    const double e_dead = rmse([&](int i) -> const SE3& { return dead_reckoning[(size_t)i]; });
+    const double e_graph = rmse([&](int i) -> const SE3& { return est.graph().values().at((Key)i); });
+    CHECK(e_dead > 1.0);                      // the biased odometry alone is metres off
+    CHECK(e_graph < 0.05 && e_graph < e_dead / 40);
+    CHECK(est.graph().numFactors() == (size_t)(1 + 2 * (n - 1) + 2));
+  }
   // --- no GPU => loud error (only checked when asked, i.e. on the CPU-only container)
   if (argc > 1 && std::string(argv[1]) == "--expect-no-gpu") {
     ICP icp;
