@@ -312,7 +312,7 @@ __global__ __launch_bounds__(256) void k_cells_count(const uint64_t* __restrict_
     }
   }
   __syncthreads();
-  if (threadIdx.x <= bits && sh[threadIdx.x]) atomicAdd(&counts[threadIdx.x], sh[threadIdx.x]);
+  if ((int)threadIdx.x <= bits && sh[threadIdx.x]) atomicAdd(&counts[threadIdx.x], sh[threadIdx.x]);
 }
 
 __device__ __forceinline__ HashEntry* table_slot(HashEntry* tab, uint32_t mask, uint32_t x,
