@@ -1,0 +1,27 @@
+#!/bin/bash
+# dev helper, run ON the GPU box through gpurun:  bash devtools/gpu_check.sh <tag> [steps...]
+# steps: tests rows2 bench bench0 prof pmc (default: tests rows2 bench bench0 prof)
+# Everything lands under gpurun_out/<tag>_*; every step has its own timeout so a hung kernel cannot eat the box.
+tag=${1:-chk}; shift
+steps=${@:-tests rows2 bench bench0 prof}
+cd "$(dirname "$0")/.." || exit 1
+mkdir -p gpurun_out
+export TMPDIR=/tmp
+for s in $steps; do
+  case $s in
+    tests)   timeout 600 python -m pytest tests -m gpu -x -q > gpurun_out/${tag}_tests.log 2>&1; echo "tests rc=$?"; tail -3 gpurun_out/${tag}_tests.log ;;
+    rows2)   LSGPU_KNN_ROWS=2 timeout 600 python -m pytest tests/test_gpu_parity.py -m gpu -q > gpurun_out/${tag}_rows2.log 2>&1; echo "rows2 rc=$?"; tail -3 gpurun_out/${tag}_rows2.log ;;
+    rows0)   LSGPU_KNN_ROWS=0 timeout 600 python -m pytest tests/test_gpu_parity.py -m gpu -q > gpurun_out/${tag}_rows0.log 2>&1; echo "rows0 rc=$?"; tail -3 gpurun_out/${tag}_rows0.log ;;
+    bench)   timeout 600 python bench.py --steps 10 --warmup 2 > gpurun_out/${tag}_bench.json 2> gpurun_out/${tag}_bench.err; echo "bench rc=$?"; cut -c1-1500 gpurun_out/${tag}_bench.json ;;
+    bench0)  LSGPU_KNN_ROWS=0 timeout 600 python bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-compute-e2e > gpurun_out/${tag}_bench0.json 2> gpurun_out/${tag}_bench0.err; echo "bench0 rc=$?"; cut -c1-600 gpurun_out/${tag}_bench0.json ;;
+    prof)    rm -rf gpurun_out/prof_${tag}
+             (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d $OLDPWD/gpurun_out/prof_${tag} -- python $OLDPWD/bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-compute-e2e > $OLDPWD/gpurun_out/${tag}_profbench.json 2> $OLDPWD/gpurun_out/${tag}_prof.err)
+             db=$(find gpurun_out/prof_${tag} -name "*results.db" | head -1)
+             [ -n "$db" ] && python profiles/summarize_rocpd.py $db > gpurun_out/${tag}_bench.stats.txt && head -16 gpurun_out/${tag}_bench.stats.txt ;;
+    pmc)     for c in FETCH_SIZE WRITE_SIZE; do
+               rm -rf gpurun_out/pmc_${tag}_$c
+               (cd /tmp && timeout 600 rocprofv3 --kernel-trace --pmc $c -d $OLDPWD/gpurun_out/pmc_${tag}_$c --output-format csv -- python $OLDPWD/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-compute-e2e > /dev/null 2> $OLDPWD/gpurun_out/${tag}_pmc_$c.err)
+             done
+             python devtools/pmc_summary.py gpurun_out/pmc_${tag}_FETCH_SIZE gpurun_out/pmc_${tag}_WRITE_SIZE > gpurun_out/${tag}_knn_traffic.json 2>> gpurun_out/${tag}_pmc.err; cat gpurun_out/${tag}_knn_traffic.json ;;
+  esac
+done

@@ -84,7 +84,7 @@ typedef struct lsgpu_iter_trace {
   float   knn_main_us;      /* k_knn_tile duration (HIP events; 0 unless profile_kernels) */
   float   knn_fallback_us;  /* k_knn_fallback duration                                    */
   uint32_t stragglers;      /* queries resolved by the fallback in this iteration         */
-  uint32_t reserved;
+  uint32_t reserved;        /* queries that had to search in this iteration (0: every query searched) */
 } lsgpu_iter_trace;
 
 int  lsgpu_icp_create(const lsgpu_icp_config* cfg, int device, lsgpu_icp** out);

@@ -15,6 +15,7 @@
 #include <cmath>
 #include <cstdint>
 #include <cstring>
+#include <functional>
 #include <istream>
 #include <map>
 #include <sstream>
@@ -154,6 +155,7 @@ class ICP {
   // T with p_reference = T * p_reading.  Throws ConvergenceError exactly where PointMatcher would.
   TransformationParameters compute(const DataPoints& reading, const DataPoints& reference,
                                    const TransformationParameters& T_init) {
+    if (override_) return override_(*this, reading, reference, T_init);
     ensureHandle();
     const int64_t nr = reference.getNbPoints(), nq = reading.getNbPoints();
     if (nr <= 0 || nq <= 0) throw ConvergenceError("empty cloud");
@@ -202,6 +204,16 @@ class ICP {
 
   // >= 0: reseed the filters' draw stream at every compute() (reproducible runs); < 0: continue it
   void setSeed(int64_t seed) { seed_ = seed; }
+  int64_t seed() const { return seed_; }
+
+  // Test seam: replaces compute() by another implementation of the same call (the parity tests inject the CPU
+  // oracle here, so that LaserTrack / IncrementalEstimator run unchanged on either ICP).  Never set by the
+  // product; with an override in place nothing touches the GPU (no handle is created).
+  using ComputeOverride = std::function<TransformationParameters(const ICP&, const DataPoints& reading,
+                                                                 const DataPoints& reference,
+                                                                 const TransformationParameters& T_init)>;
+  void setComputeOverride(ComputeOverride f) { override_ = std::move(f); }
+  bool hasComputeOverride() const { return (bool)override_; }
 
   // Steps 2-7 on already filtered clouds (device or host pointers).
   TransformationParameters computeFiltered(const float* reading_xyz1, int64_t nq, const float* ref_xyz1,
@@ -218,6 +230,7 @@ class ICP {
   const lsgpu_icp_config& config() const { return cfg_; }
   float readingSamplingProb() const { return prob_; }
   int surfaceNormalKnn() const { return knn_; }
+  float surfaceNormalRatio() const { return ratio_; }
 
  private:
   struct Module { std::string section, name; std::map<std::string, std::string> params; };
@@ -298,6 +311,7 @@ class ICP {
   int knn_ = 7;
   int64_t seed_ = -1;
   unsigned generation_ = 0;
+  ComputeOverride override_;
 };
 
 }  // namespace laser_slam_amd

@@ -164,6 +164,7 @@ class IncrementalEstimator {
     return graph_.values();
   }
 
+  ICP& loopClosureIcp() { return icp_; }  // configuration access (seed, test seam)
   const PoseGraph& graph() const { return graph_; }
   const std::vector<std::vector<unsigned int>>& linkedWorkers() const { return linked_workers_; }
   const RelativePose& lastLoopClosure() const { return last_loop_closure_; }

@@ -203,6 +203,7 @@ class LaserTrack {
   const std::vector<RelativePose>& getIcpTransformations() const { return icp_transformations_; }
   const std::vector<RelativePose>& getOdometryMeasurements() const { return odometry_measurements_; }
   const lsgpu_icp_stats& lastIcpStats() const { return icp_.lastStats(); }
+  ICP& icp() { return icp_; }  // configuration access (seed, test seam); the reference keeps icp_ private
 
   // laser_track.cpp:602-651: the scan at time_ns plus up to `radius` scans on either side, in its frame
   void buildSubMapAroundTime(const Time& time_ns, unsigned int sub_maps_radius, DataPoints* sub_map_out) const {
@@ -302,7 +303,8 @@ class LaserTrack {
     const TransformationParameters T_init = guess.transformationMatrixF();
     TransformationParameters solution = T_init;
     try {
-      if (params_.scans_on_device > 0 && (int)members.size() + 1 <= params_.scans_on_device) {
+      if (params_.scans_on_device > 0 && (int)members.size() + 1 <= params_.scans_on_device &&
+          !icp_.hasComputeOverride()) {
         // the scans stay in HBM; the sub-map is assembled there (same arithmetic as RigidTransformation::compute)
         std::vector<int> slots;
         for (size_t m : members) slots.push_back(deviceSlot(m));

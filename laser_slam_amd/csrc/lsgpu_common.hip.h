@@ -203,6 +203,39 @@ __device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) {
   v += (uint32_t)LSGPU_DPP((int)v, 0x140);
   return rl_u(v, 0) + rl_u(v, 16) + rl_u(v, 32) + rl_u(v, 48);
 }
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
+  v = max(v, (uint32_t)LSGPU_DPP((int)v, 0xB1));
+  v = max(v, (uint32_t)LSGPU_DPP((int)v, 0x4E));
+  v = max(v, (uint32_t)LSGPU_DPP((int)v, 0x141));
+  v = max(v, (uint32_t)LSGPU_DPP((int)v, 0x140));
+  return max(max(rl_u(v, 0), rl_u(v, 16)), max(rl_u(v, 32), rl_u(v, 48)));
+}
+// ---- reductions over one DPP row (16 lanes): the result is left in all 16 lanes of each row
+__device__ __forceinline__ float row_min(float v) {
+  v = fminf(v, __int_as_float(LSGPU_DPP(__float_as_int(v), 0xB1)));
+  v = fminf(v, __int_as_float(LSGPU_DPP(__float_as_int(v), 0x4E)));
+  v = fminf(v, __int_as_float(LSGPU_DPP(__float_as_int(v), 0x141)));
+  return fminf(v, __int_as_float(LSGPU_DPP(__float_as_int(v), 0x140)));
+}
+__device__ __forceinline__ float row_max(float v) {
+  v = fmaxf(v, __int_as_float(LSGPU_DPP(__float_as_int(v), 0xB1)));
+  v = fmaxf(v, __int_as_float(LSGPU_DPP(__float_as_int(v), 0x4E)));
+  v = fmaxf(v, __int_as_float(LSGPU_DPP(__float_as_int(v), 0x141)));
+  return fmaxf(v, __int_as_float(LSGPU_DPP(__float_as_int(v), 0x140)));
+}
+__device__ __forceinline__ uint32_t row_sum_u32(uint32_t v) {
+  v += (uint32_t)LSGPU_DPP((int)v, 0xB1);
+  v += (uint32_t)LSGPU_DPP((int)v, 0x4E);
+  v += (uint32_t)LSGPU_DPP((int)v, 0x141);
+  return v + (uint32_t)LSGPU_DPP((int)v, 0x140);
+}
+// inclusive prefix sum inside each row (row_shr:n with zero fill for the lanes that have no source)
+__device__ __forceinline__ uint32_t row_scan_incl_u32(uint32_t v) {
+  v += (uint32_t)LSGPU_DPP((int)v, 0x111);
+  v += (uint32_t)LSGPU_DPP((int)v, 0x112);
+  v += (uint32_t)LSGPU_DPP((int)v, 0x114);
+  return v + (uint32_t)LSGPU_DPP((int)v, 0x118);
+}
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -281,6 +281,33 @@ __global__ __launch_bounds__(256) void k_chunk_boxes(const float4* __restrict__ 
   }
 }
 
+// Chunk-blocked SoA copy of the sorted reference for the broadcast evaluation (lsgpu_knn.hip.h, tile_eval_slot):
+// chunk c owns 3 * cnt4 floats -- x[cnt4] y[cnt4] z[cnt4], cnt4 = count rounded up to 4, the rounding slots far
+// away -- so that one ds_read_b128 per coordinate hands four candidates to the packed-pair arithmetic.
+// k_chunk_cnt4: slots per chunk (scanned on the host side of the stream into first slots); k_soa_fill: one wave
+// per chunk, soa_base[c] = float4 index of the block.
+__global__ __launch_bounds__(256) void k_chunk_cnt4(const uint32_t* __restrict__ bounds, uint32_t nchunks,
+                                                    uint32_t* __restrict__ cnt4) {
+  const uint32_t c = blockIdx.x * 256u + threadIdx.x;
+  if (c < nchunks) cnt4[c] = (bounds[c + 1] - bounds[c] + 3u) & ~3u;
+}
+
+__global__ __launch_bounds__(256) void k_soa_fill(const float4* __restrict__ pts, const uint32_t* __restrict__ bounds,
+                                                  const uint32_t* __restrict__ first_slot, uint32_t nchunks,
+                                                  float* __restrict__ soa, uint32_t* __restrict__ soa_base) {
+  const uint32_t c = blockIdx.x * 4u + (threadIdx.x >> 6);
+  if (c >= nchunks) return;
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t s = bounds[c], cnt = bounds[c + 1] - s, c4 = (cnt + 3u) & ~3u, f0 = first_slot[c];
+  if (lane == 0) soa_base[c] = (3u * f0) >> 2;  // (f0 is a multiple of 4)
+  if (lane < c4) {
+    float4 p = make_float4(3e18f, 3e18f, 3e18f, 0.f);
+    if (lane < cnt) p = pts[s + lane];
+    float* o = soa + 3u * (size_t)f0;
+    o[lane] = p.x; o[c4 + lane] = p.y; o[2u * c4 + lane] = p.z;
+  }
+}
+
 // ---------------------------------------------------------------- cell tables
 // A level-l cell boundary sits between sorted points i-1 and i when their keys differ at or above
 // bit 3*(fine+l).  Returns the highest such level, or -1.

@@ -24,6 +24,7 @@
 #include "../../include/lsgpu_icp.h"
 #include "lsgpu_grid.hip.h"
 #include "lsgpu_knn.hip.h"
+#include "lsgpu_knn_rows.hip.h"
 #include "lsgpu_solve.hip.h"
 #include "lsgpu_host_math.h"
 #include "lsgpu_ssn.hip.h"
@@ -135,6 +136,8 @@ struct lsgpu_icp {
   DevBuf<HashEntry> tables;
   DevBuf<uint32_t> flags, cidx, bounds;
   DevBuf<ChunkDesc> chunks;
+  DevBuf<float> soa;            // chunk-blocked SoA copy of pts (k_soa_fill)
+  DevBuf<uint32_t> soa_base, soa_cnt4, soa_first;
   uint32_t nchunks = 0;
   DevBuf<uint4> knn_dbg_wave;
   DevBuf<unsigned long long> knn_dbg;  // LSGPU_KNN_STATS builds: 8 counters
@@ -154,6 +157,7 @@ struct lsgpu_icp {
   DevBuf<uint32_t> counters;  // [0..16] cell counts, [32] straggler count
   DevBuf<uint32_t> ang_cells; // angular occupancy of the reading (query order decision)
   DevBuf<uint32_t> sel_aux;   // predicted select: kSelBelowSlots counters + failure flag
+  DevBuf<uint32_t> work;      // compacted list of searching queries (k_knn_classify -> k_knn_rows)
 
   // device filters (lsgpu_ssn.hip.h)
   DevBuf<SsnSeg> ssn_seg_a, ssn_seg_b;
@@ -186,9 +190,12 @@ struct lsgpu_icp {
   std::vector<lsgpu_iter_trace> trace;
 };
 
-static constexpr int kNeBlocks = 512;
+static constexpr int kNeBlocksMax = 2048;
+static const int kNeBlocks = [] { const char* e = getenv("LSGPU_NE_BLOCKS"); const int v = e ? atoi(e) : 512;
+                                  return v < 64 ? 64 : v > kNeBlocksMax ? kNeBlocksMax : v; }();
 static constexpr int kStatBlocks = 512;
 static constexpr int kHistBlocks = 256;
+static constexpr int kFallbackBlocksSettled = 1024;
 static constexpr int kFallbackBlocks = 8192;  // x 4 waves: one query per wave for up to 32 k stragglers, round robin beyond
 
 extern "C" {
@@ -275,8 +282,8 @@ void lsgpu_icp_destroy(lsgpu_icp* h) {
   h->submap.release();
   h->ref_in.release(); h->nrm_in.release(); h->keys.release(); h->keys_alt.release();
   h->vals.release(); h->vals_alt.release(); h->sort_tmp.release(); h->pts.release();
-  h->nrm.release(); h->ref_inv.release(); h->tables.release(); h->flags.release(); h->cidx.release(); h->bounds.release(); h->chunks.release(); h->prev.release(); h->state.release(); h->lb.release(); h->cell_cache.release(); h->cell_tags.release(); h->ssn_seg_a.release(); h->ssn_seg_b.release(); h->ssn_seg_of.release(); h->ssn_box_pts.release(); h->ssn_box_base.release(); h->ssn_keep.release(); h->ssn_out_pos.release(); h->ssn_bb.release(); h->ssn_box_normal.release(); h->ssn_draws.release(); h->flt_in.release(); h->flt_ref.release(); h->flt_rd.release(); h->flt_nrm.release(); h->chk_hist.release(); h->trace_dev.release(); h->knn_dbg.release(); h->knn_dbg_wave.release(); h->stat_partials.release();
-  h->counters.release(); h->ang_cells.release(); h->sel_aux.release(); h->q_in.release(); h->rdq.release(); h->ids.release(); h->d2.release();
+  h->nrm.release(); h->ref_inv.release(); h->tables.release(); h->flags.release(); h->cidx.release(); h->bounds.release(); h->chunks.release(); h->soa.release(); h->soa_base.release(); h->soa_cnt4.release(); h->soa_first.release(); h->prev.release(); h->state.release(); h->lb.release(); h->cell_cache.release(); h->cell_tags.release(); h->ssn_seg_a.release(); h->ssn_seg_b.release(); h->ssn_seg_of.release(); h->ssn_box_pts.release(); h->ssn_box_base.release(); h->ssn_keep.release(); h->ssn_out_pos.release(); h->ssn_bb.release(); h->ssn_box_normal.release(); h->ssn_draws.release(); h->flt_in.release(); h->flt_ref.release(); h->flt_rd.release(); h->flt_nrm.release(); h->chk_hist.release(); h->trace_dev.release(); h->knn_dbg.release(); h->knn_dbg_wave.release(); h->stat_partials.release();
+  h->counters.release(); h->ang_cells.release(); h->sel_aux.release(); h->work.release(); h->q_in.release(); h->rdq.release(); h->ids.release(); h->d2.release();
   h->ids_io.release(); h->d2_io.release(); h->strag.release(); h->hist.release();
   h->sel.release(); h->ne_partials.release(); h->ne_out.release(); h->limit_dev.release();
   for (auto& e : h->knn_events) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); (void)hipEventDestroy(e.c); }
@@ -291,6 +298,8 @@ void lsgpu_icp_destroy(lsgpu_icp* h) {
 }  // extern "C"
 
 // ---------------------------------------------------------------- internals
+
+static int scan_u32(lsgpu_icp* h, const uint32_t* in, uint32_t* out, size_t n);
 
 static int sort_pairs(lsgpu_icp* h, int64_t n, int nbits) {
   HIPC(h->keys_alt.reserve(n));
@@ -321,7 +330,7 @@ static int ensure_loop_buffers(lsgpu_icp* h, int64_t nq) {
   HIPC(h->strag.reserve(nq));
   HIPC(h->hist.reserve(3 * kHistBins));
   HIPC(h->sel.reserve(4));
-  HIPC(h->ne_partials.reserve((size_t)kNeBlocks * 32));
+  HIPC(h->ne_partials.reserve((size_t)kNeBlocksMax * 32));
   HIPC(h->ne_out.reserve(32));
   HIPC(h->limit_dev.reserve(4));
   HIPC(h->counters.reserve(64));
@@ -338,6 +347,7 @@ static int prepare_queries(lsgpu_icp* h, const float* q_xyz1, int64_t nq, const 
   HIPC(h->rdq.reserve(nq));
   HIPC(h->prev.reserve(nq));
   HIPC(h->lb.reserve(nq));
+  HIPC(h->work.reserve(nq));
   // order of the queries inside the waves: chosen on the device from the cloud's angular sampling density
   static const int qorder = getenv("LSGPU_QUERY_ORDER") ? atoi(getenv("LSGPU_QUERY_ORDER")) : -1;   // -1: automatic
   static const float qelev = getenv("LSGPU_Q_ELEV") ? (float)atof(getenv("LSGPU_Q_ELEV")) : 0.f;   // 0: automatic
@@ -366,10 +376,13 @@ static int prepare_queries(lsgpu_icp* h, const float* q_xyz1, int64_t nq, const 
   return ensure_loop_buffers(h, nq);
 }
 
+static int run_select(lsgpu_icp* h, const float* d2, int n, uint32_t k, bool zero_hist, const IcpState* st,
+                      bool use_comm, bool predicted);
+
 static KnnArgs knn_args(lsgpu_icp* h, const Mat34& T) {
   KnnArgs a;
   a.rdq = h->rdq.p; a.nq = (int)h->nq; a.T = T; a.g = h->grid; a.pts = h->pts.p;
-  a.chunks = h->chunks.p; a.ids = h->ids.p; a.d2 = h->d2.p; a.prev = h->prev.p;
+  a.chunks = h->chunks.p; a.soa = reinterpret_cast<const float4*>(h->soa.p); a.chunk_soa = h->soa_base.p; a.ids = h->ids.p; a.d2 = h->d2.p; a.prev = h->prev.p;
   a.strag = h->strag.p; a.strag_count = h->counters.p + 32;
   a.r_cap = 1.0f; a.group_r = 0.75f; a.cap2 = INFINITY; a.st = nullptr; a.use_state_cap = 0; a.lb = nullptr;
   a.spread_route_r = 0.f; a.route_chunks = 1 << 30; a.sel_hist2 = nullptr; a.sel_below = nullptr;
@@ -377,6 +390,7 @@ static KnnArgs knn_args(lsgpu_icp* h, const Mat34& T) {
   a.ntiles = (int)((h->nq + 63) / 64); a.xcd_swizzle = 0; a.pad_index = (int)h->nr;
   { static const int budget = getenv("LSGPU_BUDGET") ? atoi(getenv("LSGPU_BUDGET")) : 128; a.chunk_budget = budget; }
   a.cell_cache = h->cell_cache.p; a.cell_tags = h->cell_tags.p; a.cache_gen = h->cache_gen;
+  a.work = h->work.p; a.work_count = h->counters.p + 34;
   a.dbg = h->knn_dbg.p;
   a.dbg_wave = h->knn_dbg_wave.p;
   { const char* e = getenv("LSGPU_KNN_DBG"); a.dbg_flags = e ? atoi(e) : 0;
@@ -392,7 +406,7 @@ static KnnArgs knn_args(lsgpu_icp* h, const Mat34& T) {
 //   capped   : search cap from the loop state (exact below cap, see lsgpu_knn.hip.h); otherwise uncapped,
 //              followed by the straggler fallback
 static int run_knn(lsgpu_icp* h, const Mat34& T, const IcpState* st, bool seed, bool capped, bool timed,
-                   bool wide = true, bool predicted = false) {
+                   bool wide = true, bool predicted = false, uint32_t seed_rank = 0xFFFFFFFFu) {
   const int nq = (int)h->nq;
   KnnArgs a = knn_args(h, T);
   h->dbg_launch_no++;
@@ -403,11 +417,22 @@ static int run_knn(lsgpu_icp* h, const Mat34& T, const IcpState* st, bool seed, 
   // `wide`: the balls may still be large (first iterations of an align, retries, kernel-level API): spread
   // waves with wide balls go to the wave-per-query pass, which is launched after the tile kernel
   static const float route_r = getenv("LSGPU_ROUTE_R") ? (float)atof(getenv("LSGPU_ROUTE_R")) : 0.02f;
-  a.spread_route_r = wide ? route_r : 0.f;
+  // settled launches (capped, balls already small): EVERY spread wave hands its lanes to the wave-per-query pass --
+  // 64 divergent per-lane searches held single waves for 190 k cycles, the tail of a 46 k-cycle launch
+  static const bool route_all = getenv("LSGPU_NO_ROUTE_ALL") == nullptr;
+  const bool settled = capped && !wide && st && route_all;
+  a.spread_route_r = wide ? route_r : settled ? 1e-30f : 0.f;
   if (predicted && !wide && capped && st) { a.sel_hist2 = h->hist.p + kHistBins; a.sel_below = h->sel_aux.p; }
   { static const int rc_ = getenv("LSGPU_ROUTE_CHUNKS") ? atoi(getenv("LSGPU_ROUTE_CHUNKS")) : 1024; a.route_chunks = rc_; }
   if (seed) HIPC(hipMemsetAsync(a.strag_count, 0, sizeof(uint32_t), h->stream));  // later: re-armed by k_normal_eq_loop
   if (seed) hipLaunchKernelGGL(k_knn_seed, dim3(nblk(nq)), dim3(256), 0, h->stream, a);
+  if (seed && capped && st && seed_rank != 0xFFFFFFFFu) {
+    // first iteration of an align: cap = trim quantile of the seed distances (k_knn_seed left them in d2)
+    const int rs = run_select(h, h->d2.p, nq, seed_rank, true, st, true, false);
+    if (rs) return rs;
+    hipLaunchKernelGGL(k_seed_cap, dim3(1), dim3(256), 0, h->stream, h->hist.p + 2 * kHistBins, h->sel.p + 2,
+                       h->state.p);
+  }
   lsgpu_icp::KnnEv* ev = nullptr;
   if (timed) {
     if (h->knn_events_used == h->knn_events.size()) {
@@ -419,18 +444,38 @@ static int run_knn(lsgpu_icp* h, const Mat34& T, const IcpState* st, bool seed, 
     HIPC(hipEventRecord(ev->a, h->stream));
   }
   static const bool lane_mode = getenv("LSGPU_KNN_LANE") != nullptr;  // experiment switch
-  if (capped && lane_mode) {
+  // 0: k_knn_tile everywhere; 1 (default): settled launches (capped, no wave-per-query pass, lower bounds
+  // carried) classify first and search row-wise on the compacted list; 2: k_knn_rows also stands in for
+  // k_knn_tile everywhere else (validation of the row-wise search against the whole parity suite)
+  static const int rows_mode = getenv("LSGPU_KNN_ROWS") ? atoi(getenv("LSGPU_KNN_ROWS")) : 0;
+  if (rows_mode >= 1 && capped && !wide && st && !lane_mode) {
+    hipLaunchKernelGGL(k_knn_classify, dim3((nq + kClassifyPerBlock - 1) / kClassifyPerBlock), dim3(256), 0, h->stream, a);
+    hipLaunchKernelGGL(k_knn_rows<true>, dim3(a.ntiles), dim3(64), 0, h->stream, a);
+    if (timed) { HIPC(hipEventRecord(ev->b, h->stream)); HIPC(hipEventRecord(ev->c, h->stream)); }
+  } else if (rows_mode >= 2 && !lane_mode) {
+    a.spread_route_r = 0.f;  // (no routing in the row-wise kernel; stragglers by radius still go to the fallback)
+    hipLaunchKernelGGL(k_knn_rows<false>, dim3(a.ntiles), dim3(64), 0, h->stream, a);
+    if (timed) HIPC(hipEventRecord(ev->b, h->stream));
+    if (!capped) hipLaunchKernelGGL(k_knn_fallback, dim3(kFallbackBlocks), dim3(256), 0, h->stream, a);
+    if (timed) HIPC(hipEventRecord(ev->c, h->stream));
+  } else if (capped && lane_mode) {
     hipLaunchKernelGGL(k_knn_lane, dim3(nblk(nq)), dim3(256), 0, h->stream, a);
     if (timed) { HIPC(hipEventRecord(ev->b, h->stream)); HIPC(hipEventRecord(ev->c, h->stream)); }
   } else {
-    const int tile_threads = 64;
+    static const int tile_waves = getenv("LSGPU_TILE_WAVES") ? atoi(getenv("LSGPU_TILE_WAVES")) : 1;
+    const int tile_threads = tile_waves == 4 ? 256 : 64;
     static const int swz = getenv("LSGPU_XCD_SWIZZLE") ? atoi(getenv("LSGPU_XCD_SWIZZLE")) : 0;
     a.xcd_swizzle = swz;
     const int waves_per_block = tile_threads / 64;
-    hipLaunchKernelGGL(k_knn_tile<1>, dim3((a.ntiles + waves_per_block - 1) / waves_per_block), dim3(tile_threads), 0, h->stream, a);
+    if (waves_per_block == 4)
+      hipLaunchKernelGGL(k_knn_tile<4>, dim3((a.ntiles + 3) / 4), dim3(256), 0, h->stream, a);
+    else
+      hipLaunchKernelGGL(k_knn_tile<1>, dim3(a.ntiles), dim3(64), 0, h->stream, a);
     if (timed) HIPC(hipEventRecord(ev->b, h->stream));
     // stragglers (balls > r_cap) only exist in uncapped launches
-    if (!capped || a.spread_route_r > 0.f) hipLaunchKernelGGL(k_knn_fallback, dim3(kFallbackBlocks), dim3(256), 0, h->stream, a);
+    // (a settled launch routes a few thousand queries at most: a small grid keeps the pass short)
+    if (!capped || a.spread_route_r > 0.f)
+      hipLaunchKernelGGL(k_knn_fallback, dim3(settled ? kFallbackBlocksSettled : kFallbackBlocks), dim3(256), 0, h->stream, a);
     if (timed) HIPC(hipEventRecord(ev->c, h->stream));
   }
   HIPC(hipGetLastError());
@@ -447,8 +492,8 @@ static int run_knn(lsgpu_icp* h, const Mat34& T, const IcpState* st, bool seed, 
   } while (0)
 
 // TrimmedDist order statistic of d2[0..n) -> rank k; leaves hist3 + sel[2] for select_limit().
-static int run_select(lsgpu_icp* h, const float* d2, int n, uint32_t k, bool zero_hist = true,
-                      const IcpState* st = nullptr, bool use_comm = false, bool predicted = false) {
+static int run_select(lsgpu_icp* h, const float* d2, int n, uint32_t k, bool zero_hist, const IcpState* st,
+                      bool use_comm, bool predicted) {
   if (zero_hist) HIPC(hipMemsetAsync(h->hist.p, 0, 3 * kHistBins * sizeof(uint32_t), h->stream));
   if (zero_hist) {  // sel[0] = {0, k}: constant during an align, uploaded once
     SelState s0{0u, k};
@@ -581,6 +626,15 @@ int lsgpu_icp_set_reference(lsgpu_icp* h, const float* ref_xyz1, const float* re
                      nr, h->bounds.p);
   hipLaunchKernelGGL(k_chunk_boxes, dim3((nchunks + 3) / 4), dim3(256), 0, h->stream, h->pts.p,
                      h->bounds.p, nchunks, h->chunks.p);
+  // chunk-blocked SoA copy for the broadcast evaluation: <= 3 rounding slots per chunk
+  HIPC(h->soa_cnt4.reserve(nchunks)); HIPC(h->soa_first.reserve(nchunks)); HIPC(h->soa_base.reserve(nchunks));
+  HIPC(h->soa.reserve(3 * ((size_t)nr + 3 * (size_t)nchunks) + 16));
+  hipLaunchKernelGGL(k_chunk_cnt4, dim3((nchunks + 255) / 256), dim3(256), 0, h->stream, h->bounds.p, nchunks,
+                     h->soa_cnt4.p);
+  rc = scan_u32(h, h->soa_cnt4.p, h->soa_first.p, nchunks);
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_soa_fill, dim3((nchunks + 3) / 4), dim3(256), 0, h->stream, h->pts.p, h->bounds.p,
+                     h->soa_first.p, nchunks, h->soa.p, h->soa_base.p);
   HIPC(h->tables.reserve(total));
   HIPC(hipMemsetAsync(h->tables.p, 0xFF, total * sizeof(HashEntry), h->stream));
   TableSet ts;
@@ -684,7 +738,7 @@ int lsgpu_trim_limit(lsgpu_icp* h, const float* d2, int64_t n, float ratio, floa
     HIPC(hipMemcpyAsync(h->d2_io.p, d2, (size_t)n * 4, hipMemcpyHostToDevice, h->stream));
     src = h->d2_io.p;
   }
-  rc = run_select(h, src, (int)n, trim_rank(n, ratio));
+  rc = run_select(h, src, (int)n, trim_rank(n, ratio), true, nullptr, false, false);
   if (rc) return rc;
   hipLaunchKernelGGL(k_limit_out, dim3(1), dim3(256), 0, h->stream, h->hist.p + 2 * kHistBins,
                      h->sel.p + 2, h->limit_dev.p);
@@ -1219,7 +1273,7 @@ int lsgpu_icp_align(lsgpu_icp* h, const float* reading_xyz1, int64_t nq, const f
     HIPC(hipMemcpyAsync(h->chk_hist.p, hh, 8 * sizeof(float), hipMemcpyHostToDevice, h->stream));
   }
   HIPC(hipMemcpyAsync(h->state.p, hst, sizeof(IcpState), hipMemcpyHostToDevice, h->stream));
-  HIPC(hipMemsetAsync(h->counters.p + 32, 0, 2 * sizeof(uint32_t), h->stream));  // stragglers, NE ticket
+  HIPC(hipMemsetAsync(h->counters.p + 32, 0, 3 * sizeof(uint32_t), h->stream));  // stragglers, NE ticket, work-list length
   HIPC(h->sel_aux.reserve(kSelFailFlag + 4));
   HIPC(hipMemsetAsync(h->sel_aux.p, 0, (kSelFailFlag + 4) * sizeof(uint32_t), h->stream));
 
@@ -1249,7 +1303,7 @@ int lsgpu_icp_align(lsgpu_icp* h, const float* reading_xyz1, int64_t nq, const f
     const bool predicted = predict_select && knn && capped && !wide && !h->comm;
     int r = LSGPU_OK;
     if (knn) {
-      r = run_knn(h, Tdummy, h->state.p, seed, capped, timed, wide, predicted);                // 6a+6b
+      r = run_knn(h, Tdummy, h->state.p, seed, capped, timed, wide, predicted, seed && capped ? k : 0xFFFFFFFFu);  // 6a+6b
       if (r) return r;
       ev_of_launch.push_back(h->knn_events_used ? h->knn_events_used - 1 : 0);
     }
@@ -1279,7 +1333,9 @@ int lsgpu_icp_align(lsgpu_icp* h, const float* reading_xyz1, int64_t nq, const f
 
   // the first launches still have wide balls: their spread waves go to the wave-per-query pass
   static const int wide_iters = getenv("LSGPU_WIDE_ITERS") ? atoi(getenv("LSGPU_WIDE_ITERS")) : 3;
-  rc = enqueue_iteration(true, false, true);  // iteration 0: seeded, uncapped
+  // iteration 0: seeded; capped by the trim quantile of the seed distances (a guaranteed bound: no retry can follow)
+  static const bool seed_cap = getenv("LSGPU_NO_SEED_CAP") == nullptr;
+  rc = enqueue_iteration(true, seed_cap && h->cfg.reserved[0] == 0, true);
   if (rc) return rc;
   int enq = 1, since_check = 1, sel_retries = 0;
   std::vector<std::pair<int, size_t>> launch_of_iter;  // (enqueue ordinal -> event) bookkeeping below

@@ -24,7 +24,11 @@
 //     an exact search, the verified radius otherwise).  Between two iterations a query moves by
 //     delta = |T_new r - T_old r|, so its new NN distance is >= lb - delta (triangle inequality): if
 //     that already exceeds the cap the lane is "far" without searching at all.
-// Ties in distance: any nearest point is returned (libnabo's order is implementation defined).
+// Ties in distance: libnabo's order is implementation defined, so any nearest point is a valid answer; this
+// library returns the one with the SMALLEST index in its Morton-sorted reference, whichever kernel or wave
+// composition found it (the broadcast evaluations record the first group that reaches the minimum and detect a
+// second group at exactly the same distance through the runner-up they track anyway; the rare tie is then
+// settled by canonical_tie).  Results therefore do not depend on how queries are grouped into waves.
 #pragma once
 #include "lsgpu_common.hip.h"
 
@@ -41,6 +45,8 @@ struct KnnArgs {
   GridDev g;
   const float4* pts;        // Morton-sorted centred reference
   const ChunkDesc* chunks;
+  const float4* soa;        // chunk-blocked SoA copy of pts for the broadcast evaluation: chunk c = x[cnt4] y[cnt4] z[cnt4]
+  const uint32_t* chunk_soa;  //   float4 index of chunk c's block (cnt4 = count rounded up to 4, pads far away)
   int* ids;                 // out: sorted-reference index of the NN
   float* d2;                // out: squared distance
   float4* prev;             // in/out: warm start = the query's current match {x,y,z, sorted index bits}
@@ -66,6 +72,8 @@ struct KnnArgs {
   ulonglong2* cell_tags;    // per tile: which block (generation, level, origin, extent) the cache holds
   uint32_t cache_gen;       // bumped by every set_reference / align: older entries never match
   int xcd_swizzle;          // 1: block b -> XCD (b % 8) gets a contiguous eighth of the tiles
+  uint32_t* work;           // compacted list of the queries that have to search (k_knn_classify -> k_knn_rows)
+  uint32_t* work_count;     //   its length; re-armed by the last block of k_normal_eq_loop
   int dbg_flags;            // LSGPU_KNN_STATS builds: ablation switches (1 no eval, 2 no refine, 4 no search)
 };
 
@@ -100,6 +108,7 @@ __global__ __launch_bounds__(256) void k_knn_seed(KnnArgs a) {
   const int fz = fine_coord(q.z, g.oz, g.inv_hf, lim);
   int bi = 0;
   float4 bp = a.pts[0];
+  float bd = INFINITY;
   for (int l = 0; l <= g.bits; ++l) {
     const int sh = g.fine + l;
     uint32_t cs, ce;
@@ -121,9 +130,14 @@ __global__ __launch_bounds__(256) void k_knn_seed(KnnArgs a) {
       if (d2 < best) { best = d2; bi = (int)t + 2; bp = c2; }
       if (d3 < best) { best = d3; bi = (int)t + 3; bp = c3; }
     }
+    bd = best;
     break;
   }
   a.prev[j] = make_float4(bp.x, bp.y, bp.z, __int_as_float(bi));
+  // the seed distance bounds the nearest-neighbour distance from above, query by query, hence so does every order
+  // statistic: the trim quantile of the seed distances is a guaranteed search cap for the first iteration
+  a.d2[j] = bd;
+  if (a.lb) a.lb[j] = 0.f;  // nothing is known yet about the other points: no keep / far skip in the first search
 }
 
 // ---------------------------------------------------------------- per-lane ball search
@@ -184,14 +198,25 @@ __device__ __forceinline__ void lane_ball_search(const KnnArgs& a, float cap2, f
         const float d1 = dist2(qx - p1.x, qy - p1.y, qz - p1.z);
         const float d2 = dist2(qx - p2.x, qy - p2.y, qz - p2.z);
         const float d3 = dist2(qx - p3.x, qy - p3.y, qz - p3.z);
-        if (d0 < best) { best = d0; bi = (int)(st + t); }
-        if (d1 < best) { best = d1; bi = (int)(st + t + 1); }
-        if (d2 < best) { best = d2; bi = (int)(st + t + 2); }
-        if (d3 < best) { best = d3; bi = (int)(st + t + 3); }
+        // equal distances: the smaller index wins, whatever the visiting order (canonical ties, see header)
+        if (d0 < best || (d0 == best && (int)(st + t) < bi)) { best = d0; bi = (int)(st + t); }
+        if (d1 < best || (d1 == best && (int)(st + t + 1) < bi)) { best = d1; bi = (int)(st + t + 1); }
+        if (d2 < best || (d2 == best && (int)(st + t + 2) < bi)) { best = d2; bi = (int)(st + t + 2); }
+        if (d3 < best || (d3 == best && (int)(st + t + 3) < bi)) { best = d3; bi = (int)(st + t + 3); }
       }
       prune = fminf(best, cap2);
     }
   }
+}
+
+// Two different reference points at exactly the distance `best`: the smaller index wins (rare path).
+__device__ __forceinline__ float4 canonical_tie(const KnnArgs& a, float qx, float qy, float qz, float best, float4 mp) {
+  int bi = __float_as_int(mp.w);
+  const int before = bi;
+  float b = best;
+  lane_ball_search(a, INFINITY, qx, qy, qz, b, bi);  // nothing is closer than best; equal distance + smaller index wins
+  if (bi != before) { const float4 p = a.pts[bi]; mp = make_float4(p.x, p.y, p.z, __int_as_float(bi)); }
+  return mp;
 }
 
 // ---------------------------------------------------------------- tile search
@@ -225,15 +250,18 @@ __device__ __forceinline__ float prune_lim(float b, float gap, float cap2) {
 
 __device__ __forceinline__ void tile_eval_slot(const float4* __restrict__ slot, uint32_t st, uint32_t cnt,
                                                float qx, float qy, float qz, float& best, float& sec, int& grp) {
-  const uint32_t cnt4 = (cnt + 3u) & ~3u;
+  // the slot holds the chunk's SoA block: x[cnt4] y[cnt4] z[cnt4].  One ds_read_b128 per coordinate fetches four
+  // candidates as two register pairs, exactly the operands of the packed-pair arithmetic (no shuffles).
+  const uint32_t c4 = (cnt + 3u) >> 2;  // float4s per coordinate
   const f32x2 q2x = {qx, qx}, q2y = {qy, qy}, q2z = {qz, qz};
-  for (uint32_t t = 0; t < cnt4; t += 4) {
-    const float4 c0 = slot[t], c1 = slot[t + 1], c2 = slot[t + 2], c3 = slot[t + 3];
-    const f32x2 d0 = dist2_pair(q2x, q2y, q2z, f32x2{c0.x, c1.x}, f32x2{c0.y, c1.y}, f32x2{c0.z, c1.z});
-    const f32x2 d1 = dist2_pair(q2x, q2y, q2z, f32x2{c2.x, c3.x}, f32x2{c2.y, c3.y}, f32x2{c2.z, c3.z});
+#pragma unroll 2
+  for (uint32_t t = 0; t < c4; ++t) {
+    const float4 x = slot[t], y = slot[c4 + t], z = slot[2u * c4 + t];
+    const f32x2 d0 = dist2_pair(q2x, q2y, q2z, f32x2{x.x, x.y}, f32x2{y.x, y.y}, f32x2{z.x, z.y});
+    const f32x2 d1 = dist2_pair(q2x, q2y, q2z, f32x2{x.z, x.w}, f32x2{y.z, y.w}, f32x2{z.z, z.w});
     const float m4 = fminf(fminf(fminf(d0.x, d0.y), d1.x), d1.y);
     sec = __builtin_amdgcn_fmed3f(best, m4, sec);  // second smallest group minimum (best <= sec always)
-    if (m4 < best) { best = m4; grp = (int)(st + t); }
+    if (m4 < best) { best = m4; grp = (int)(st + 4u * t); }
   }
 }
 
@@ -246,10 +274,12 @@ __device__ __forceinline__ void tile_process_batch(const KnnArgs& a, float cap2,
                                                    float thz, float& maxbest, float ub, float gap, float& best,
                                                    float& sec, int& grp, uint32_t& n_eval, uint32_t& n_surv) {
   float4 b0 = make_float4(0.f, 0.f, 0.f, 0.f), b1 = b0;
+  uint32_t sbase = 0;
   bool pass = false;
   if (valid) {
     const float4* cd = reinterpret_cast<const float4*>(a.chunks + ch);
     b0 = cd[0]; b1 = cd[1];
+    sbase = a.chunk_soa[ch];
     const float gx = fmaxf(fmaxf(b0.x - thx, tlx - b1.x), 0.f);
     const float gy = fmaxf(fmaxf(b0.y - thy, tly - b1.y), 0.f);
     const float gz = fmaxf(fmaxf(b0.z - thz, tlz - b1.z), 0.f);
@@ -306,9 +336,11 @@ __device__ __forceinline__ void tile_process_batch(const KnnArgs& a, float cap2,
     needm &= needm - 1;
     st = rl_u(__float_as_uint(b0.w), k);
     cnt = rl_u(__float_as_uint(b1.w), k);
-    // lanes past the chunk's end fetch a far pad point: the slot is always fully defined
-    const float4* src = a.pts + ((uint32_t)lane < cnt ? st + (uint32_t)lane : (uint32_t)a.pad_index);
-    __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)&lds.slot[slot][0], 16, 0, 0);
+    // the chunk's SoA block is 3 * cnt4 / 4 float4s (<= 48): one per lane, the other lanes stay out of it (nothing
+    // reads the slot beyond the block)
+    const uint32_t nf4 = 3u * ((cnt + 3u) >> 2);
+    const float4* src = a.soa + rl_u(sbase, k) + (uint32_t)lane;
+    if ((uint32_t)lane < nf4) __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)&lds.slot[slot][0], 16, 0, 0);
     return 1;
   };
   int na = issue(0, sa0, ca0);
@@ -582,7 +614,11 @@ __global__ __launch_bounds__(WAVES * 64, 8) void k_knn_tile(KnnArgs a) {
         float s4 = INFINITY;
         mp = tile_resolve_match(a, grp, qx, qy, qz, best, mp, s4);
         float others = fminf(fminf(sec, s4), lim_f);
-        const bool same = __float_as_int(mp.w) == bi;
+        bool same = __float_as_int(mp.w) == bi;
+        if (sec == best || (!same && best == ub)) {  // a second point at exactly this distance: smallest index
+          mp = canonical_tie(a, qx, qy, qz, best, mp);
+          same = __float_as_int(mp.w) == bi;
+        }
         if (!same) others = fminf(others, ub);  // (covers a warm-start point whose chunk was not needed)
         nb = sqrtf(others) * (1.0f - 1e-5f);
         if (same) nb = fmaxf(nb, lbn);
@@ -599,10 +635,12 @@ __global__ __launch_bounds__(WAVES * 64, 8) void k_knn_tile(KnnArgs a) {
   }
   if (a.sel_below && a.st->sel_mode) {
     // first two passes of the trimmed-distance select, folded into this kernel (every distance of the launch is
-    // final here: launches with a wave-per-query pass never predict)
+    // final here; the lanes routed to the wave-per-query pass are counted there)
+    // (lanes handed to the wave-per-query pass get their final distance, and their count, there)
+    const bool fin = act && !routed && !straggler;
     const uint32_t bits = __float_as_uint(best), top = bits >> 20, b1 = a.st->sel_bin1;
-    const unsigned long long below = __ballot(act && top < b1);
-    if (act && top == b1) atomicAdd(&a.sel_hist2[(bits >> 9) & 0x7FFu], 1u);
+    const unsigned long long below = __ballot(fin && top < b1);
+    if (fin && top == b1) atomicAdd(&a.sel_hist2[(bits >> 9) & 0x7FFu], 1u);
     if (lane == 0 && below) atomicAdd(&a.sel_below[(tile & (kSelBelowSlots - 1)) * kSelBelowStride], (uint32_t)__popcll(below));
   }
 #ifdef LSGPU_KNN_STATS
@@ -719,6 +757,11 @@ __global__ __launch_bounds__(256) void k_knn_fallback(KnnArgs a) {
       const float4 p = a.pts[id];
       a.ids[j] = id;
       a.d2[j] = __uint_as_float((uint32_t)(bestp >> 32));
+      if (a.sel_below && a.st->sel_mode) {  // predicted select: this query's share (see k_knn_tile)
+        const uint32_t bits = (uint32_t)(bestp >> 32), top = bits >> 20, b1 = a.st->sel_bin1;
+        if (top < b1) atomicAdd(&a.sel_below[(j & (kSelBelowSlots - 1)) * kSelBelowStride], 1u);
+        else if (top == b1) atomicAdd(&a.sel_hist2[(bits >> 9) & 0x7FFu], 1u);
+      }
       a.prev[j] = make_float4(p.x, p.y, p.z, __int_as_float(id));
       if (a.lb) {
         // every other point is at least as far as the neighbour found, or beyond the verified radius

@@ -140,6 +140,16 @@ __global__ __launch_bounds__(256) void k_limit_out(const uint32_t* __restrict__ 
   if (threadIdx.x == 0) *out = lim;
 }
 
+// First iteration: the select just ran over the SEED distances (upper bounds of the true ones); its result is a
+// valid cap for the first search (limit(true distances) <= limit(upper bounds)).
+__global__ __launch_bounds__(256) void k_seed_cap(const uint32_t* __restrict__ hist3,
+                                                  const SelState* __restrict__ st, IcpState* __restrict__ ist) {
+  __shared__ uint32_t sc[260];
+  if (ist->done) return;
+  const float lim = select_limit(hist3, st, sc);
+  if (threadIdx.x == 0) ist->cap2 = lim;
+}
+
 // ---------------------------------------------------------------- point-to-plane normal equations
 // Per pair with weight 1: J = [p x n ; n] (float, as libpointmatcher), r = (p - q).n ;
 // accumulate 21 upper-tri J J^T, 6 of -J r, count, r^2 in double.  Per-block partials, then a
@@ -250,7 +260,7 @@ __device__ inline void icp_update_lane(IcpState* st, const double* ne_out, float
     tr.limit = limit; tr.n_used = used;
     for (int i = 0; i < 36; ++i) tr.A[i] = A[i];
     for (int i = 0; i < 6; ++i) { tr.b[i] = b[i]; tr.x[i] = x[i]; }
-    tr.knn_main_us = 0.f; tr.knn_fallback_us = 0.f; tr.stragglers = (uint32_t)nstrag; tr.reserved = 0;
+    tr.knn_main_us = 0.f; tr.knn_fallback_us = 0.f; tr.stragglers = (uint32_t)nstrag; tr.reserved = (uint32_t)ne_out[31];
   }
   st->prev_limit = limit;
   {
@@ -385,6 +395,13 @@ __global__ __launch_bounds__(256) void k_normal_eq_loop(const float4* __restrict
     if (col < kNe) {
       const int nb = (int)gridDim.x;
       int b = grp;
+      for (; b + 120 < nb; b += 128) {  // 16 independent loads in flight, summed in row order
+        double v[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) v[u] = partials[(size_t)(b + 8 * u) * 32 + col];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) s += v[u];
+      }
       for (; b + 56 < nb; b += 64) {  // 8 independent loads in flight, summed in row order
         const double v0 = partials[(size_t)b * 32 + col], v1 = partials[(size_t)(b + 8) * 32 + col];
         const double v2 = partials[(size_t)(b + 16) * 32 + col], v3 = partials[(size_t)(b + 24) * 32 + col];
@@ -407,7 +424,10 @@ __global__ __launch_bounds__(256) void k_normal_eq_loop(const float4* __restrict
     const double ns = (double)__hip_atomic_load(strag_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     out[29] = (double)limit; fin[29] = (double)limit;
     out[30] = ns; fin[30] = ns;
+    const double nw = (double)__hip_atomic_load(strag_count + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    out[31] = nw; fin[31] = nw;  // queries that had to search in this iteration (k_knn_classify), for the trace
     __hip_atomic_store(strag_count, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(strag_count + 2, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // work-list length (k_knn_classify)
     __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   for (int i = threadIdx.x; i < 3 * kHistBins; i += 256) hist[i] = 0u;  // every block has read hist3 by now

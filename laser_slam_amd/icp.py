@@ -270,7 +270,7 @@ class IcpHandle:
                             n_used=t.n_used, A=np.array(t.A[:]).reshape(6, 6),
                             b=np.array(t.b[:]), x=np.array(t.x[:]),
                             knn_main_us=t.knn_main_us, knn_fallback_us=t.knn_fallback_us,
-                            stragglers=t.stragglers))
+                            stragglers=t.stragglers, searching=t.reserved))
         return out
 
     # ---- kernel-level entry points (reference-mean frame)

@@ -176,3 +176,115 @@ def pose_error(Ta: np.ndarray, Tb: np.ndarray):
     sn = float(np.linalg.norm(s))
     c = (np.trace(Rd) - 1.0) * 0.5
     return dt, float(np.arctan2(sn, c))
+
+
+# ---------------------------------------------------------------- BASELINE configs[4]: a long sequence
+class FieldScene(Scene):
+    """Open field for the figure-eight sequence (SURVEY.md §8d, config 5 of the survey = configs[4]): ground plane,
+    no street walls, boxes and cylinders scattered over [-ext_x, ext_x] x [-ext_y, ext_y] at about the density of the
+    street scene; nothing closer than `clear` metres to the driven path.  Ray casting only looks at the primitives
+    within `cull` metres of the sensor (fixed per scan, identical for every consumer of the scan)."""
+
+    def __init__(self, seed: int, path_xy: np.ndarray, ext_x: float, ext_y: float, n_boxes: int = 700, n_cyl: int = 500,
+                 clear: float = 2.5, cull: float = 70.0):
+        rng = np.random.default_rng(seed)
+        self.wall_y = None
+        self.wall_h = 0.0
+        self.cull = cull
+        step = max(1, len(path_xy) // 4000)
+        path = path_xy[::step]
+
+        def free(xy, r):
+            d = np.sqrt(((xy[:, None, :] - path[None, :, :]) ** 2).sum(-1)).min(1)
+            return d > clear + r
+
+        cx, cy = rng.uniform(-ext_x, ext_x, n_boxes), rng.uniform(-ext_y, ext_y, n_boxes)
+        sx, sy, sz = rng.uniform(0.5, 4.0, n_boxes), rng.uniform(0.5, 4.0, n_boxes), rng.uniform(0.5, 3.0, n_boxes)
+        ok = free(np.stack([cx, cy], 1), np.hypot(sx, sy) / 2)
+        self.box_lo = np.stack([cx - sx / 2, cy - sy / 2, np.zeros(n_boxes)], 1)[ok]
+        self.box_hi = np.stack([cx + sx / 2, cy + sy / 2, sz], 1)[ok]
+        kx, ky = rng.uniform(-ext_x, ext_x, n_cyl), rng.uniform(-ext_y, ext_y, n_cyl)
+        kr, kh = rng.uniform(0.15, 0.6, n_cyl), rng.uniform(2.0, 8.0, n_cyl)
+        ok = free(np.stack([kx, ky], 1), kr)
+        self.cyl_c, self.cyl_r, self.cyl_h = np.stack([kx, ky], 1)[ok], kr[ok], kh[ok]
+
+    def raycast(self, o: np.ndarray, d: np.ndarray) -> np.ndarray:
+        t = np.full(d.shape[0], np.inf)
+        with np.errstate(divide="ignore", invalid="ignore"):
+            tg = -o[2] / d[:, 2]
+            tg[~(tg > 0)] = np.inf
+            t = np.minimum(t, tg)
+            inv = 1.0 / d
+            bc = (self.box_lo[:, :2] + self.box_hi[:, :2]) / 2
+            for k in np.nonzero(np.hypot(bc[:, 0] - o[0], bc[:, 1] - o[1]) < self.cull)[0]:
+                t1 = (self.box_lo[k] - o) * inv
+                t2 = (self.box_hi[k] - o) * inv
+                tn = np.nanmax(np.minimum(t1, t2), axis=1)
+                tf = np.nanmin(np.maximum(t1, t2), axis=1)
+                hit = (tf >= tn) & (tf > 0)
+                tb = np.where(tn > 0, tn, tf)
+                tb[~hit] = np.inf
+                t = np.minimum(t, tb)
+            a = d[:, 0] ** 2 + d[:, 1] ** 2
+            for k in np.nonzero(np.hypot(self.cyl_c[:, 0] - o[0], self.cyl_c[:, 1] - o[1]) < self.cull)[0]:
+                c, r, h = self.cyl_c[k], self.cyl_r[k], self.cyl_h[k]
+                ox, oy = o[0] - c[0], o[1] - c[1]
+                b = 2 * (ox * d[:, 0] + oy * d[:, 1])
+                disc = b * b - 4 * a * (ox * ox + oy * oy - r * r)
+                sq = np.sqrt(np.where(disc > 0, disc, np.nan))
+                tc = (-b - sq) / (2 * a)
+                z = o[2] + tc * d[:, 2]
+                tc[~((tc > 0) & (z >= 0) & (z <= h))] = np.inf
+                t = np.minimum(t, np.nan_to_num(tc, nan=np.inf))
+        return t
+
+
+def figure_eight(n_poses: int, step_m: float = 0.8, laps: int = 2):
+    """Ground-truth poses (4x4, world <- sensor) on a figure-eight (lemniscate of Gerono) driven `laps` times,
+    `step_m` apart on average, heading along the path.  Returns (poses, half_extent_x, half_extent_y)."""
+    A = n_poses * step_m / (6.0973 * laps)          # curve length of one lap = 6.0973 A
+    # equal arc-length parametrisation (numerically), so that consecutive poses are step_m apart everywhere
+    tt = np.linspace(0.0, 2 * np.pi * laps, 200 * n_poses + 1)
+    x, y = A * np.sin(tt), A * np.sin(tt) * np.cos(tt)
+    s = np.concatenate([[0.0], np.cumsum(np.hypot(np.diff(x), np.diff(y)))])
+    ti = np.interp(np.arange(n_poses) * (s[-1] / n_poses), s, tt)
+    poses = []
+    for t in ti:
+        dx, dy = A * np.cos(t), A * np.cos(2 * t)
+        poses.append(se3(A * np.sin(t), A * np.sin(t) * np.cos(t), SENSOR_HEIGHT, yaw=np.arctan2(dy, dx)))
+    return poses, float(A), float(A / 2)
+
+
+def drifting_odometry(truth, seed: int, sigma_t: float = 0.02, sigma_r_deg: float = 0.1, bias=(0.004, 0.0, 0.0, 0.02)):
+    """Odometry pose measurements: truth increments perturbed by N(0, [sigma_t m, sigma_r deg]) per step
+    plus a small constant bias (bias = dx, dy, dz [m], dyaw [deg]) -- dead reckoning drifts by metres over a lap."""
+    rng = np.random.default_rng(seed)
+    odom = [truth[0].copy()]
+    for i in range(1, len(truth)):
+        rel = np.linalg.inv(truth[i - 1]) @ truth[i]
+        e = rng.normal(0.0, 1.0, 6)
+        err = se3(bias[0] + sigma_t * e[0], bias[1] + sigma_t * e[1], bias[2] + 0.25 * sigma_t * e[2],
+                  yaw=np.deg2rad(bias[3] + sigma_r_deg * e[3]), pitch=np.deg2rad(0.25 * sigma_r_deg * e[4]),
+                  roll=np.deg2rad(0.25 * sigma_r_deg * e[5]))
+        odom.append(odom[-1] @ rel @ err)
+    return odom
+
+
+def quat_wxyz(T: np.ndarray):
+    """Unit quaternion (w, x, y, z) of a 4x4 pose (Shepperd's method)."""
+    R = T[:3, :3]
+    tr = np.trace(R)
+    if tr > 0:
+        s = np.sqrt(tr + 1.0) * 2
+        q = [0.25 * s, (R[2, 1] - R[1, 2]) / s, (R[0, 2] - R[2, 0]) / s, (R[1, 0] - R[0, 1]) / s]
+    elif R[0, 0] > R[1, 1] and R[0, 0] > R[2, 2]:
+        s = np.sqrt(1.0 + R[0, 0] - R[1, 1] - R[2, 2]) * 2
+        q = [(R[2, 1] - R[1, 2]) / s, 0.25 * s, (R[0, 1] + R[1, 0]) / s, (R[0, 2] + R[2, 0]) / s]
+    elif R[1, 1] > R[2, 2]:
+        s = np.sqrt(1.0 + R[1, 1] - R[0, 0] - R[2, 2]) * 2
+        q = [(R[0, 2] - R[2, 0]) / s, (R[0, 1] + R[1, 0]) / s, 0.25 * s, (R[1, 2] + R[2, 1]) / s]
+    else:
+        s = np.sqrt(1.0 + R[2, 2] - R[0, 0] - R[1, 1]) * 2
+        q = [(R[1, 0] - R[0, 1]) / s, (R[0, 2] + R[2, 0]) / s, (R[1, 2] + R[2, 1]) / s, 0.25 * s]
+    q = np.asarray(q, np.float64)
+    return q / np.linalg.norm(q)
