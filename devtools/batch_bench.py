@@ -1,10 +1,13 @@
-"""dev helper (not a test): BASELINE config 3 shape -- 32 pairs of 200 k points on one GPU, pairs/s vs pool size."""
-import sys, os, time
+"""BASELINE configs[2] shape on one GPU: independent 200 k-point scan pairs through lsgpu_icp_align_batch, pairs/s against
+the number of handles (streams) -- the per-GPU share of "256 pairs over 8 GPUs" is 32 pairs.
+usage: batch_bench.py [n_az=3125] [pairs=32] [out.json]      (writes the JSON artifact kept under profiles/)"""
+import json, sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from laser_slam_amd import synth, icp
 n_az = int(sys.argv[1]) if len(sys.argv) > 1 else 3125
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 32
+out_path = sys.argv[3] if len(sys.argv) > 3 else None
 uniq = []
 for i in range(4):
     ref, rd, Tt, Ti = synth.scan_pair(n_az, noise_seeds=(1000 + i, 2000 + i), guess_seed=1000 + i)
@@ -14,12 +17,22 @@ torch.cuda.synchronize()
 pairs = [uniq[i % 4] for i in range(B)]
 refs, nrms, rds, Tis, Tts = map(list, zip(*pairs))
 print("points per cloud", rds[0].shape[0], "pairs", B)
+rows = []
 for pool in (1, 2, 4, 8, 16):
     hs = [icp.IcpHandle() for _ in range(pool)]
     icp.align_batch(hs, refs, nrms, rds, Tis)
-    t = time.perf_counter()
-    T, st, rc = icp.align_batch(hs, refs, nrms, rds, Tis)
-    dt = time.perf_counter() - t
+    best = None
+    for rep in range(3):
+        t = time.perf_counter()
+        T, st, rc = icp.align_batch(hs, refs, nrms, rds, Tis)
+        dt = time.perf_counter() - t
+        best = dt if best is None else min(best, dt)
     err = max(synth.pose_error(T[i], Tts[i])[0] for i in range(B))
-    print("pool %2d: %.1f ms  %.1f pairs/s  iters %s  max |t err| %.4f m  rc %s" % (pool, dt * 1e3, B / dt, st[0].iterations, err, set(rc.tolist())))
+    print("pool %2d: %.1f ms  %.1f pairs/s  iters %s  max |t err| %.4f m  rc %s" % (pool, best * 1e3, B / best, st[0].iterations, err, set(rc.tolist())))
+    rows.append({"handles": pool, "ms_per_batch": best * 1e3, "pairs_per_s": B / best, "iterations_per_pair": int(st[0].iterations),
+                 "max_trans_err_m": err})
     for h in hs: h.close()
+if out_path:
+    json.dump({"workload": "configs[2] per-GPU share: %d independent pairs of %d x %d points (64 x %d rays), default yaml checker, chain F clouds resident in HBM"
+                           % (B, rds[0].shape[0], refs[0].shape[0], n_az), "entry_point": "lsgpu_icp_align_batch", "rows": rows,
+               "command": "python devtools/batch_bench.py %d %d %s" % (n_az, B, out_path)}, open(out_path, "w"), indent=1)

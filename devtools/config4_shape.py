@@ -1,4 +1,5 @@
-"""dev helper: BASELINE config 4 shape on one GPU -- 8 aggregated scans (8M-pt sub-map) vs one 1M-pt scan."""
+"""BASELINE configs[3] shape on one GPU -- 8 aggregated scans (8.4 M-point sub-map) vs one 1 M-point scan.
+usage: config4_shape.py [n_az=16384] [oracle|-] [out.json]   (writes the JSON artifact kept under profiles/)"""
 import ctypes as C, sys, os, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -21,11 +22,12 @@ rd = synth.hdl64_scan(scene, poses[8], n_az, 40)
 T_true = np.linalg.inv(T_ref) @ poses[8]
 T_init = synth.se3(0.25, -0.1, 0.05, yaw=np.deg2rad(1.2)) @ T_true
 print("gen", time.time() - t, ref.shape, rd.shape)
-t = time.time(); rf, rn = icp.sampling_surface_normal(ref, 10, 1.0, 0); print("normals (host)", time.time() - t)
+hf = icp.IcpHandle()
+t = time.time(); d_rf, d_rn = hf.filter_reference(torch.from_numpy(ref).cuda(), 10, 1.0, 0); rf, rn = d_rf.cpu().numpy(), d_rn.cpu().numpy(); hf.close(); print("normals (device filter)", time.time() - t)
 cfg = IcpConfig(); lib().lsgpu_icp_config_yaml(C.byref(cfg)); cfg.min_diff_rot, cfg.min_diff_trans = 1e-5, 1e-4; cfg.profile_kernels = 1
 h = icp.IcpHandle(cfg)
 dref, dn, drd = torch.from_numpy(rf).cuda(), torch.from_numpy(rn).cuda(), torch.from_numpy(rd).cuda()
-for rep in range(2):
+for rep in range(3):
     t = time.perf_counter(); h.set_reference(dref, dn); torch.cuda.synchronize(); t1 = time.perf_counter()
     T, st = h.align(drd, T_init); t2 = time.perf_counter()
 print("set_reference ms %.2f align ms %.2f iters %d knn avg us %.1f cap_retries %d" % ((t1 - t) * 1e3, (t2 - t1) * 1e3, st.iterations, st.t_knn_ms / max(st.knn_launches, 1) * 1e3, st.cap_retries))
@@ -40,3 +42,13 @@ if len(sys.argv) > 2 and sys.argv[2] == "oracle":
     trg = h.trace()
     print("limits equal:", [np.float32(a["limit"]) == np.float32(b["limit"]) for a, b in zip(trg, tro)].count(True), "of", len(tro),
           "| n_used equal:", [a["n_used"] == b["n_used"] for a, b in zip(trg, tro)].count(True))
+
+if len(sys.argv) > 3:
+    import json
+    et, er = synth.pose_error(T.astype(np.float64), T_true)
+    json.dump({"workload": "configs[3] on ONE GPU: %d-point aggregated local map (8 scans) vs %d-point scan, chain F, differential checker 1e-4 m / 1e-5 rad" % (rf.shape[0], rd.shape[0]),
+               "set_reference_ms": (t1 - t) * 1e3, "align_ms": (t2 - t1) * 1e3, "iterations": int(st.iterations),
+               "knn_avg_us_per_launch": st.t_knn_ms / max(st.knn_launches, 1) * 1e3, "select_avg_us": st.t_select_ms / max(st.knn_launches, 1) * 1e3,
+               "ne_avg_us": st.t_ne_ms / max(st.knn_launches, 1) * 1e3, "cap_retries": int(st.cap_retries), "chunks": int(h.info().n_chunks),
+               "trans_err_vs_truth_m": et, "rot_err_vs_truth_rad": er, "command": "python devtools/config4_shape.py %d - %s" % (n_az, sys.argv[3])},
+              open(sys.argv[3], "w"), indent=1)

@@ -16,6 +16,13 @@
  *   TransformationParameters 4x4 float column major; p_reference = T * p_reading.
  * Every pointer argument may be host memory or device (HBM) memory of the handle's device; the
  * library detects which.  Host buffers are copied, never retained.  No exceptions cross this ABI.
+ *
+ * Stream contract: every call does its device work on the HANDLE'S OWN stream (created non-blocking: it does not
+ * synchronise with the null stream or with any stream of the caller) and returns after that work has completed, so
+ * outputs are valid on return.  Device INPUTS must be complete before the call: a buffer still being written by
+ * the caller's stream has to be synchronised first (hipStreamSynchronize / an event wait on the producing stream).
+ * The Python twin (laser_slam_amd/icp.py) synchronises torch's current stream before every call that passes a
+ * device tensor.
  */
 #ifndef LSGPU_ICP_H_
 #define LSGPU_ICP_H_
@@ -26,7 +33,7 @@
 extern "C" {
 #endif
 
-#define LSGPU_ABI_VERSION 1
+#define LSGPU_ABI_VERSION 2
 
 /* Return codes.  NO_CONVERGENCE is PointMatcher::ConvergenceError: laser_track.cpp:499-502 catches it
  * and keeps the odometry guess; incremental_estimator.cpp:108 lets it propagate. */
@@ -69,7 +76,9 @@ typedef struct lsgpu_icp_stats {
   double  t_knn_fallback_ms; /* k_knn_fallback only                                     */
   int     cap_retries;       /* iterations repeated because the radius-cap prediction failed */
   int     pad_;              /* iterations whose predicted select missed and was redone in full (info)  */
-  double  t_reserved[1];
+  double  t_reserved[1];     /* lsgpu_icp_compute: milliseconds in the two filters + set_reference */
+  double  t_select_ms;       /* sum over the iterations: trimmed-distance select kernels (profile_kernels=1) */
+  double  t_ne_ms;           /* sum over the iterations: normal equations + solve + checkers (profile_kernels=1) */
 } lsgpu_icp_stats;
 
 /* One record per iteration (optional parity/debug trace; replaces the VTKFileInspector dump of
@@ -217,6 +226,55 @@ int lsgpu_filter_cylinder(lsgpu_icp* h, const float* xyz1, int64_t n, const floa
  * the voxel index would overflow an int (PCL refuses such leaf sizes as well). */
 int lsgpu_filter_voxel_grid(lsgpu_icp* h, const float* xyz1, int64_t n, const float leaf[3], int min_points,
                             float* out_xyz1, int64_t* n_out);
+
+/* ---- the input filter chain -------------------------------------------------
+ * LaserTrack loads a libpointmatcher DataPointsFilters chain from `icp_input_filters_file` (laser_slam/src/
+ * laser_track.cpp:24-30, LOG(FATAL) if the file cannot be opened) and applies it to every incoming scan before the
+ * scan is stored or matched (laser_track.cpp:81, :146: input_filters_.apply(scan.scan)).  The filters below run on the
+ * device, one after the other, each on the output of the previous one, order of the surviving points preserved:
+ *   MaxDistDataPointsFilter      dim -1: keep |p| <  maxDist          dim 0..2: keep |p[dim]| <  maxDist
+ *   MinDistDataPointsFilter      dim -1: keep |p| >  minDist          dim 0..2: keep |p[dim]| >  minDist
+ *   BoundingBoxDataPointsFilter  inside = xMin < x < xMax && ...;     keeps inside (removeInside 0) or outside (1)
+ *   FixStepSamplingDataPointsFilter  keeps points phase, phase + step, ...; phase = rand() % step; afterwards
+ *                                step *= stepMult, clamped at endStep (the step persists from scan to scan: `state`)
+ *   RandomSamplingDataPointsFilter   keeps point i iff draw_i < prob
+ * |p| = sqrt(fma(z,z,fma(y,y,x*x))) in float.  Draws: the library's glibc-sequence stream (see lsgpu_icp_compute);
+ * seed >= 0 reseeds it before the first filter.  LSGPU_NO_CONVERGENCE if a filter is handed an empty cloud
+ * (PointMatcher::ConvergenceError "no points to filter" upstream); an empty chain copies the cloud. */
+enum {
+  LSGPU_FILTER_MAX_DIST = 1,
+  LSGPU_FILTER_MIN_DIST = 2,
+  LSGPU_FILTER_BOUNDING_BOX = 3,
+  LSGPU_FILTER_FIX_STEP_SAMPLING = 4,
+  LSGPU_FILTER_RANDOM_SAMPLING = 5
+};
+typedef struct lsgpu_point_filter {
+  int    type;     /* LSGPU_FILTER_*                                                                          */
+  int    dim;      /* Max/MinDist: -1 radial, 0..2 one axis                                                   */
+  int    flag;     /* BoundingBox: removeInside                                                               */
+  int    pad_;
+  float  v[6];     /* MaxDist {maxDist}  MinDist {minDist}  BoundingBox {xMin,xMax,yMin,yMax,zMin,zMax}        */
+                   /* FixStepSampling {startStep,endStep,stepMult}  RandomSampling {prob}                      */
+  double state;    /* FixStepSampling: current step (0: start at startStep); updated by every apply            */
+} lsgpu_point_filter;
+int lsgpu_apply_point_filters(lsgpu_icp* h, lsgpu_point_filter* filters, int n_filters, const float* xyz1,
+                              int64_t n, int64_t seed, float* out_xyz1, int64_t* n_out);
+
+/* ---- the ROS message surface of the scan path ----------------------------------
+ * LaserSlamWorker::scanCallback turns the incoming sensor_msgs/PointCloud2 into DataPoints with
+ * PointMatcher_ros::rosMsgToPointMatcherCloud<float> (laser_slam_ros/src/laser_slam_worker.cpp:125) and publishes
+ * clouds through lpmToPcl / pcl::toROSMsg (laser_slam_ros/include/laser_slam_ros/common.hpp:159-191).  Both are
+ * pure layout changes and run on the device so that a scan crosses PCIe once, as the message's byte block.
+ *   from: `data` = the message's data block (n_points records of point_step bytes, host or device memory), the
+ *         FLOAT32 fields x, y, z at byte offsets off_x/y/z inside a record (any alignment), optionally byte-swapped
+ *         (is_bigendian); out = x,y,z,1 per point.  drop_non_finite (= !is_dense): records with a NaN / Inf
+ *         coordinate are removed, order preserved.
+ *   to  : x,y,z,1 -> the data block of a PointCloud2 / pcl::PointCloud<pcl::PointXYZ> with fields x@0 y@4 z@8,
+ *         point_step 16 (what pcl::toROSMsg emits for PointXYZ; the 4th float of a record is padding, written 1). */
+int lsgpu_cloud_from_pointcloud2(lsgpu_icp* h, const unsigned char* data, int64_t n_points, int point_step, int off_x,
+                                 int off_y, int off_z, int is_bigendian, int drop_non_finite, float* out_xyz1,
+                                 int64_t* n_out);
+int lsgpu_cloud_to_pointxyz(lsgpu_icp* h, const float* xyz1, int64_t n, unsigned char* out_data /* 16 n bytes */);
 
 /* ---- host-side versions of the two filters (same output as the device filters) and O(1) helpers ---- */
 

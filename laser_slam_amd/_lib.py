@@ -24,7 +24,8 @@ ABI_SYMBOLS = [
     "lsgpu_icp_get_reference_mean", "lsgpu_icp_get_info", "lsgpu_comm_get_unique_id", "lsgpu_icp_comm_init", "lsgpu_knn", "lsgpu_trim_limit", "lsgpu_normal_eq",
     "lsgpu_transform_points", "lsgpu_filter_random_sampling",
     "lsgpu_filter_sampling_surface_normal", "lsgpu_check_rigid", "lsgpu_correct_rigid",
-    "lsgpu_strerror", "lsgpu_last_error", "lsgpu_abi_version",
+    "lsgpu_strerror", "lsgpu_last_error", "lsgpu_abi_version", "lsgpu_apply_point_filters",
+    "lsgpu_cloud_from_pointcloud2", "lsgpu_cloud_to_pointxyz",
 ]
 
 
@@ -66,6 +67,8 @@ class IcpStats(C.Structure):
         ("cap_retries", C.c_int),
         ("pad_", C.c_int),
         ("t_reserved", C.c_double * 1),
+        ("t_select_ms", C.c_double),
+        ("t_ne_ms", C.c_double),
     ]
 
 
@@ -94,6 +97,15 @@ class IcpInfo(C.Structure):
         ("cells", C.c_uint32 * 17),
         ("table_bytes", C.c_uint64),
     ]
+
+
+class PointFilter(C.Structure):
+    """lsgpu_point_filter (include/lsgpu_icp.h): one module of the input filter chain."""
+    _fields_ = [("type", C.c_int), ("dim", C.c_int), ("flag", C.c_int), ("pad_", C.c_int), ("v", C.c_float * 6),
+                ("state", C.c_double)]
+
+
+FILTER_MAX_DIST, FILTER_MIN_DIST, FILTER_BOUNDING_BOX, FILTER_FIX_STEP_SAMPLING, FILTER_RANDOM_SAMPLING = 1, 2, 3, 4, 5
 
 
 class LsgpuError(RuntimeError):
@@ -144,6 +156,10 @@ def lib() -> C.CDLL:
     L.lsgpu_filter_cylinder.argtypes = [vp, fp, i64, C.POINTER(C.c_float), C.c_double, C.c_double, C.c_int, fp,
                                         C.POINTER(i64)]
     L.lsgpu_filter_voxel_grid.argtypes = [vp, fp, i64, C.POINTER(C.c_float), C.c_int, fp, C.POINTER(i64)]
+    L.lsgpu_apply_point_filters.argtypes = [vp, C.POINTER(PointFilter), C.c_int, fp, i64, i64, fp, C.POINTER(i64)]
+    L.lsgpu_cloud_from_pointcloud2.argtypes = [vp, fp, i64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, fp,
+                                               C.POINTER(i64)]
+    L.lsgpu_cloud_to_pointxyz.argtypes = [vp, fp, i64, fp]
     L.lsgpu_cloud_upload.argtypes = [vp, C.c_int, fp, i64]
     L.lsgpu_cloud_release.argtypes = [vp, C.c_int]
     L.lsgpu_cloud_size.argtypes = [vp, C.c_int, C.POINTER(i64)]

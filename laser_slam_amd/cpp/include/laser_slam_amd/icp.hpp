@@ -101,6 +101,133 @@ inline void correctTransformationMatrix(TransformationParameters* T) {
   if (!RigidTransformation::checkParameters(*T)) *T = RigidTransformation::correctParameters(*T);
 }
 
+namespace detail {
+
+struct YamlModule { std::string section, name; std::map<std::string, std::string> params; };
+
+inline std::string trim(const std::string& s) {
+  size_t a = 0, b = s.size();
+  while (a < b && std::isspace((unsigned char)s[a])) ++a;
+  while (b > a && std::isspace((unsigned char)s[b - 1])) --b;
+  return s.substr(a, b - a);
+}
+inline void parseInline(const std::string& body, std::map<std::string, std::string>* out) {  // {k: v, k: v}
+  std::stringstream ss(body);
+  std::string kv;
+  while (std::getline(ss, kv, ',')) {
+    const size_t c = kv.find(':');
+    if (c != std::string::npos) (*out)[trim(kv.substr(0, c))] = trim(kv.substr(c + 1));
+  }
+}
+// A libpointmatcher DataPointsFilters file: a top-level YAML sequence of modules, `- Name` / `- Name:` followed by an
+// indented `key: value` block, or `- Name: {key: value, ...}`; `#` comments.  An empty document is an empty chain.
+inline std::vector<YamlModule> parseYamlList(std::istream& in) {
+  std::vector<YamlModule> mods;
+  std::string line;
+  int item_indent = -1;
+  while (std::getline(in, line)) {
+    const size_t hash = line.find('#');
+    if (hash != std::string::npos) line = line.substr(0, hash);
+    std::string t = trim(line);
+    if (t.empty() || t == "---" || t == "[]") continue;
+    int indent = 0;
+    while (indent < (int)line.size() && line[indent] == ' ') ++indent;
+    const bool item = t[0] == '-';
+    if (item) t = trim(t.substr(1));
+    const size_t c = t.find(':');
+    const std::string key = trim(c == std::string::npos ? t : t.substr(0, c));
+    const std::string val = c == std::string::npos ? "" : trim(t.substr(c + 1));
+    if (item) {
+      YamlModule m{"", key, {}};
+      if (!val.empty() && val.front() == '{' && val.back() == '}') parseInline(val.substr(1, val.size() - 2), &m.params);
+      else if (!val.empty()) throw std::runtime_error("input filters yaml: unexpected scalar after " + key);
+      mods.push_back(m);
+      item_indent = indent;
+    } else {
+      if (mods.empty() || indent <= item_indent) throw std::runtime_error("input filters yaml: a sequence of modules is expected");
+      mods.back().params[key] = val;
+    }
+  }
+  return mods;
+}
+
+}  // namespace detail
+
+// PointMatcher::DataPointsFilters as LaserTrack uses it: built from a YAML stream (laser_slam/src/laser_track.cpp:27),
+// applied in place to every incoming scan (laser_track.cpp:81, :146).  The supported modules run on the device
+// (lsgpu_apply_point_filters); any other module is a configuration error, like an unknown name is for
+// PointMatcher's registrar.  FixStepSampling keeps its step between calls, as the upstream object does.
+class DataPointsFilters {
+ public:
+  DataPointsFilters() = default;
+  explicit DataPointsFilters(std::istream& in, int device = 0) : device_(device) {
+    for (const auto& m : detail::parseYamlList(in)) {
+      auto num = [&](const char* key, double def) {
+        auto it = m.params.find(key);
+        return it == m.params.end() ? def : std::stod(it->second);
+      };
+      auto only = [&](std::initializer_list<const char*> keys) {
+        for (const auto& kv : m.params) {
+          bool known = false;
+          for (const char* k : keys) known = known || kv.first == k;
+          if (!known) throw ConfigError(m.name + ": unknown parameter " + kv.first);
+        }
+      };
+      lsgpu_point_filter f;
+      std::memset(&f, 0, sizeof(f));
+      if (m.name == "MaxDistDataPointsFilter") {
+        only({"dim", "maxDist"});
+        f.type = LSGPU_FILTER_MAX_DIST; f.dim = (int)num("dim", -1); f.v[0] = (float)num("maxDist", 1.0);
+      } else if (m.name == "MinDistDataPointsFilter") {
+        only({"dim", "minDist"});
+        f.type = LSGPU_FILTER_MIN_DIST; f.dim = (int)num("dim", -1); f.v[0] = (float)num("minDist", 1.0);
+      } else if (m.name == "BoundingBoxDataPointsFilter") {
+        only({"xMin", "xMax", "yMin", "yMax", "zMin", "zMax", "removeInside"});
+        f.type = LSGPU_FILTER_BOUNDING_BOX;
+        f.v[0] = (float)num("xMin", -1.0); f.v[1] = (float)num("xMax", 1.0);
+        f.v[2] = (float)num("yMin", -1.0); f.v[3] = (float)num("yMax", 1.0);
+        f.v[4] = (float)num("zMin", -1.0); f.v[5] = (float)num("zMax", 1.0);
+        f.flag = (int)num("removeInside", 1);
+      } else if (m.name == "FixStepSamplingDataPointsFilter") {
+        only({"startStep", "endStep", "stepMult"});
+        f.type = LSGPU_FILTER_FIX_STEP_SAMPLING;
+        f.v[0] = (float)num("startStep", 10); f.v[1] = (float)num("endStep", 10); f.v[2] = (float)num("stepMult", 1);
+      } else if (m.name == "RandomSamplingDataPointsFilter") {
+        only({"prob"});
+        f.type = LSGPU_FILTER_RANDOM_SAMPLING; f.v[0] = (float)num("prob", 0.75);
+      } else {
+        throw ConfigError("input filters: module " + m.name + " is not implemented on the HIP path");
+      }
+      filters_.push_back(f);
+    }
+  }
+  ~DataPointsFilters() { if (h_) lsgpu_icp_destroy(h_); }
+  DataPointsFilters(const DataPointsFilters&) = delete;
+  DataPointsFilters& operator=(const DataPointsFilters&) = delete;
+  DataPointsFilters(DataPointsFilters&& o) noexcept { *this = std::move(o); }
+  DataPointsFilters& operator=(DataPointsFilters&& o) noexcept {
+    if (this != &o) {
+      if (h_) lsgpu_icp_destroy(h_);
+      filters_ = std::move(o.filters_); h_ = o.h_; o.h_ = nullptr; device_ = o.device_; seed_ = o.seed_;
+    }
+    return *this;
+  }
+
+  size_t size() const { return filters_.size(); }
+  bool empty() const { return filters_.empty(); }
+  const std::vector<lsgpu_point_filter>& modules() const { return filters_; }
+  void setSeed(int64_t seed) { seed_ = seed; }  // >= 0: reseed the draw stream at every apply(); < 0: continue it
+
+  // DataPointsFilters::apply: in place; throws ConvergenceError if a filter is handed an empty cloud.
+  void apply(DataPoints& cloud);
+
+ private:
+  std::vector<lsgpu_point_filter> filters_;
+  lsgpu_icp* h_ = nullptr;
+  int device_ = 0;
+  int64_t seed_ = -1;
+};
+
 class ICP {
  public:
   ICP() { setDefault(); }
@@ -125,6 +252,14 @@ class ICP {
     float prob = 0.75f, ratio = 0.5f;
     int knn = 7;
     const auto mods = parseYaml(in);
+    // libpointmatcher's loadFromYaml starts from EMPTY chains: a section the file does not mention means "no such
+    // module", not "the default module".  A missing filter section therefore keeps every point (prob / ratio 1 is
+    // not expressible for the reference filter: the normals come from it); the modules the device loop cannot run
+    // without are required.
+    bool has_reading = false, has_reference = false, has_matcher = false, has_outlier = false, has_minimizer = false,
+         has_counter = false, has_differential = false;
+    prob = 1.0f;
+    c.trim_ratio = 1.0f;
     for (const auto& m : mods) {
       const std::string& sec = m.section;
       const std::string& name = m.name;
@@ -132,22 +267,38 @@ class ICP {
         auto it = m.params.find(key);
         return it == m.params.end() ? def : std::stod(it->second);
       };
-      if (sec == "readingDataPointsFilters" && name == "RandomSamplingDataPointsFilter") prob = (float)num("prob", 0.75);
-      else if (sec == "referenceDataPointsFilters" && name == "SamplingSurfaceNormalDataPointsFilter") {
+      if (sec == "readingDataPointsFilters" && name == "RandomSamplingDataPointsFilter") {
+        if (has_reading) throw ConfigError("readingDataPointsFilters: one RandomSamplingDataPointsFilter at most");
+        has_reading = true; prob = (float)num("prob", 0.75);
+      } else if (sec == "referenceDataPointsFilters" && name == "SamplingSurfaceNormalDataPointsFilter") {
+        if (has_reference) throw ConfigError("referenceDataPointsFilters: one SamplingSurfaceNormalDataPointsFilter at most");
+        has_reference = true;
         knn = (int)num("knn", 7); ratio = (float)num("ratio", 0.5);
         if ((int)num("samplingMethod", 0) != 0) throw ConfigError("samplingMethod != 0 is not implemented");
       } else if (sec == "matcher" && name == "KDTreeMatcher") {
+        has_matcher = true;
         if ((int)num("knn", 1) != 1 || num("epsilon", 0) != 0.0) throw ConfigError("only knn 1 / epsilon 0");
-      } else if (sec == "outlierFilters" && name == "TrimmedDistOutlierFilter") c.trim_ratio = (float)num("ratio", 0.85);
-      else if (sec == "errorMinimizer" && name == "PointToPlaneErrorMinimizer") {}
-      else if (sec == "transformationCheckers" && name == "CounterTransformationChecker") c.max_iterations = (int)num("maxIterationCount", 40);
-      else if (sec == "transformationCheckers" && name == "DifferentialTransformationChecker") {
+      } else if (sec == "outlierFilters" && name == "TrimmedDistOutlierFilter") {
+        if (has_outlier) throw ConfigError("outlierFilters: one TrimmedDistOutlierFilter at most");
+        has_outlier = true; c.trim_ratio = (float)num("ratio", 0.85);
+      } else if (sec == "errorMinimizer" && name == "PointToPlaneErrorMinimizer") { has_minimizer = true; }
+      else if (sec == "transformationCheckers" && name == "CounterTransformationChecker") {
+        has_counter = true; c.max_iterations = (int)num("maxIterationCount", 40);
+      } else if (sec == "transformationCheckers" && name == "DifferentialTransformationChecker") {
+        has_differential = true;
         c.min_diff_rot = (float)num("minDiffRotErr", 0.001);
         c.min_diff_trans = (float)num("minDiffTransErr", 0.001);
         c.smooth_length = (int)num("smoothLength", 3);
       } else if (sec == "inspector" || sec == "logger") {}  // debug output only (yaml:32-44)
       else throw ConfigError(sec + ": module " + name + " is not implemented on the HIP path");
     }
+    // what the device loop needs: normals for the point-to-plane minimiser, the 1-NN matcher, the minimiser itself
+    // and a stopping rule.  (Absent reading filter: every point; absent outlier filter: every pair, ratio 1.)
+    if (!has_reference) throw ConfigError("referenceDataPointsFilters: SamplingSurfaceNormalDataPointsFilter is required (it provides the normals)");
+    if (!has_matcher) throw ConfigError("matcher: KDTreeMatcher is required");
+    if (!has_minimizer) throw ConfigError("errorMinimizer: PointToPlaneErrorMinimizer is required");
+    if (!has_counter) throw ConfigError("transformationCheckers: CounterTransformationChecker is required (the loop would not stop)");
+    if (!has_differential) { c.min_diff_rot = -1.f; c.min_diff_trans = -1.f; c.smooth_length = 1; }  // never satisfied: the counter stops
     cfg_ = c; prob_ = prob; knn_ = knn; ratio_ = ratio;
     release();
   }
@@ -167,6 +318,7 @@ class ICP {
     TransformationParameters T = T_init;
     check(lsgpu_icp_compute(h_, reading.features.data(), nq, reference.features.data(), nr, T_init.data(),
                             &chain, T.data(), &stats_), "lsgpu_icp_compute");
+    if (observer_) observer_(*this, reading, reference, T_init, T);
     return T;
   }
 
@@ -214,6 +366,11 @@ class ICP {
                                                                  const TransformationParameters& T_init)>;
   void setComputeOverride(ComputeOverride f) { override_ = std::move(f); }
   bool hasComputeOverride() const { return (bool)override_; }
+  // Test seam: called after every successful device compute() with its inputs and its result (the parity tests run
+  // the CPU oracle on exactly the clouds the facade handed to the device).  Never set by the product.
+  using ComputeObserver = std::function<void(const ICP&, const DataPoints& reading, const DataPoints& reference,
+                                             const TransformationParameters& T_init, const TransformationParameters& T)>;
+  void setComputeObserver(ComputeObserver f) { observer_ = std::move(f); }
 
   // Steps 2-7 on already filtered clouds (device or host pointers).
   TransformationParameters computeFiltered(const float* reading_xyz1, int64_t nq, const float* ref_xyz1,
@@ -228,27 +385,15 @@ class ICP {
 
   const lsgpu_icp_stats& lastStats() const { return stats_; }
   const lsgpu_icp_config& config() const { return cfg_; }
+  lsgpu_icp* handle() { ensureHandle(); return h_; }  // the C-ABI handle (device conversions of ros_msgs.hpp)
   float readingSamplingProb() const { return prob_; }
   int surfaceNormalKnn() const { return knn_; }
   float surfaceNormalRatio() const { return ratio_; }
 
  private:
-  struct Module { std::string section, name; std::map<std::string, std::string> params; };
-
-  static std::string trim(const std::string& s) {
-    size_t a = 0, b = s.size();
-    while (a < b && std::isspace((unsigned char)s[a])) ++a;
-    while (b > a && std::isspace((unsigned char)s[b - 1])) --b;
-    return s.substr(a, b - a);
-  }
-  static void parseInline(const std::string& body, std::map<std::string, std::string>* out) {  // {k: v, k: v}
-    std::stringstream ss(body);
-    std::string kv;
-    while (std::getline(ss, kv, ',')) {
-      const size_t c = kv.find(':');
-      if (c != std::string::npos) (*out)[trim(kv.substr(0, c))] = trim(kv.substr(c + 1));
-    }
-  }
+  using Module = detail::YamlModule;
+  static std::string trim(const std::string& s) { return detail::trim(s); }
+  static void parseInline(const std::string& body, std::map<std::string, std::string>* out) { detail::parseInline(body, out); }
   // The YAML subset libpointmatcher configurations use: top-level `section:`, module either as a list
   // item `- Name:` / `- Name` or as a mapping `Name:` / scalar `section: Name`, parameters as an
   // indented `key: value` block or an inline `{...}` map; `#` comments.
@@ -312,6 +457,27 @@ class ICP {
   int64_t seed_ = -1;
   unsigned generation_ = 0;
   ComputeOverride override_;
+  ComputeObserver observer_;
 };
+
+inline void DataPointsFilters::apply(DataPoints& cloud) {
+  if (filters_.empty()) return;
+  if (!cloud.normals.empty()) throw std::logic_error("DataPointsFilters: descriptors are not carried through the input filters");
+  if (!h_) {
+    lsgpu_icp_config c;
+    lsgpu_icp_config_default(&c);
+    if (lsgpu_icp_create(&c, device_, &h_) != LSGPU_OK) throw DeviceError("lsgpu_icp_create failed (no ROCm GPU visible?)");
+  }
+  const int64_t n = cloud.getNbPoints();
+  std::vector<float> out((size_t)std::max<int64_t>(n, 1) * 4);
+  int64_t m = 0;
+  const int rc = lsgpu_apply_point_filters(h_, filters_.data(), (int)filters_.size(), cloud.features.data(), n, seed_,
+                                           out.data(), &m);
+  if (rc == LSGPU_NO_CONVERGENCE) throw ConvergenceError("no points to filter");
+  if (rc == LSGPU_BAD_CONFIG) throw ConfigError(std::string("input filters: ") + lsgpu_last_error(h_));
+  if (rc != LSGPU_OK) throw DeviceError(std::string("lsgpu_apply_point_filters: ") + lsgpu_strerror(rc) + " [" + lsgpu_last_error(h_) + "]");
+  out.resize((size_t)m * 4);
+  cloud.features.swap(out);
+}
 
 }  // namespace laser_slam_amd

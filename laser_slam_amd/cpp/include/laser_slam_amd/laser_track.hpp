@@ -55,8 +55,9 @@ struct LaserTrackParams {  // laser_slam/include/laser_slam/parameters.hpp:8-23
   bool add_m_estimator_on_odom = false;
   bool add_m_estimator_on_icp = false;
   std::string icp_configuration_file;
-  std::string icp_input_filters_file;   // input filter chain (K0): the file is not in the reference repo;
-                                        // empty = no input filters
+  std::string icp_input_filters_file;   // input filter chain (K0), a libpointmatcher DataPointsFilters YAML list.  As in
+                                        // the reference the file MUST be readable (laser_track.cpp:24-30 LOG(FATAL)s
+                                        // otherwise); a file without modules is an empty chain
   bool use_icp_factors = true;
   bool use_odom_factors = true;
   int nscan_in_sub_map = 3;
@@ -113,6 +114,10 @@ class LaserTrack {
     std::ifstream ifs(params_.icp_configuration_file.c_str());
     if (!params_.icp_configuration_file.empty() && ifs.good()) icp_.loadFromYaml(ifs);
     else icp_.setDefault();
+    // laser_track.cpp:24-30: the input filter chain; LOG(FATAL) upstream if the file cannot be opened
+    std::ifstream ifs_filters(params_.icp_input_filters_file.c_str());
+    if (!ifs_filters.good()) throw ConfigError("Could not open ICP input filters configuration file.");
+    input_filters_ = DataPointsFilters(ifs_filters, params_.device);
     trajectory_.setFirstKey((Key)laser_track_id_ << 40);  // per-track key range
   }
 
@@ -124,7 +129,10 @@ class LaserTrack {
   void processLaserScan(const LaserScan& in_scan) {  // laser_track.cpp:74-120
     std::lock_guard<std::recursive_mutex> lock(mutex_);
     LaserScan scan = in_scan;
-    registerScan(&scan, nullptr);
+    input_filters_.apply(scan.scan);  // laser_track.cpp:81
+    // (this entry point runs the ICP BEFORE it stores the new scan, laser_track.cpp:112-119: the transformation it
+    // records matches the previously stored scan against its predecessors)
+    registerScan(&scan, nullptr, /*icp_before_store=*/true);
   }
 
   void processPoseAndLaserScan(const Pose& pose, const LaserScan& in_scan, FactorList* newFactors = nullptr,
@@ -134,10 +142,11 @@ class LaserTrack {
     if (newFactors && !newFactors->empty()) throw std::logic_error("newFactors must be empty");
     if (newValues) newValues->clear();
     LaserScan scan = in_scan;
+    input_filters_.apply(scan.scan);  // laser_track.cpp:146
     pose_measurements_.push_back(pose);
     const bool first = trajectory_.isEmpty();
     RelativePose odom;
-    registerScan(&scan, &odom);
+    registerScan(&scan, &odom, /*icp_before_store=*/false);
     if (first) {
       if (newFactors) {
         Pose prior = pose;
@@ -204,6 +213,7 @@ class LaserTrack {
   const std::vector<RelativePose>& getOdometryMeasurements() const { return odometry_measurements_; }
   const lsgpu_icp_stats& lastIcpStats() const { return icp_.lastStats(); }
   ICP& icp() { return icp_; }  // configuration access (seed, test seam); the reference keeps icp_ private
+  DataPointsFilters& inputFilters() { return input_filters_; }
 
   // laser_track.cpp:602-651: the scan at time_ns plus up to `radius` scans on either side, in its frame
   void buildSubMapAroundTime(const Time& time_ns, unsigned int sub_maps_radius, DataPoints* sub_map_out) const {
@@ -251,8 +261,8 @@ class LaserTrack {
     throw std::logic_error("Could not find the scan.");
   }
 
-  // shared tail of processLaserScan / processPoseAndLaserScan (:154-206)
-  void registerScan(LaserScan* scan, RelativePose* odom_out) {
+  // shared tail of processLaserScan (:86-120: ICP, then store) and processPoseAndLaserScan (:154-206: store, then ICP)
+  void registerScan(LaserScan* scan, RelativePose* odom_out, bool icp_before_store) {
     if (trajectory_.isEmpty()) {
       scan->key = trajectory_.extend(scan->time_ns, getPoseMeasurement(scan->time_ns));
       setPoseKey(scan->time_ns, scan->key);
@@ -266,12 +276,12 @@ class LaserTrack {
     rel.key_a = getPoseKey(t_last);
     rel.time_b_ns = scan->time_ns;
     scan->key = trajectory_.extend(scan->time_ns, trajectory_.evaluate(t_last) * rel.T_a_b);
-    setPoseKey(scan->time_ns, scan->key);
-    laser_scans_.push_back(*scan);
+    if (!icp_before_store) { setPoseKey(scan->time_ns, scan->key); laser_scans_.push_back(*scan); }
     rel.key_b = scan->key;
     rel.track_id_a = rel.track_id_b = laser_track_id_;
     odometry_measurements_.push_back(rel);
     if (params_.use_icp_factors) computeICPTransformations();
+    if (icp_before_store) { setPoseKey(scan->time_ns, scan->key); laser_scans_.push_back(*scan); }
     if (odom_out) *odom_out = rel;
   }
 
@@ -342,6 +352,7 @@ class LaserTrack {
   LaserTrackParams params_;
   unsigned int laser_track_id_;
   ICP icp_;
+  DataPointsFilters input_filters_;
   Trajectory trajectory_;
   std::vector<Pose> pose_measurements_;
   std::vector<RelativePose> odometry_measurements_;

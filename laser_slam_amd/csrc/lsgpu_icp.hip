@@ -54,6 +54,7 @@ struct RcclApi {
   ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
   ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
   ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*CommAbort)(ncclComm_t) = nullptr;  // optional
   const char* (*GetErrorString)(ncclResult_t) = nullptr;
 };
 RcclApi* rccl_api() {
@@ -70,6 +71,7 @@ RcclApi* rccl_api() {
       api.CommInitRank = reinterpret_cast<decltype(api.CommInitRank)>(dlsym(api.lib, "ncclCommInitRank"));
       api.AllReduce = reinterpret_cast<decltype(api.AllReduce)>(dlsym(api.lib, "ncclAllReduce"));
       api.CommDestroy = reinterpret_cast<decltype(api.CommDestroy)>(dlsym(api.lib, "ncclCommDestroy"));
+      api.CommAbort = reinterpret_cast<decltype(api.CommAbort)>(dlsym(api.lib, "ncclCommAbort"));
       api.GetErrorString = reinterpret_cast<decltype(api.GetErrorString)>(dlsym(api.lib, "ncclGetErrorString"));
       if (!api.GetUniqueId || !api.CommInitRank || !api.AllReduce || !api.CommDestroy) api.lib = nullptr;
     }
@@ -112,6 +114,13 @@ double wall_ms() {
 }
 
 inline int nblk(int64_t n) { return (int)((n + 255) / 256); }
+
+}  // namespace
+
+struct lsgpu_icp;
+static int wait_stream(lsgpu_icp* h);
+
+namespace {
 
 }  // namespace
 
@@ -180,15 +189,40 @@ struct lsgpu_icp {
   DevBuf<uint32_t> hist;      // 3 * kHistBins
   DevBuf<SelState> sel;       // [0] input rank, [1] after pass 2, [2] after pass 3
   DevBuf<double> ne_partials; // kNeBlocks * 32
+  DevBuf<double> ne_gpartials;  // (kNeBlocksMax / kNeGroup) * 32: first-level sums of k_normal_eq_loop
+  DevBuf<uint32_t> ne_tickets;  // 1 + kNeBlocksMax / kNeGroup
   DevBuf<double> ne_out;      // 32 (29 + limit slot)
   DevBuf<float> limit_dev;
   double* h_pinned = nullptr; // 64 doubles of pinned host staging
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
-  struct KnnEv { hipEvent_t a, b, c; };
+  struct KnnEv { hipEvent_t a, b, c, d, e; };  // before kNN, after the main pass, after the wave-per-query pass, after the select, after the normal equations
   std::vector<KnnEv> knn_events;   // pool, reused across aligns
   size_t knn_events_used = 0;
   std::vector<lsgpu_iter_trace> trace;
 };
+
+// Wait for the handle's stream.  Plain handles block; a handle with a communicator polls with a deadline
+// (LSGPU_COMM_TIMEOUT_MS, default 30 s): if a peer rank died inside the loop the collectives never complete, the
+// communicator is aborted and the caller gets LSGPU_HIP_ERROR instead of a hang.
+static int wait_stream(lsgpu_icp* h) {
+  if (!h->comm) { HIPC(hipStreamSynchronize(h->stream)); return LSGPU_OK; }
+  static const double limit_ms = getenv("LSGPU_COMM_TIMEOUT_MS") ? atof(getenv("LSGPU_COMM_TIMEOUT_MS")) : 30000.0;
+  const double t0 = wall_ms();
+  for (int spin = 0;; ++spin) {
+    const hipError_t e = hipStreamQuery(h->stream);
+    if (e == hipSuccess) return LSGPU_OK;
+    if (e != hipErrorNotReady) { (void)hipGetLastError(); h->err = std::string("stream: ") + hipGetErrorString(e); return LSGPU_HIP_ERROR; }
+    (void)hipGetLastError();
+    if (wall_ms() - t0 > limit_ms) {
+      h->err = "split-scan: a collective did not complete in time (peer rank lost?); communicator aborted";
+      RcclApi* api = rccl_api();
+      if (api && api->CommAbort) (void)api->CommAbort(h->comm); else if (api) (void)api->CommDestroy(h->comm);
+      h->comm = nullptr; h->comm_size = 1; h->comm_rank = 0;
+      return LSGPU_HIP_ERROR;
+    }
+    if (spin > 200) std::this_thread::sleep_for(std::chrono::microseconds(20));
+  }
+}
 
 static constexpr int kNeBlocksMax = 2048;
 static const int kNeBlocks = [] { const char* e = getenv("LSGPU_NE_BLOCKS"); const int v = e ? atoi(e) : 512;
@@ -285,8 +319,8 @@ void lsgpu_icp_destroy(lsgpu_icp* h) {
   h->nrm.release(); h->ref_inv.release(); h->tables.release(); h->flags.release(); h->cidx.release(); h->bounds.release(); h->chunks.release(); h->soa.release(); h->soa_base.release(); h->soa_cnt4.release(); h->soa_first.release(); h->prev.release(); h->state.release(); h->lb.release(); h->cell_cache.release(); h->cell_tags.release(); h->ssn_seg_a.release(); h->ssn_seg_b.release(); h->ssn_seg_of.release(); h->ssn_box_pts.release(); h->ssn_box_base.release(); h->ssn_keep.release(); h->ssn_out_pos.release(); h->ssn_bb.release(); h->ssn_box_normal.release(); h->ssn_draws.release(); h->flt_in.release(); h->flt_ref.release(); h->flt_rd.release(); h->flt_nrm.release(); h->chk_hist.release(); h->trace_dev.release(); h->knn_dbg.release(); h->knn_dbg_wave.release(); h->stat_partials.release();
   h->counters.release(); h->ang_cells.release(); h->sel_aux.release(); h->work.release(); h->q_in.release(); h->rdq.release(); h->ids.release(); h->d2.release();
   h->ids_io.release(); h->d2_io.release(); h->strag.release(); h->hist.release();
-  h->sel.release(); h->ne_partials.release(); h->ne_out.release(); h->limit_dev.release();
-  for (auto& e : h->knn_events) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); (void)hipEventDestroy(e.c); }
+  h->sel.release(); h->ne_partials.release(); h->ne_gpartials.release(); h->ne_tickets.release(); h->ne_out.release(); h->limit_dev.release();
+  for (auto& e : h->knn_events) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); (void)hipEventDestroy(e.c); (void)hipEventDestroy(e.d); (void)hipEventDestroy(e.e); }
   if (h->ev0) (void)hipEventDestroy(h->ev0);
   if (h->ev1) (void)hipEventDestroy(h->ev1);
   if (h->h_pinned) (void)hipHostFree(h->h_pinned);
@@ -331,6 +365,8 @@ static int ensure_loop_buffers(lsgpu_icp* h, int64_t nq) {
   HIPC(h->hist.reserve(3 * kHistBins));
   HIPC(h->sel.reserve(4));
   HIPC(h->ne_partials.reserve((size_t)kNeBlocksMax * 32));
+  HIPC(h->ne_gpartials.reserve((size_t)(kNeBlocksMax / kNeGroup + 1) * 32));
+  HIPC(h->ne_tickets.reserve((size_t)(kNeBlocksMax / kNeGroup + 2)));
   HIPC(h->ne_out.reserve(32));
   HIPC(h->limit_dev.reserve(4));
   HIPC(h->counters.reserve(64));
@@ -438,6 +474,7 @@ static int run_knn(lsgpu_icp* h, const Mat34& T, const IcpState* st, bool seed, 
     if (h->knn_events_used == h->knn_events.size()) {
       lsgpu_icp::KnnEv n{};
       HIPC(hipEventCreate(&n.a)); HIPC(hipEventCreate(&n.b)); HIPC(hipEventCreate(&n.c));
+      HIPC(hipEventCreate(&n.d)); HIPC(hipEventCreate(&n.e));
       h->knn_events.push_back(n);
     }
     ev = &h->knn_events[h->knn_events_used++];
@@ -680,6 +717,7 @@ int lsgpu_icp_comm_init(lsgpu_icp* h, int rank, int nranks, const void* id) {
   if (h->comm) { (void)api->CommDestroy(h->comm); h->comm = nullptr; }
   ncclUniqueId u;
   std::memcpy(&u, id, sizeof(u));
+  HIPC(h->comm_tmp.reserve(4));  // entry handshake of every align (allocated here: the handshake itself must not fail locally)
   RCCLC(api->CommInitRank(&h->comm, nranks, u, rank));
   h->comm_rank = rank; h->comm_size = nranks;
   return LSGPU_OK;
@@ -1147,6 +1185,138 @@ int lsgpu_filter_voxel_grid(lsgpu_icp* h, const float* xyz1, int64_t n, const fl
   return LSGPU_OK;
 }
 
+int lsgpu_apply_point_filters(lsgpu_icp* h, lsgpu_point_filter* filters, int n_filters, const float* xyz1,
+                              int64_t n, int64_t seed, float* out_xyz1, int64_t* n_out) {
+  if (!h || !n_out || n_filters < 0 || (n_filters > 0 && !filters) || n < 0 || (n > 0 && (!xyz1 || !out_xyz1))) return LSGPU_BAD_ARG;
+  h->err.clear();
+  *n_out = 0;
+  if (n > 0x7FFFFFF0ll) return LSGPU_BAD_ARG;
+  for (int k = 0; k < n_filters; ++k) {
+    const lsgpu_point_filter& f = filters[k];
+    const bool ok = (f.type == LSGPU_FILTER_MAX_DIST || f.type == LSGPU_FILTER_MIN_DIST) ? (f.dim >= -1 && f.dim <= 2)
+                    : f.type == LSGPU_FILTER_BOUNDING_BOX ? true
+                    : f.type == LSGPU_FILTER_FIX_STEP_SAMPLING ? (f.v[0] >= 1.f && f.v[1] >= 1.f && f.v[2] > 0.f)
+                    : f.type == LSGPU_FILTER_RANDOM_SAMPLING ? (f.v[0] >= 0.f && f.v[0] <= 1.f) : false;
+    if (!ok) { h->err = "apply_point_filters: unknown filter type or parameter out of range"; return LSGPU_BAD_CONFIG; }
+  }
+  if (seed >= 0) DrawStream::global().take(seed, 0, nullptr);
+  if (n == 0) return LSGPU_OK;  // DataPointsFilters::apply returns at once on an empty cloud
+  HIPC(hipSetDevice(h->device));
+  const float4* cur = nullptr;
+  int rc = stage_points(h, xyz1, n, h->flt_in, &cur);
+  if (rc) return rc;
+  HIPC(h->flt_ref.reserve(n));
+  HIPC(h->flt_rd.reserve(n));
+  HIPC(h->ssn_keep.reserve(n));
+  HIPC(h->ssn_out_pos.reserve(n));
+  float4* ping = h->flt_ref.p;
+  float4* pong = h->flt_rd.p;
+  int64_t m = n;
+  for (int k = 0; k < n_filters; ++k) {
+    lsgpu_point_filter& f = filters[k];
+    if (m == 0) { h->err = "apply_point_filters: no points to filter"; return LSGPU_NO_CONVERGENCE; }
+    PointFilterDev d;
+    std::memset(&d, 0, sizeof(d));
+    d.type = f.type; d.dim = f.dim; d.flag = f.flag;
+    for (int i = 0; i < 6; ++i) d.v[i] = f.v[i];
+    d.step = 1; d.phase = 0;
+    if (f.type == LSGPU_FILTER_FIX_STEP_SAMPLING) {
+      double step = f.state > 0.0 ? f.state : (double)f.v[0];
+      const int istep = std::max(1, (int)step);
+      d.step = (uint32_t)istep;
+      d.phase = DrawStream::global().take_raw(-1) % (uint32_t)istep;  // rand() % iStep
+      const double delta = (double)f.v[0] * (double)f.v[2] - (double)f.v[0];
+      step *= (double)f.v[2];
+      if (delta >= 0 && step > (double)f.v[1]) step = (double)f.v[1];
+      if (delta < 0 && step < (double)f.v[1]) step = (double)f.v[1];
+      f.state = step;
+    } else if (f.type == LSGPU_FILTER_RANDOM_SAMPLING) {
+      rc = upload_draws_begin(h, -1, (size_t)m);
+      if (rc) return rc;
+      DrawStream::global().commit((size_t)m);  // one draw per point
+    }
+    hipLaunchKernelGGL(k_point_filter_select, dim3(nblk(m)), dim3(256), 0, h->stream, cur, (int)m, d, h->ssn_draws.p,
+                       h->ssn_keep.p);
+    rc = scan_u32(h, h->ssn_keep.p, h->ssn_out_pos.p, (size_t)m);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_compact_points, dim3(nblk(m)), dim3(256), 0, h->stream, cur, (int)m, h->ssn_keep.p,
+                       h->ssn_out_pos.p, ping);
+    HIPC(hipGetLastError());
+    uint32_t unused = 0, kept = 0;
+    rc = scan_totals(h, nullptr, nullptr, 0, h->ssn_keep.p, h->ssn_out_pos.p, (size_t)m, &unused, &kept);
+    if (rc) return rc;
+    m = kept;
+    cur = ping;
+    std::swap(ping, pong);
+  }
+  *n_out = m;
+  if (m) HIPC(hipMemcpyAsync(out_xyz1, cur, (size_t)m * 16, hipMemcpyDefault, h->stream));
+  HIPC(hipStreamSynchronize(h->stream));
+  return LSGPU_OK;
+}
+
+int lsgpu_cloud_from_pointcloud2(lsgpu_icp* h, const unsigned char* data, int64_t n, int point_step, int off_x,
+                                 int off_y, int off_z, int is_bigendian, int drop_non_finite, float* out_xyz1,
+                                 int64_t* n_out) {
+  if (!h || !n_out || n < 0 || (n > 0 && (!data || !out_xyz1))) return LSGPU_BAD_ARG;
+  h->err.clear();
+  *n_out = 0;
+  const int lo = std::min(off_x, std::min(off_y, off_z)), hi = std::max(off_x, std::max(off_y, off_z));
+  if (point_step < 12 || lo < 0 || hi + 4 > point_step) { h->err = "from_pointcloud2: x/y/z fields do not fit a record"; return LSGPU_BAD_ARG; }
+  if (n == 0) return LSGPU_OK;
+  if (n > 0x7FFFFFF0ll) return LSGPU_BAD_ARG;
+  HIPC(hipSetDevice(h->device));
+  const unsigned char* src = data;
+  if (!is_device_ptr(data)) {  // the message's byte block crosses PCIe once, as it is
+    HIPC(h->sort_tmp.reserve((size_t)n * (size_t)point_step));
+    HIPC(hipMemcpyAsync(h->sort_tmp.p, data, (size_t)n * (size_t)point_step, hipMemcpyHostToDevice, h->stream));
+    src = reinterpret_cast<const unsigned char*>(h->sort_tmp.p);
+  }
+  HIPC(h->flt_in.reserve(n));
+  HIPC(h->ssn_keep.reserve(n));
+  HIPC(h->ssn_out_pos.reserve(n));
+  hipLaunchKernelGGL(k_pc2_unpack, dim3(nblk(n)), dim3(256), 0, h->stream, src, (int)n, point_step, off_x, off_y, off_z,
+                     is_bigendian ? 1 : 0, drop_non_finite ? 1 : 0, h->flt_in.p, h->ssn_keep.p);
+  const bool dev_x = is_device_ptr(out_xyz1);
+  int64_t m = n;
+  const float4* res = h->flt_in.p;
+  if (drop_non_finite) {
+    HIPC(h->flt_rd.reserve(n));
+    int rc = scan_u32(h, h->ssn_keep.p, h->ssn_out_pos.p, (size_t)n);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_compact_points, dim3(nblk(n)), dim3(256), 0, h->stream, h->flt_in.p, (int)n, h->ssn_keep.p,
+                       h->ssn_out_pos.p, h->flt_rd.p);
+    uint32_t unused = 0, kept = 0;
+    rc = scan_totals(h, nullptr, nullptr, 0, h->ssn_keep.p, h->ssn_out_pos.p, (size_t)n, &unused, &kept);
+    if (rc) return rc;
+    m = kept;
+    res = h->flt_rd.p;
+  }
+  HIPC(hipGetLastError());
+  *n_out = m;
+  if (m) HIPC(hipMemcpyAsync(out_xyz1, res, (size_t)m * 16, dev_x ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, h->stream));
+  HIPC(hipStreamSynchronize(h->stream));
+  return LSGPU_OK;
+}
+
+int lsgpu_cloud_to_pointxyz(lsgpu_icp* h, const float* xyz1, int64_t n, unsigned char* out_data) {
+  if (!h || n < 0 || (n > 0 && (!xyz1 || !out_data))) return LSGPU_BAD_ARG;
+  h->err.clear();
+  if (n == 0) return LSGPU_OK;
+  HIPC(hipSetDevice(h->device));
+  const float4* src = nullptr;
+  int rc = stage_points(h, xyz1, n, h->flt_in, &src);
+  if (rc) return rc;
+  const bool dev_o = is_device_ptr(out_data);
+  float4* dst = reinterpret_cast<float4*>(out_data);
+  if (!dev_o) { HIPC(h->flt_rd.reserve(n)); dst = h->flt_rd.p; }
+  hipLaunchKernelGGL(k_pc2_pack, dim3(nblk(n)), dim3(256), 0, h->stream, src, n, dst);
+  HIPC(hipGetLastError());
+  if (!dev_o) HIPC(hipMemcpyAsync(out_data, dst, (size_t)n * 16, hipMemcpyDeviceToHost, h->stream));
+  HIPC(hipStreamSynchronize(h->stream));
+  return LSGPU_OK;
+}
+
 int lsgpu_cloud_upload(lsgpu_icp* h, int slot, const float* xyz1, int64_t n) {
   if (!h || slot < 0 || slot >= (1 << 20) || n < 0 || n > 0x7FFFFFF0ll || (n > 0 && !xyz1)) return LSGPU_BAD_ARG;
   h->err.clear();
@@ -1232,11 +1402,16 @@ int lsgpu_icp_align(lsgpu_icp* h, const float* reading_xyz1, int64_t nq, const f
   std::memset(&st, 0, sizeof(st));
   if (stats) *stats = st;
   h->trace.clear();
+  // Local reasons not to start.  In the split-scan mode they are NOT returned yet: a rank that left here would
+  // leave its peers blocked in the first collective, so every rank first takes part in the entry handshake below.
+  int local_rc = LSGPU_OK;
   if (h->nr <= 0 || nq <= 0 || !reading_xyz1) {  // empty cloud: ConvergenceError upstream
     h->err = "align: empty reading or no reference";
-    return LSGPU_NO_CONVERGENCE;
+    local_rc = LSGPU_NO_CONVERGENCE;
+  } else if (nq > 0x7FFFFFF0ll) {
+    local_rc = LSGPU_BAD_ARG;
   }
-  if (nq > 0x7FFFFFF0ll) return LSGPU_BAD_ARG;
+  if (local_rc && !h->comm) return local_rc;
   HIPC(hipSetDevice(h->device));
   const double t0 = wall_ms();
   h->knn_events_used = 0;
@@ -1245,8 +1420,27 @@ int lsgpu_icp_align(lsgpu_icp* h, const float* reading_xyz1, int64_t nq, const f
   float T_rm_in[16];
   std::memcpy(T_rm_in, T_init, sizeof(T_rm_in));
   for (int d = 0; d < 3; ++d) T_rm_in[12 + d] = T_init[12 + d] - h->mean[d];
-  int rc = prepare_queries(h, reading_xyz1, nq, to_mat34(T_rm_in));
-  if (rc) return rc;
+  int rc = local_rc ? local_rc : prepare_queries(h, reading_xyz1, nq, to_mat34(T_rm_in));
+  if (rc && !h->comm) return rc;
+  int64_t nq_total = nq;
+  if (h->comm) {
+    // entry handshake: {shard size, cannot-start flag} summed over the ranks.  TrimmedDist ranks over ALL matches, so
+    // the rank uses the global count; and either every rank enters the loop or none does.
+    long long* hn = reinterpret_cast<long long*>(h->h_pinned + 60);
+    hn[0] = rc ? 0 : (long long)nq;
+    hn[1] = rc ? 1 : 0;
+    HIPC(hipMemcpyAsync(h->comm_tmp.p, hn, 2 * sizeof(long long), hipMemcpyHostToDevice, h->stream));
+    RCCLC(rccl_api()->AllReduce(h->comm_tmp.p, h->comm_tmp.p + 2, 2, ncclInt64, ncclSum, h->comm, h->stream));
+    HIPC(hipMemcpyAsync(hn, h->comm_tmp.p + 2, 2 * sizeof(long long), hipMemcpyDeviceToHost, h->stream));
+    const int w = wait_stream(h);
+    if (w) return w;
+    nq_total = (int64_t)hn[0];
+    if (rc) return rc;
+    if (hn[1] != 0) {
+      h->err = "align (split-scan): another rank could not start; all ranks give up together";
+      return LSGPU_NO_CONVERGENCE;
+    }
+  }
 
   // step 6: the loop runs on the device.  Every iteration is {kNN, select x3, normal equations,
   // update}; k_icp_update solves, moves T_iter, runs the checkers and raises `done`, after which the
@@ -1273,21 +1467,11 @@ int lsgpu_icp_align(lsgpu_icp* h, const float* reading_xyz1, int64_t nq, const f
     HIPC(hipMemcpyAsync(h->chk_hist.p, hh, 8 * sizeof(float), hipMemcpyHostToDevice, h->stream));
   }
   HIPC(hipMemcpyAsync(h->state.p, hst, sizeof(IcpState), hipMemcpyHostToDevice, h->stream));
-  HIPC(hipMemsetAsync(h->counters.p + 32, 0, 3 * sizeof(uint32_t), h->stream));  // stragglers, NE ticket, work-list length
+  HIPC(hipMemsetAsync(h->counters.p + 32, 0, 3 * sizeof(uint32_t), h->stream));  // stragglers, (unused), work-list length
+  HIPC(hipMemsetAsync(h->ne_tickets.p, 0, (size_t)(kNeBlocksMax / kNeGroup + 2) * sizeof(uint32_t), h->stream));
   HIPC(h->sel_aux.reserve(kSelFailFlag + 4));
   HIPC(hipMemsetAsync(h->sel_aux.p, 0, (kSelFailFlag + 4) * sizeof(uint32_t), h->stream));
 
-  int64_t nq_total = nq;
-  if (h->comm) {  // TrimmedDist ranks over ALL matches: the rank uses the global count
-    HIPC(h->comm_tmp.reserve(2));
-    long long* hn = reinterpret_cast<long long*>(h->h_pinned + 60);
-    *hn = (long long)nq;
-    HIPC(hipMemcpyAsync(h->comm_tmp.p, hn, sizeof(long long), hipMemcpyHostToDevice, h->stream));
-    RCCLC(rccl_api()->AllReduce(h->comm_tmp.p, h->comm_tmp.p + 1, 1, ncclInt64, ncclSum, h->comm, h->stream));
-    HIPC(hipMemcpyAsync(hn, h->comm_tmp.p + 1, sizeof(long long), hipMemcpyDeviceToHost, h->stream));
-    HIPC(hipStreamSynchronize(h->stream));
-    nq_total = (int64_t)*hn;
-  }
   const uint32_t k = trim_rank(nq_total, h->cfg.trim_ratio);
   const int nb = std::min(kNeBlocks, nblk(nq));
   const bool timed = h->cfg.profile_kernels != 0;
@@ -1310,9 +1494,11 @@ int lsgpu_icp_align(lsgpu_icp* h, const float* reading_xyz1, int64_t nq, const f
     r = run_select(h, h->d2.p, (int)nq, k, first_select, h->state.p, true, predicted);         // 6c
     first_select = false;
     if (r) return r;
+    lsgpu_icp::KnnEv* ev = (timed && knn && h->knn_events_used) ? &h->knn_events[h->knn_events_used - 1] : nullptr;
+    if (ev) HIPC(hipEventRecord(ev->d, h->stream));
     hipLaunchKernelGGL(k_normal_eq_loop, dim3(nb), dim3(256), 0, h->stream, h->rdq.p, (int)nq,
                        h->state.p, h->prev.p, h->d2.p, h->nrm.p, h->hist.p, h->sel.p + 2,
-                       h->counters.p + 32, h->counters.p + 33, h->ne_partials.p, h->ne_out.p,
+                       h->counters.p + 32, h->ne_tickets.p, h->ne_partials.p, h->ne_gpartials.p, h->ne_out.p,
                        h->chk_hist.p, h->trace_dev.p, max_it, capped ? 1 : 0, h->comm ? 0 : 1,
                        h->comm ? (uint32_t*)nullptr : h->sel_aux.p);                            // 6d (+6e)
     if (h->comm) {   // split scan: every rank gets the sums over all shards (the limit, slot 29, is already global)
@@ -1323,12 +1509,12 @@ int lsgpu_icp_align(lsgpu_icp* h, const float* reading_xyz1, int64_t nq, const f
       hipLaunchKernelGGL(k_icp_update, dim3(1), dim3(64), 0, h->stream, h->state.p, h->ne_out.p,
                          h->chk_hist.p, h->trace_dev.p, max_it, capped ? 1 : 0);           // 6d+6e
     }
+    if (ev) HIPC(hipEventRecord(ev->e, h->stream));
     return hipGetLastError() == hipSuccess ? LSGPU_OK : LSGPU_HIP_ERROR;
   };
   auto fetch_state = [&]() -> int {
     HIPC(hipMemcpyAsync(hst, h->state.p, sizeof(IcpState), hipMemcpyDeviceToHost, h->stream));
-    HIPC(hipStreamSynchronize(h->stream));
-    return LSGPU_OK;
+    return wait_stream(h);  // (bounded in the split-scan mode: a dead peer must not hang this rank)
   };
 
   // the first launches still have wide balls: their spread waves go to the wave-per-query pass
@@ -1420,6 +1606,9 @@ int lsgpu_icp_align(lsgpu_icp* h, const float* reading_xyz1, int64_t nq, const f
       if (st.knn_launches >= it + st.cap_retries) break;  // the rest exited immediately (enqueued past the end)
       if (m1 < 0.02f) continue;  // exited immediately (enqueued behind an iteration that had to be repeated)
       st.t_knn_main_ms += m1; st.t_knn_fallback_ms += m2; st.t_knn_ms += m1 + m2; st.knn_launches++;
+      float m3 = 0.f, m4 = 0.f;
+      if (hipEventElapsedTime(&m3, e.c, e.d) == hipSuccess && hipEventElapsedTime(&m4, e.d, e.e) == hipSuccess) { st.t_select_ms += m3; st.t_ne_ms += m4; }
+      else (void)hipGetLastError();
       if (t < h->trace.size()) { h->trace[t].knn_main_us = m1 * 1e3f; h->trace[t].knn_fallback_us = m2 * 1e3f; ++t; }
     }
   }

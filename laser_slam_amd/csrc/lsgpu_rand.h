@@ -30,6 +30,16 @@ class DrawStream {
     commit_locked(k);
   }
 
+  // one raw draw: the integer std::rand() would return (FixStepSampling's `rand() % step`)
+  uint32_t take_raw(int64_t seed) {
+    std::lock_guard<std::mutex> g(mu_);
+    if (seed >= 0) reseed_locked((unsigned)seed);
+    generate_locked(1, nullptr);
+    const uint32_t r = raw_[31] >> 1;
+    commit_locked(1);
+    return r;
+  }
+
   // Speculative use: begin() locks the stream and produces up to kmax draws WITHOUT consuming them,
   // commit(k) consumes the first k <= kmax of them and unlocks.  (The device filters learn how many
   // draws the sequential filter would have made only after their kernels ran; the draws themselves are

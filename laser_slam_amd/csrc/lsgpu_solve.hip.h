@@ -155,6 +155,7 @@ __global__ __launch_bounds__(256) void k_seed_cap(const uint32_t* __restrict__ h
 // accumulate 21 upper-tri J J^T, 6 of -J r, count, r^2 in double.  Per-block partials, then a
 // single-block fixed-order reduction => bitwise reproducible.
 constexpr int kNe = 29;
+constexpr int kNeGroup = 16;   // k_normal_eq_loop: blocks per first-level reduction group
 
 template <bool IDS_ORIG, bool LIMIT_DEV>
 __global__ __launch_bounds__(256) void k_normal_eq(const float4* __restrict__ rdq, int nq, Mat34 T,
@@ -303,8 +304,9 @@ __global__ __launch_bounds__(256) void k_normal_eq_loop(const float4* __restrict
                                                         uint32_t* __restrict__ hist,  // 3 x kHistBins
                                                         const SelState* __restrict__ st,
                                                         uint32_t* __restrict__ strag_count,
-                                                        uint32_t* __restrict__ ticket,
+                                                        uint32_t* __restrict__ ticket,  // [0] groups done, [1 + g] blocks of group g done
                                                         double* __restrict__ partials,
+                                                        double* __restrict__ gpartials,
                                                         double* __restrict__ out /* 32 doubles */,
                                                         float* __restrict__ chk_hist,
                                                         lsgpu_iter_trace* __restrict__ trace, int trace_cap,
@@ -375,51 +377,63 @@ __global__ __launch_bounds__(256) void k_normal_eq_loop(const float4* __restrict
   if (threadIdx.x < kNe)
     partials[(size_t)blockIdx.x * 32 + threadIdx.x] =
         ((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x];
-  // ---- publish, take a ticket
+  // ---- publish.  Two-level, fixed-order reduction of the block partials (bitwise reproducible whichever block
+  // ends up doing it): blocks form groups of kNeGroup; the LAST block of a group to finish sums that group's rows in
+  // row order into a group partial, the LAST group to finish sums the group partials in group order.  Two short
+  // dependent rounds (<= 16 rows, <= 128 rows with 16 loads in flight) instead of one block walking every row: the
+  // single-block walk was half of this kernel's time (partials of other XCDs come from memory, ~1-2 us per round).
+  const uint32_t g_id = blockIdx.x / kNeGroup, n_grp = (gridDim.x + kNeGroup - 1) / kNeGroup;
+  const uint32_t g_first = g_id * kNeGroup;
+  const uint32_t g_size = gridDim.x - g_first < (uint32_t)kNeGroup ? gridDim.x - g_first : (uint32_t)kNeGroup;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const uint32_t t = __hip_atomic_fetch_add(ticket + 1 + g_id, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    is_last = (t == g_size - 1);
+  }
+  __syncthreads();
+  if (!is_last) return;
+  if (threadIdx.x == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  __syncthreads();
+  if (threadIdx.x < 32) {  // the group's rows, in row order
+    double v[kNeGroup];
+#pragma unroll
+    for (int u = 0; u < kNeGroup; ++u)
+      v[u] = ((uint32_t)u < g_size && threadIdx.x < kNe) ? partials[(size_t)(g_first + u) * 32 + threadIdx.x] : 0.0;
+    double sgrp = 0.0;
+#pragma unroll
+    for (int u = 0; u < kNeGroup; ++u) sgrp += v[u];
+    gpartials[(size_t)g_id * 32 + threadIdx.x] = sgrp;
+  }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   if (threadIdx.x == 0) {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     const uint32_t t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    is_last = (t == gridDim.x - 1);
+    is_last = (t == n_grp - 1);
   }
   __syncthreads();
   if (!is_last) return;
   if (threadIdx.x == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
   __syncthreads();
-  // ---- fixed-order final reduction: 8 groups of 32 columns, group r sums rows r, r+8, ...
-  {
-    const int col = threadIdx.x & 31, grp = threadIdx.x >> 5;
-    double s = 0.0;
-    if (col < kNe) {
-      const int nb = (int)gridDim.x;
-      int b = grp;
-      for (; b + 120 < nb; b += 128) {  // 16 independent loads in flight, summed in row order
-        double v[16];
-#pragma unroll
-        for (int u = 0; u < 16; ++u) v[u] = partials[(size_t)(b + 8 * u) * 32 + col];
-#pragma unroll
-        for (int u = 0; u < 16; ++u) s += v[u];
-      }
-      for (; b + 56 < nb; b += 64) {  // 8 independent loads in flight, summed in row order
-        const double v0 = partials[(size_t)b * 32 + col], v1 = partials[(size_t)(b + 8) * 32 + col];
-        const double v2 = partials[(size_t)(b + 16) * 32 + col], v3 = partials[(size_t)(b + 24) * 32 + col];
-        const double v4 = partials[(size_t)(b + 32) * 32 + col], v5 = partials[(size_t)(b + 40) * 32 + col];
-        const double v6 = partials[(size_t)(b + 48) * 32 + col], v7 = partials[(size_t)(b + 56) * 32 + col];
-        s = ((((((((s + v0) + v1) + v2) + v3) + v4) + v5) + v6) + v7);
-      }
-      for (; b < nb; b += 8) s += partials[(size_t)b * 32 + col];
-    }
-    red[grp][col] = s;
-  }
-  __syncthreads();
-  if (threadIdx.x < kNe) {
+  if (threadIdx.x < 32) {  // the group partials, in group order
     double t = 0.0;
-    for (int r = 0; r < 8; ++r) t += red[r][threadIdx.x];
-    out[threadIdx.x] = t;
-    fin[threadIdx.x] = t;
+    uint32_t gidx = 0;
+    for (; gidx + 16 <= n_grp; gidx += 16) {
+      double v[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) v[u] = gpartials[(size_t)(gidx + u) * 32 + threadIdx.x];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) t += v[u];
+    }
+    for (; gidx < n_grp; ++gidx) t += gpartials[(size_t)gidx * 32 + threadIdx.x];
+    if (threadIdx.x < kNe) { out[threadIdx.x] = t; fin[threadIdx.x] = t; }
   }
+  for (uint32_t i = threadIdx.x; i < n_grp; i += 256)  // re-arm the group tickets (every group is done)
+    __hip_atomic_store(ticket + 1 + i, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   if (threadIdx.x == 32) {
     const double ns = (double)__hip_atomic_load(strag_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     out[29] = (double)limit; fin[29] = (double)limit;

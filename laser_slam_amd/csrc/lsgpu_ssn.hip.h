@@ -390,4 +390,61 @@ __global__ __launch_bounds__(256) void k_voxel_centroids(const float4* __restric
   kept[i] = k;
 }
 
+// ---------------------------------------------------------------- input filter chain (include/lsgpu_icp.h)
+// One predicate per launch: keep[i] = 1 if point i survives filter f.  laser_slam/src/laser_track.cpp:146
+// (input_filters_.apply(scan.scan)); semantics restated in the header.
+struct PointFilterDev {
+  int type, dim, flag;
+  float v[6];
+  uint32_t step, phase;  // FixStepSampling
+};
+
+__global__ __launch_bounds__(256) void k_point_filter_select(const float4* __restrict__ src, int n, PointFilterDev f,
+                                                             const float* __restrict__ draws,
+                                                             uint32_t* __restrict__ keep) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const float4 p = src[i];
+  bool k = true;
+  if (f.type == 1 || f.type == 2) {  // Max / MinDist
+    const float val = f.dim < 0 ? sqrtf(__fmaf_rn(p.z, p.z, __fmaf_rn(p.y, p.y, p.x * p.x)))
+                                : fabsf(f.dim == 0 ? p.x : f.dim == 1 ? p.y : p.z);
+    k = f.type == 1 ? val < f.v[0] : val > f.v[0];
+  } else if (f.type == 3) {          // BoundingBox
+    const bool in = p.x > f.v[0] && p.x < f.v[1] && p.y > f.v[2] && p.y < f.v[3] && p.z > f.v[4] && p.z < f.v[5];
+    k = f.flag ? !in : in;
+  } else if (f.type == 4) {          // FixStepSampling
+    k = (uint32_t)i >= f.phase && ((uint32_t)i - f.phase) % f.step == 0u;
+  } else if (f.type == 5) {          // RandomSampling
+    k = draws[i] < f.v[0];
+  }
+  keep[i] = k ? 1u : 0u;
+}
+
+// ---------------------------------------------------------------- PointCloud2 <-> x,y,z,1 (include/lsgpu_icp.h)
+__device__ __forceinline__ float pc2_field(const unsigned char* __restrict__ rec, int off, int big) {
+  const uint32_t b0 = rec[off], b1 = rec[off + 1], b2 = rec[off + 2], b3 = rec[off + 3];  // any alignment
+  const uint32_t u = big ? (b0 << 24) | (b1 << 16) | (b2 << 8) | b3 : b0 | (b1 << 8) | (b2 << 16) | (b3 << 24);
+  return __uint_as_float(u);
+}
+// rosMsgToPointMatcherCloud<float> (laser_slam_worker.cpp:125): record i -> out[i] = {x, y, z, 1}; keep[i] = finite
+__global__ __launch_bounds__(256) void k_pc2_unpack(const unsigned char* __restrict__ data, int n, int step, int ox,
+                                                    int oy, int oz, int big, int drop, float4* __restrict__ out,
+                                                    uint32_t* __restrict__ keep) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const unsigned char* rec = data + (size_t)i * (size_t)step;
+  const float x = pc2_field(rec, ox, big), y = pc2_field(rec, oy, big), z = pc2_field(rec, oz, big);
+  out[i] = make_float4(x, y, z, 1.f);
+  const bool fin = isfinite(x) && isfinite(y) && isfinite(z);
+  keep[i] = (!drop || fin) ? 1u : 0u;
+}
+// lpmToPcl / pcl::toROSMsg<PointXYZ> (common.hpp:159-191): the same 16-byte records, padding written as 1
+__global__ __launch_bounds__(256) void k_pc2_pack(const float4* __restrict__ in, int64_t n, float4* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const float4 p = in[i];
+  out[i] = make_float4(p.x, p.y, p.z, 1.f);
+}
+
 }  // namespace lsgpu

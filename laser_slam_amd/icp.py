@@ -41,6 +41,10 @@ def _as_f32(x, cols: int):
             x = x.to(torch.float32).contiguous()
         if x.dim() != 2 or x.shape[1] != cols:
             raise ValueError(f"expected (N,{cols}) tensor, got {tuple(x.shape)}")
+        if x.is_cuda:
+            # stream contract of include/lsgpu_icp.h: the library works on the handle's own (non-blocking) stream, so
+            # whatever torch still has in flight for this tensor -- including the copy made just above -- must be done
+            torch.cuda.current_stream(x.device).synchronize()
         return (x.data_ptr() if x.numel() else None), x, x.shape[0]
     a = np.ascontiguousarray(x, np.float32)
     if a.ndim != 2 or a.shape[1] != cols:
@@ -80,6 +84,7 @@ class IcpHandle:
             cfg = IcpConfig()
             L.lsgpu_icp_config_yaml(C.byref(cfg))
         self.cfg = cfg
+        self.device = device
         self._h = C.c_void_p()
         rc = L.lsgpu_icp_create(C.byref(cfg), device, C.byref(self._h))
         if rc != _lib.OK:
@@ -226,6 +231,51 @@ class IcpHandle:
         if rc != _lib.OK:
             _raise(rc, "lsgpu_filter_voxel_grid", self._h)
         return o[:m.value]
+
+    # ---- the input filter chain (laser_track.cpp:24-30, :146)
+    def apply_point_filters(self, filters, xyz1, seed: int = -1):
+        """`filters`: ctypes array of _lib.PointFilter (FixStepSampling's `state` is updated in place)."""
+        p, _k, n = _as_f32(xyz1, 4)
+        o, po = self._filter_out(xyz1, n)
+        m = C.c_int64(0)
+        rc = _lib.lib().lsgpu_apply_point_filters(self._h, filters, len(filters), p, n, seed, po, C.byref(m))
+        if rc != _lib.OK:
+            _raise(rc, "lsgpu_apply_point_filters", self._h)
+        return o[:m.value]
+
+    # ---- ROS message surface: sensor_msgs/PointCloud2 data block <-> x,y,z,1 (laser_slam_worker.cpp:125, common.hpp:159-191)
+    def cloud_from_pointcloud2(self, data, n_points: int, point_step: int, off_x: int, off_y: int, off_z: int,
+                               is_bigendian: bool = False, is_dense: bool = True, device_out: bool = False):
+        """`data`: bytes / uint8 numpy array / uint8 torch tensor holding n_points records of point_step bytes."""
+        if _is_torch(data):
+            if data.is_cuda:
+                torch.cuda.current_stream(data.device).synchronize()
+            keep, p = data, data.data_ptr()
+        else:
+            keep = np.frombuffer(data, np.uint8) if isinstance(data, (bytes, bytearray, memoryview)) else np.ascontiguousarray(data, np.uint8)
+            p = keep.ctypes.data
+        if device_out:
+            o = torch.empty((max(n_points, 1), 4), dtype=torch.float32, device=f"cuda:{self.device}")
+            torch.cuda.synchronize()
+            po = o.data_ptr()
+        else:
+            o = np.empty((max(n_points, 1), 4), np.float32)
+            po = o.ctypes.data
+        m = C.c_int64(0)
+        rc = _lib.lib().lsgpu_cloud_from_pointcloud2(self._h, p, n_points, point_step, off_x, off_y, off_z,
+                                                     int(is_bigendian), int(not is_dense), po, C.byref(m))
+        if rc != _lib.OK:
+            _raise(rc, "lsgpu_cloud_from_pointcloud2", self._h)
+        return o[:m.value]
+
+    def cloud_to_pointxyz(self, xyz1) -> np.ndarray:
+        """x,y,z,1 -> the data block (uint8, 16 bytes per point) of a PointCloud2 / pcl::PointCloud<PointXYZ>."""
+        p, _k, n = _as_f32(xyz1, 4)
+        o = np.empty(16 * max(n, 1), np.uint8)
+        rc = _lib.lib().lsgpu_cloud_to_pointxyz(self._h, p, n, o.ctypes.data)
+        if rc != _lib.OK:
+            _raise(rc, "lsgpu_cloud_to_pointxyz", self._h)
+        return o[:16 * n]
 
     # ---- clouds kept in HBM between calls; sub-map assembly on the device (laser_track.cpp:474-486)
     def cloud_upload(self, slot: int, xyz1):
@@ -455,8 +505,12 @@ class ICP:
                 doc = yaml.safe_load(stream)
         if not isinstance(doc, dict):
             raise LsgpuError(_lib.BAD_CONFIG, "load_from_yaml", "not a YAML mapping")
-        ch = ChainConfig(reading_sampling_prob=0.75, surface_normal_knn=7, trim_ratio=0.85,
-                         min_diff_trans=0.001, smooth_length=3)  # module defaults
+        # libpointmatcher's loadFromYaml starts from EMPTY chains: a section the file does not mention means "no such
+        # module".  No reading filter = every point (prob 1), no outlier filter = every pair (ratio 1), no differential
+        # checker = only the counter stops the loop; the modules the device loop cannot run without are required.
+        ch = ChainConfig(reading_sampling_prob=1.0, surface_normal_knn=7, trim_ratio=1.0,
+                         min_diff_rot=-1.0, min_diff_trans=-1.0, smooth_length=1)
+        seen = set()
 
         def modules(section):
             v = doc.get(section)
@@ -477,6 +531,9 @@ class ICP:
                 if name not in allowed:
                     raise LsgpuError(_lib.BAD_CONFIG, "load_from_yaml",
                                      f"{section}: module {name} is not implemented on the HIP path")
+                if name in seen and name != "KDTreeMatcher":
+                    raise LsgpuError(_lib.BAD_CONFIG, "load_from_yaml", f"{section}: {name} given twice")
+                seen.add(name)
                 if name == "RandomSamplingDataPointsFilter":
                     ch.reading_sampling_prob = float(params.get("prob", 0.75))
                 elif name == "SamplingSurfaceNormalDataPointsFilter":
@@ -498,6 +555,11 @@ class ICP:
                     ch.smooth_length = int(params.get("smoothLength", 3))
         if modules("readingStepDataPointsFilters"):
             raise LsgpuError(_lib.BAD_CONFIG, "load_from_yaml", "readingStepDataPointsFilters")
+        for need, why in (("SamplingSurfaceNormalDataPointsFilter", "it provides the normals"),
+                          ("KDTreeMatcher", "the matcher"), ("PointToPlaneErrorMinimizer", "the error minimizer"),
+                          ("CounterTransformationChecker", "the loop would not stop")):
+            if need not in seen:
+                raise LsgpuError(_lib.BAD_CONFIG, "load_from_yaml", f"{need} is required ({why})")
         # inspector / logger (yaml:32-44) only produce debug dumps: accepted and ignored
         self.chain = ch
         self._handle = None

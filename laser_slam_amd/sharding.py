@@ -48,8 +48,13 @@ def gather_results(local: List[Tuple[int, object]]):
 
 def split_shard(n_points: int, rank: int, world: int):
     """Contiguous query shard of rank `rank` for the split-scan mode (BASELINE config 4): slice object."""
-    per = (n_points + world - 1) // world
-    return slice(min(rank * per, n_points), min((rank + 1) * per, n_points))
+    # balanced: the first n % world ranks get one point more, so every rank owns >= 1 point whenever n >= world
+    # (an empty shard would leave its rank out of the per-iteration collectives)
+    if n_points < world:
+        raise ValueError(f"split-scan mode needs at least one point per rank ({n_points} points, {world} ranks)")
+    base, extra = divmod(n_points, world)
+    start = rank * base + min(rank, extra)
+    return slice(start, start + base + (1 if rank < extra else 0))
 
 
 def init_split_comm(handle, device=None):

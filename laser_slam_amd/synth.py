@@ -219,8 +219,9 @@ class FieldScene(Scene):
             for k in np.nonzero(np.hypot(bc[:, 0] - o[0], bc[:, 1] - o[1]) < self.cull)[0]:
                 t1 = (self.box_lo[k] - o) * inv
                 t2 = (self.box_hi[k] - o) * inv
-                tn = np.nanmax(np.minimum(t1, t2), axis=1)
-                tf = np.nanmin(np.maximum(t1, t2), axis=1)
+                lo_, hi_ = np.minimum(t1, t2), np.maximum(t1, t2)
+                tn = np.fmax(np.fmax(lo_[:, 0], lo_[:, 1]), lo_[:, 2])   # (fmax / fmin skip NaNs like nanmax / nanmin)
+                tf = np.fmin(np.fmin(hi_[:, 0], hi_[:, 1]), hi_[:, 2])
                 hit = (tf >= tn) & (tf > 0)
                 tb = np.where(tn > 0, tn, tf)
                 tb[~hit] = np.inf

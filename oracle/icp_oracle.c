@@ -942,3 +942,53 @@ int64_t lso_voxel_grid(const float* xyz1, int64_t n, const float leaf[3], int mi
   free(pr);
   return m;
 }
+
+/* ------------------------------------------------------------------ input filter chain (K0) */
+/* laser_slam/src/laser_track.cpp:146  input_filters_.apply(scan.scan).  DataPointsFilters::apply runs the
+ * filters in order and throws ConvergenceError("no points to filter") when one of them receives an empty cloud. */
+int64_t lso_apply_point_filters(lso_point_filter* filters, int n_filters, const float* xyz1, int64_t n,
+                                int64_t seed, float* out_xyz1) {
+  if (seed >= 0) srand((unsigned)seed);
+  if (n <= 0) return 0;
+  float* cur = (float*)malloc(sizeof(float) * 4 * (size_t)n);
+  memcpy(cur, xyz1, sizeof(float) * 4 * (size_t)n);
+  int64_t m = n;
+  for (int k = 0; k < n_filters; ++k) {
+    lso_point_filter* f = &filters[k];
+    if (m == 0) { free(cur); return -1; }
+    int64_t o = 0;
+    uint32_t step = 1, phase = 0;
+    if (f->type == 4) { /* FixStepSamplingDataPointsFilter::inPlaceFilter */
+      double st = f->state > 0.0 ? f->state : (double)f->v[0];
+      const int istep = (int)st < 1 ? 1 : (int)st;
+      step = (uint32_t)istep;
+      phase = (uint32_t)rand() % (uint32_t)istep;
+      const double delta = (double)f->v[0] * (double)f->v[2] - (double)f->v[0];
+      st *= (double)f->v[2];
+      if (delta >= 0 && st > (double)f->v[1]) st = (double)f->v[1];
+      if (delta < 0 && st < (double)f->v[1]) st = (double)f->v[1];
+      f->state = st;
+    }
+    for (int64_t i = 0; i < m; ++i) {
+      const float x = cur[4 * i], y = cur[4 * i + 1], z = cur[4 * i + 2];
+      int keep = 1;
+      if (f->type == 1 || f->type == 2) {
+        const float val = f->dim < 0 ? sqrtf(fmaf(z, z, fmaf(y, y, x * x))) : fabsf(f->dim == 0 ? x : f->dim == 1 ? y : z);
+        keep = f->type == 1 ? (val < f->v[0]) : (val > f->v[0]);
+      } else if (f->type == 3) {
+        const int in = x > f->v[0] && x < f->v[1] && y > f->v[2] && y < f->v[3] && z > f->v[4] && z < f->v[5];
+        keep = f->flag ? !in : in;
+      } else if (f->type == 4) {
+        keep = (uint64_t)i >= phase && ((uint64_t)i - phase) % step == 0;
+      } else if (f->type == 5) {
+        const float r = (float)rand() / (float)RAND_MAX;
+        keep = r < f->v[0];
+      }
+      if (keep) { if (o != i) memcpy(cur + 4 * o, cur + 4 * i, 16); ++o; }
+    }
+    m = o;
+  }
+  memcpy(out_xyz1, cur, sizeof(float) * 4 * (size_t)m);
+  free(cur);
+  return m;
+}

@@ -126,6 +126,23 @@ int64_t lso_cylinder_filter(const float* xyz1, int64_t n, const float center[3],
  * Returns the number of output points, or -1 if the index would overflow an int (PCL refuses as well). */
 int64_t lso_voxel_grid(const float* xyz1, int64_t n, const float leaf[3], int min_points, float* out_xyz1);
 
+/* ---- the input filter chain: laser_slam/src/laser_track.cpp:24-30 loads a libpointmatcher
+ * DataPointsFilters chain, :81 and :146 apply it to every incoming scan.  The chain file is not in the reference
+ * repository; this restates the published semantics of the five filters the HIP path supports (libpointmatcher
+ * DataPointsFilters/{MaxDist,MinDist,BoundingBox,FixStepSampling,RandomSampling}.cpp), one after the other, each on
+ * the output of the previous one.  Field meaning as in include/lsgpu_icp.h (lsgpu_point_filter); draws: libc rand().
+ * Returns the number of output points, or -1 if a filter is handed an empty cloud ("no points to filter"). */
+typedef struct lso_point_filter {
+  int    type;    /* 1 MaxDist, 2 MinDist, 3 BoundingBox, 4 FixStepSampling, 5 RandomSampling */
+  int    dim;
+  int    flag;
+  int    pad_;
+  float  v[6];
+  double state;
+} lso_point_filter;
+int64_t lso_apply_point_filters(lso_point_filter* filters, int n_filters, const float* xyz1, int64_t n,
+                                int64_t seed, float* out_xyz1);
+
 #ifdef __cplusplus
 }
 #endif

@@ -276,3 +276,20 @@ def voxel_grid(xyz1, leaf, min_points=1):
     if m < 0:
         raise OverflowError("voxel index overflows an int")
     return out[:m].copy()
+
+
+class PointFilter(C.Structure):
+    """lso_point_filter: same layout as lsgpu_point_filter."""
+    _fields_ = [("type", C.c_int), ("dim", C.c_int), ("flag", C.c_int), ("pad_", C.c_int), ("v", C.c_float * 6),
+                ("state", C.c_double)]
+
+
+def apply_point_filters(filters, xyz1, seed=-1):
+    """Input filter chain (laser_track.cpp:146).  Returns the filtered cloud, or None if a filter got an empty cloud."""
+    L = lib()
+    L.lso_apply_point_filters.argtypes = [C.POINTER(PointFilter), C.c_int, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p]
+    L.lso_apply_point_filters.restype = C.c_int64
+    a = np.ascontiguousarray(xyz1, np.float32)
+    out = np.empty((max(a.shape[0], 1), 4), np.float32)
+    m = L.lso_apply_point_filters(filters, len(filters), a.ctypes.data, a.shape[0], seed, out.ctypes.data)
+    return None if m < 0 else out[:m]

@@ -13,6 +13,9 @@ static int fails = 0;
 #define CHECK(c) do { if (!(c)) { std::printf("FAIL %s:%d %s\n", __FILE__, __LINE__, #c); ++fails; } } while (0)
 
 int main(int argc, char** argv) {
+  const std::string golden = std::getenv("LSGPU_GOLDEN_DIR") ? std::getenv("LSGPU_GOLDEN_DIR") : "tests/golden";
+  const std::string no_filters = golden + "/input_filters_none.yaml";
+
   // --- YAML
   {
     ICP icp;
@@ -30,9 +33,12 @@ int main(int argc, char** argv) {
     CHECK(icp.config().max_iterations == 40 && icp.config().smooth_length == 4);
     CHECK(std::fabs(icp.config().min_diff_trans - 0.01f) < 1e-7f);
     CHECK(std::fabs(icp.readingSamplingProb() - 0.5f) < 1e-7f && icp.surfaceNormalKnn() == 10);
-    std::stringstream inl("outlierFilters:\n  - TrimmedDistOutlierFilter: {ratio: 0.9}\nerrorMinimizer: PointToPlaneErrorMinimizer\n");
+    std::stringstream inl("referenceDataPointsFilters:\n  - SamplingSurfaceNormalDataPointsFilter\nmatcher: KDTreeMatcher\n"
+                          "outlierFilters:\n  - TrimmedDistOutlierFilter: {ratio: 0.9}\nerrorMinimizer: PointToPlaneErrorMinimizer\n"
+                          "transformationCheckers:\n  - CounterTransformationChecker\n  - DifferentialTransformationChecker\n");
     icp.loadFromYaml(inl);
-    CHECK(std::fabs(icp.config().trim_ratio - 0.9f) < 1e-7f && icp.config().smooth_length == 3);
+    CHECK(std::fabs(icp.config().trim_ratio - 0.9f) < 1e-7f && icp.config().smooth_length == 3);   // module defaults
+    CHECK(icp.surfaceNormalKnn() == 7 && icp.config().max_iterations == 40);
     icp.setDefault();
     CHECK(std::fabs(icp.config().trim_ratio - 0.85f) < 1e-7f && icp.surfaceNormalKnn() == 7);
     bool threw = false;
@@ -80,7 +86,14 @@ int main(int argc, char** argv) {
   {
     LaserTrackParams p;
     p.use_icp_factors = false;
+    {  // laser_track.cpp:24-30: an unreadable input-filter file is fatal
+      bool fatal = false;
+      try { LaserTrack t(p, 0u); } catch (const ConfigError&) { fatal = true; }
+      CHECK(fatal);
+    }
+    p.icp_input_filters_file = no_filters;
     LaserTrack track(p, 2u);
+    CHECK(track.inputFilters().empty());
     bool threw = false;
     LaserScan s; s.time_ns = 5; s.scan.features = {0, 0, 0, 1};
     try { track.processLaserScan(s); } catch (const std::logic_error&) { threw = true; }  // no pose registered
@@ -190,6 +203,7 @@ int main(int argc, char** argv) {
   // the first-association noise model is used, and both trajectories end up in one frame
   {
     EstimatorParams ep;
+    ep.laser_track_params.icp_input_filters_file = no_filters;
     ep.laser_track_params.use_icp_factors = false;
     ep.laser_track_params.force_priors = true;
     ep.laser_track_params.odometry_noise_model = {0.05, 0.05, 0.05, 0.01, 0.01, 0.01};
@@ -239,6 +253,7 @@ int main(int argc, char** argv) {
   // IncrementalEstimator::registerPrior / estimate / estimateAndRemove exactly like the worker does
   {
     EstimatorParams ep;
+    ep.laser_track_params.icp_input_filters_file = no_filters;
     ep.laser_track_params.use_icp_factors = false;
     IncrementalEstimator est(ep, 1u);
     const int n = 240;
@@ -294,6 +309,80 @@ int main(int argc, char** argv) {
     CHECK(e_dead > 1.0);                      // the biased odometry alone is metres off
     CHECK(e_graph < 0.05 && e_graph < e_dead / 40);
     CHECK(est.graph().numFactors() == (size_t)(1 + 2 * (n - 1) + 2));
+  }
+  // --- the input filter chain file (laser_track.cpp:24-30): libpointmatcher's YAML list -> device filter descriptors
+  {
+    std::ifstream f(golden + "/input_filters.yaml");
+    CHECK(f.good());
+    DataPointsFilters chain(f);
+    CHECK(chain.size() == 5);
+    const auto& m = chain.modules();
+    CHECK(m[0].type == LSGPU_FILTER_BOUNDING_BOX && m[0].flag == 1 && m[0].v[0] == -1.5f && m[0].v[5] == 0.5f);
+    CHECK(m[1].type == LSGPU_FILTER_MAX_DIST && m[1].dim == -1 && m[1].v[0] == 60.f);
+    CHECK(m[2].type == LSGPU_FILTER_MIN_DIST && m[2].v[0] == 2.5f);
+    CHECK(m[3].type == LSGPU_FILTER_FIX_STEP_SAMPLING && m[3].v[0] == 3.f && m[3].v[1] == 5.f && std::fabs(m[3].v[2] - 1.3f) < 1e-6f);
+    CHECK(m[4].type == LSGPU_FILTER_RANDOM_SAMPLING && m[4].v[0] == 0.8f);
+    std::istringstream unknown("- SurfaceNormalDataPointsFilter: {knn: 5}\n");
+    bool threw = false;
+    try { DataPointsFilters bad(unknown); } catch (const ConfigError&) { threw = true; }
+    CHECK(threw);
+    std::istringstream typo("- MaxDistDataPointsFilter: {maxDistance: 5}\n");
+    threw = false;
+    try { DataPointsFilters bad(typo); } catch (const ConfigError&) { threw = true; }
+    CHECK(threw);
+    std::istringstream none("# nothing\n");
+    DataPointsFilters empty(none);
+    CHECK(empty.empty());
+    DataPoints d; d.features = {1, 2, 3, 1};
+    empty.apply(d);  // an empty chain touches neither the cloud nor the GPU
+    CHECK(d.getNbPoints() == 1);
+  }
+  // --- loadFromYaml starts from EMPTY chains: an absent section is "no module", not "the default module"
+  {
+    ICP icp;
+    std::istringstream y("referenceDataPointsFilters:\n  - SamplingSurfaceNormalDataPointsFilter: {knn: 9}\n"
+                         "matcher:\n  KDTreeMatcher: {knn: 1}\nerrorMinimizer: PointToPlaneErrorMinimizer\n"
+                         "transformationCheckers:\n  - CounterTransformationChecker: {maxIterationCount: 12}\n");
+    icp.loadFromYaml(y);
+    CHECK(icp.readingSamplingProb() == 1.0f);        // no reading filter: every point
+    CHECK(icp.config().trim_ratio == 1.0f);          // no outlier filter: every pair
+    CHECK(icp.surfaceNormalKnn() == 9 && icp.config().max_iterations == 12);
+    CHECK(icp.config().min_diff_rot < 0.f);          // no differential checker: only the counter stops the loop
+    std::istringstream no_counter("referenceDataPointsFilters:\n  - SamplingSurfaceNormalDataPointsFilter\n"
+                                  "matcher:\n  KDTreeMatcher\nerrorMinimizer: PointToPlaneErrorMinimizer\n");
+    bool threw = false;
+    try { icp.loadFromYaml(no_counter); } catch (const ConfigError&) { threw = true; }
+    CHECK(threw);
+    std::istringstream no_normals("matcher:\n  KDTreeMatcher\nerrorMinimizer: PointToPlaneErrorMinimizer\n"
+                                  "transformationCheckers:\n  - CounterTransformationChecker\n");
+    threw = false;
+    try { icp.loadFromYaml(no_normals); } catch (const ConfigError&) { threw = true; }
+    CHECK(threw);
+  }
+  // --- processLaserScan runs the ICP BEFORE it stores the scan (laser_track.cpp:112-119), processPoseAndLaserScan
+  // after (:197-206): with three scans the first records one transformation (scan 0 -> 1), the second two
+  {
+    auto fake = [](const ICP&, const DataPoints&, const DataPoints&, const TransformationParameters& T) { return T; };
+    LaserTrackParams p;
+    p.icp_input_filters_file = no_filters;
+    LaserTrack a(p, 0u), b(p, 0u);
+    a.icp().setComputeOverride(fake);
+    b.icp().setComputeOverride(fake);
+    for (int i = 0; i < 3; ++i) {
+      Pose pose; pose.time_ns = 100 * (i + 1); pose.T_w = SE3({1, 0, 0, 0}, {0.8 * i, 0, 0});
+      LaserScan sc; sc.time_ns = pose.time_ns; sc.scan.features = {float(i), 0, 0, 1};
+      a.processPose(pose);
+      a.processLaserScan(sc);
+      b.processPoseAndLaserScan(pose, sc);
+    }
+    CHECK(a.getNumScans() == 3 && b.getNumScans() == 3);
+    CHECK(a.getIcpTransformations().size() == 1 && b.getIcpTransformations().size() == 2);
+    if (a.getIcpTransformations().size() == 1) {
+      CHECK(a.getIcpTransformations()[0].time_a_ns == 100 && a.getIcpTransformations()[0].time_b_ns == 200);
+      CHECK(std::fabs(a.getIcpTransformations()[0].T_a_b.position()[0] - 0.8) < 1e-6);
+    }
+    if (b.getIcpTransformations().size() == 2)
+      CHECK(b.getIcpTransformations()[1].time_a_ns == 200 && b.getIcpTransformations()[1].time_b_ns == 300);
   }
   // --- no GPU => loud error (only checked when asked, i.e. on the CPU-only container)
   if (argc > 1 && std::string(argv[1]) == "--expect-no-gpu") {

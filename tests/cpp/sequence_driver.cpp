@@ -1,0 +1,227 @@
+// sequence_driver.cpp -- BASELINE configs[4]: a long scan sequence through the C++ mirror, once with the device ICP
+// and once with the CPU oracle's ICP injected behind the SAME facade (ICP::setComputeOverride), in one pass over the
+// scan stream.  Per scan: LaserTrack::processPoseAndLaserScan (laser_slam/src/laser_track.cpp:122-231), then
+// IncrementalEstimator::registerPrior / estimate (incremental_estimator.cpp:151-163, 268-291) and
+// updateFromGTSAMValues, exactly the loop of LaserSlamWorker::scanCallback (laser_slam_ros/src/laser_slam_worker.cpp:
+// 133-176); loop closures go through IncrementalEstimator::processLoopClosure with the ICP step
+// (incremental_estimator.cpp:89-115).
+//
+//   usage: sequence_driver <icp_yaml> <nscan_in_sub_map> <lc_radius> <backends: dev|ora|both|shadow> <oracle_threads> < stream
+// "both": two independent runs (each feeds its own estimates back into its sub-maps and initial guesses).  "shadow":
+// the device run drives; at every ICP call the oracle aligns the SAME clouds from the SAME guess ("call" lines), and a
+// second pose graph receives the device run's factors with the oracle's transforms in place of the device's
+// ("pose sha" lines): the CPU-reference trajectory on identical inputs.  (Independent runs of this pipeline separate
+// by millimetres after a 1e-6 m change of a single ICP result -- trimmed ICP on 16 k-point scans is discontinuous at
+// that level -- so only the identical-input comparison can be held to 1e-4 m / 1e-5 rad per call.)
+// stream (little endian): int32 n_scans; per scan { int64 t_ns; double odom[7]; double truth[7]  (qw qx qy qz px py pz);
+//   int32 n_points; float xyz1[4 n]; int32 n_lc; int32 lc_with[n_lc] }  -- after scan i, one loop closure against each
+//   earlier scan lc_with[k]; the place recogniser is emulated: it reports the true relative pose off by 20 cm / 1 deg.
+// Output: "factor <backend> <scan> <key_a> <key_b> qw qx qy qz px py pz" per ICP factor, "lc <backend> ..." per loop
+// closure measurement, "pose <backend> <i> qw qx qy qz px py pz" for the final trajectory, "time <backend> <ms>".
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "laser_slam_amd/incremental_estimator.hpp"
+#include "../../oracle/icp_oracle.h"
+
+using namespace laser_slam_amd;
+
+static bool readAll(void* dst, size_t bytes) { return std::fread(dst, 1, bytes, stdin) == bytes; }
+
+static SE3 poseOf(const double v[7]) { return SE3({v[0], v[1], v[2], v[3]}, {v[4], v[5], v[6]}); }
+
+static void printPose(const char* tag, const char* be, long a, long b, long c, const SE3& T) {
+  std::printf("%s %s %ld %ld %ld %.17g %.17g %.17g %.17g %.17g %.17g %.17g\n", tag, be, a, b, c, T.quaternion()[0],
+              T.quaternion()[1], T.quaternion()[2], T.quaternion()[3], T.position()[0], T.position()[1], T.position()[2]);
+}
+
+struct Run {
+  std::string name;
+  std::unique_ptr<IncrementalEstimator> est;
+  std::shared_ptr<LaserTrack> track;
+  double ms = 0;
+  int icp_iterations = 0;
+};
+
+static int g_oracle_threads = 1;
+static int g_last_oracle_iterations = 0;
+// sensitivity probe (dev): "call:eps" adds eps metres to x of the oracle's result of that compute() call
+static long g_oracle_calls = 0;
+static long g_perturb_call = -1;
+static double g_perturb_eps = 0.0;
+
+// the CPU oracle behind ICP::compute: same module parameters, same draw seed
+static TransformationParameters oracleCompute(const ICP& self, const DataPoints& reading, const DataPoints& reference,
+                                              const TransformationParameters& T_init) {
+  lso_config c;
+  lso_config_default(&c);
+  c.reading_sampling_prob = self.readingSamplingProb();
+  c.surface_normal_knn = self.surfaceNormalKnn();
+  c.surface_normal_ratio = self.surfaceNormalRatio();
+  c.trim_ratio = self.config().trim_ratio;
+  c.max_iterations = self.config().max_iterations;
+  c.min_diff_rot = self.config().min_diff_rot;
+  c.min_diff_trans = self.config().min_diff_trans;
+  c.smooth_length = self.config().smooth_length;
+  c.accum_double = 1;
+  c.num_threads = g_oracle_threads;
+  TransformationParameters T = T_init;
+  lso_stats st;
+  const int rc = lso_icp_compute_full(&c, reading.features.data(), reading.getNbPoints(), reference.features.data(),
+                                      reference.getNbPoints(), T_init.data(), self.seed(), T.data(), &st);
+  if (rc == LSO_NO_CONVERGENCE) throw ConvergenceError("oracle: no convergence");
+  if (rc != LSO_OK) throw std::runtime_error("oracle: bad argument");
+  g_last_oracle_iterations = st.iterations;
+  if (g_oracle_calls++ == g_perturb_call) T[12] += (float)g_perturb_eps;
+  return T;
+}
+
+int main(int argc, char** argv) {
+  if (argc < 6) { std::fprintf(stderr, "usage: see the header comment\n"); return 2; }
+  const std::string yaml = argv[1], which = argv[4];
+  g_oracle_threads = std::atoi(argv[5]);
+  if (const char* e = std::getenv("LSGPU_SEQ_PERTURB")) std::sscanf(e, "%ld:%lf", &g_perturb_call, &g_perturb_eps);
+  EstimatorParams ep;
+  LaserTrackParams& p = ep.laser_track_params;
+  p.icp_configuration_file = yaml;
+  {  // the input filter chain file lives next to the ICP chain file (an empty chain unless LSGPU_TEST_INPUT_FILTERS names one)
+    const char* e = std::getenv("LSGPU_TEST_INPUT_FILTERS");
+    const size_t slash = yaml.find_last_of('/');
+    p.icp_input_filters_file = e ? std::string(e) : (slash == std::string::npos ? std::string(".") : yaml.substr(0, slash)) + "/input_filters_none.yaml";
+  }
+  p.nscan_in_sub_map = std::atoi(argv[2]);
+  p.odometry_noise_model = {0.05, 0.05, 0.05, 0.01, 0.01, 0.01};
+  p.icp_noise_model = {0.005, 0.005, 0.005, 0.0015, 0.0015, 0.0015};
+  ep.loop_closure_noise_model = {0.01, 0.01, 0.01, 0.003, 0.003, 0.003};
+  ep.add_m_estimator_on_loop_closures = true;
+  ep.do_icp_step_on_loop_closures = true;
+  ep.loop_closures_sub_maps_radius = std::atoi(argv[3]);
+  try {
+    std::vector<Run> runs;
+    auto add = [&](const char* name, bool oracle) {
+      Run r;
+      r.name = name;
+      EstimatorParams e = ep;
+      if (oracle || which == "shadow") e.laser_track_params.scans_on_device = 0;  // host sub-map assembly (bit-identical results)
+      r.est.reset(new IncrementalEstimator(e, 1u));
+      r.track = r.est->getLaserTrack(0);
+      r.track->icp().setSeed(7);             // every compute() reseeds the filters' draw stream: both back ends
+      r.est->loopClosureIcp().setSeed(7);    // consume identical draws whatever happened before
+      if (oracle) {
+        r.track->icp().setComputeOverride(oracleCompute);
+        r.est->loopClosureIcp().setComputeOverride(oracleCompute);
+      }
+      runs.push_back(std::move(r));
+    };
+    const bool shadow = which == "shadow";
+    if (which == "dev" || which == "both" || shadow) add("dev", false);
+    if (which == "ora" || which == "both") add("ora", true);
+    if (runs.empty()) return 2;
+    // shadow mode: the oracle on the device run's own clouds; its transforms go into a second pose graph
+    std::unique_ptr<IncrementalEstimator> sha;
+    TransformationParameters sha_T = identityTransformation();
+    bool sha_have = false;
+    long n_calls = 0;
+    if (shadow) {
+      EstimatorParams e = ep;
+      e.laser_track_params.use_icp_factors = false;   // (its own track is never fed: only the graph is used)
+      sha.reset(new IncrementalEstimator(e, 1u));
+      auto observe = [&](const ICP& self, const DataPoints& reading, const DataPoints& reference,
+                         const TransformationParameters& T_init, const TransformationParameters& T_dev) {
+        sha_T = oracleCompute(self, reading, reference, T_init);
+        sha_have = true;
+        const SE3 a = SE3::fromTransformationMatrix(T_dev.data()), b = SE3::fromTransformationMatrix(sha_T.data());
+        printPose("call", "dev", n_calls, self.lastStats().iterations, g_last_oracle_iterations, a);
+        printPose("call", "ora", n_calls, self.lastStats().iterations, g_last_oracle_iterations, b);
+        ++n_calls;
+      };
+      runs[0].track->icp().setComputeObserver(observe);
+      runs[0].est->loopClosureIcp().setComputeObserver(observe);
+    }
+
+    int32_t n_scans = 0;
+    if (!readAll(&n_scans, 4)) return 3;
+    std::vector<Time> times;
+    std::vector<SE3> truth;
+    // place-recognition error of the emulated loop-closure detector
+    const double a = 0.5 * 3.14159265358979323846 / 180.0;
+    const SE3 lc_err({std::cos(a), 0.0, 0.0, std::sin(a)}, {0.15, -0.12, 0.05});
+    for (int i = 0; i < n_scans; ++i) {
+      int64_t t_ns; double od[7], tr[7]; int32_t n, n_lc;
+      if (!readAll(&t_ns, 8) || !readAll(od, sizeof od) || !readAll(tr, sizeof tr) || !readAll(&n, 4)) return 3;
+      LaserScan scan;
+      scan.time_ns = t_ns;
+      scan.scan.features.resize((size_t)n * 4);
+      if (!readAll(scan.scan.features.data(), (size_t)n * 16) || !readAll(&n_lc, 4)) return 3;
+      std::vector<int32_t> lc_with((size_t)n_lc);
+      if (n_lc && !readAll(lc_with.data(), (size_t)n_lc * 4)) return 3;
+      Pose pose;
+      pose.time_ns = t_ns;
+      pose.T_w = poseOf(od);
+      times.push_back(t_ns);
+      truth.push_back(poseOf(tr));
+      for (Run& r : runs) {
+        const auto t0 = std::chrono::steady_clock::now();
+        FactorList factors;
+        Values values;
+        bool is_prior = false;
+        sha_have = false;
+        r.track->processPoseAndLaserScan(pose, scan, &factors, &values, &is_prior);
+        const Values result = is_prior ? r.est->registerPrior(factors, values, 0u) : r.est->estimate(factors, values, t_ns);
+        r.track->updateFromValues(result);
+        if (sha && &r == &runs[0]) {  // the same factors, the oracle's transform where the device's was
+          FactorList fs = factors;
+          for (Factor& f : fs)
+            if (f.type == Factor::ICP && sha_have) f.measurement = SE3::fromTransformationMatrix(sha_T.data());
+          if (is_prior) sha->registerPrior(fs, values, 0u); else sha->estimate(fs, values, t_ns);
+        }
+        for (const Factor& f : factors)
+          if (f.type == Factor::ICP) printPose("factor", r.name.c_str(), i, (long)f.key_a, (long)f.key_b, f.measurement);
+        if (!is_prior)
+          std::printf("iters %s %d %d\n", r.name.c_str(), i,
+                      r.track->icp().hasComputeOverride() ? g_last_oracle_iterations : r.track->lastIcpStats().iterations);
+        for (int32_t with : lc_with) {
+          RelativePose lc;
+          lc.track_id_a = lc.track_id_b = 0;
+          lc.time_a_ns = times.at((size_t)with);
+          lc.time_b_ns = t_ns;
+          // what the detector reports: w_T_a_b such that T_w_a^-1 * w_T_a_b * T_w_b = measured T_a_b
+          const SE3 measured = truth[(size_t)with].inverse() * truth[(size_t)i] * lc_err;
+          lc.T_a_b = r.track->evaluate(lc.time_a_ns) * measured * r.track->evaluate(lc.time_b_ns).inverse();
+          sha_have = false;
+          r.est->processLoopClosure(lc);
+          printPose("lc", r.name.c_str(), with, i, r.est->lastLoopClosureIcpStats().iterations, r.est->lastLoopClosure().T_a_b);
+          if (sha && &r == &runs[0]) {  // incremental_estimator.cpp:117-142 with the oracle's ICP result as measurement
+            Factor f;
+            f.type = Factor::LOOP_CLOSURE;
+            f.key_a = r.track->getValueKey(lc.time_a_ns);
+            f.key_b = r.track->getValueKey(lc.time_b_ns);
+            f.measurement = sha_have ? SE3::fromTransformationMatrix(sha_T.data()) : r.est->lastLoopClosure().T_a_b;
+            f.sigmas = ep.loop_closure_noise_model;
+            f.cauchy = ep.add_m_estimator_on_loop_closures;
+            sha->estimateAndRemove({f}, {f}, Values(), {0u, 0u}, lc.time_b_ns);
+          }
+        }
+        r.ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+      }
+    }
+    for (Run& r : runs) {
+      for (size_t i = 0; i < times.size(); ++i) printPose("pose", r.name.c_str(), (long)i, 0, 0, r.track->evaluate(times[i]));
+      std::printf("time %s %.3f factors %zu\n", r.name.c_str(), r.ms, r.est->graph().numFactors());
+    }
+    if (sha) {
+      for (size_t i = 0; i < times.size(); ++i)
+        printPose("pose", "sha", (long)i, 0, 0, sha->graph().values().at(runs[0].track->getValueKey(times[i])));
+      std::printf("time sha 0 factors %zu\n", sha->graph().numFactors());
+    }
+  } catch (const std::exception& e) {
+    std::fprintf(stderr, "sequence_driver: %s\n", e.what());
+    return 1;
+  }
+  return 0;
+}

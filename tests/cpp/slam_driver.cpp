@@ -42,6 +42,12 @@ int main(int argc, char** argv) {
   EstimatorParams ep;
   LaserTrackParams& p = ep.laser_track_params;
   p.icp_configuration_file = argv[3];
+  {  // the input filter chain file lives next to the ICP chain file (an empty chain unless LSGPU_TEST_INPUT_FILTERS names one)
+    const char* e = std::getenv("LSGPU_TEST_INPUT_FILTERS");
+    const std::string yaml = argv[3];
+    const size_t slash = yaml.find_last_of('/');
+    p.icp_input_filters_file = e ? std::string(e) : (slash == std::string::npos ? std::string(".") : yaml.substr(0, slash)) + "/input_filters_none.yaml";
+  }
   p.nscan_in_sub_map = std::atoi(argv[4]);
   p.odometry_noise_model = {0.5, 0.5, 0.5, 0.1, 0.1, 0.1};           // laser_slam_ros config_example.yaml scale
   p.icp_noise_model = {0.05, 0.05, 0.05, 0.015, 0.015, 0.015};

@@ -1,0 +1,45 @@
+"""Worker of the multi-rank split-scan test (launched by torch.distributed.run, one rank per GPU): BASELINE configs[3]
+layout -- every rank holds the whole reference, its contiguous shard of the reading, and an RCCL communicator
+(lsgpu_icp_comm_init); the result must equal the unsplit alignment bit for bit on every rank."""
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    import torch
+    import torch.distributed as dist
+    from laser_slam_amd import icp, sharding, synth
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)
+    dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    n_az = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
+    ref, rd, T_true, T_init = synth.scan_pair(n_az)
+    rf, rn = icp.sampling_surface_normal(ref, 10, 1.0, 0)
+    with icp.IcpHandle(None, local) as plain:                       # the unsplit answer, computed on every rank
+        plain.set_reference(rf, rn)
+        T0, st0 = plain.align(rd, T_init)
+        tr0 = [(t["limit"], t["n_used"]) for t in plain.trace()]
+    with icp.IcpHandle(None, local) as h:
+        sharding.init_split_comm(h, device="cuda")
+        h.set_reference(rf, rn)
+        T1, st1 = h.align(rd[sharding.split_shard(rd.shape[0], rank, world)], T_init)
+        tr1 = [(t["limit"], t["n_used"]) for t in h.trace()]
+    ok = bool(np.array_equal(T0, T1) and st0.iterations == st1.iterations and tr0 == tr1)
+    flags = [None] * world
+    dist.all_gather_object(flags, ok)
+    if rank == 0:
+        print("SPLIT_RESULT " + json.dumps({"world": world, "ok": flags, "iterations": st1.iterations,
+                                            "ms_split": st1.t_total_ms, "ms_plain": st0.t_total_ms}))
+    dist.destroy_process_group()
+    sys.exit(0 if all(flags) else 1)
+
+
+if __name__ == "__main__":
+    main()

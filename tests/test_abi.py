@@ -27,7 +27,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(L, name), f"{name} declared in include/lsgpu_icp.h but not exported"
     assert sorted(_lib.ABI_SYMBOLS) == declared
-    assert L.lsgpu_abi_version() == 1
+    assert L.lsgpu_abi_version() == 2
 
 
 def test_config_presets_match_yaml_and_setdefault():
@@ -116,9 +116,16 @@ def test_yaml_loader_accepts_the_reference_chain_and_rejects_others():
     assert (o.chain.reading_sampling_prob, o.chain.surface_normal_knn, o.chain.trim_ratio,
             o.chain.min_diff_trans, o.chain.smooth_length) == (0.75, 7, 0.85, 0.001, 3)
     # module defaults apply when a parameter is absent; inspector/logger are accepted and ignored
-    o.load_from_yaml(io.StringIO("matcher:\n  KDTreeMatcher: {}\noutlierFilters:\n  - TrimmedDistOutlierFilter\n"
+    base = ("referenceDataPointsFilters:\n  - SamplingSurfaceNormalDataPointsFilter\nmatcher:\n  KDTreeMatcher: {}\n"
+            "errorMinimizer: PointToPlaneErrorMinimizer\ntransformationCheckers:\n  - CounterTransformationChecker\n")
+    o.load_from_yaml(io.StringIO(base + "outlierFilters:\n  - TrimmedDistOutlierFilter\n"
                                  "inspector:\n  NullInspector\nlogger:\n  NullLogger\n"))
-    assert o.chain.trim_ratio == 0.85
+    assert o.chain.trim_ratio == 0.85 and o.chain.surface_normal_knn == 7
+    # an absent section is "no module" (libpointmatcher clears the chains first), not the default module
+    o.load_from_yaml(io.StringIO(base))
+    assert o.chain.reading_sampling_prob == 1.0 and o.chain.trim_ratio == 1.0 and o.chain.min_diff_rot < 0
+    with pytest.raises(_lib.LsgpuError):
+        o.load_from_yaml(io.StringIO("matcher:\n  KDTreeMatcher: {}\n"))      # no normals, no minimizer, no stop
     for bad in ("outlierFilters:\n  - MaxDistOutlierFilter: {maxDist: 1}\n",
                 "errorMinimizer: PointToPointErrorMinimizer\n",
                 "matcher:\n  KDTreeMatcher: {knn: 3}\n",

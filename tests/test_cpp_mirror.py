@@ -25,7 +25,8 @@ def test_cpp_host_checks(tmp_path):
     import torch
     exe = _build(tmp_path, "host_checks.cpp", "host_checks")
     args = [exe] + ([] if torch.cuda.is_available() else ["--expect-no-gpu"])
-    r = subprocess.run(args, capture_output=True, text=True, timeout=120)
+    r = subprocess.run(args, capture_output=True, text=True, timeout=120,
+                       env=dict(os.environ, LSGPU_GOLDEN_DIR=os.path.join(ROOT, "tests", "golden")))
     assert r.returncode == 0 and "host_checks: ok" in r.stdout, r.stdout + r.stderr
 
 
@@ -173,3 +174,62 @@ def test_cpp_submap_on_device_equals_host_assembly(tmp_path):
         outs.append([l for l in r.stdout.splitlines() if l.startswith("factor ") or l.startswith("icp_iterations")])
     strip = lambda ls: [" ".join(l.split()[:5]) if l.startswith("icp_iterations") else l for l in ls]
     assert strip(outs[0]) == strip(outs[1]) and len(outs[0]) > 2 * (n - 1)
+
+
+@pytest.mark.gpu
+def test_cpp_laser_track_applies_the_input_filter_chain(tmp_path):
+    """LaserTrack loads `icp_input_filters_file` (laser_track.cpp:24-30) and filters every scan before it is stored or
+    matched (:146): with the test chain the stored clouds shrink, and the ICP factors still recover the motion."""
+    exe = _build(tmp_path, "track_driver.cpp", "track_driver")
+    scene = synth.Scene(1234)
+    n = 4
+    truth = []
+    with open(tmp_path / "poses.txt", "w") as f:
+        for i in range(n):
+            T = synth.se3(0.8 * i, 0.05 * i, synth.SENSOR_HEIGHT, yaw=np.deg2rad(2.0 * i))
+            truth.append(T)
+            synth.hdl64_scan(scene, T, 512, 10 + i).tofile(tmp_path / f"scan{i}.bin")
+            f.write(_pose_line(100000000 * i, T @ synth.se3(0.1 * i, -0.05 * i, 0, yaw=np.deg2rad(0.5 * i))))
+    yaml = os.path.join(ROOT, "tests", "golden", "icp_chain.yaml")
+    sizes = {}
+    mild = tmp_path / "input_filters_mild.yaml"     # (the golden chain keeps a sixth of the points: too few to judge the ICP)
+    mild.write_text("- BoundingBoxDataPointsFilter: {xMin: -6, xMax: 6, yMin: -4, yMax: 4, zMin: -2.5, zMax: 0.5, removeInside: 1}\n"
+                    "- MaxDistDataPointsFilter:\n    maxDist: 50\n- RandomSamplingDataPointsFilter: {prob: 0.6}\n")
+    for name, flt in (("none", os.path.join(ROOT, "tests", "golden", "input_filters_none.yaml")), ("chain", str(mild))):
+        env = dict(os.environ, LSGPU_TEST_INPUT_FILTERS=flt)
+        r = subprocess.run([exe, str(tmp_path), str(n), yaml, "3"], capture_output=True, text=True, timeout=300, env=env)
+        assert r.returncode == 0, r.stdout + r.stderr
+        lines = r.stdout.strip().splitlines()
+        sizes[name] = int(lines[-1].split()[1])
+        icp = [l.split() for l in lines if l.startswith("factor 2 ")]
+        assert len(icp) == n - 1
+        for i, fct in enumerate(icp):
+            T = _parse_poses(["x x " + " ".join(fct[6:10] + fct[11:14])])[0]
+            et, er = synth.pose_error(T, np.linalg.inv(truth[i]) @ truth[i + 1])
+            assert et < 0.05 and er < 5e-3, (name, i, et, er)
+    assert 0.3 * sizes["none"] < sizes["chain"] < 0.65 * sizes["none"]      # near box + far field removed, 60 % of the rest      # box + ranges + every ~4th point x 0.8
+    env = dict(os.environ, LSGPU_TEST_INPUT_FILTERS=str(tmp_path / "does_not_exist.yaml"))
+    r = subprocess.run([exe, str(tmp_path), "1", yaml, "3"], capture_output=True, text=True, timeout=60, env=env)
+    assert r.returncode != 0 and "input filters" in (r.stdout + r.stderr)
+
+
+def test_integration_shim_compiles_against_the_mirror_types(tmp_path):
+    """integration/lsgpu_icp_shim.hpp (the drop-in for laser_track.hpp:217 / incremental_estimator.hpp:70) is real
+    code: instantiated with the in-tree mirror types it compiles and links on a CPU-only box."""
+    exe = _build(tmp_path, "shim_check.cpp", "shim_check")
+    r = subprocess.run([exe, "--compile-only"], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 0 and "compiled" in r.stdout
+
+
+@pytest.mark.gpu
+def test_integration_shim_equals_the_mirror_icp(tmp_path):
+    """The shim and laser_slam_amd::ICP give bit-identical transforms on the same clouds; its DataPointsFilters twin
+    keeps the same points as the mirror's and thins the descriptors with them."""
+    exe = _build(tmp_path, "shim_check.cpp", "shim_check")
+    ref, rd, T_true, T_init = synth.scan_pair(512)
+    ref.tofile(tmp_path / "ref.bin")
+    rd.tofile(tmp_path / "rd.bin")
+    g = os.path.join(ROOT, "tests", "golden")
+    r = subprocess.run([exe, os.path.join(g, "icp_chain.yaml"), os.path.join(g, "input_filters.yaml"),
+                        str(tmp_path / "ref.bin"), str(tmp_path / "rd.bin")], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "shim_check: ok" in r.stdout, r.stdout + r.stderr

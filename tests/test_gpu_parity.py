@@ -13,6 +13,8 @@ from laser_slam_amd import synth
 
 pytestmark = pytest.mark.gpu
 
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
 TOL_T = 1e-4    # m
 TOL_R = 1e-5    # rad
 
@@ -267,8 +269,18 @@ def test_golden_vectors(icp_mod):
         Tm[12:15] -= g["mean"]
         ids, d2 = h.knn(g["rd"], Tm)
         assert np.array_equal(d2, g["nn_d2"])
-        same = ids == g["nn_ids"]
-        assert same.mean() > 0.999  # ids may differ only at exact distance ties
+        # ids may differ from the fixture only where two reference points are at exactly the same distance
+        # (libnabo's tie order is implementation defined): the tie rule of _check_nn
+        neq = np.flatnonzero(ids != g["nn_ids"])
+        if neq.size:
+            ref_c = g["ref"][:, :3] - g["mean"]
+            q = h.transform_points(Tm, g["rd"])
+            diff = q[neq, :3] - ref_c[ids[neq]]
+            dx, dy, dz = (diff[:, k].astype(np.float32) for k in range(3))
+            dd = np.float32(dx * dx)
+            dd = (dy.astype(np.float64) * dy + dd).astype(np.float32)
+            dd = (dz.astype(np.float64) * dz + dd).astype(np.float32)
+            assert np.array_equal(dd, g["nn_d2"][neq])
         lim = h.trim_limit(d2, 0.75)
         assert np.float32(lim) == g["limit0"]
         A, b, used, _ = h.normal_eq(g["rd"], Tm, g["nn_ids"], g["nn_d2"], lim)
@@ -637,3 +649,179 @@ def test_align_runs_to_the_iteration_cap_like_the_oracle(icp_mod, oracle, pair64
             assert stg.iterations == sto.iterations == 25
             dt, dr = synth.pose_error(Tg, synth.from_colmajor(To))
             assert dt <= TOL_T and dr <= TOL_R, (dt, dr)
+
+
+@pytest.mark.gpu
+def test_split_scan_two_ranks_equals_unsplit():
+    """BASELINE configs[3] with a real exchange: two ranks (one per GPU, RCCL over xGMI), reading sharded, reference
+    replicated; every rank must reproduce the unsplit alignment bit for bit.  Skips on a box with fewer than 2 GPUs."""
+    import socket
+    import subprocess
+    import sys
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs 2 GPUs")
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                        "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "tests", "split_worker.py"), "1024"],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "SPLIT_RESULT" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(900)
+def test_config3_full_size_submap_vs_scan(icp_mod):
+    """BASELINE configs[3] at full size on one GPU: an 8-scan aggregated local map (8 x 1 M rays -> 8.4 M points) against
+    a 1 M-point scan.  The oracle needs minutes at this size, so: (a) kNN self-consistency + sampled brute force,
+    (b) the alignment recovers the synthetic motion, (c) the one-rank communicator path (every collective of the split
+    layout executed) reproduces the plain result bit for bit, (d) the device-resident sub-map assembly
+    (lsgpu_icp_compute_clouds, laser_track.cpp:474-486) runs at this size."""
+    import torch
+    scene = synth.Scene(1234)
+    poses = [synth.se3(0.8 * i, 0.05 * i, synth.SENSOR_HEIGHT, yaw=np.deg2rad(2.0 * i)) for i in range(9)]
+    scans = [synth.hdl64_scan(scene, poses[i], 16384, 20 + i) for i in range(9)]
+    rel = [np.linalg.inv(poses[7]) @ poses[i] for i in range(8)]
+    T_true = np.linalg.inv(poses[7]) @ poses[8]
+    T_init = synth.se3(0.25, -0.1, 0.05, yaw=np.deg2rad(1.2)) @ T_true
+    rd = scans[8]
+    from laser_slam_amd._lib import IcpConfig, lib
+    import ctypes as C
+    cfg = IcpConfig()
+    lib().lsgpu_icp_config_yaml(C.byref(cfg))
+    cfg.min_diff_rot, cfg.min_diff_trans = 1e-5, 1e-4     # "to 1e-4 m tolerance" (BASELINE configs[1]); the yaml
+    with icp_mod.IcpHandle(cfg) as h:                      # thresholds (1e-3 rad / 1e-2 m) stop 20 cm short here
+        parts = [torch.from_numpy(h.transform_points(synth.colmajor(rel[i]), scans[i])) for i in range(8)]
+        ref = torch.cat(parts).cuda()
+        assert ref.shape[0] > 8_000_000
+        d_rf, d_rn = h.filter_reference(ref, 10, 1.0, 0)            # chain F: every point keeps its box normal
+        d_rf, d_rn = d_rf.clone(), d_rn.clone()
+        assert d_rf.shape[0] == ref.shape[0]
+        h.set_reference(d_rf, d_rn)
+        mean = h.reference_mean()
+        T = synth.colmajor(T_init).copy()
+        T[12:15] -= mean
+        ids, d2 = h.knn(rd, T)
+        q = h.transform_points(T, rd)
+        rf = d_rf.cpu().numpy()
+        ref_c = rf[:, :3] - mean
+        dd = ((q[:, :3] - ref_c[ids]).astype(np.float64) ** 2).sum(1)
+        assert np.allclose(dd, d2, rtol=1e-5, atol=1e-12)
+        pick = np.random.default_rng(0).choice(rd.shape[0], 48, replace=False)
+        for j in pick:                                             # brute force over all 8.4 M reference points
+            best = ((ref_c.astype(np.float64) - q[j, :3].astype(np.float64)) ** 2).sum(1).min()
+            assert best >= d2[j] * (1 - 1e-5), (j, best, d2[j])
+        d_rd = torch.from_numpy(rd).cuda()
+        Tg, st = h.align(d_rd, T_init)
+        tr0 = [(t["limit"], t["n_used"]) for t in h.trace()]
+        et, er = synth.pose_error(Tg.astype(np.float64), T_true)
+        et0, er0 = synth.pose_error(T_init, T_true)
+        # (the 8-scan street map constrains the driving direction weakly: trimmed point-to-plane ICP closes the
+        # 27 cm / 1.2 deg offset of the guess only in part within the 40-iteration budget -- what matters here is that
+        # it moves towards the truth, stays finite, and that every code path below reproduces it bit for bit)
+        assert et < et0 and er < 0.1 * er0 and 2 <= st.iterations <= 40, (et, er, et0, er0, st.iterations)
+        h.comm_init(0, 1, icp_mod.comm_unique_id())
+        T1, st1 = h.align(d_rd, T_init)
+        assert np.array_equal(Tg, T1) and st1.iterations == st.iterations
+        assert tr0 == [(t["limit"], t["n_used"]) for t in h.trace()]
+    with icp_mod.IcpHandle(cfg) as h2:                             # (d) sub-map assembled on the device from resident scans
+        for i in range(9):
+            h2.cloud_upload(i, scans[i])
+        Tc, stc = h2.compute_clouds(8, list(range(8)), [synth.colmajor(r) for r in rel], T_init, 1.0, 10, 1.0, seed=0)
+        assert int(h2.info().n_reference) == ref.shape[0]
+        assert np.array_equal(Tc, Tg)                              # same clouds, same chain: the same transform
+
+
+def _chain(mod, specs):
+    arr = (mod.PointFilter * len(specs))()
+    for a, (typ, dim, flag, v) in zip(arr, specs):
+        a.type, a.dim, a.flag = typ, dim, flag
+        for i, x in enumerate(v):
+            a.v[i] = x
+        a.state = 0.0
+    return arr
+
+
+def test_input_filter_chain_matches_oracle(icp_mod, oracle):
+    """The input filter chain (laser_track.cpp:24-30, :146) on the device against its oracle restatement: same points,
+    same order, bit for bit -- every filter alone, the whole chain, and the step of FixStepSampling carried from one
+    scan to the next like the upstream filter object does."""
+    from laser_slam_amd import _lib
+    scene = synth.Scene(1234)
+    scans = [synth.hdl64_scan(scene, synth.se3(0.8 * i, 0.0, synth.SENSOR_HEIGHT), 512, 70 + i) for i in range(3)]
+    specs = [(_lib.FILTER_BOUNDING_BOX, 0, 1, [-6.0, 6.0, -4.0, 4.0, -2.5, 0.5]),
+             (_lib.FILTER_MAX_DIST, -1, 0, [60.0]),
+             (_lib.FILTER_MIN_DIST, -1, 0, [2.5]),
+             (_lib.FILTER_FIX_STEP_SAMPLING, 0, 0, [3.0, 5.0, 1.3]),
+             (_lib.FILTER_RANDOM_SAMPLING, 0, 0, [0.8])]
+    extra = [(_lib.FILTER_MAX_DIST, 2, 0, [1.0]), (_lib.FILTER_MIN_DIST, 0, 0, [4.0]),
+             (_lib.FILTER_BOUNDING_BOX, 0, 0, [-20.0, 20.0, -6.0, 6.0, -3.0, 3.0]),
+             (_lib.FILTER_FIX_STEP_SAMPLING, 0, 0, [7.0, 2.0, 0.6])]
+    with icp_mod.IcpHandle() as h:
+        removed_something = False
+        for sp in specs + extra:                                   # each filter on its own
+            got = h.apply_point_filters(_chain(_lib, [sp]), scans[0], seed=5)
+            want = oracle.apply_point_filters(_chain(oracle, [sp]), scans[0], seed=5)
+            assert 0 < got.shape[0] <= scans[0].shape[0] and np.array_equal(got, want), sp
+            removed_something = removed_something or got.shape[0] < scans[0].shape[0]
+        assert removed_something
+        dev, ora = _chain(_lib, specs), _chain(oracle, specs)     # the chain, state carried over three scans
+        sizes = []
+        for i, s in enumerate(scans):
+            got = h.apply_point_filters(dev, s, seed=9 if i == 0 else -1)
+            want = oracle.apply_point_filters(ora, s, seed=9 if i == 0 else -1)
+            assert np.array_equal(got, want)
+            assert dev[3].state == ora[3].state
+            sizes.append(got.shape[0])
+        assert [round(dev[3].state, 6)] == [5.0] and sizes[0] > sizes[2] > 0     # step 3 -> 3.9 -> 5 (clamped)
+        import torch
+        d = h.apply_point_filters(_chain(_lib, specs), torch.from_numpy(scans[0]).cuda(), seed=9)   # device in, device out
+        assert d.is_cuda and np.array_equal(d.cpu().numpy(), oracle.apply_point_filters(_chain(oracle, specs), scans[0], seed=9))
+        # a filter that is handed an empty cloud: ConvergenceError ("no points to filter") / None from the oracle
+        empty_after = [(_lib.FILTER_MAX_DIST, -1, 0, [0.001]), (_lib.FILTER_MIN_DIST, -1, 0, [1.0])]
+        with pytest.raises(_lib.ConvergenceError):
+            h.apply_point_filters(_chain(_lib, empty_after), scans[0])
+        assert oracle.apply_point_filters(_chain(oracle, empty_after), scans[0]) is None
+        assert h.apply_point_filters(_chain(_lib, empty_after[:1]), scans[0]).shape[0] == 0     # ... the last one may empty it
+        with pytest.raises(_lib.LsgpuError):
+            h.apply_point_filters(_chain(_lib, [(77, 0, 0, [1.0])]), scans[0])
+
+
+def test_pointcloud2_conversion_round_trip(icp_mod):
+    """sensor_msgs/PointCloud2 data block -> DataPoints.features on the device (rosMsgToPointMatcherCloud<float>,
+    laser_slam_worker.cpp:125) against a numpy restatement of the record layout: Velodyne-style 22-byte records with
+    x/y/z at unaligned offsets, big-endian variant, NaN records dropped when the message is not dense; and back to the
+    16-byte PointXYZ records that lpmToPcl / pcl::toROSMsg produce (common.hpp:159-191)."""
+    import torch
+    rng = np.random.default_rng(5)
+    n, step = 50_000, 22                                             # x@1 y@5 z@9 (unaligned), intensity@13, ring@17, pad
+    xyz = rng.normal(0, 20, (n, 3)).astype(np.float32)
+    xyz[rng.choice(n, 500, replace=False), rng.integers(0, 3, 500)] = np.nan
+    xyz[7, 1] = np.inf
+    rec = np.zeros((n, step), np.uint8)
+    rec[:] = rng.integers(0, 255, (n, step), dtype=np.uint8)
+    for k, off in enumerate((1, 5, 9)):
+        rec[:, off:off + 4] = xyz[:, k:k + 1].view(np.uint8).reshape(n, 4)
+    fin = np.isfinite(xyz).all(1)
+    want_all = np.concatenate([xyz, np.ones((n, 1), np.float32)], 1)
+    with icp_mod.IcpHandle() as h:
+        got = h.cloud_from_pointcloud2(rec.tobytes(), n, step, 1, 5, 9, is_dense=True)
+        assert np.array_equal(got.view(np.uint32), want_all.view(np.uint32))            # dense: records as they are
+        got = h.cloud_from_pointcloud2(rec, n, step, 1, 5, 9, is_dense=False)
+        assert np.array_equal(got, want_all[fin])                                       # NaN / Inf records dropped, in order
+        big = rec.copy()
+        for off in (1, 5, 9):
+            big[:, off:off + 4] = rec[:, off:off + 4][:, ::-1]
+        got_b = h.cloud_from_pointcloud2(big, n, step, 1, 5, 9, is_bigendian=True, is_dense=False)
+        assert np.array_equal(got_b, want_all[fin])
+        d = h.cloud_from_pointcloud2(torch.from_numpy(rec).cuda(), n, step, 1, 5, 9, is_dense=False, device_out=True)
+        assert d.is_cuda and np.array_equal(d.cpu().numpy(), want_all[fin])             # device in, device out
+        back = h.cloud_to_pointxyz(d)
+        assert back.size == 16 * int(fin.sum())
+        pts = back.view(np.float32).reshape(-1, 4)
+        assert np.array_equal(pts[:, :3], xyz[fin]) and (pts[:, 3] == 1).all()
+        with pytest.raises(icp_mod.LsgpuError):
+            h.cloud_from_pointcloud2(rec, n, step, 1, 5, 20)                            # z would leave the record
+        assert h.cloud_from_pointcloud2(b"", 0, step, 1, 5, 9).shape[0] == 0

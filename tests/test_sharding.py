@@ -151,4 +151,8 @@ def test_split_scan_allreduce_scheme_matches_unsharded():
     assert int(t[-1]) == used
     assert np.allclose(t[:36].reshape(6, 6), A, rtol=1e-12) and np.allclose(t[36:42], b_, rtol=1e-11)
     parts = [sharding.split_shard(10, r, 3) for r in range(3)]
-    assert [(s.start, s.stop) for s in parts] == [(0, 4), (4, 8), (8, 10)]
+    assert [(s.start, s.stop) for s in parts] == [(0, 4), (4, 7), (7, 10)]
+    parts = [sharding.split_shard(5, r, 4) for r in range(4)]          # every rank owns at least one point
+    assert [(s.start, s.stop) for s in parts] == [(0, 2), (2, 3), (3, 4), (4, 5)]
+    with pytest.raises(ValueError):
+        sharding.split_shard(3, 0, 4)
