@@ -22,6 +22,13 @@ for s in $steps; do
                rm -rf gpurun_out/pmc_${tag}_$c
                (cd /tmp && timeout 600 rocprofv3 --kernel-trace --pmc $c -d $OLDPWD/gpurun_out/pmc_${tag}_$c --output-format csv -- python $OLDPWD/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-compute-e2e > /dev/null 2> $OLDPWD/gpurun_out/${tag}_pmc_$c.err)
              done
-             python devtools/pmc_summary.py gpurun_out/pmc_${tag}_FETCH_SIZE gpurun_out/pmc_${tag}_WRITE_SIZE > gpurun_out/${tag}_knn_traffic.json 2>> gpurun_out/${tag}_pmc.err; cat gpurun_out/${tag}_knn_traffic.json ;;
+             f=$(find gpurun_out/pmc_${tag}_FETCH_SIZE -name "*counter_collection.csv" | head -1); w=$(find gpurun_out/pmc_${tag}_WRITE_SIZE -name "*counter_collection.csv" | head -1)
+             python devtools/knn_traffic.py $f $w gpurun_out/${tag}_knn_traffic.json ${tag} 2>> gpurun_out/${tag}_pmc.err
+             gzip -c $f > gpurun_out/${tag}_pmc_fetch.csv.gz; gzip -c $w > gpurun_out/${tag}_pmc_write.csv.gz ;;
+    batch)   timeout 600 python devtools/batch_bench.py 3125 32 gpurun_out/${tag}_batch200k.json 2>&1 | tail -6 ;;
+    cfg3)    timeout 600 python devtools/config4_shape.py 16384 - gpurun_out/${tag}_config3_1gpu.json 2>&1 | tail -3 ;;
+    sq)      rm -rf gpurun_out/sq_${tag}
+             (cd /tmp && timeout 600 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS -d $OLDPWD/gpurun_out/sq_${tag} --output-format csv -- python $OLDPWD/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-compute-e2e > /dev/null 2> $OLDPWD/gpurun_out/${tag}_sq.err)
+             python devtools/pmc_summary.py $(find gpurun_out/sq_${tag} -name "*counter_collection.csv" | head -1) k_knn_tile > gpurun_out/${tag}_knn_sq_counters.txt 2>> gpurun_out/${tag}_sq.err; cat gpurun_out/${tag}_knn_sq_counters.txt ;;
   esac
 done

@@ -5,7 +5,7 @@ def mean_counter(path, name):
     vals = {}
     for r in csv.DictReader(open(path)):
         k = r["Kernel_Name"]
-        if r["Counter_Name"] == name and ("k_knn_tile" in k or "k_knn_fallback" in k):
+        if r["Counter_Name"] == name and ("k_knn_tile" in k or "k_knn_fallback" in k or "k_knn_rowq" in k):
             vals.setdefault("tile" if "k_knn_tile" in k else "fallback", []).append(float(r["Counter_Value"]))
     tile = vals.get("tile", [])
     fb = vals.get("fallback", [])
@@ -13,10 +13,10 @@ def mean_counter(path, name):
     return (sum(tile) + sum(fb)) / max(len(tile), 1), len(tile), len(fb)
 f, nt, nf = mean_counter(sys.argv[1], "FETCH_SIZE")
 w, _, _ = mean_counter(sys.argv[2], "WRITE_SIZE")
-out = {"n_az": 16384, "kernel": "k_knn_tile (+ k_knn_fallback where it follows)",
+out = {"n_az": 16384, "kernel": "k_knn_tile (+ the wave-per-query / row-per-query pass that follows it)",
        "fetch_size_kb_per_launch": f, "write_size_kb_per_launch": w,
        "hbm_bytes_per_launch": (2 * f + w) * 1024,
-       "dispatches": {"k_knn_tile": nt, "k_knn_fallback": nf},
+       "dispatches": {"k_knn_tile": nt, "k_knn_fallback + k_knn_rowq": nf},
        "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes with --kernel-trace, mean over all "
                  "kNN launches of `python bench.py --steps 2 --warmup 1 --no-cpu-baseline`; bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 "
                  "(gfx950 FETCH_SIZE counts 128-B requests as 64 B: MI355X_MICROARCH.md HBM section; WRITE_SIZE uncalibrated)",

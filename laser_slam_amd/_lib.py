@@ -10,7 +10,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-SO_PATH = os.path.join(_HERE, "liblsgpu_icp.so")
+SO_PATH = os.environ.get("LSGPU_SO") or os.path.join(_HERE, "liblsgpu_icp.so")   # (LSGPU_SO: another build of the same library)
 
 OK, NO_CONVERGENCE, BAD_CONFIG, HIP_ERROR, BAD_ARG = 0, 1, 2, 3, 4
 

@@ -225,11 +225,12 @@ static int wait_stream(lsgpu_icp* h) {
 }
 
 static constexpr int kNeBlocksMax = 2048;
-static const int kNeBlocks = [] { const char* e = getenv("LSGPU_NE_BLOCKS"); const int v = e ? atoi(e) : 512;
+static const int kNeBlocks = [] { const char* e = getenv("LSGPU_NE_BLOCKS"); const int v = e ? atoi(e) : 256;
                                   return v < 64 ? 64 : v > kNeBlocksMax ? kNeBlocksMax : v; }();
 static constexpr int kStatBlocks = 512;
 static constexpr int kHistBlocks = 256;
 static constexpr int kFallbackBlocksSettled = 1024;
+static constexpr int kRowqBlocks = 512;  // x 16 rows: 8192 queries side by side, round robin beyond
 static constexpr int kFallbackBlocks = 8192;  // x 4 waves: one query per wave for up to 32 k stragglers, round robin beyond
 
 extern "C" {
@@ -511,7 +512,10 @@ static int run_knn(lsgpu_icp* h, const Mat34& T, const IcpState* st, bool seed, 
     if (timed) HIPC(hipEventRecord(ev->b, h->stream));
     // stragglers (balls > r_cap) only exist in uncapped launches
     // (a settled launch routes a few thousand queries at most: a small grid keeps the pass short)
-    if (!capped || a.spread_route_r > 0.f)
+    static const bool rowq = getenv("LSGPU_NO_ROWQ") == nullptr;
+    if (settled && rowq)
+      hipLaunchKernelGGL(k_knn_rowq, dim3(kRowqBlocks), dim3(256), 0, h->stream, a);   // one DPP row per handed-over query
+    else if (!capped || a.spread_route_r > 0.f)
       hipLaunchKernelGGL(k_knn_fallback, dim3(settled ? kFallbackBlocksSettled : kFallbackBlocks), dim3(256), 0, h->stream, a);
     if (timed) HIPC(hipEventRecord(ev->c, h->stream));
   }
@@ -1478,7 +1482,8 @@ int lsgpu_icp_align(lsgpu_icp* h, const float* reading_xyz1, int64_t nq, const f
   const Mat34 Tdummy = to_mat34(hst->T_iter);
   bool first_select = true;
   std::vector<size_t> ev_of_launch;  // event index of every enqueued iteration
-  static const bool predict_select = getenv("LSGPU_NO_PREDICT") == nullptr;
+  static const bool split_update = getenv("LSGPU_SPLIT_UPDATE") != nullptr;  // (profiling: the update as its own launch)
+  static const bool predict_select = getenv("LSGPU_NO_PREDICT") == nullptr && !split_update;
   auto enqueue_iteration = [&](bool seed, bool capped, bool wide, bool knn = true) -> int {
     // capped launches without a wave-per-query pass may fold the first half of the select into the kNN kernel
     // (the device decides per iteration, IcpState::sel_mode); not in the RCCL mode (the counts are per shard).
@@ -1499,10 +1504,10 @@ int lsgpu_icp_align(lsgpu_icp* h, const float* reading_xyz1, int64_t nq, const f
     hipLaunchKernelGGL(k_normal_eq_loop, dim3(nb), dim3(256), 0, h->stream, h->rdq.p, (int)nq,
                        h->state.p, h->prev.p, h->d2.p, h->nrm.p, h->hist.p, h->sel.p + 2,
                        h->counters.p + 32, h->ne_tickets.p, h->ne_partials.p, h->ne_gpartials.p, h->ne_out.p,
-                       h->chk_hist.p, h->trace_dev.p, max_it, capped ? 1 : 0, h->comm ? 0 : 1,
+                       h->chk_hist.p, h->trace_dev.p, max_it, capped ? 1 : 0, (h->comm || split_update) ? 0 : 1,
                        h->comm ? (uint32_t*)nullptr : h->sel_aux.p);                            // 6d (+6e)
-    if (h->comm) {   // split scan: every rank gets the sums over all shards (the limit, slot 29, is already global)
-      if (rccl_api()->AllReduce(h->ne_out.p, h->ne_out.p, kNe, ncclDouble, ncclSum, h->comm, h->stream) != ncclSuccess) {
+    if (h->comm || split_update) {   // split scan: every rank gets the sums over all shards (the limit, slot 29, is already global)
+      if (h->comm && rccl_api()->AllReduce(h->ne_out.p, h->ne_out.p, kNe, ncclDouble, ncclSum, h->comm, h->stream) != ncclSuccess) {
         h->err = "RCCL all-reduce of the normal equations failed";
         return LSGPU_HIP_ERROR;
       }

@@ -388,8 +388,11 @@ __device__ __forceinline__ float4 tile_resolve_match(const KnnArgs& a, int grp, 
   return mp;
 }
 
+#ifndef LSGPU_TILE_OCC
+#define LSGPU_TILE_OCC 7   // waves per SIMD the register budget is cut for (7: 72 VGPRs, no spills; 8 spills 48 B per lane)
+#endif
 template <int WAVES>
-__global__ __launch_bounds__(WAVES * 64, 8) void k_knn_tile(KnnArgs a) {
+__global__ __launch_bounds__(WAVES * 64, LSGPU_TILE_OCC) void k_knn_tile(KnnArgs a) {
   __shared__ TileLds lds_all[WAVES];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   TileLds& lds = lds_all[w];

@@ -389,4 +389,126 @@ __global__ __launch_bounds__(64, 4) void k_knn_rows(KnnArgs a) {
 #endif
 }
 
+// ---------------------------------------------------------------- row-per-query pass (settled launches)
+// The queries a settled launch hands over (lanes of spread waves: a few thousand, small balls) do not need a whole
+// wave each: one DPP row of 16 lanes takes one query -- lanes 0..7 probe the <= 2x2x2 cells the ball touches, the
+// cells' chunks are culled 16 at a time (lane = chunk) against the ball itself, a surviving chunk is evaluated one
+// point per lane -- and a wave runs four queries side by side.  Same results as k_knn_fallback (exact nearest point
+// inside the cap, smallest index on ties, lower bound for the next iterations); three to five dependent memory
+// round trips per query instead of one per chunk and per reduction of a 64-lane wave.
+constexpr int kRowqList = 64;  // chunk ids staged per row and window
+
+__global__ __launch_bounds__(256) void k_knn_rowq(KnnArgs a) {
+  __shared__ uint32_t list_sh[16][kRowqList];
+  const int lane = threadIdx.x & 63, row = lane >> 4, k16 = lane & 15, wave = threadIdx.x >> 6;
+  uint32_t* list = list_sh[wave * 4 + row];
+  Mat34 T; float cap2;
+  if (!iter_params(a.st, a.T, a.cap2, a.use_state_cap, T, cap2)) return;
+  const float cap2s = cap2 * kCapSearchMargin2;
+  const uint32_t count = *a.strag_count;
+  const GridDev& g = a.g;
+  const int lim = (1 << (g.bits + g.fine)) - 1;
+  for (uint32_t base = (blockIdx.x * 4u + (uint32_t)wave) * 4u; base < count; base += gridDim.x * 16u) {
+    const uint32_t s = base + (uint32_t)row;
+    const bool have = s < count;
+    const uint32_t j = have ? a.strag[s] : 0u;
+    float qx = 0.f, qy = 0.f, qz = 0.f, ub = 0.f;
+    unsigned long long bestp = ~0ull;
+    if (have) {
+      const float4 r = a.rdq[j];
+      const float3 q = xform(T, r.x, r.y, r.z);
+      qx = q.x; qy = q.y; qz = q.z;
+      ub = a.d2[j];  // distance to the warm-start point
+      bestp = ((unsigned long long)__float_as_uint(ub) << 32) | (uint32_t)a.ids[j];
+    }
+    float best = fminf(ub, cap2s);  // only neighbours inside the cap must be exact
+    // ---- the ball's cells: the level at which it spans at most two cells per axis
+    uint32_t cs = 0, ce = 0;
+    {
+      const float B = sqrtf(best) * (1.0f + 1e-5f) + 1e-7f + kFineSlack * g.hf;
+      const int flx = fine_coord(qx - B, g.ox, g.inv_hf, lim), fhx = fine_coord(qx + B, g.ox, g.inv_hf, lim);
+      const int fly = fine_coord(qy - B, g.oy, g.inv_hf, lim), fhy = fine_coord(qy + B, g.oy, g.inv_hf, lim);
+      const int flz = fine_coord(qz - B, g.oz, g.inv_hf, lim), fhz = fine_coord(qz + B, g.oz, g.inv_hf, lim);
+      int l = 0;
+      for (int sh = g.fine; l < g.bits; ++l, ++sh)
+        if ((fhx >> sh) - (flx >> sh) < 2 && (fhy >> sh) - (fly >> sh) < 2 && (fhz >> sh) - (flz >> sh) < 2) break;
+      unsigned long long todo = __ballot(have);
+      while (todo) {  // rows may sit on different levels: one pass per distinct level keeps table base / mask scalar
+        const int L = __builtin_amdgcn_readlane(l, __ffsll((long long)todo) - 1);
+        const bool mine = have && l == L;
+        todo &= ~__ballot(mine);
+        if (mine && k16 < 8) {
+          const int sh = g.fine + L;
+          const int cx = (flx >> sh) + (k16 & 1), cy = (fly >> sh) + ((k16 >> 1) & 1), cz = (flz >> sh) + (k16 >> 2);
+          if (cx <= (fhx >> sh) && cy <= (fhy >> sh) && cz <= (fhz >> sh))
+            if (!grid_lookup(g, L, (uint32_t)cx, (uint32_t)cy, (uint32_t)cz, cs, ce)) { cs = 0; ce = 0; }
+        }
+      }
+    }
+    const uint32_t nch = ce - cs;
+    const uint32_t incl = row_scan_incl_u32(nch), excl = incl - nch;
+    const uint32_t tot = row_sum_u32(nch);
+    const uint32_t totmax = wave_max_u32(tot);
+    for (uint32_t wbase = 0; wbase < totmax; wbase += (uint32_t)kRowqList) {  // (one window unless the ball is huge)
+      // this lane's chunks whose list position falls into the window
+      for (uint32_t c = 0; c < nch; ++c) {
+        const uint32_t pos = excl + c;
+        if (pos >= wbase && pos < wbase + (uint32_t)kRowqList) list[pos - wbase] = cs + c;
+      }
+      const uint32_t wlen = tot > wbase ? (tot - wbase < (uint32_t)kRowqList ? tot - wbase : (uint32_t)kRowqList) : 0u;
+      const uint32_t wmax = wave_max_u32(wlen);
+      for (uint32_t e0 = 0; e0 < wmax; e0 += 16u) {
+        const uint32_t e = e0 + (uint32_t)k16;
+        float bd = INFINITY;
+        uint32_t st = 0, cnt = 0;
+        if (e < wlen) {
+          const float4* cd = reinterpret_cast<const float4*>(a.chunks + list[e]);
+          const float4 b0 = cd[0], b1 = cd[1];
+          bd = box_dist2(b0.x, b0.y, b0.z, b1.x, b1.y, b1.z, qx, qy, qz) * kPruneShrink;
+          st = __float_as_uint(b0.w); cnt = __float_as_uint(b1.w);
+        }
+        uint32_t m16 = (uint32_t)(__ballot(bd <= best) >> (row * 16)) & 0xFFFFu;
+        while (__ballot(m16 != 0u)) {
+          const bool has = m16 != 0u;
+          const int src = row * 16 + (has ? __ffs((int)m16) - 1 : 0);
+          m16 &= m16 - 1u;
+          const float cbd = __shfl(bd, src, 64);
+          const uint32_t cst = (uint32_t)__shfl((int)st, src, 64), ccnt = (uint32_t)__shfl((int)cnt, src, 64);
+          float dmin = INFINITY;
+          if (has && cbd <= best) {  // (the bound may have shrunk since the cull)
+            for (uint32_t o = (uint32_t)k16; o < ccnt; o += 16u) {
+              const float4 p = a.pts[cst + o];
+              const float d = dist2(qx - p.x, qy - p.y, qz - p.z);
+              const unsigned long long pk = ((unsigned long long)__float_as_uint(d) << 32) | (cst + o);
+              bestp = pk < bestp ? pk : bestp;
+              dmin = fminf(dmin, d);
+            }
+          }
+          best = fminf(best, row_min(dmin));
+        }
+      }
+    }
+    // ---- the row's answer: smallest (distance, index) pair over its 16 lanes
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) {
+      const unsigned long long w = __shfl_xor(bestp, o, 64);
+      bestp = w < bestp ? w : bestp;
+    }
+    if (have && k16 == 0) {
+      const int id = (int)(uint32_t)(bestp & 0xFFFFFFFFull);
+      const float fd = __uint_as_float((uint32_t)(bestp >> 32));
+      const float4 p = a.pts[id];
+      a.ids[j] = id;
+      a.d2[j] = fd;
+      a.prev[j] = make_float4(p.x, p.y, p.z, __int_as_float(id));
+      if (a.sel_below && a.st->sel_mode) {  // predicted select: this query's share (see k_knn_tile)
+        const uint32_t bits = (uint32_t)(bestp >> 32), top = bits >> 20, b1 = a.st->sel_bin1;
+        if (top < b1) atomicAdd(&a.sel_below[(j & (kSelBelowSlots - 1)) * kSelBelowStride], 1u);
+        else if (top == b1) atomicAdd(&a.sel_hist2[(bits >> 9) & 0x7FFu], 1u);
+      }
+      if (a.lb) a.lb[j] = fd <= cap2s ? sqrtf(fd) * (1.0f - 1e-6f) : fmaxf(a.lb[j], sqrtf(cap2s) * (1.0f - 1e-5f));
+    }
+  }
+}
+
 }  // namespace lsgpu

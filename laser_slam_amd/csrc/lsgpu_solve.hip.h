@@ -293,7 +293,7 @@ __global__ __launch_bounds__(64) void k_icp_update(IcpState* __restrict__ st,
 
 // The align loop's variant: the matched point comes coalesced from the warm-start array (xyz + sorted
 // index of every query's neighbour, written by the kNN kernels), only the normal is gathered.  The
-// LAST block to finish (agent-scope release / ticket / acquire, cdna guide G16) reduces the block
+// LAST block to finish (ticket; partial sums exchanged with agent-scope accesses) reduces the block
 // partials in a fixed order, publishes {29 sums, limit, straggler count} and re-arms the per-iteration
 // scratch (histograms, straggler counter, ticket) so the next iteration needs no memset launches.
 __global__ __launch_bounds__(256) void k_normal_eq_loop(const float4* __restrict__ rdq, int nq,
@@ -374,62 +374,62 @@ __global__ __launch_bounds__(256) void k_normal_eq_loop(const float4* __restrict
     for (int k = 0; k < kNe; ++k) red[w][k] = acc[k];
   }
   __syncthreads();
+  // Hand-off between blocks WITHOUT fences: the partial sums are written and read with agent-scope (sc1) accesses,
+  // which go past the per-CU L1 and the per-XCD L2 on both sides (MI355X_MICROARCH.md, inter-workgroup visibility:
+  // "sc1 stores and loads both sides"); a release / acquire fence pair costs 1.7-6.5 us per block on this chip and
+  // every block would pay it.  s_waitcnt vmcnt(0) orders a block's stores before its ticket.
   if (threadIdx.x < kNe)
-    partials[(size_t)blockIdx.x * 32 + threadIdx.x] =
-        ((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x];
+    __hip_atomic_store(&partials[(size_t)blockIdx.x * 32 + threadIdx.x],
+                       ((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x],
+                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   // ---- publish.  Two-level, fixed-order reduction of the block partials (bitwise reproducible whichever block
   // ends up doing it): blocks form groups of kNeGroup; the LAST block of a group to finish sums that group's rows in
   // row order into a group partial, the LAST group to finish sums the group partials in group order.  Two short
-  // dependent rounds (<= 16 rows, <= 128 rows with 16 loads in flight) instead of one block walking every row: the
-  // single-block walk was half of this kernel's time (partials of other XCDs come from memory, ~1-2 us per round).
+  // dependent rounds (<= 16 rows, <= 128 rows with 16 loads in flight) instead of one block walking every row.
   const uint32_t g_id = blockIdx.x / kNeGroup, n_grp = (gridDim.x + kNeGroup - 1) / kNeGroup;
   const uint32_t g_first = g_id * kNeGroup;
   const uint32_t g_size = gridDim.x - g_first < (uint32_t)kNeGroup ? gridDim.x - g_first : (uint32_t)kNeGroup;
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   if (threadIdx.x == 0) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     const uint32_t t = __hip_atomic_fetch_add(ticket + 1 + g_id, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     is_last = (t == g_size - 1);
   }
   __syncthreads();
   if (!is_last) return;
-  if (threadIdx.x == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-  __syncthreads();
   if (threadIdx.x < 32) {  // the group's rows, in row order
     double v[kNeGroup];
 #pragma unroll
     for (int u = 0; u < kNeGroup; ++u)
-      v[u] = ((uint32_t)u < g_size && threadIdx.x < kNe) ? partials[(size_t)(g_first + u) * 32 + threadIdx.x] : 0.0;
+      v[u] = ((uint32_t)u < g_size && threadIdx.x < kNe)
+                 ? __hip_atomic_load(&partials[(size_t)(g_first + u) * 32 + threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                 : 0.0;
     double sgrp = 0.0;
 #pragma unroll
     for (int u = 0; u < kNeGroup; ++u) sgrp += v[u];
-    gpartials[(size_t)g_id * 32 + threadIdx.x] = sgrp;
+    __hip_atomic_store(&gpartials[(size_t)g_id * 32 + threadIdx.x], sgrp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   if (threadIdx.x == 0) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     const uint32_t t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     is_last = (t == n_grp - 1);
   }
   __syncthreads();
   if (!is_last) return;
-  if (threadIdx.x == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-  __syncthreads();
   if (threadIdx.x < 32) {  // the group partials, in group order
     double t = 0.0;
     uint32_t gidx = 0;
     for (; gidx + 16 <= n_grp; gidx += 16) {
       double v[16];
 #pragma unroll
-      for (int u = 0; u < 16; ++u) v[u] = gpartials[(size_t)(gidx + u) * 32 + threadIdx.x];
+      for (int u = 0; u < 16; ++u)
+        v[u] = __hip_atomic_load(&gpartials[(size_t)(gidx + u) * 32 + threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
       for (int u = 0; u < 16; ++u) t += v[u];
     }
-    for (; gidx < n_grp; ++gidx) t += gpartials[(size_t)gidx * 32 + threadIdx.x];
+    for (; gidx < n_grp; ++gidx)
+      t += __hip_atomic_load(&gpartials[(size_t)gidx * 32 + threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (threadIdx.x < kNe) { out[threadIdx.x] = t; fin[threadIdx.x] = t; }
   }
   for (uint32_t i = threadIdx.x; i < n_grp; i += 256)  // re-arm the group tickets (every group is done)
