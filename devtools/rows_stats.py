@@ -29,7 +29,8 @@ for rep in range(2):
     h.set_reference(dref, dn)
     T, st = h.align(drd, Ti)
 tr = h.trace(64)
-print("iterations", st.iterations, "align ms %.3f" % st.t_total_ms, "knn ms %.3f" % st.t_knn_ms)
+print("iterations", st.iterations, "align ms %.3f" % st.t_total_ms, "knn ms %.3f" % st.t_knn_ms, "select ms %.3f ne ms %.3f" % (st.t_select_ms, st.t_ne_ms),
+      "committed-select iterations", st.committed_select_iterations, "select misses", st.pad_, "cap retries", st.cap_retries)
 print(" it   knn_us  fb_us  searching      n_used   limit")
 for i, t in enumerate(tr):
     print("%3d %8.1f %6.1f %10d %11d %9.3e" % (i, t["knn_main_us"], t["knn_fallback_us"], t["searching"], t["n_used"], t["limit"]))

@@ -79,6 +79,8 @@ typedef struct lsgpu_icp_stats {
   double  t_reserved[1];     /* lsgpu_icp_compute: milliseconds in the two filters + set_reference */
   double  t_select_ms;       /* sum over the iterations: trimmed-distance select kernels (profile_kernels=1) */
   double  t_ne_ms;           /* sum over the iterations: normal equations + solve + checkers (profile_kernels=1) */
+  int     committed_select_iterations;  /* iterations whose trim limit came from the search kernels' own tables (no select launch) */
+  int     pad2_;
 } lsgpu_icp_stats;
 
 /* One record per iteration (optional parity/debug trace; replaces the VTKFileInspector dump of

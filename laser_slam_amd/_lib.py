@@ -69,6 +69,8 @@ class IcpStats(C.Structure):
         ("t_reserved", C.c_double * 1),
         ("t_select_ms", C.c_double),
         ("t_ne_ms", C.c_double),
+        ("committed_select_iterations", C.c_int),
+        ("pad2_", C.c_int),
     ]
 
 

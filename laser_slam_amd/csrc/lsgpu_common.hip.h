@@ -98,10 +98,20 @@ struct IcpState {
   // first two passes of the radix select; verified afterwards (k_hist_refine<3>), failure repeats the iteration
   uint32_t sel_bin1;  // top 12 bits of the last limit
   int sel_mode;
+  // committed select: once the limit has stayed within kSelStreakBins second-level bins of its predecessor for a few
+  // iterations, the host stops launching the select kernels altogether; the search kernels then also histogram the
+  // last 9 bits of the distances that fall into a window of second-level bins around the last limit, and the normal-
+  // equation kernel reads the order statistic from those tables in its prologue (verified; a miss repeats the
+  // iteration's select in full)
+  uint32_t sel_bin2;  // bits [19:9] of the last limit
+  int sel_streak;     // consecutive iterations whose limit stayed in the same 12-bit bin and close in the second level
 };
 constexpr int kSelBelowSlots = 64;   // counters of "distance below the predicted bin", hashed by tile ...
 constexpr int kSelBelowStride = 32;  // ... one per 128-byte line (atomics on one line serialise in L2)
 constexpr int kSelFailFlag = kSelBelowSlots * kSelBelowStride;  // word index of the failure flag
+constexpr int kSelWinRows = 128;     // committed select: second-level bins covered by the window table ...
+constexpr int kSelWinHalf = 64;      // ... centred on the last limit's bin (relative width of a bin: 2^-14)
+constexpr int kSelStreakBins = 40;   // a limit that moved less than this many second-level bins counts as "stayed"
 constexpr int kStatusCapFailed = 100;
 constexpr int kStatusSelFailed = 101;  // predicted select missed: the host repeats select + normal equations only
 

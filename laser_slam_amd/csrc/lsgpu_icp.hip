@@ -166,6 +166,7 @@ struct lsgpu_icp {
   DevBuf<uint32_t> counters;  // [0..16] cell counts, [32] straggler count
   DevBuf<uint32_t> ang_cells; // angular occupancy of the reading (query order decision)
   DevBuf<uint32_t> sel_aux;   // predicted select: kSelBelowSlots counters + failure flag
+  DevBuf<uint32_t> sel_win;   // committed select: kSelWinRows x 512 window histogram
   DevBuf<uint32_t> work;      // compacted list of searching queries (k_knn_classify -> k_knn_rows)
 
   // device filters (lsgpu_ssn.hip.h)
@@ -318,7 +319,7 @@ void lsgpu_icp_destroy(lsgpu_icp* h) {
   h->ref_in.release(); h->nrm_in.release(); h->keys.release(); h->keys_alt.release();
   h->vals.release(); h->vals_alt.release(); h->sort_tmp.release(); h->pts.release();
   h->nrm.release(); h->ref_inv.release(); h->tables.release(); h->flags.release(); h->cidx.release(); h->bounds.release(); h->chunks.release(); h->soa.release(); h->soa_base.release(); h->soa_cnt4.release(); h->soa_first.release(); h->prev.release(); h->state.release(); h->lb.release(); h->cell_cache.release(); h->cell_tags.release(); h->ssn_seg_a.release(); h->ssn_seg_b.release(); h->ssn_seg_of.release(); h->ssn_box_pts.release(); h->ssn_box_base.release(); h->ssn_keep.release(); h->ssn_out_pos.release(); h->ssn_bb.release(); h->ssn_box_normal.release(); h->ssn_draws.release(); h->flt_in.release(); h->flt_ref.release(); h->flt_rd.release(); h->flt_nrm.release(); h->chk_hist.release(); h->trace_dev.release(); h->knn_dbg.release(); h->knn_dbg_wave.release(); h->stat_partials.release();
-  h->counters.release(); h->ang_cells.release(); h->sel_aux.release(); h->work.release(); h->q_in.release(); h->rdq.release(); h->ids.release(); h->d2.release();
+  h->counters.release(); h->ang_cells.release(); h->sel_aux.release(); h->sel_win.release(); h->work.release(); h->q_in.release(); h->rdq.release(); h->ids.release(); h->d2.release();
   h->ids_io.release(); h->d2_io.release(); h->strag.release(); h->hist.release();
   h->sel.release(); h->ne_partials.release(); h->ne_gpartials.release(); h->ne_tickets.release(); h->ne_out.release(); h->limit_dev.release();
   for (auto& e : h->knn_events) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); (void)hipEventDestroy(e.c); (void)hipEventDestroy(e.d); (void)hipEventDestroy(e.e); }
@@ -423,6 +424,7 @@ static KnnArgs knn_args(lsgpu_icp* h, const Mat34& T) {
   a.strag = h->strag.p; a.strag_count = h->counters.p + 32;
   a.r_cap = 1.0f; a.group_r = 0.75f; a.cap2 = INFINITY; a.st = nullptr; a.use_state_cap = 0; a.lb = nullptr;
   a.spread_route_r = 0.f; a.route_chunks = 1 << 30; a.sel_hist2 = nullptr; a.sel_below = nullptr;
+  a.sel_hist3w = nullptr; a.sel_force = 0;
   { static const float gap = getenv("LSGPU_GAP") ? (float)atof(getenv("LSGPU_GAP")) : 0.002f; a.gap = gap; }
   a.ntiles = (int)((h->nq + 63) / 64); a.xcd_swizzle = 0; a.pad_index = (int)h->nr;
   { static const int budget = getenv("LSGPU_BUDGET") ? atoi(getenv("LSGPU_BUDGET")) : 128; a.chunk_budget = budget; }
@@ -443,7 +445,7 @@ static KnnArgs knn_args(lsgpu_icp* h, const Mat34& T) {
 //   capped   : search cap from the loop state (exact below cap, see lsgpu_knn.hip.h); otherwise uncapped,
 //              followed by the straggler fallback
 static int run_knn(lsgpu_icp* h, const Mat34& T, const IcpState* st, bool seed, bool capped, bool timed,
-                   bool wide = true, bool predicted = false, uint32_t seed_rank = 0xFFFFFFFFu) {
+                   bool wide = true, bool predicted = false, uint32_t seed_rank = 0xFFFFFFFFu, bool committed = false) {
   const int nq = (int)h->nq;
   KnnArgs a = knn_args(h, T);
   h->dbg_launch_no++;
@@ -460,6 +462,7 @@ static int run_knn(lsgpu_icp* h, const Mat34& T, const IcpState* st, bool seed, 
   const bool settled = capped && !wide && st && route_all;
   a.spread_route_r = wide ? route_r : settled ? 1e-30f : 0.f;
   if (predicted && !wide && capped && st) { a.sel_hist2 = h->hist.p + kHistBins; a.sel_below = h->sel_aux.p; }
+  if (committed && a.sel_below) { a.sel_hist3w = h->sel_win.p; a.sel_force = 1; }
   { static const int rc_ = getenv("LSGPU_ROUTE_CHUNKS") ? atoi(getenv("LSGPU_ROUTE_CHUNKS")) : 1024; a.route_chunks = rc_; }
   if (seed) HIPC(hipMemsetAsync(a.strag_count, 0, sizeof(uint32_t), h->stream));  // later: re-armed by k_normal_eq_loop
   if (seed) hipLaunchKernelGGL(k_knn_seed, dim3(nblk(nq)), dim3(256), 0, h->stream, a);
@@ -1475,6 +1478,8 @@ int lsgpu_icp_align(lsgpu_icp* h, const float* reading_xyz1, int64_t nq, const f
   HIPC(hipMemsetAsync(h->ne_tickets.p, 0, (size_t)(kNeBlocksMax / kNeGroup + 2) * sizeof(uint32_t), h->stream));
   HIPC(h->sel_aux.reserve(kSelFailFlag + 4));
   HIPC(hipMemsetAsync(h->sel_aux.p, 0, (kSelFailFlag + 4) * sizeof(uint32_t), h->stream));
+  HIPC(h->sel_win.reserve((size_t)kSelWinRows * 512));
+  HIPC(hipMemsetAsync(h->sel_win.p, 0, (size_t)kSelWinRows * 512 * sizeof(uint32_t), h->stream));
 
   const uint32_t k = trim_rank(nq_total, h->cfg.trim_ratio);
   const int nb = std::min(kNeBlocks, nblk(nq));
@@ -1484,28 +1489,38 @@ int lsgpu_icp_align(lsgpu_icp* h, const float* reading_xyz1, int64_t nq, const f
   std::vector<size_t> ev_of_launch;  // event index of every enqueued iteration
   static const bool split_update = getenv("LSGPU_SPLIT_UPDATE") != nullptr;  // (profiling: the update as its own launch)
   static const bool predict_select = getenv("LSGPU_NO_PREDICT") == nullptr && !split_update;
+  // committed select (device reports a steady limit): no select kernels at all, see IcpState::sel_streak
+  static const bool commit_select = getenv("LSGPU_NO_COMMIT") == nullptr &&
+                                    !(getenv("LSGPU_KNN_ROWS") && atoi(getenv("LSGPU_KNN_ROWS")) != 0);  // (the experimental row-wise path does not fill the window table)
+  bool commit_ok = false;
+  int committed_iterations = 0;
   auto enqueue_iteration = [&](bool seed, bool capped, bool wide, bool knn = true) -> int {
     // capped launches without a wave-per-query pass may fold the first half of the select into the kNN kernel
     // (the device decides per iteration, IcpState::sel_mode); not in the RCCL mode (the counts are per shard).
     // knn == false: only select + normal equations + update on the distances already there (after a missed
     // prediction)
     const bool predicted = predict_select && knn && capped && !wide && !h->comm;
+    const bool committed = predicted && commit_select && commit_ok && !first_select;
     int r = LSGPU_OK;
     if (knn) {
-      r = run_knn(h, Tdummy, h->state.p, seed, capped, timed, wide, predicted, seed && capped ? k : 0xFFFFFFFFu);  // 6a+6b
+      r = run_knn(h, Tdummy, h->state.p, seed, capped, timed, wide, predicted, seed && capped ? k : 0xFFFFFFFFu, committed);  // 6a+6b
       if (r) return r;
       ev_of_launch.push_back(h->knn_events_used ? h->knn_events_used - 1 : 0);
     }
-    r = run_select(h, h->d2.p, (int)nq, k, first_select, h->state.p, true, predicted);         // 6c
-    first_select = false;
-    if (r) return r;
+    if (!committed) {
+      r = run_select(h, h->d2.p, (int)nq, k, first_select, h->state.p, true, predicted);       // 6c
+      first_select = false;
+      if (r) return r;
+    } else {
+      ++committed_iterations;
+    }
     lsgpu_icp::KnnEv* ev = (timed && knn && h->knn_events_used) ? &h->knn_events[h->knn_events_used - 1] : nullptr;
     if (ev) HIPC(hipEventRecord(ev->d, h->stream));
     hipLaunchKernelGGL(k_normal_eq_loop, dim3(nb), dim3(256), 0, h->stream, h->rdq.p, (int)nq,
                        h->state.p, h->prev.p, h->d2.p, h->nrm.p, h->hist.p, h->sel.p + 2,
                        h->counters.p + 32, h->ne_tickets.p, h->ne_partials.p, h->ne_gpartials.p, h->ne_out.p,
                        h->chk_hist.p, h->trace_dev.p, max_it, capped ? 1 : 0, (h->comm || split_update) ? 0 : 1,
-                       h->comm ? (uint32_t*)nullptr : h->sel_aux.p);                            // 6d (+6e)
+                       h->comm ? (uint32_t*)nullptr : h->sel_aux.p, h->sel_win.p, committed ? 1 : 0);   // 6d (+6e)
     if (h->comm || split_update) {   // split scan: every rank gets the sums over all shards (the limit, slot 29, is already global)
       if (h->comm && rccl_api()->AllReduce(h->ne_out.p, h->ne_out.p, kNe, ncclDouble, ncclSum, h->comm, h->stream) != ncclSuccess) {
         h->err = "RCCL all-reduce of the normal equations failed";
@@ -1546,6 +1561,7 @@ int lsgpu_icp_align(lsgpu_icp* h, const float* reading_xyz1, int64_t nq, const f
     rc = fetch_state();
     if (rc) return rc;
     since_check = 0;
+    commit_ok = hst->sel_streak >= 1 && hst->status == 0;  // (a miss below clears it until the streak is rebuilt)
     if (hst->done && hst->status == kStatusCapFailed) {
       // the cap prediction failed for iteration hst->iter: repeat it uncapped, then carry on
       st.cap_retries++;
@@ -1561,6 +1577,8 @@ int lsgpu_icp_align(lsgpu_icp* h, const float* reading_xyz1, int64_t nq, const f
       // the limit left the predicted 12-bit bin in iteration hst->iter: its distances stand, the full select
       // and everything after it run again
       sel_retries++;
+      commit_ok = false;
+      hst->sel_streak = 0;
       hst->done = 0; hst->status = 0;
       HIPC(hipMemcpyAsync(h->state.p, hst, sizeof(IcpState), hipMemcpyHostToDevice, h->stream));
       HIPC(hipStreamSynchronize(h->stream));
@@ -1618,6 +1636,7 @@ int lsgpu_icp_align(lsgpu_icp* h, const float* reading_xyz1, int64_t nq, const f
     }
   }
   st.pad_ = sel_retries;  // (select predictions that missed; informational)
+  st.committed_select_iterations = committed_iterations;
   st.t_total_ms = wall_ms() - t0;
   if (stats) *stats = st;
   return rc;

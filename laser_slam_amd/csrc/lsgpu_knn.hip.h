@@ -61,6 +61,8 @@ struct KnnArgs {
   int route_chunks;         // (with spread_route_r > 0) so does any wave whose cell block holds more chunks than this
   uint32_t* sel_hist2;      // predicted select (IcpState::sel_mode): 2048-bin histogram of bits [19:9] inside the bin
   uint32_t* sel_below;      //   kSelBelowSlots counters of distances below the bin (nullable: launch without prediction)
+  uint32_t* sel_hist3w;     // committed select: kSelWinRows x 512 histogram of bits [8:0] around the last limit (nullable)
+  int sel_force;            //   1: histogram against the last limit's bins whatever IcpState::sel_mode says
   const IcpState* st;       // loop state (nullable): overrides T (and cap2 if use_state_cap)
   int use_state_cap;
   unsigned long long* dbg;  // optional counters (LSGPU_KNN_STATS builds only)
@@ -89,6 +91,17 @@ __device__ __forceinline__ float box_dist2(float lx, float ly, float lz, float h
   const float dy = fmaxf(fmaxf(ly - qy, qy - hy), 0.f);
   const float dz = fmaxf(fmaxf(lz - qz, qz - hz), 0.f);
   return dx * dx + dy * dy + dz * dz;
+}
+
+// One final distance's share of the predicted / committed select (inside the predicted 12-bit bin): second-level
+// histogram, and the third-level window table where the launch carries one.
+__device__ __forceinline__ void sel_count_inside(const KnnArgs& a, uint32_t bits) {
+  const uint32_t bin2 = (bits >> 9) & 0x7FFu;
+  atomicAdd(&a.sel_hist2[bin2], 1u);
+  if (a.sel_hist3w) {
+    const uint32_t d = bin2 - a.st->sel_bin2 + (uint32_t)kSelWinHalf;
+    if (d < (uint32_t)kSelWinRows) atomicAdd(&a.sel_hist3w[d * 512u + (bits & 0x1FFu)], 1u);
+  }
 }
 
 // ---------------------------------------------------------------- seed
@@ -272,7 +285,8 @@ __device__ __forceinline__ void tile_process_batch(const KnnArgs& a, float cap2,
                                                    uint32_t ch, bool ing, float qx, float qy, float qz,
                                                    float tlx, float tly, float tlz, float thx, float thy,
                                                    float thz, float& maxbest, float ub, float gap, float& best,
-                                                   float& sec, int& grp, uint32_t& n_eval, uint32_t& n_surv) {
+                                                   float& sec, int& grp, uint32_t& n_eval, uint32_t& n_surv,
+                                                   uint32_t& c_eval /* stats builds: cycles spent fetching + evaluating */) {
   float4 b0 = make_float4(0.f, 0.f, 0.f, 0.f), b1 = b0;
   uint32_t sbase = 0;
   bool pass = false;
@@ -329,6 +343,9 @@ __device__ __forceinline__ void tile_process_batch(const KnnArgs& a, float cap2,
   // flight while the current pair is evaluated (slots 0,1 <-> 2,3)
   typedef __attribute__((address_space(1))) const void* gptr_t;
   typedef __attribute__((address_space(3))) void* lptr_t;
+#ifdef LSGPU_KNN_STATS
+  const long long t_ev0 = clock64();
+#endif
   uint32_t sa0 = 0, sa1 = 0, ca0 = 0, ca1 = 0, sb0 = 0, sb1 = 0, cb0 = 0, cb1 = 0;
   auto issue = [&](int slot, uint32_t& st, uint32_t& cnt) -> int {
     if (!needm) return 0;
@@ -367,6 +384,11 @@ __device__ __forceinline__ void tile_process_batch(const KnnArgs& a, float cap2,
     if (nb > 1) tile_eval_slot(lds.slot[3], sb1, cb1, qx, qy, qz, best, sec, grp);
   }
   maxbest = wave_max(ing ? prune_lim(fminf(best, ub), gap, cap2) : 0.f);
+#ifdef LSGPU_KNN_STATS
+  c_eval += (uint32_t)(clock64() - t_ev0);
+#else
+  (void)c_eval;
+#endif
 }
 
 // Which point of the recorded group of 4 is at distance `best` (first one; pts is padded, and a point
@@ -427,6 +449,15 @@ __global__ __launch_bounds__(WAVES * 64, LSGPU_TILE_OCC) void k_knn_tile(KnnArgs
     mp = a.prev[j];  // coalesced: no dependent gather of pts[prev]
     if (a.lb) lb_in = a.lb[j];
   }
+  // the tile's cached cell block (tag + 64 probe results) travels with the same round trip: whether it still fits
+  // is only known after the reductions below, but waiting until then cost two more dependent loads (40 % of a
+  // settled wave's time was this prologue)
+  ulonglong2 tag_pre = make_ulonglong2(0ull, 0ull);
+  uint2 cc_pre = make_uint2(0u, 0u);
+  if (a.cell_cache) {
+    tag_pre = a.cell_tags[tile];
+    cc_pre = a.cell_cache[(size_t)tile * 64 + lane];
+  }
   Mat34 T; float cap2;
   if (!iter_params(a.st, a.T, a.cap2, a.use_state_cap, T, cap2)) return;
   // Search / verification radius 5 % beyond the cap: a lane verified to have nothing inside keeps a
@@ -437,7 +468,7 @@ __global__ __launch_bounds__(WAVES * 64, LSGPU_TILE_OCC) void k_knn_tile(KnnArgs
   if ((a.dbg_flags & 2048) && (tile & 3u)) return;
 #endif
   const GridDev& g = a.g;
-  uint32_t n_eval = 0, n_surv = 0, n_grp = 0, lvl_max = 0;
+  uint32_t n_eval = 0, n_surv = 0, n_grp = 0, lvl_max = 0, c_eval = 0;
 
   // ub: distance to the warm-start point (prev match); best / sec: smallest and second smallest distance
   // among the points this search evaluates (the warm-start point is one of them whenever its chunk is)
@@ -520,14 +551,9 @@ __global__ __launch_bounds__(WAVES * 64, LSGPU_TILE_OCC) void k_knn_tile(KnnArgs
       const unsigned long long tag0 = ((unsigned long long)a.cache_gen << 32) | ((unsigned long long)l << 24) |
                                       ((unsigned long long)nx << 16) | ((unsigned long long)ny << 8) | (unsigned long long)nz;
       const unsigned long long tag1 = (unsigned long long)x0 | ((unsigned long long)y0 << 21) | ((unsigned long long)z0 << 42);
-      bool hit = false;
-      if (a.cell_cache) {
-        const ulonglong2 t = a.cell_tags[tile];
-        hit = (t.x == tag0) && (t.y == tag1);
-      }
+      const bool hit = a.cell_cache && tag_pre.x == tag0 && tag_pre.y == tag1;
       if (hit) {
-        const uint2 c = a.cell_cache[(size_t)tile * 64 + lane];
-        cs = c.x; ce = c.y;
+        cs = cc_pre.x; ce = cc_pre.y;
       } else {
         const int cx = lane & 3, cy = (lane >> 2) & 3, cz = lane >> 4;
         if (cx < nx && cy < ny && cz < nz) {
@@ -585,7 +611,7 @@ __global__ __launch_bounds__(WAVES * 64, LSGPU_TILE_OCC) void k_knn_tile(KnnArgs
             fill -= 64u;
             const uint32_t ch = lds.list[fill + lane];
             tile_process_batch(a, cap2s, lds, lane, true, ch, ing, qx, qy, qz, tlx, tly, tlz, thx, thy, thz,
-                               maxbest, ub, gap, best, sec, grp, n_eval, n_surv);
+                               maxbest, ub, gap, best, sec, grp, n_eval, n_surv, c_eval);
           }
         }
       }
@@ -593,12 +619,13 @@ __global__ __launch_bounds__(WAVES * 64, LSGPU_TILE_OCC) void k_knn_tile(KnnArgs
         const bool v = (uint32_t)lane < fill;
         const uint32_t ch = v ? lds.list[lane] : 0u;
         tile_process_batch(a, cap2s, lds, lane, v, ch, ing, qx, qy, qz, tlx, tly, tlz, thx, thy, thz,
-                           maxbest, ub, gap, best, sec, grp, n_eval, n_surv);
+                           maxbest, ub, gap, best, sec, grp, n_eval, n_surv, c_eval);
       }
     }
   }
 #ifdef LSGPU_KNN_STATS
   if (a.dbg_flags & (64 | 128 | 256 | 512)) return;
+  const long long t_loop_end = clock64();
 #endif
   if (act) {
     float nb;  // new lower bound on the distance to every point other than the (new) match
@@ -636,14 +663,14 @@ __global__ __launch_bounds__(WAVES * 64, LSGPU_TILE_OCC) void k_knn_tile(KnnArgs
     if (a.lb) a.lb[j] = nb;
     if (straggler || routed) a.strag[atomicAdd(a.strag_count, 1u)] = (uint32_t)j;
   }
-  if (a.sel_below && a.st->sel_mode) {
+  if (a.sel_below && (a.st->sel_mode || a.sel_force)) {
     // first two passes of the trimmed-distance select, folded into this kernel (every distance of the launch is
     // final here; the lanes routed to the wave-per-query pass are counted there)
     // (lanes handed to the wave-per-query pass get their final distance, and their count, there)
     const bool fin = act && !routed && !straggler;
     const uint32_t bits = __float_as_uint(best), top = bits >> 20, b1 = a.st->sel_bin1;
     const unsigned long long below = __ballot(fin && top < b1);
-    if (fin && top == b1) atomicAdd(&a.sel_hist2[(bits >> 9) & 0x7FFu], 1u);
+    if (fin && top == b1) sel_count_inside(a, bits);
     if (lane == 0 && below) atomicAdd(&a.sel_below[(tile & (kSelBelowSlots - 1)) * kSelBelowStride], (uint32_t)__popcll(below));
   }
 #ifdef LSGPU_KNN_STATS
@@ -654,10 +681,15 @@ __global__ __launch_bounds__(WAVES * 64, LSGPU_TILE_OCC) void k_knn_tile(KnnArgs
     atomicAdd(&a.dbg[0], (unsigned long long)n_grp); atomicAdd(&a.dbg[3], (unsigned long long)n_surv);
     atomicAdd(&a.dbg[4], (unsigned long long)n_eval);
   }
-  if (lane == 0 && a.dbg_wave)
-    a.dbg_wave[tile] = make_uint4((uint32_t)(clock64() - t_begin), n_eval, n_surv, (n_act << 16) | (n_grp << 8) | lvl_max);
+  if (lane == 0 && a.dbg_wave) {
+    const long long t_end = clock64();
+    a.dbg_wave[tile] = make_uint4((uint32_t)(t_end - t_begin), n_eval, n_surv, (n_act << 16) | (n_grp << 8) | lvl_max);
+    if (a.dbg_flags & 4096)  // second record per tile (the buffer holds 2 x ntiles records): where the cycles went
+      a.dbg_wave[(uint32_t)a.ntiles + tile] = make_uint4((uint32_t)(t_look - t_begin), (uint32_t)(t_loop_end - t_look), c_eval,
+                                                          (uint32_t)(t_end - t_loop_end));
+  }
 #else
-  (void)n_grp; (void)lvl_max;
+  (void)n_grp; (void)lvl_max; (void)c_eval;
 #endif
 }
 
@@ -760,10 +792,10 @@ __global__ __launch_bounds__(256) void k_knn_fallback(KnnArgs a) {
       const float4 p = a.pts[id];
       a.ids[j] = id;
       a.d2[j] = __uint_as_float((uint32_t)(bestp >> 32));
-      if (a.sel_below && a.st->sel_mode) {  // predicted select: this query's share (see k_knn_tile)
+      if (a.sel_below && (a.st->sel_mode || a.sel_force)) {  // predicted select: this query's share (see k_knn_tile)
         const uint32_t bits = (uint32_t)(bestp >> 32), top = bits >> 20, b1 = a.st->sel_bin1;
         if (top < b1) atomicAdd(&a.sel_below[(j & (kSelBelowSlots - 1)) * kSelBelowStride], 1u);
-        else if (top == b1) atomicAdd(&a.sel_hist2[(bits >> 9) & 0x7FFu], 1u);
+        else if (top == b1) sel_count_inside(a, bits);
       }
       a.prev[j] = make_float4(p.x, p.y, p.z, __int_as_float(id));
       if (a.lb) {

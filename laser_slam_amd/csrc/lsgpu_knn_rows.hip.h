@@ -501,10 +501,10 @@ __global__ __launch_bounds__(256) void k_knn_rowq(KnnArgs a) {
       a.ids[j] = id;
       a.d2[j] = fd;
       a.prev[j] = make_float4(p.x, p.y, p.z, __int_as_float(id));
-      if (a.sel_below && a.st->sel_mode) {  // predicted select: this query's share (see k_knn_tile)
+      if (a.sel_below && (a.st->sel_mode || a.sel_force)) {  // predicted select: this query's share (see k_knn_tile)
         const uint32_t bits = (uint32_t)(bestp >> 32), top = bits >> 20, b1 = a.st->sel_bin1;
         if (top < b1) atomicAdd(&a.sel_below[(j & (kSelBelowSlots - 1)) * kSelBelowStride], 1u);
-        else if (top == b1) atomicAdd(&a.sel_hist2[(bits >> 9) & 0x7FFu], 1u);
+        else if (top == b1) sel_count_inside(a, bits);
       }
       if (a.lb) a.lb[j] = fd <= cap2s ? sqrtf(fd) * (1.0f - 1e-6f) : fmaxf(a.lb[j], sqrtf(cap2s) * (1.0f - 1e-5f));
     }

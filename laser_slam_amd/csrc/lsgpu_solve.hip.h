@@ -265,9 +265,12 @@ __device__ inline void icp_update_lane(IcpState* st, const double* ne_out, float
   }
   st->prev_limit = limit;
   {
-    const uint32_t b1 = __float_as_uint(limit) >> 20;
+    const uint32_t lb = __float_as_uint(limit), b1 = lb >> 20, b2 = (lb >> 9) & 0x7FFu;
+    const uint32_t moved = b2 > st->sel_bin2 ? b2 - st->sel_bin2 : st->sel_bin2 - b2;
+    st->sel_streak = (b1 == st->sel_bin1 && moved <= (uint32_t)kSelStreakBins) ? st->sel_streak + 1 : 0;
     st->sel_mode = (b1 == st->sel_bin1) ? 1 : 0;  // predict only a bin that has just been confirmed
     st->sel_bin1 = b1;
+    st->sel_bin2 = b2;
   }
   st->cap2 = st->cap_enabled ? limit * kCapFactor : INFINITY;
   st->iter = it + 1;
@@ -311,7 +314,9 @@ __global__ __launch_bounds__(256) void k_normal_eq_loop(const float4* __restrict
                                                         float* __restrict__ chk_hist,
                                                         lsgpu_iter_trace* __restrict__ trace, int trace_cap,
                                                         int capped_launch, int fuse_update,
-                                                        uint32_t* __restrict__ sel_aux) {
+                                                        uint32_t* __restrict__ sel_aux,
+                                                        uint32_t* __restrict__ hist3w /* committed select: window table */,
+                                                        int committed) {
   __shared__ uint32_t sc[260];
   __shared__ double fin[32];
   __shared__ double red[8][33];
@@ -320,14 +325,47 @@ __global__ __launch_bounds__(256) void k_normal_eq_loop(const float4* __restrict
   Mat34 T;
 #pragma unroll
   for (int i = 0; i < 12; ++i) T.m[i] = ist->T_rows[i];
-  const float limit = select_limit(hist + 2 * kHistBins, st, sc);
+  float limit;
+  bool sel_ok = true;
+  if (committed) {
+    // No select kernel ran: the search kernels left {counts below the last limit's 12-bit bin, the 11-bit histogram
+    // inside it, the 9-bit histograms of a window of second-level bins around it}.  Every block derives the order
+    // statistic from them (3 short scans); a rank outside the bin or the window voids the iteration.
+    __shared__ uint32_t cnt[8];
+    uint32_t below = 0, inside = 0;
+    for (int i = threadIdx.x; i < kSelBelowSlots; i += 256) below += sel_aux[i * kSelBelowStride];
+    for (int i = threadIdx.x; i < kHistBins; i += 256) inside += hist[kHistBins + i];
+    below = wave_sum_u32(below); inside = wave_sum_u32(inside);
+    if ((threadIdx.x & 63) == 0) { cnt[threadIdx.x >> 6] = below; cnt[4 + (threadIdx.x >> 6)] = inside; }
+    __syncthreads();
+    below = cnt[0] + cnt[1] + cnt[2] + cnt[3];
+    inside = cnt[4] + cnt[5] + cnt[6] + cnt[7];
+    __syncthreads();
+    const uint32_t k = st[-2].k;  // sel[0] = {0, rank}: constant during an align
+    limit = 0.f;
+    if (k < below || k - below >= inside) {
+      sel_ok = false;
+    } else {
+      uint32_t bin2, krem2, bin3, krem3;
+      find_bin(hist + kHistBins, kHistBins, k - below, &bin2, &krem2, sc);
+      const uint32_t d = bin2 - ist->sel_bin2 + (uint32_t)kSelWinHalf;
+      if (d >= (uint32_t)kSelWinRows) {
+        sel_ok = false;
+      } else {
+        find_bin(hist3w + d * 512u, 512, krem2, &bin3, &krem3, sc);
+        limit = __uint_as_float((ist->sel_bin1 << 20) | (bin2 << 9) | bin3);
+      }
+    }
+  } else {
+    limit = select_limit(hist + 2 * kHistBins, st, sc);
+  }
   double acc[kNe];
 #pragma unroll
   for (int k = 0; k < kNe; ++k) acc[k] = 0.0;
   // four points per step: their loads (distance, match, query, gathered normal) are issued together, the sums
   // are still taken in index order, so the result does not depend on the unrolling
   const int stride = gridDim.x * 256;
-  for (int j0 = blockIdx.x * 256 + threadIdx.x; j0 < nq; j0 += 4 * stride) {
+  for (int j0 = blockIdx.x * 256 + threadIdx.x; j0 < (sel_ok ? nq : 0); j0 += 4 * stride) {
     float dd[4]; float4 qq[4], rr[4], nn[4]; bool use[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
@@ -446,6 +484,11 @@ __global__ __launch_bounds__(256) void k_normal_eq_loop(const float4* __restrict
   }
   for (int i = threadIdx.x; i < 3 * kHistBins; i += 256) hist[i] = 0u;  // every block has read hist3 by now
   if (sel_aux && threadIdx.x < kSelBelowSlots) sel_aux[threadIdx.x * kSelBelowStride] = 0u;
+  if (hist3w) {  // the window table of the committed select (written only by launches that carry it)
+    uint4* w4 = reinterpret_cast<uint4*>(hist3w);
+    for (int i = threadIdx.x; i < kSelWinRows * 512 / 4; i += 256) w4[i] = make_uint4(0u, 0u, 0u, 0u);
+  }
+  if (!sel_ok && sel_aux && threadIdx.x == 0) sel_aux[kSelFailFlag] = 1u;  // (committed select missed: same handling as a missed prediction)
   if (fuse_update) {  // every other block has finished: the loop state is this block's to advance
     __syncthreads();
     if (threadIdx.x == 0) icp_update_lane(ist, fin, chk_hist, trace, trace_cap, capped_launch, sel_aux);
