@@ -52,9 +52,21 @@ __global__ __launch_bounds__(256) void k_ref_stats(const float4* __restrict__ in
   }
 }
 
+// Grid geometry, derived ON THE DEVICE from the reference statistics so that the grid build does not have to wait
+// for a host round trip between the statistics and the keys (the host reads it back later, together with the cell
+// counts it needs anyway).
+struct GeomDev {
+  float mean[3];      // the float mean ICP::compute subtracts (step 2)
+  float ox, oy, oz;   // grid origin = bounding-box minimum in the mean frame
+  float h0, hf, inv_hf;
+  int fine, bits;
+  int bad;            // non-finite coordinates
+};
+
 // One wave; fixed summation tree => deterministic mean.  nblocks <= 512.
 __global__ __launch_bounds__(64) void k_ref_stats_final(const RefStats* __restrict__ partials,
-                                                        int nblocks, RefStats* __restrict__ out) {
+                                                        int nblocks, RefStats* __restrict__ out, int64_t n,
+                                                        float cell_size_cfg, GeomDev* __restrict__ geom) {
   const int lane = threadIdx.x;
   double s[3] = {0, 0, 0};
   float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
@@ -70,17 +82,40 @@ __global__ __launch_bounds__(64) void k_ref_stats_final(const RefStats* __restri
     r.mn[d] = wave_min(mn[d]);
     r.mx[d] = wave_max(mx[d]);
   }
-  if (lane == 0) *out = r;
+  if (lane == 0) {
+    *out = r;
+    // same arithmetic the host used to do: float mean from the double sums, box in the mean frame, then 16 key bits per
+    // axis split between level-0 cells (`bits`) and the order inside a cell (`fine`)
+    GeomDev gm;
+    float mn[3], mx[3];
+    gm.bad = 0;
+    for (int d = 0; d < 3; ++d) {
+      gm.mean[d] = (float)(r.sum[d] / (double)n);
+      mn[d] = r.mn[d] - gm.mean[d];
+      mx[d] = r.mx[d] - gm.mean[d];
+      if (!isfinite(mn[d]) || !isfinite(mx[d])) gm.bad = 1;
+    }
+    const float ext = fmaxf(fmaxf(mx[0] - mn[0], mx[1] - mn[1]), mx[2] - mn[2]);
+    int bits = 11, fine = 5;
+    float h0 = cell_size_cfg > 0.f ? cell_size_cfg : 0.125f;
+    while (bits < 13 && h0 * (float)((1 << bits) - 1) < ext * 1.0001f) { ++bits; --fine; }
+    while (!gm.bad && h0 * (float)((1 << bits) - 1) < ext * 1.0001f) h0 *= 2.f;
+    gm.ox = mn[0]; gm.oy = mn[1]; gm.oz = mn[2];
+    gm.h0 = h0; gm.hf = h0 / (float)(1 << fine); gm.inv_hf = 1.0f / gm.hf; gm.fine = fine; gm.bits = bits;
+    *geom = gm;
+  }
 }
 
 // ---------------------------------------------------------------- keys
 // Reference: centre on the mean, quantise at hf, Morton key of (fine + bits) bits per axis.
 __global__ __launch_bounds__(256) void k_ref_keys(const float4* __restrict__ in, int64_t n,
-                                                  float mx, float my, float mz, GridDev g,
+                                                  const GeomDev* __restrict__ geom,
                                                   uint64_t* __restrict__ keys,
                                                   uint32_t* __restrict__ vals) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
+  const GeomDev g = *geom;
+  const float mx = g.mean[0], my = g.mean[1], mz = g.mean[2];
   const float4 p = in[i];
   const int lim = (1 << (g.bits + g.fine)) - 1;
   const int ix = fine_coord(p.x - mx, g.ox, g.inv_hf, lim);
@@ -197,10 +232,11 @@ __global__ __launch_bounds__(256) void k_query_keys(const float4* __restrict__ i
 // sorted reference: pts[j] = {centred xyz, original index}, nrm[j] = {normal, 0}, inv[orig] = j
 __global__ __launch_bounds__(256) void k_ref_gather(const float4* __restrict__ in,
                                                     const float* __restrict__ nrm_in, int64_t n,
-                                                    const uint32_t* __restrict__ perm, float mx,
-                                                    float my, float mz, float4* __restrict__ pts,
+                                                    const uint32_t* __restrict__ perm,
+                                                    const GeomDev* __restrict__ geom, float4* __restrict__ pts,
                                                     float4* __restrict__ nrm,
                                                     uint32_t* __restrict__ inv) {
+  const float mx = geom->mean[0], my = geom->mean[1], mz = geom->mean[2];
   const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (j >= n) {  // 8 far pad points behind the array (4-wide point loads may run past the end)
     if (j < n + 8) pts[j] = make_float4(3e18f, 3e18f, 3e18f, 0.f);
@@ -239,9 +275,10 @@ __global__ __launch_bounds__(256) void k_transform(const float4* __restrict__ in
 // ---------------------------------------------------------------- chunks
 // A chunk starts at every level-0 cell boundary and at every 64th sorted point.
 __global__ __launch_bounds__(256) void k_chunk_flags(const uint64_t* __restrict__ keys, int64_t n,
-                                                     int fine, uint32_t* __restrict__ flags) {
+                                                     const GeomDev* __restrict__ geom, uint32_t* __restrict__ flags) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
+  const int fine = geom->fine;
   uint32_t f = ((i & (kChunkMax - 1)) == 0);
   if (i > 0 && ((keys[i] ^ keys[i - 1]) >> (3 * fine)) != 0) f = 1;
   flags[i] = f;
@@ -318,9 +355,10 @@ __device__ __forceinline__ int boundary_level(uint64_t k, uint64_t kp, int fine)
 }
 
 __global__ __launch_bounds__(256) void k_cells_count(const uint64_t* __restrict__ keys, int64_t n,
-                                                     int fine, int bits,
+                                                     const GeomDev* __restrict__ geom,
                                                      uint32_t* __restrict__ counts) {
   __shared__ uint32_t sh[kMaxLevels];
+  const int fine = geom->fine, bits = geom->bits;
   if (threadIdx.x < kMaxLevels) sh[threadIdx.x] = 0;
   __syncthreads();
   // grid-stride: few blocks, so that the final global adds (same 12 addresses for every block) stay cheap

@@ -163,6 +163,7 @@ struct lsgpu_icp {
   DevBuf<lsgpu_iter_trace> trace_dev;
   DevBuf<float4> prev;       // warm start of every query: its current match {xyz, sorted index}
   DevBuf<RefStats> stat_partials;
+  DevBuf<GeomDev> geom;      // grid geometry derived on the device (k_ref_stats_final)
   DevBuf<uint32_t> counters;  // [0..16] cell counts, [32] straggler count
   DevBuf<uint32_t> ang_cells; // angular occupancy of the reading (query order decision)
   DevBuf<uint32_t> sel_aux;   // predicted select: kSelBelowSlots counters + failure flag
@@ -318,7 +319,7 @@ void lsgpu_icp_destroy(lsgpu_icp* h) {
   h->submap.release();
   h->ref_in.release(); h->nrm_in.release(); h->keys.release(); h->keys_alt.release();
   h->vals.release(); h->vals_alt.release(); h->sort_tmp.release(); h->pts.release();
-  h->nrm.release(); h->ref_inv.release(); h->tables.release(); h->flags.release(); h->cidx.release(); h->bounds.release(); h->chunks.release(); h->soa.release(); h->soa_base.release(); h->soa_cnt4.release(); h->soa_first.release(); h->prev.release(); h->state.release(); h->lb.release(); h->cell_cache.release(); h->cell_tags.release(); h->ssn_seg_a.release(); h->ssn_seg_b.release(); h->ssn_seg_of.release(); h->ssn_box_pts.release(); h->ssn_box_base.release(); h->ssn_keep.release(); h->ssn_out_pos.release(); h->ssn_bb.release(); h->ssn_box_normal.release(); h->ssn_draws.release(); h->flt_in.release(); h->flt_ref.release(); h->flt_rd.release(); h->flt_nrm.release(); h->chk_hist.release(); h->trace_dev.release(); h->knn_dbg.release(); h->knn_dbg_wave.release(); h->stat_partials.release();
+  h->nrm.release(); h->ref_inv.release(); h->tables.release(); h->flags.release(); h->cidx.release(); h->bounds.release(); h->chunks.release(); h->soa.release(); h->soa_base.release(); h->soa_cnt4.release(); h->soa_first.release(); h->prev.release(); h->state.release(); h->lb.release(); h->cell_cache.release(); h->cell_tags.release(); h->ssn_seg_a.release(); h->ssn_seg_b.release(); h->ssn_seg_of.release(); h->ssn_box_pts.release(); h->ssn_box_base.release(); h->ssn_keep.release(); h->ssn_out_pos.release(); h->ssn_bb.release(); h->ssn_box_normal.release(); h->ssn_draws.release(); h->flt_in.release(); h->flt_ref.release(); h->flt_rd.release(); h->flt_nrm.release(); h->chk_hist.release(); h->trace_dev.release(); h->knn_dbg.release(); h->knn_dbg_wave.release(); h->stat_partials.release(); h->geom.release();
   h->counters.release(); h->ang_cells.release(); h->sel_aux.release(); h->sel_win.release(); h->work.release(); h->q_in.release(); h->rdq.release(); h->ids.release(); h->d2.release();
   h->ids_io.release(); h->d2_io.release(); h->strag.release(); h->hist.release();
   h->sel.release(); h->ne_partials.release(); h->ne_gpartials.release(); h->ne_tickets.release(); h->ne_out.release(); h->limit_dev.release();
@@ -594,48 +595,26 @@ int lsgpu_icp_set_reference(lsgpu_icp* h, const float* ref_xyz1, const float* re
       nsrc = h->nrm_in.p;
     }
   }
-  // ---- mean + bounding box (step 2)
+  // ---- mean + bounding box (step 2) and the grid geometry, all on the device: nothing below waits for the host
+  // until the cell counts are needed (one round trip per set_reference; there used to be two)
   HIPC(h->stat_partials.reserve(kStatBlocks + 1));
+  HIPC(h->geom.reserve(1));
   const int sb = std::min(kStatBlocks, nblk(nr));
   hipLaunchKernelGGL(k_ref_stats, dim3(sb), dim3(256), 0, h->stream, src, nr, h->stat_partials.p);
   hipLaunchKernelGGL(k_ref_stats_final, dim3(1), dim3(64), 0, h->stream, h->stat_partials.p, sb,
-                     h->stat_partials.p + kStatBlocks);
-  RefStats* hs = reinterpret_cast<RefStats*>(h->h_pinned);
-  HIPC(hipMemcpyAsync(hs, h->stat_partials.p + kStatBlocks, sizeof(RefStats), hipMemcpyDeviceToHost, h->stream));
-  HIPC(hipStreamSynchronize(h->stream));
-  float mn[3], mx[3];
-  for (int d = 0; d < 3; ++d) {
-    h->mean[d] = (float)(hs->sum[d] / (double)nr);
-    mn[d] = hs->mn[d] - h->mean[d];
-    mx[d] = hs->mx[d] - h->mean[d];
-    if (!std::isfinite(mn[d]) || !std::isfinite(mx[d])) { h->err = "set_reference: non-finite coordinates"; return LSGPU_BAD_ARG; }
-  }
-  // ---- grid geometry: level-0 cells of h0 (2^bits per axis), keys quantised at hf = h0 / 2^fine
-  const float ext = std::max(std::max(mx[0] - mn[0], mx[1] - mn[1]), mx[2] - mn[2]);
-  // 16 key bits per axis in total: `bits` of them address level-0 cells, `fine` order points inside
-  // a cell.  Start from the requested level-0 edge and trade fine bits for cell bits until the
-  // bounding box fits (bits <= 13); beyond that the cells grow.
-  int bits = 11, fine = 5;
-  float h0 = h->cfg.cell_size > 0.f ? h->cfg.cell_size : 0.125f;
-  while (bits < 13 && h0 * (float)((1 << bits) - 1) < ext * 1.0001f) { ++bits; --fine; }
-  while (h0 * (float)((1 << bits) - 1) < ext * 1.0001f) h0 *= 2.f;
-  GridDev g;
-  std::memset(&g, 0, sizeof(g));
-  g.ox = mn[0]; g.oy = mn[1]; g.oz = mn[2];
-  g.h0 = h0; g.hf = h0 / (float)(1 << fine); g.inv_hf = 1.0f / g.hf; g.fine = fine; g.bits = bits;
-  // ---- keys, sort, gather
+                     h->stat_partials.p + kStatBlocks, nr, h->cfg.cell_size, h->geom.p);
+  // ---- keys, sort, gather: 16 key bits per axis in total (`bits` address level-0 cells, `fine` order points inside
+  // a cell; the split is chosen by k_ref_stats_final), i.e. always 48 key bits
   HIPC(h->keys.reserve(nr)); HIPC(h->vals.reserve(nr));
   HIPC(h->pts.reserve(nr + 8)); HIPC(h->nrm.reserve(nr)); HIPC(h->ref_inv.reserve(nr));
-  hipLaunchKernelGGL(k_ref_keys, dim3(nblk(nr)), dim3(256), 0, h->stream, src, nr, h->mean[0],
-                     h->mean[1], h->mean[2], g, h->keys.p, h->vals.p);
-  rc = sort_pairs(h, nr, 3 * (bits + fine));
+  hipLaunchKernelGGL(k_ref_keys, dim3(nblk(nr)), dim3(256), 0, h->stream, src, nr, h->geom.p, h->keys.p, h->vals.p);
+  rc = sort_pairs(h, nr, 48);
   if (rc) return rc;
   hipLaunchKernelGGL(k_ref_gather, dim3(nblk(nr + 8)), dim3(256), 0, h->stream, src, nsrc, nr,
-                     h->vals_alt.p, h->mean[0], h->mean[1], h->mean[2], h->pts.p, h->nrm.p,
-                     h->ref_inv.p);
+                     h->vals_alt.p, h->geom.p, h->pts.p, h->nrm.p, h->ref_inv.p);
   // ---- chunks: flags -> inclusive scan -> bounds
   HIPC(h->flags.reserve(nr)); HIPC(h->cidx.reserve(nr));
-  hipLaunchKernelGGL(k_chunk_flags, dim3(nblk(nr)), dim3(256), 0, h->stream, h->keys_alt.p, nr, fine,
+  hipLaunchKernelGGL(k_chunk_flags, dim3(nblk(nr)), dim3(256), 0, h->stream, h->keys_alt.p, nr, h->geom.p,
                      h->flags.p);
   {
     size_t bytes = 0;
@@ -646,15 +625,26 @@ int lsgpu_icp_set_reference(lsgpu_icp* h, const float* ref_xyz1, const float* re
     HIPC(rocprim::inclusive_scan((void*)h->sort_tmp.p, bytes, h->flags.p, h->cidx.p, (size_t)nr,
                                  rocprim::plus<uint32_t>(), h->stream));
   }
-  // ---- cell counts per level (+ chunk count) -> host, to size the tables
+  // ---- cell counts per level (+ chunk count, + the geometry) -> host, to size the tables
   HIPC(h->counters.reserve(64));
   HIPC(hipMemsetAsync(h->counters.p, 0, 64 * sizeof(uint32_t), h->stream));
-  hipLaunchKernelGGL(k_cells_count, dim3(std::min(512, nblk(nr))), dim3(256), 0, h->stream, h->keys_alt.p, nr, fine,
-                     bits, h->counters.p);
+  hipLaunchKernelGGL(k_cells_count, dim3(std::min(512, nblk(nr))), dim3(256), 0, h->stream, h->keys_alt.p, nr, h->geom.p,
+                     h->counters.p);
   uint32_t* hc = reinterpret_cast<uint32_t*>(h->h_pinned);
+  GeomDev* hg = reinterpret_cast<GeomDev*>(h->h_pinned + 16);
+  static_assert(sizeof(GeomDev) <= 16 * sizeof(double), "geometry staging");
   HIPC(hipMemcpyAsync(hc, h->counters.p, kMaxLevels * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
   HIPC(hipMemcpyAsync(hc + 20, h->cidx.p + (nr - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
+  HIPC(hipMemcpyAsync(hg, h->geom.p, sizeof(GeomDev), hipMemcpyDeviceToHost, h->stream));
   HIPC(hipStreamSynchronize(h->stream));
+  if (hg->bad) { h->err = "set_reference: non-finite coordinates"; return LSGPU_BAD_ARG; }
+  for (int d = 0; d < 3; ++d) h->mean[d] = hg->mean[d];
+  const int bits = hg->bits, fine = hg->fine;
+  const float h0 = hg->h0;
+  GridDev g;
+  std::memset(&g, 0, sizeof(g));
+  g.ox = hg->ox; g.oy = hg->oy; g.oz = hg->oz;
+  g.h0 = h0; g.hf = hg->hf; g.inv_hf = hg->inv_hf; g.fine = fine; g.bits = bits;
   const uint32_t nchunks = hc[20];
   size_t total = 0, off[kMaxLevels];
   uint32_t cap[kMaxLevels], ncell[kMaxLevels];
