@@ -425,7 +425,7 @@ static KnnArgs knn_args(lsgpu_icp* h, const Mat34& T) {
   a.strag = h->strag.p; a.strag_count = h->counters.p + 32;
   a.r_cap = 1.0f; a.group_r = 0.75f; a.cap2 = INFINITY; a.st = nullptr; a.use_state_cap = 0; a.lb = nullptr;
   a.spread_route_r = 0.f; a.route_chunks = 1 << 30; a.sel_hist2 = nullptr; a.sel_below = nullptr;
-  a.sel_hist3w = nullptr; a.sel_force = 0;
+  a.sel_hist3w = nullptr; a.sel_force = 0; a.write_all = 1;
   { static const float gap = getenv("LSGPU_GAP") ? (float)atof(getenv("LSGPU_GAP")) : 0.002f; a.gap = gap; }
   a.ntiles = (int)((h->nq + 63) / 64); a.xcd_swizzle = 0; a.pad_index = (int)h->nr;
   { static const int budget = getenv("LSGPU_BUDGET") ? atoi(getenv("LSGPU_BUDGET")) : 128; a.chunk_budget = budget; }
@@ -453,6 +453,7 @@ static int run_knn(lsgpu_icp* h, const Mat34& T, const IcpState* st, bool seed, 
   a.st = st;
   a.lb = st ? h->lb.p : nullptr;
   a.use_state_cap = capped ? 1 : 0;
+  a.write_all = (seed || !capped || !st) ? 1 : 0;
   if (capped) a.r_cap = INFINITY;  // capped balls are never larger than the cap: no straggler by radius
   // `wide`: the balls may still be large (first iterations of an align, retries, kernel-level API): spread
   // waves with wide balls go to the wave-per-query pass, which is launched after the tile kernel

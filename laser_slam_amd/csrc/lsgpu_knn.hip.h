@@ -63,6 +63,8 @@ struct KnnArgs {
   uint32_t* sel_below;      //   kSelBelowSlots counters of distances below the bin (nullable: launch without prediction)
   uint32_t* sel_hist3w;     // committed select: kSelWinRows x 512 histogram of bits [8:0] around the last limit (nullable)
   int sel_force;            //   1: histogram against the last limit's bins whatever IcpState::sel_mode says
+  int write_all;            // 1: store index + warm start of every query (first search of an align, kernel-level API);
+                            // 0: only where the match changed (they were stored by an earlier launch)
   const IcpState* st;       // loop state (nullable): overrides T (and cap2 if use_state_cap)
   int use_state_cap;
   unsigned long long* dbg;  // optional counters (LSGPU_KNN_STATS builds only)
@@ -449,6 +451,7 @@ __global__ __launch_bounds__(WAVES * 64, LSGPU_TILE_OCC) void k_knn_tile(KnnArgs
     mp = a.prev[j];  // coalesced: no dependent gather of pts[prev]
     if (a.lb) lb_in = a.lb[j];
   }
+  const int id_in = __float_as_int(mp.w);  // the match this query came in with
   // the tile's cached cell block (tag + 64 probe results) travels with the same round trip: whether it still fits
   // is only known after the reductions below, but waiting until then cost two more dependent loads (40 % of a
   // settled wave's time was this prologue)
@@ -657,9 +660,13 @@ __global__ __launch_bounds__(WAVES * 64, LSGPU_TILE_OCC) void k_knn_tile(KnnArgs
         best = ub;
       }
     }
-    a.ids[j] = __float_as_int(mp.w);
+    // a settled iteration leaves most matches where they were: 20 of the 28 bytes a query used to write per launch
+    // were its unchanged index and warm-start point
+    if (a.write_all || __float_as_int(mp.w) != id_in) {
+      a.ids[j] = __float_as_int(mp.w);
+      a.prev[j] = mp;
+    }
     a.d2[j] = best;
-    a.prev[j] = mp;
     if (a.lb) a.lb[j] = nb;
     if (straggler || routed) a.strag[atomicAdd(a.strag_count, 1u)] = (uint32_t)j;
   }
