@@ -55,6 +55,8 @@ struct RcclApi {
   ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
   ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
   ncclResult_t (*CommAbort)(ncclComm_t) = nullptr;  // optional
+  ncclResult_t (*GroupStart)() = nullptr;           // optional (fused exchange of the committed select)
+  ncclResult_t (*GroupEnd)() = nullptr;
   const char* (*GetErrorString)(ncclResult_t) = nullptr;
 };
 RcclApi* rccl_api() {
@@ -73,6 +75,9 @@ RcclApi* rccl_api() {
       api.CommDestroy = reinterpret_cast<decltype(api.CommDestroy)>(dlsym(api.lib, "ncclCommDestroy"));
       api.CommAbort = reinterpret_cast<decltype(api.CommAbort)>(dlsym(api.lib, "ncclCommAbort"));
       api.GetErrorString = reinterpret_cast<decltype(api.GetErrorString)>(dlsym(api.lib, "ncclGetErrorString"));
+      api.GroupStart = reinterpret_cast<decltype(api.GroupStart)>(dlsym(api.lib, "ncclGroupStart"));
+      api.GroupEnd = reinterpret_cast<decltype(api.GroupEnd)>(dlsym(api.lib, "ncclGroupEnd"));
+      if (!api.GroupStart || !api.GroupEnd) { api.GroupStart = nullptr; api.GroupEnd = nullptr; }
       if (!api.GetUniqueId || !api.CommInitRank || !api.AllReduce || !api.CommDestroy) api.lib = nullptr;
     }
   }
@@ -1483,6 +1488,7 @@ int lsgpu_icp_align(lsgpu_icp* h, const float* reading_xyz1, int64_t nq, const f
   // committed select (device reports a steady limit): no select kernels at all, see IcpState::sel_streak
   static const bool commit_select = getenv("LSGPU_NO_COMMIT") == nullptr &&
                                     !(getenv("LSGPU_KNN_ROWS") && atoi(getenv("LSGPU_KNN_ROWS")) != 0);  // (the experimental row-wise path does not fill the window table)
+  static const bool comm_commit = getenv("LSGPU_NO_COMM_COMMIT") == nullptr;
   bool commit_ok = false;
   int committed_iterations = 0;
   auto enqueue_iteration = [&](bool seed, bool capped, bool wide, bool knn = true) -> int {
@@ -1490,13 +1496,25 @@ int lsgpu_icp_align(lsgpu_icp* h, const float* reading_xyz1, int64_t nq, const f
     // (the device decides per iteration, IcpState::sel_mode); not in the RCCL mode (the counts are per shard).
     // knn == false: only select + normal equations + update on the distances already there (after a missed
     // prediction)
-    const bool predicted = predict_select && knn && capped && !wide && !h->comm;
-    const bool committed = predicted && commit_select && commit_ok && !first_select;
+    // RCCL mode: the per-shard tables of a *committed* iteration are summed over the ranks in ONE grouped
+    // all-reduce (the host knows beforehand that no select kernel will run: sel_streak comes from the global limit,
+    // so every rank takes the same decision); un-committed iterations there run the plain three-pass select.
+    const bool can_commit = commit_select && commit_ok && !first_select && (!h->comm || comm_commit);
+    const bool predicted = predict_select && knn && capped && !wide && (!h->comm || can_commit);
+    const bool committed = predicted && can_commit;
     int r = LSGPU_OK;
     if (knn) {
       r = run_knn(h, Tdummy, h->state.p, seed, capped, timed, wide, predicted, seed && capped ? k : 0xFFFFFFFFu, committed);  // 6a+6b
       if (r) return r;
       ev_of_launch.push_back(h->knn_events_used ? h->knn_events_used - 1 : 0);
+    }
+    if (committed && h->comm) {  // one exchange for the whole select: {counts below, 11-bit histogram, window table}
+      RcclApi* api = rccl_api();
+      if (api->GroupStart) RCCLC(api->GroupStart());
+      RCCLC(api->AllReduce(h->sel_aux.p, h->sel_aux.p, kSelFailFlag, ncclUint32, ncclSum, h->comm, h->stream));
+      RCCLC(api->AllReduce(h->hist.p + kHistBins, h->hist.p + kHistBins, kHistBins, ncclUint32, ncclSum, h->comm, h->stream));
+      RCCLC(api->AllReduce(h->sel_win.p, h->sel_win.p, (size_t)kSelWinRows * 512, ncclUint32, ncclSum, h->comm, h->stream));
+      if (api->GroupEnd) RCCLC(api->GroupEnd());
     }
     if (!committed) {
       r = run_select(h, h->d2.p, (int)nq, k, first_select, h->state.p, true, predicted);       // 6c
@@ -1511,14 +1529,14 @@ int lsgpu_icp_align(lsgpu_icp* h, const float* reading_xyz1, int64_t nq, const f
                        h->state.p, h->prev.p, h->d2.p, h->nrm.p, h->hist.p, h->sel.p + 2,
                        h->counters.p + 32, h->ne_tickets.p, h->ne_partials.p, h->ne_gpartials.p, h->ne_out.p,
                        h->chk_hist.p, h->trace_dev.p, max_it, capped ? 1 : 0, (h->comm || split_update) ? 0 : 1,
-                       h->comm ? (uint32_t*)nullptr : h->sel_aux.p, h->sel_win.p, committed ? 1 : 0);   // 6d (+6e)
+                       h->sel_aux.p, h->sel_win.p, committed ? 1 : 0);   // 6d (+6e)
     if (h->comm || split_update) {   // split scan: every rank gets the sums over all shards (the limit, slot 29, is already global)
       if (h->comm && rccl_api()->AllReduce(h->ne_out.p, h->ne_out.p, kNe, ncclDouble, ncclSum, h->comm, h->stream) != ncclSuccess) {
         h->err = "RCCL all-reduce of the normal equations failed";
         return LSGPU_HIP_ERROR;
       }
       hipLaunchKernelGGL(k_icp_update, dim3(1), dim3(64), 0, h->stream, h->state.p, h->ne_out.p,
-                         h->chk_hist.p, h->trace_dev.p, max_it, capped ? 1 : 0);           // 6d+6e
+                         h->chk_hist.p, h->trace_dev.p, max_it, capped ? 1 : 0, h->sel_aux.p);           // 6d+6e
     }
     if (ev) HIPC(hipEventRecord(ev->e, h->stream));
     return hipGetLastError() == hipSuccess ? LSGPU_OK : LSGPU_HIP_ERROR;

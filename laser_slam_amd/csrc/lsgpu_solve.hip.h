@@ -289,8 +289,8 @@ __global__ __launch_bounds__(64) void k_icp_update(IcpState* __restrict__ st,
                                                    const double* __restrict__ ne_out,
                                                    float* __restrict__ chk_hist,
                                                    lsgpu_iter_trace* __restrict__ trace, int trace_cap,
-                                                   int capped_launch) {
-  if (threadIdx.x == 0) icp_update_lane(st, ne_out, chk_hist, trace, trace_cap, capped_launch, nullptr);
+                                                   int capped_launch, uint32_t* __restrict__ sel_aux) {
+  if (threadIdx.x == 0) icp_update_lane(st, ne_out, chk_hist, trace, trace_cap, capped_launch, sel_aux);
 }
 
 

@@ -22,21 +22,35 @@ def main():
     n_az = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
     ref, rd, T_true, T_init = synth.scan_pair(n_az)
     rf, rn = icp.sampling_surface_normal(ref, 10, 1.0, 0)
-    with icp.IcpHandle(None, local) as plain:                       # the unsplit answer, computed on every rank
+    import ctypes as C
+    from laser_slam_amd._lib import IcpConfig, lib
+    cfg = IcpConfig()
+    lib().lsgpu_icp_config_yaml(C.byref(cfg))
+    cfg.min_diff_rot, cfg.min_diff_trans = 1e-5, 1e-4              # long enough for the committed select to engage
+    with icp.IcpHandle(cfg, local) as plain:                        # the unsplit answer, computed on every rank
         plain.set_reference(rf, rn)
         T0, st0 = plain.align(rd, T_init)
         tr0 = [(t["limit"], t["n_used"]) for t in plain.trace()]
-    with icp.IcpHandle(None, local) as h:
+    with icp.IcpHandle(cfg, local) as h:
         sharding.init_split_comm(h, device="cuda")
         h.set_reference(rf, rn)
         T1, st1 = h.align(rd[sharding.split_shard(rd.shape[0], rank, world)], T_init)
         tr1 = [(t["limit"], t["n_used"]) for t in h.trace()]
-    ok = bool(np.array_equal(T0, T1) and st0.iterations == st1.iterations and tr0 == tr1)
+    # Integer results of the first iteration (same T_init -> same matches -> same order statistic and inlier count) are
+    # bit-exact.  The 29 double sums are added over the ranks by RCCL in its own order, not in the one-GPU fixed order,
+    # so later iterations may differ in the last bits of the solve: the bar for the transform is 1e-6 (absolute, metres /
+    # matrix entries), the same iteration count, and inlier counts within 2 per iteration; `bitwise` is reported.
+    bitwise = bool(np.array_equal(T0, T1) and tr0 == tr1)
+    ok = bool(st0.iterations == st1.iterations and tr0[0] == tr1[0]
+              and float(np.abs(T0.astype(np.float64) - T1.astype(np.float64)).max()) < 1e-6
+              and all(abs(a[1] - b[1]) <= 2 for a, b in zip(tr0, tr1)))
     flags = [None] * world
     dist.all_gather_object(flags, ok)
     if rank == 0:
         print("SPLIT_RESULT " + json.dumps({"world": world, "ok": flags, "iterations": st1.iterations,
-                                            "ms_split": st1.t_total_ms, "ms_plain": st0.t_total_ms}))
+                                            "ms_split": st1.t_total_ms, "ms_plain": st0.t_total_ms, "bitwise": bitwise,
+                                            "committed_plain": st0.committed_select_iterations,
+                                            "committed_split": st1.committed_select_iterations}))
     dist.destroy_process_group()
     sys.exit(0 if all(flags) else 1)
 

@@ -370,6 +370,30 @@ def test_split_scan_world1_equals_plain(icp_mod, pair64k):
     assert np.array_equal(T0, T1)
 
 
+@pytest.mark.gpu
+def test_split_scan_world1_committed_exchange(icp_mod, pair64k):
+    """Long alignment (tight checker) in the split-scan mode: once the trim limit is steady the three select passes and
+    their three all-reduces are replaced by ONE grouped exchange of the search kernels' tables; a one-rank communicator
+    runs every one of those collectives and must reproduce the plain loop bit for bit, committed iterations included."""
+    import ctypes as C
+    from laser_slam_amd._lib import IcpConfig, lib
+    rf, rn = _filtered(icp_mod, pair64k)
+    cfg = IcpConfig()
+    lib().lsgpu_icp_config_yaml(C.byref(cfg))
+    cfg.min_diff_rot, cfg.min_diff_trans, cfg.max_iterations = 0.0, 0.0, 40
+    with icp_mod.IcpHandle(cfg) as h:
+        h.set_reference(rf, rn)
+        T0, st0 = h.align(pair64k["rd"], pair64k["T_init"])
+        tr0 = [(t["limit"], t["n_used"]) for t in h.trace()]
+        h.comm_init(0, 1, icp_mod.comm_unique_id())
+        T1, st1 = h.align(pair64k["rd"], pair64k["T_init"])
+        tr1 = [(t["limit"], t["n_used"]) for t in h.trace()]
+    assert st0.iterations == st1.iterations == 40 and tr0 == tr1
+    assert np.array_equal(T0, T1)
+    assert st0.committed_select_iterations > 0, "the plain loop never committed its select on a 40-iteration alignment"
+    assert st1.committed_select_iterations > 0, "the split-scan loop never used the fused exchange"
+
+
 def test_submap_vs_scan_matches_oracle(icp_mod, oracle):
     """BASELINE config 4 shape at reduced size: an aggregated 8-scan sub-map (the reference of
     localScanToSubMap with nscan_in_sub_map = 8, laser_track.cpp:474-486) against one scan."""
@@ -654,7 +678,10 @@ def test_align_runs_to_the_iteration_cap_like_the_oracle(icp_mod, oracle, pair64
 @pytest.mark.gpu
 def test_split_scan_two_ranks_equals_unsplit():
     """BASELINE configs[3] with a real exchange: two ranks (one per GPU, RCCL over xGMI), reading sharded, reference
-    replicated; every rank must reproduce the unsplit alignment bit for bit.  Skips on a box with fewer than 2 GPUs."""
+    replicated; every rank must reproduce the unsplit alignment: integer results of the first iteration bit for bit, the
+    final transform to 1e-6 (RCCL adds the 29 double sums in its own order), same iteration count; the worker also
+    reports whether the whole trace came out bitwise equal and how many iterations used the fused (committed) exchange.
+    Skips on a box with fewer than 2 GPUs."""
     import socket
     import subprocess
     import sys
