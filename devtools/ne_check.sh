@@ -1,0 +1,8 @@
+cd /root/repo
+for lib in liblsgpu_ne4.so liblsgpu_icp.so liblsgpu_ne16.so; do
+  echo "$lib"
+  LSGPU_SO=/root/repo/laser_slam_amd/$lib timeout 200 python bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-compute-e2e 2>/dev/null | python -c "
+import json,sys
+d=json.loads(sys.stdin.read()); r=d['roofline']; print(round(d['value'],1), 'ms', round(d['ms_per_step'],3), 'ne us', round(d['roofline_ne']['avg_us'],1), 'sel', round(d['roofline_select']['avg_us'],1), 'knn', round(r['avg_main_us'],1), round(r['avg_fallback_us'],1), d['final_error_vs_truth'])"
+done
+timeout 900 python -m pytest tests -m gpu -q -x -k "not config4_sequence and not config3_full" 2>&1 | grep -v "^RCCL\|^HIP ver\|^ROCm\|^Hostname\|^Librccl" | tail -3

@@ -215,13 +215,15 @@ __global__ __launch_bounds__(256) void k_query_keys(const float4* __restrict__ i
     uint32_t e32, s32; float azim, range;
     angular_cell(p, __uint_as_float(order_flag[1]), __uint_as_float(order_flag[2]), e32, s32, azim, range);
     const uint64_t eb = e32, sec = s32;
-    const uint64_t rb = (uint64_t)fminf(fmaxf(range, 0.f), 4095.f);                              // 1 m
-    const uint64_t fine = (uint64_t)fminf(fmaxf(azim * 166886.05f, 0.f), 1048575.f);             // 2 pi -> 2^20
-    keys[i] = (((eb * 4096ull + sec) * 4096ull + rb) << 20) | fine;
+    // 48 key bits (6 radix passes): 10 elevation + 12 sector + 10 range (1 m bins) + 16 azimuth (2 pi -> 2^16, four
+    // steps per firing of a 16384-column scanner); the sort is stable, coarser fields only leave more input order
+    const uint64_t rb = (uint64_t)fminf(fmaxf(range, 0.f), 1023.f);
+    const uint64_t fine = (uint64_t)fminf(fmaxf(azim * 10430.378f, 0.f), 65535.f);
+    keys[i] = (((eb * 4096ull + sec) * 1024ull + rb) << 16) | fine;
     vals[i] = (uint32_t)i;
     return;
   }
-  const float lim = 2097151.f, half = 1048576.f;
+  const float lim = 65535.f, half = 32768.f;   // 48-bit Morton key: 7.8 mm cells, +-256 m (beyond: clamped)
   const uint32_t ix = (uint32_t)fminf(fmaxf(floorf(p.x * 128.f) + half, 0.f), lim);
   const uint32_t iy = (uint32_t)fminf(fmaxf(floorf(p.y * 128.f) + half, 0.f), lim);
   const uint32_t iz = (uint32_t)fminf(fmaxf(floorf(p.z * 128.f) + half, 0.f), lim);

@@ -94,7 +94,13 @@ LSGPU_HD void delta_from_x(const float x[6], float* dT) {
   const float ang = sqrtf(x[0] * x[0] + x[1] * x[1] + x[2] * x[2]);
   if (ang > 0.f && ang <= 3.4e38f) {
     const float ax = x[0] / ang, ay = x[1] / ang, az = x[2] / ang;
+#if defined(__HIP_DEVICE_COMPILE__)
+    double sd, cd;   // one range reduction for both (the device library's sin / cos are this same routine)
+    sincos((double)ang, &sd, &cd);
+    const float s = (float)sd, c = (float)cd;
+#else
     const float s = sin_f32(ang), c = cos_f32(ang);
+#endif
     const float sx = s * ax, sy = s * ay, sz = s * az;
     const float kx = (1.f - c) * ax, ky = (1.f - c) * ay, kz = (1.f - c) * az;
     float t = kx * ay; set(dT, 0, 1, t - sz); set(dT, 1, 0, t + sz);
@@ -142,7 +148,7 @@ LSGPU_HD float angular_distance(const float a[4], const float b[4]) {
 }
 
 // Counter (first) then Differential, in the order icp_default.yaml:21-27 lists them.  The history
-// lives in caller-provided arrays of (max_iter + 2) entries: hist[i] = {qw,qx,qy,qz, tx,ty,tz, 0}.
+// lives in caller-provided arrays of (max_iter + 2) entries: hist[i] = {qw,qx,qy,qz, tx,ty,tz, |rotation to entry i-1|}.
 struct CheckerState {
   int counter;
   int n_hist;
@@ -151,7 +157,10 @@ struct CheckerState {
 LSGPU_HD void checker_push(CheckerState* s, float* hist, const float* T) {
   float* e = hist + 8 * s->n_hist;
   quat_from_rotation(T, e);
-  e[4] = at(T, 0, 3); e[5] = at(T, 1, 3); e[6] = at(T, 2, 3); e[7] = 0.f;
+  e[4] = at(T, 0, 3); e[5] = at(T, 1, 3); e[6] = at(T, 2, 3);
+  // slot 7: the rotation between this entry and its predecessor -- the differential checker looks at every pair
+  // `smooth` times over consecutive iterations; computed once, here (an atan2 evaluated in double each)
+  e[7] = s->n_hist > 0 ? fabsf(angular_distance(e, e - 8)) : 0.f;
   s->n_hist++;
 }
 
@@ -166,7 +175,7 @@ LSGPU_HD bool checker_check(CheckerState* s, float* hist, int max_iter, int smoo
     for (int i = n - 1; i >= n - smooth; --i) {
       const float* a = hist + 8 * i;
       const float* b = hist + 8 * (i - 1);
-      rot += fabsf(angular_distance(a, b));
+      rot += a[7];   // = fabsf(angular_distance(a, b)), see checker_push
       const float dx = a[4] - b[4], dy = a[5] - b[5], dz = a[6] - b[6];
       trans += fabsf(sqrtf(dx * dx + dy * dy + dz * dz));
     }

@@ -28,6 +28,7 @@
 #include "lsgpu_solve.hip.h"
 #include "lsgpu_host_math.h"
 #include "lsgpu_ssn.hip.h"
+#include "lsgpu_sort.hip.h"
 #include "lsgpu_rand.h"
 
 using namespace lsgpu;
@@ -145,6 +146,7 @@ struct lsgpu_icp {
   DevBuf<uint64_t> keys, keys_alt;
   DevBuf<uint32_t> vals, vals_alt;
   DevBuf<char> sort_tmp;
+  DevBuf<uint32_t> sort_hist;  // radix sort: 256 x blocks digit histograms + 256 digit totals
   DevBuf<float4> pts, nrm;
   DevBuf<uint32_t> ref_inv;
   DevBuf<HashEntry> tables;
@@ -237,7 +239,7 @@ static const int kNeBlocks = [] { const char* e = getenv("LSGPU_NE_BLOCKS"); con
 static constexpr int kStatBlocks = 512;
 static constexpr int kHistBlocks = 256;
 static constexpr int kFallbackBlocksSettled = 1024;
-static constexpr int kRowqBlocks = 512;  // x 16 rows: 8192 queries side by side, round robin beyond
+static constexpr int kRowqBlocks = 2048;  // x 16 rows side by side, round robin beyond (512 -> 2048: 24.7 -> 20.8 us per pass)
 static constexpr int kFallbackBlocks = 8192;  // x 4 waves: one query per wave for up to 32 k stragglers, round robin beyond
 
 extern "C" {
@@ -323,7 +325,7 @@ void lsgpu_icp_destroy(lsgpu_icp* h) {
   for (auto& c : h->clouds) c.release();
   h->submap.release();
   h->ref_in.release(); h->nrm_in.release(); h->keys.release(); h->keys_alt.release();
-  h->vals.release(); h->vals_alt.release(); h->sort_tmp.release(); h->pts.release();
+  h->vals.release(); h->vals_alt.release(); h->sort_tmp.release(); h->sort_hist.release(); h->pts.release();
   h->nrm.release(); h->ref_inv.release(); h->tables.release(); h->flags.release(); h->cidx.release(); h->bounds.release(); h->chunks.release(); h->soa.release(); h->soa_base.release(); h->soa_cnt4.release(); h->soa_first.release(); h->prev.release(); h->state.release(); h->lb.release(); h->cell_cache.release(); h->cell_tags.release(); h->ssn_seg_a.release(); h->ssn_seg_b.release(); h->ssn_seg_of.release(); h->ssn_box_pts.release(); h->ssn_box_base.release(); h->ssn_keep.release(); h->ssn_out_pos.release(); h->ssn_bb.release(); h->ssn_box_normal.release(); h->ssn_draws.release(); h->flt_in.release(); h->flt_ref.release(); h->flt_rd.release(); h->flt_nrm.release(); h->chk_hist.release(); h->trace_dev.release(); h->knn_dbg.release(); h->knn_dbg_wave.release(); h->stat_partials.release(); h->geom.release();
   h->counters.release(); h->ang_cells.release(); h->sel_aux.release(); h->sel_win.release(); h->work.release(); h->q_in.release(); h->rdq.release(); h->ids.release(); h->d2.release();
   h->ids_io.release(); h->d2_io.release(); h->strag.release(); h->hist.release();
@@ -343,9 +345,43 @@ void lsgpu_icp_destroy(lsgpu_icp* h) {
 
 static int scan_u32(lsgpu_icp* h, const uint32_t* in, uint32_t* out, size_t n);
 
+template <int ITEMS>
+static void radix_pass(lsgpu_icp* h, const uint64_t* kin, const uint32_t* vin, uint64_t* kout, uint32_t* vout, int64_t n,
+                       int shift, uint32_t mask, int nblocks) {
+  uint32_t* bh = h->sort_hist.p;
+  uint32_t* dtot = bh + (size_t)256 * nblocks;
+  hipLaunchKernelGGL(k_rs_hist<ITEMS>, dim3(nblocks), dim3(256), 0, h->stream, kin, n, shift, mask, bh, nblocks);
+  hipLaunchKernelGGL(k_rs_scan, dim3(256), dim3(256), 0, h->stream, bh, nblocks, dtot);
+  hipLaunchKernelGGL(k_rs_scatter<ITEMS>, dim3(nblocks), dim3(256), 0, h->stream, kin, vin, kout, vout, n, shift, mask,
+                     bh, dtot, nblocks);
+}
+
+// Stable sort of (h->keys, h->vals)[0..n) by the low `nbits` key bits; the result is in h->keys_alt / h->vals_alt
+// (callers re-read those members: the two buffer pairs may have changed places).
 static int sort_pairs(lsgpu_icp* h, int64_t n, int nbits) {
   HIPC(h->keys_alt.reserve(n));
   HIPC(h->vals_alt.reserve(n));
+  static const bool lib_sort = getenv("LSGPU_ROCPRIM_SORT") != nullptr;
+  if (!lib_sort && n >= 8192 && nbits > 0) {   // own radix sort (lsgpu_sort.hip.h); tiny inputs stay with the library
+    static const int items_env = getenv("LSGPU_SORT_ITEMS") ? atoi(getenv("LSGPU_SORT_ITEMS")) : 0;
+    const int items = items_env ? items_env : n >= (1 << 21) ? 16 : n >= (1 << 19) ? 8 : 4;
+    const int nblocks = (int)((n + 256 * items - 1) / (256 * items));
+    HIPC(h->sort_hist.reserve((size_t)256 * nblocks + 256));
+    const int passes = (nbits + 7) / 8;
+    uint64_t *kin = h->keys.p, *kout = h->keys_alt.p;
+    uint32_t *vin = h->vals.p, *vout = h->vals_alt.p;
+    for (int p = 0; p < passes; ++p) {
+      const int shift = 8 * p, width = std::min(8, nbits - shift);
+      const uint32_t mask = (1u << width) - 1u;
+      if (items == 16) radix_pass<16>(h, kin, vin, kout, vout, n, shift, mask, nblocks);
+      else if (items == 8) radix_pass<8>(h, kin, vin, kout, vout, n, shift, mask, nblocks);
+      else radix_pass<4>(h, kin, vin, kout, vout, n, shift, mask, nblocks);
+      std::swap(kin, kout); std::swap(vin, vout);
+    }
+    HIPC(hipGetLastError());
+    if ((passes & 1) == 0) { std::swap(h->keys, h->keys_alt); std::swap(h->vals, h->vals_alt); }  // result is in `keys`
+    return LSGPU_OK;
+  }
   size_t bytes = 0;
   HIPC(rocprim::radix_sort_pairs(nullptr, bytes, h->keys.p, h->keys_alt.p, h->vals.p,
                                  h->vals_alt.p, (size_t)n, 0, nbits, h->stream));
@@ -402,7 +438,7 @@ static int prepare_queries(lsgpu_icp* h, const float* q_xyz1, int64_t nq, const 
   hipLaunchKernelGGL(k_query_order, dim3(1), dim3(1024), 0, h->stream, h->ang_cells.p, qorder, qelev, qsect);
   hipLaunchKernelGGL(k_query_keys, dim3(nblk(nq)), dim3(256), 0, h->stream, src, nq, h->keys.p, h->vals.p,
                      h->ang_cells.p + kDecCells + 2);
-  rc = sort_pairs(h, nq, 63);
+  rc = sort_pairs(h, nq, 48);
   if (rc) return rc;
   hipLaunchKernelGGL(k_query_gather, dim3(nblk(nq)), dim3(256), 0, h->stream, src, nq,
                      h->vals_alt.p, T, h->rdq.p);
@@ -430,7 +466,7 @@ static KnnArgs knn_args(lsgpu_icp* h, const Mat34& T) {
   a.strag = h->strag.p; a.strag_count = h->counters.p + 32;
   a.r_cap = 1.0f; a.group_r = 0.75f; a.cap2 = INFINITY; a.st = nullptr; a.use_state_cap = 0; a.lb = nullptr;
   a.spread_route_r = 0.f; a.route_chunks = 1 << 30; a.sel_hist2 = nullptr; a.sel_below = nullptr;
-  a.sel_hist3w = nullptr; a.sel_force = 0; a.write_all = 1;
+  a.sel_hist3w = nullptr; a.sel_force = 0; a.write_all = 1; a.sparse_lanes = 0;
   { static const float gap = getenv("LSGPU_GAP") ? (float)atof(getenv("LSGPU_GAP")) : 0.002f; a.gap = gap; }
   a.ntiles = (int)((h->nq + 63) / 64); a.xcd_swizzle = 0; a.pad_index = (int)h->nr;
   { static const int budget = getenv("LSGPU_BUDGET") ? atoi(getenv("LSGPU_BUDGET")) : 128; a.chunk_budget = budget; }
@@ -468,6 +504,10 @@ static int run_knn(lsgpu_icp* h, const Mat34& T, const IcpState* st, bool seed, 
   static const bool route_all = getenv("LSGPU_NO_ROUTE_ALL") == nullptr;
   const bool settled = capped && !wide && st && route_all;
   a.spread_route_r = wide ? route_r : settled ? 1e-30f : 0.f;
+  static const int sparse_lanes = getenv("LSGPU_SPARSE_LANES") ? atoi(getenv("LSGPU_SPARSE_LANES")) : 0;
+  static const int rowq_blocks = getenv("LSGPU_ROWQ_BLOCKS") ? atoi(getenv("LSGPU_ROWQ_BLOCKS")) : kRowqBlocks;
+  static const bool rowq = getenv("LSGPU_NO_ROWQ") == nullptr;
+  a.sparse_lanes = settled && rowq ? sparse_lanes : 0;
   if (predicted && !wide && capped && st) { a.sel_hist2 = h->hist.p + kHistBins; a.sel_below = h->sel_aux.p; }
   if (committed && a.sel_below) { a.sel_hist3w = h->sel_win.p; a.sel_force = 1; }
   { static const int rc_ = getenv("LSGPU_ROUTE_CHUNKS") ? atoi(getenv("LSGPU_ROUTE_CHUNKS")) : 1024; a.route_chunks = rc_; }
@@ -522,9 +562,8 @@ static int run_knn(lsgpu_icp* h, const Mat34& T, const IcpState* st, bool seed, 
     if (timed) HIPC(hipEventRecord(ev->b, h->stream));
     // stragglers (balls > r_cap) only exist in uncapped launches
     // (a settled launch routes a few thousand queries at most: a small grid keeps the pass short)
-    static const bool rowq = getenv("LSGPU_NO_ROWQ") == nullptr;
-    if (settled && rowq)
-      hipLaunchKernelGGL(k_knn_rowq, dim3(kRowqBlocks), dim3(256), 0, h->stream, a);   // one DPP row per handed-over query
+    if (settled && rowq)   // one DPP row per handed-over query
+      hipLaunchKernelGGL(k_knn_rowq, dim3(rowq_blocks), dim3(256), 0, h->stream, a);
     else if (!capped || a.spread_route_r > 0.f)
       hipLaunchKernelGGL(k_knn_fallback, dim3(settled ? kFallbackBlocksSettled : kFallbackBlocks), dim3(256), 0, h->stream, a);
     if (timed) HIPC(hipEventRecord(ev->c, h->stream));
@@ -1700,6 +1739,14 @@ int lsgpu_dev_knn_wave_stats(lsgpu_icp* h, unsigned int* out, int nwaves) {
   HIPC(hipMemcpy(out, h->knn_dbg_wave.p, (size_t)nwaves * 16, hipMemcpyDeviceToHost));
   return LSGPU_OK;
 }
+#ifdef LSGPU_KNN_STATS
+int lsgpu_dev_ne_phases(lsgpu_icp* h, unsigned long long out[16]) {  // stats build only (devtools/ne_phases.py)
+  if (!h) return LSGPU_BAD_ARG;
+  HIPC(hipStreamSynchronize(h->stream));
+  HIPC(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_ne_dbg), 128));
+  return LSGPU_OK;
+}
+#endif
 int lsgpu_dev_knn_counters(lsgpu_icp* h, unsigned long long out[8]) {
   if (!h) return LSGPU_BAD_ARG;
   if (!h->knn_dbg.p) {

@@ -59,6 +59,7 @@ struct KnnArgs {
   float gap;                // capped launches search `gap` metres beyond the current best (keep-match bound)
   float spread_route_r;     // > 0: a spread wave whose largest ball exceeds this hands its lanes to k_knn_fallback
   int route_chunks;         // (with spread_route_r > 0) so does any wave whose cell block holds more chunks than this
+  int sparse_lanes;         // > 0: a wave with at most this many searching lanes hands them to k_knn_rowq
   uint32_t* sel_hist2;      // predicted select (IcpState::sel_mode): 2048-bin histogram of bits [19:9] inside the bin
   uint32_t* sel_below;      //   kSelBelowSlots counters of distances below the bin (nullable: launch without prediction)
   uint32_t* sel_hist3w;     // committed select: kSelWinRows x 512 histogram of bits [8:0] around the last limit (nullable)
@@ -511,12 +512,26 @@ __global__ __launch_bounds__(WAVES * 64, LSGPU_TILE_OCC) void k_knn_tile(KnnArgs
   // only neighbours closer than the lane's search radius can matter
   const float R = sqrtf(prune_lim(ub, gap, cap2s)) * (1.0f + 1e-5f) + 1e-7f;
   const bool straggler = act && !skip && !(R <= a.r_cap);
+  // (Tried and measured slower, 82 -> 84..88 us: letting a tile that has to search take its keep / far lanes along
+  // with a margin sized from the displacement, so that whole tiles would be skipped in between -- the slack a lane keeps
+  // is limited by the distance between its nearest and second nearest reference point, a few millimetres on densely
+  // sampled surfaces, not by the search margin: most lanes have to search again after one or two iterations anyway.)
   const bool ing = act && !straggler && !skip;
   bool routed = false;
+  const unsigned long long ing_mask = __ballot(ing);
+  // Experiment (LSGPU_SPARSE_LANES, default off): a wave with few searching lanes evaluates every candidate of its
+  // region for all 64 lanes (about 1400 vector instructions whatever the number of lanes that need them), so hand
+  // those lanes to the row-per-query pass.  Measured: the tile kernel does get shorter (79 -> 57 us with <= 48 lanes
+  // handed over), but the row pass pays ~11 us of dependent round trips per query and row, and thousands of waves
+  // appending to one list counter serialise in the L2 -- a net loss at every threshold (kNN section).
+  const bool sparse = a.sparse_lanes > 0 && __popcll(ing_mask) <= a.sparse_lanes;
+  if (sparse) {
+    routed = ing;
+  } else
 #ifdef LSGPU_KNN_STATS
-  if (__ballot(ing) && !(a.dbg_flags & 4)) {
+  if (ing_mask && !(a.dbg_flags & 4)) {
 #else
-  if (__ballot(ing)) {
+  if (ing_mask) {
 #endif
     // query box, largest ball, largest bound of the wave
     const float tlx = wave_min(ing ? qx : INFINITY), thx = wave_max(ing ? qx : -INFINITY);
@@ -668,7 +683,15 @@ __global__ __launch_bounds__(WAVES * 64, LSGPU_TILE_OCC) void k_knn_tile(KnnArgs
     }
     a.d2[j] = best;
     if (a.lb) a.lb[j] = nb;
-    if (straggler || routed) a.strag[atomicAdd(a.strag_count, 1u)] = (uint32_t)j;
+  }
+  {  // hand-over list: one atomic per wave, the wave's queries stay neighbours in the list
+    const unsigned long long hm = __ballot(act && (straggler || routed));
+    if (hm) {
+      uint32_t base = 0;
+      if (lane == 0) base = atomicAdd(a.strag_count, (uint32_t)__popcll(hm));
+      base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+      if (act && (straggler || routed)) a.strag[base + (uint32_t)__popcll(hm & ((1ull << lane) - 1ull))] = (uint32_t)j;
+    }
   }
   if (a.sel_below && (a.st->sel_mode || a.sel_force)) {
     // first two passes of the trimmed-distance select, folded into this kernel (every distance of the launch is

@@ -405,23 +405,33 @@ __global__ __launch_bounds__(256) void k_knn_rowq(KnnArgs a) {
   Mat34 T; float cap2;
   if (!iter_params(a.st, a.T, a.cap2, a.use_state_cap, T, cap2)) return;
   const float cap2s = cap2 * kCapSearchMargin2;
-  const uint32_t count = *a.strag_count;
+  const float gap = a.use_state_cap ? a.gap : 0.f;
   const GridDev& g = a.g;
   const int lim = (1 << (g.bits + g.fine)) - 1;
-  for (uint32_t base = (blockIdx.x * 4u + (uint32_t)wave) * 4u; base < count; base += gridDim.x * 16u) {
+  const uint32_t count = *a.strag_count;
+  const uint32_t base0 = (blockIdx.x * 4u + (uint32_t)wave) * 4u, stride = gridDim.x * 16u;
+  const uint32_t* qsrc = a.strag;
+  for (uint32_t base = base0; base < count; base += stride) {
     const uint32_t s = base + (uint32_t)row;
     const bool have = s < count;
-    const uint32_t j = have ? a.strag[s] : 0u;
+    const uint32_t j = have ? qsrc[s] : 0u;
     float qx = 0.f, qy = 0.f, qz = 0.f, ub = 0.f;
     unsigned long long bestp = ~0ull;
+    int id_in = -1;
     if (have) {
       const float4 r = a.rdq[j];
       const float3 q = xform(T, r.x, r.y, r.z);
       qx = q.x; qy = q.y; qz = q.z;
       ub = a.d2[j];  // distance to the warm-start point
-      bestp = ((unsigned long long)__float_as_uint(ub) << 32) | (uint32_t)a.ids[j];
+      id_in = a.ids[j];
+      bestp = ((unsigned long long)__float_as_uint(ub) << 32) | (uint32_t)id_in;
     }
-    float best = fminf(ub, cap2s);  // only neighbours inside the cap must be exact
+    // Search `gap` beyond the current bound (never beyond the cap), like the tile kernel: the second smallest distance
+    // found, or the search radius, then bounds "every other point" well enough for the next iterations' keep test --
+    // with the bare distance to the match as the bound, a query searched here would have to search again every time.
+    float bcur = ub;          // the row's smallest distance so far
+    float sec = INFINITY;     // this lane: smallest distance among the points it evaluated other than its own best
+    float best = prune_lim(bcur, gap, cap2s);  // squared search radius
     // ---- the ball's cells: the level at which it spans at most two cells per axis
     uint32_t cs = 0, ce = 0;
     {
@@ -480,19 +490,27 @@ __global__ __launch_bounds__(256) void k_knn_rowq(KnnArgs a) {
               const float4 p = a.pts[cst + o];
               const float d = dist2(qx - p.x, qy - p.y, qz - p.z);
               const unsigned long long pk = ((unsigned long long)__float_as_uint(d) << 32) | (cst + o);
-              bestp = pk < bestp ? pk : bestp;
+              if (pk < bestp) { sec = fminf(sec, __uint_as_float((uint32_t)(bestp >> 32))); bestp = pk; }
+              else if (pk != bestp) sec = fminf(sec, d);   // (pk == bestp: the warm-start point itself)
               dmin = fminf(dmin, d);
             }
           }
-          best = fminf(best, row_min(dmin));
+          bcur = fminf(bcur, row_min(dmin));
+          best = prune_lim(bcur, gap, cap2s);
         }
       }
     }
-    // ---- the row's answer: smallest (distance, index) pair over its 16 lanes
+    // ---- the row's answer: smallest (distance, index) pair over its 16 lanes; every other lane's best is an "other"
+    {
+      unsigned long long gb = bestp;
 #pragma unroll
-    for (int o = 8; o > 0; o >>= 1) {
-      const unsigned long long w = __shfl_xor(bestp, o, 64);
-      bestp = w < bestp ? w : bestp;
+      for (int o = 8; o > 0; o >>= 1) {
+        const unsigned long long w = __shfl_xor(gb, o, 64);
+        gb = w < gb ? w : gb;
+      }
+      if (bestp != gb) sec = fminf(sec, __uint_as_float((uint32_t)(bestp >> 32)));
+      sec = row_min(sec);
+      bestp = gb;
     }
     if (have && k16 == 0) {
       const int id = (int)(uint32_t)(bestp & 0xFFFFFFFFull);
@@ -506,7 +524,11 @@ __global__ __launch_bounds__(256) void k_knn_rowq(KnnArgs a) {
         if (top < b1) atomicAdd(&a.sel_below[(j & (kSelBelowSlots - 1)) * kSelBelowStride], 1u);
         else if (top == b1) sel_count_inside(a, bits);
       }
-      if (a.lb) a.lb[j] = fd <= cap2s ? sqrtf(fd) * (1.0f - 1e-6f) : fmaxf(a.lb[j], sqrtf(cap2s) * (1.0f - 1e-5f));
+      if (a.lb) {  // every unevaluated point lies beyond the final search radius
+        float nb = sqrtf(fminf(sec, prune_lim(fd, gap, cap2s))) * (1.0f - 1e-5f);
+        if (id == id_in) nb = fmaxf(nb, a.lb[j]);  // (the tile kernel left the carried bound there)
+        a.lb[j] = nb;
+      }
     }
   }
 }

@@ -224,11 +224,14 @@ constexpr float kCapFactor = 1.1f;  // next search cap = this x the current trim
 // checkers, trace record, next cap.  Same code as the host (lsgpu_host_math.h).
 __device__ inline void icp_update_lane(IcpState* st, const double* ne_out, float* chk_hist,
                                        lsgpu_iter_trace* trace, int trace_cap, int capped_launch,
-                                       uint32_t* sel_aux) {
+                                       uint32_t* sel_aux, int sel_failed = -1 /* -1: read (and clear) the flag in sel_aux */) {
   if (st->done) return;
-  if (sel_aux && sel_aux[kSelFailFlag]) {
+  if (sel_failed < 0) {
+    sel_failed = (sel_aux && sel_aux[kSelFailFlag]) ? 1 : 0;
+    if (sel_failed) sel_aux[kSelFailFlag] = 0u;
+  }
+  if (sel_failed) {
     // the predicted select missed (the limit left its 12-bit bin): nothing of this iteration is usable
-    sel_aux[kSelFailFlag] = 0u;
     st->sel_mode = 0;
     st->status = kStatusSelFailed;  // the distances of this iteration stand: the host re-runs the full select on them
     st->done = 1;
@@ -299,6 +302,17 @@ __global__ __launch_bounds__(64) void k_icp_update(IcpState* __restrict__ st,
 // LAST block to finish (ticket; partial sums exchanged with agent-scope accesses) reduces the block
 // partials in a fixed order, publishes {29 sums, limit, straggler count} and re-arms the per-iteration
 // scratch (histograms, straggler counter, ticket) so the next iteration needs no memset launches.
+#ifdef LSGPU_KNN_STATS
+// stats build only: where k_normal_eq_loop spends its time.  [0] launches, [1..3] sum over blocks of the cycles in
+// {prologue (limit), main loop, wave+block reduce and hand-off}, [4] blocks, [5] first block start (100 MHz wall clock,
+// re-armed by the last block), [6] latest end of a main loop, [7] sum of (last loop end - first start), [8] sum of
+// (kernel end - last loop end), [9] sum of (first loop START - first start) i.e. prologue wall time of the earliest block
+__device__ unsigned long long g_ne_dbg[16] = {0, 0, 0, 0, 0, ~0ull, 0, 0, 0, 0, ~0ull, 0, 0, 0, 0, 0};
+#endif
+#ifndef LSGPU_NE_UNROLL
+#define LSGPU_NE_UNROLL 8
+#endif
+constexpr int kNeUnroll = LSGPU_NE_UNROLL;  // points whose loads are in flight together, per lane
 __global__ __launch_bounds__(256) void k_normal_eq_loop(const float4* __restrict__ rdq, int nq,
                                                         IcpState* __restrict__ ist,
                                                         const float4* __restrict__ match,
@@ -322,6 +336,10 @@ __global__ __launch_bounds__(256) void k_normal_eq_loop(const float4* __restrict
   __shared__ double red[8][33];
   __shared__ int is_last;
   if (ist->done) return;
+#ifdef LSGPU_KNN_STATS
+  const long long c0 = clock64();
+  if (threadIdx.x == 0) atomicMin(&g_ne_dbg[5], (unsigned long long)wall_clock64());
+#endif
   Mat34 T;
 #pragma unroll
   for (int i = 0; i < 12; ++i) T.m[i] = ist->T_rows[i];
@@ -359,16 +377,20 @@ __global__ __launch_bounds__(256) void k_normal_eq_loop(const float4* __restrict
   } else {
     limit = select_limit(hist + 2 * kHistBins, st, sc);
   }
+#ifdef LSGPU_KNN_STATS
+  const long long c1 = clock64();
+  if (threadIdx.x == 0) atomicMin(&g_ne_dbg[10], (unsigned long long)wall_clock64());
+#endif
   double acc[kNe];
 #pragma unroll
   for (int k = 0; k < kNe; ++k) acc[k] = 0.0;
   // four points per step: their loads (distance, match, query, gathered normal) are issued together, the sums
   // are still taken in index order, so the result does not depend on the unrolling
   const int stride = gridDim.x * 256;
-  for (int j0 = blockIdx.x * 256 + threadIdx.x; j0 < (sel_ok ? nq : 0); j0 += 4 * stride) {
-    float dd[4]; float4 qq[4], rr[4], nn[4]; bool use[4];
+  for (int j0 = blockIdx.x * 256 + threadIdx.x; j0 < (sel_ok ? nq : 0); j0 += kNeUnroll * stride) {
+    float dd[kNeUnroll]; float4 qq[kNeUnroll], rr[kNeUnroll], nn[kNeUnroll]; bool use[kNeUnroll];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < kNeUnroll; ++u) {
       const int j = j0 + u * stride;
       use[u] = j < nq;
       dd[u] = use[u] ? d2[j] : INFINITY;
@@ -378,9 +400,9 @@ __global__ __launch_bounds__(256) void k_normal_eq_loop(const float4* __restrict
       use[u] = use[u] && __float_as_int(qq[u].w) >= 0;
     }
 #pragma unroll
-    for (int u = 0; u < 4; ++u) nn[u] = use[u] ? nrm[__float_as_int(qq[u].w)] : make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int u = 0; u < kNeUnroll; ++u) nn[u] = use[u] ? nrm[__float_as_int(qq[u].w)] : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < kNeUnroll; ++u) {
     if (!use[u]) continue;
     const float4 q = qq[u];
     const float4 r = rr[u];
@@ -404,6 +426,11 @@ __global__ __launch_bounds__(256) void k_normal_eq_loop(const float4* __restrict
     acc[28] += (double)res * (double)res;
     }
   }
+#ifdef LSGPU_KNN_STATS
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  const long long c2 = clock64();
+  if (threadIdx.x == 0) atomicMax(&g_ne_dbg[6], (unsigned long long)wall_clock64());
+#endif
 #pragma unroll
   for (int k = 0; k < kNe; ++k) acc[k] = wave_sum(acc[k]);
   const int w = threadIdx.x >> 6;
@@ -420,79 +447,123 @@ __global__ __launch_bounds__(256) void k_normal_eq_loop(const float4* __restrict
     __hip_atomic_store(&partials[(size_t)blockIdx.x * 32 + threadIdx.x],
                        ((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x],
                        __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  // ---- publish.  Two-level, fixed-order reduction of the block partials (bitwise reproducible whichever block
-  // ends up doing it): blocks form groups of kNeGroup; the LAST block of a group to finish sums that group's rows in
-  // row order into a group partial, the LAST group to finish sums the group partials in group order.  Two short
-  // dependent rounds (<= 16 rows, <= 128 rows with 16 loads in flight) instead of one block walking every row.
-  const uint32_t g_id = blockIdx.x / kNeGroup, n_grp = (gridDim.x + kNeGroup - 1) / kNeGroup;
-  const uint32_t g_first = g_id * kNeGroup;
-  const uint32_t g_size = gridDim.x - g_first < (uint32_t)kNeGroup ? gridDim.x - g_first : (uint32_t)kNeGroup;
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    const uint32_t t = __hip_atomic_fetch_add(ticket + 1 + g_id, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    is_last = (t == g_size - 1);
-  }
-  __syncthreads();
-  if (!is_last) return;
-  if (threadIdx.x < 32) {  // the group's rows, in row order
-    double v[kNeGroup];
-#pragma unroll
-    for (int u = 0; u < kNeGroup; ++u)
-      v[u] = ((uint32_t)u < g_size && threadIdx.x < kNe)
-                 ? __hip_atomic_load(&partials[(size_t)(g_first + u) * 32 + threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
-                 : 0.0;
-    double sgrp = 0.0;
-#pragma unroll
-    for (int u = 0; u < kNeGroup; ++u) sgrp += v[u];
-    __hip_atomic_store(&gpartials[(size_t)g_id * 32 + threadIdx.x], sgrp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
+  // ---- publish.  The LAST block to finish (one ticket) sums the block partials in a fixed order -- thread (g, c) adds
+  // the rows of slice g of column c in row order, the 8 slice sums are added in slice order -- so the result is
+  // bitwise reproducible whichever block ends up doing it; all loads of a thread's slice are in flight together:
+  // one ticket and one load round trip after the last block's own loop.  (A two-level variant -- groups of 16 blocks,
+  // then the groups -- paid two more dependent agent-scope round trips; measured 24 us from the last loop end to the
+  // kernel's end, of which 8 us in the update lane, before this and the LDS staging below.)
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   if (threadIdx.x == 0) {
     const uint32_t t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    is_last = (t == n_grp - 1);
+    is_last = (t == gridDim.x - 1);
+#ifdef LSGPU_KNN_STATS
+    const long long c3 = clock64();
+    atomicAdd(&g_ne_dbg[1], (unsigned long long)(c1 - c0)); atomicAdd(&g_ne_dbg[2], (unsigned long long)(c2 - c1));
+    atomicAdd(&g_ne_dbg[3], (unsigned long long)(c3 - c2)); atomicAdd(&g_ne_dbg[4], 1ull);
+#endif
   }
   __syncthreads();
   if (!is_last) return;
-  if (threadIdx.x < 32) {  // the group partials, in group order
+  // the loop state and the select's failure flag travel with the same round trip as the partials: the update lane
+  // then works on an LDS copy (a dozen dependent global round trips of one lane otherwise)
+  __shared__ IcpState st_sh;
+  __shared__ uint32_t fail_sh, cnt_sh[2];
+  constexpr int kStWords = (int)(sizeof(IcpState) / sizeof(uint32_t));
+  uint32_t* sw = reinterpret_cast<uint32_t*>(&st_sh);
+  uint32_t* gw = reinterpret_cast<uint32_t*>(ist);
+  uint32_t st_word[(kStWords + 255) / 256];
+  if (fuse_update) {
+#pragma unroll
+    for (int i = 0; i < (kStWords + 255) / 256; ++i)
+      st_word[i] = (int)threadIdx.x + 256 * i < kStWords ? gw[threadIdx.x + 256 * i] : 0u;
+  }
+  uint32_t fail_word = 0u, ns_word = 0u, nw_word = 0u;
+  if (threadIdx.x == 255) {
+    if (sel_aux) fail_word = sel_aux[kSelFailFlag];
+    ns_word = __hip_atomic_load(strag_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    nw_word = __hip_atomic_load(strag_count + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  {
+    const int col = threadIdx.x & 31, slice = threadIdx.x >> 5;          // 8 slices of rows
+    const uint32_t per = (gridDim.x + 7u) / 8u;
+    const uint32_t r0 = (uint32_t)slice * per, r1 = r0 + per < gridDim.x ? r0 + per : gridDim.x;
     double t = 0.0;
-    uint32_t gidx = 0;
-    for (; gidx + 16 <= n_grp; gidx += 16) {
+    uint32_t r = r0;
+    for (; r + 16 <= r1; r += 16) {
       double v[16];
 #pragma unroll
       for (int u = 0; u < 16; ++u)
-        v[u] = __hip_atomic_load(&gpartials[(size_t)(gidx + u) * 32 + threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        v[u] = __hip_atomic_load(&partials[(size_t)(r + u) * 32 + col], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
       for (int u = 0; u < 16; ++u) t += v[u];
     }
-    for (; gidx < n_grp; ++gidx)
-      t += __hip_atomic_load(&gpartials[(size_t)gidx * 32 + threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (threadIdx.x < kNe) { out[threadIdx.x] = t; fin[threadIdx.x] = t; }
+    for (; r < r1; ++r)
+      t += __hip_atomic_load(&partials[(size_t)r * 32 + col], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    red[slice][col] = t;
   }
-  for (uint32_t i = threadIdx.x; i < n_grp; i += 256)  // re-arm the group tickets (every group is done)
-    __hip_atomic_store(ticket + 1 + i, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (fuse_update) {
+#pragma unroll
+    for (int i = 0; i < (kStWords + 255) / 256; ++i)
+      if ((int)threadIdx.x + 256 * i < kStWords) sw[threadIdx.x + 256 * i] = st_word[i];
+  }
+  if (threadIdx.x == 255) {
+    fail_sh = fail_word | (sel_ok ? 0u : 1u);  // (a missed committed select: same handling as a missed prediction)
+    cnt_sh[0] = ns_word; cnt_sh[1] = nw_word;
+  }
+  __syncthreads();
+  if (threadIdx.x < kNe) {
+    double t = red[0][threadIdx.x];
+#pragma unroll
+    for (int g = 1; g < 8; ++g) t += red[g][threadIdx.x];
+    out[threadIdx.x] = t; fin[threadIdx.x] = t;
+  }
   if (threadIdx.x == 32) {
-    const double ns = (double)__hip_atomic_load(strag_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const double ns = (double)cnt_sh[0];
     out[29] = (double)limit; fin[29] = (double)limit;
     out[30] = ns; fin[30] = ns;
-    const double nw = (double)__hip_atomic_load(strag_count + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const double nw = (double)cnt_sh[1];
     out[31] = nw; fin[31] = nw;  // queries that had to search in this iteration (k_knn_classify), for the trace
     __hip_atomic_store(strag_count, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __hip_atomic_store(strag_count + 2, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // work-list length (k_knn_classify)
     __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
-  for (int i = threadIdx.x; i < 3 * kHistBins; i += 256) hist[i] = 0u;  // every block has read hist3 by now
-  if (sel_aux && threadIdx.x < kSelBelowSlots) sel_aux[threadIdx.x * kSelBelowStride] = 0u;
-  if (hist3w) {  // the window table of the committed select (written only by launches that carry it)
-    uint4* w4 = reinterpret_cast<uint4*>(hist3w);
-    for (int i = threadIdx.x; i < kSelWinRows * 512 / 4; i += 256) w4[i] = make_uint4(0u, 0u, 0u, 0u);
+#ifdef LSGPU_KNN_STATS
+  unsigned long long w_pre = 0;
+  if (threadIdx.x == 0) w_pre = (unsigned long long)wall_clock64();
+#endif
+  __syncthreads();
+  // wave 0's first lane advances the loop state; the other waves re-arm the iteration's scratch meanwhile (every
+  // block has read hist3 / the window table by now)
+  if (threadIdx.x == 0) {
+    if (fuse_update) icp_update_lane(&st_sh, fin, chk_hist, trace, trace_cap, capped_launch, nullptr, (int)fail_sh);
+    else if (sel_aux && fail_sh) sel_aux[kSelFailFlag] = 1u;   // the stand-alone update kernel reads it there
+  } else if (threadIdx.x >= 64) {
+    const int t = (int)threadIdx.x - 64;
+    for (int i = t; i < 3 * kHistBins; i += 192) hist[i] = 0u;
+    if (sel_aux && t < kSelBelowSlots) sel_aux[t * kSelBelowStride] = 0u;
+    if (sel_aux && fuse_update && t == kSelBelowSlots) sel_aux[kSelFailFlag] = 0u;
+    if (hist3w) {  // the window table of the committed select (written only by launches that carry it)
+      uint4* w4 = reinterpret_cast<uint4*>(hist3w);
+      for (int i = t; i < kSelWinRows * 512 / 4; i += 192) w4[i] = make_uint4(0u, 0u, 0u, 0u);
+    }
   }
-  if (!sel_ok && sel_aux && threadIdx.x == 0) sel_aux[kSelFailFlag] = 1u;  // (committed select missed: same handling as a missed prediction)
-  if (fuse_update) {  // every other block has finished: the loop state is this block's to advance
+  if (fuse_update) {
     __syncthreads();
-    if (threadIdx.x == 0) icp_update_lane(ist, fin, chk_hist, trace, trace_cap, capped_launch, sel_aux);
+#pragma unroll
+    for (int i = 0; i < (kStWords + 255) / 256; ++i)
+      if ((int)threadIdx.x + 256 * i < kStWords) gw[threadIdx.x + 256 * i] = sw[threadIdx.x + 256 * i];
   }
+#ifdef LSGPU_KNN_STATS
+  if (threadIdx.x == 0) {
+    const unsigned long long wend = (unsigned long long)wall_clock64();
+    const unsigned long long w0 = g_ne_dbg[5], w2 = g_ne_dbg[6], w1 = g_ne_dbg[10];
+    g_ne_dbg[0] += 1ull; g_ne_dbg[7] += w2 - w0; g_ne_dbg[8] += wend - w2; g_ne_dbg[9] += w1 - w0;
+    g_ne_dbg[11] += wend - w_pre;  // the update lane alone
+    g_ne_dbg[5] = ~0ull; g_ne_dbg[6] = 0ull; g_ne_dbg[10] = ~0ull;
+  }
+#endif
 }
 
 // 1024 threads = 32 groups of 32: group r sums rows r, r+32, ... of its column, then the 32 group
