@@ -26,3 +26,4 @@ print("launches %d, blocks per launch %.0f, iterations %d" % (n, blocks / n, st.
 print("per block (shader cycles): prologue %.0f | main loop %.0f | wave+block reduce, hand-off %.0f" % (d[1] / blocks, d[2] / blocks, d[3] / blocks))
 print("wall (us, 100 MHz clock): first start -> first loop start %.2f | first start -> last loop end %.2f | last loop end -> kernel end %.2f (update lane %.2f)"
       % (d[9] / n / 100, d[7] / n / 100, d[8] / n / 100, d[11] / n / 100))
+print("update lane (shader cycles per launch): unpack + LLT %.0f | delta, T update %.0f | trace record %.0f | checker %.0f" % tuple(d[12:16] / n))

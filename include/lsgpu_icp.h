@@ -80,7 +80,7 @@ typedef struct lsgpu_icp_stats {
   double  t_select_ms;       /* sum over the iterations: trimmed-distance select kernels (profile_kernels=1) */
   double  t_ne_ms;           /* sum over the iterations: normal equations + solve + checkers (profile_kernels=1) */
   int     committed_select_iterations;  /* iterations whose trim limit came from the search kernels' own tables (no select launch) */
-  int     pad2_;
+  int     spread_tiles;                 /* 64-query tiles whose queries share no candidates (searched row-wise by the front of the tile kernel) */
 } lsgpu_icp_stats;
 
 /* One record per iteration (optional parity/debug trace; replaces the VTKFileInspector dump of

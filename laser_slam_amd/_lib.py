@@ -70,7 +70,7 @@ class IcpStats(C.Structure):
         ("t_select_ms", C.c_double),
         ("t_ne_ms", C.c_double),
         ("committed_select_iterations", C.c_int),
-        ("pad2_", C.c_int),
+        ("spread_tiles", C.c_int),
     ]
 
 

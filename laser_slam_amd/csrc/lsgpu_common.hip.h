@@ -105,6 +105,10 @@ struct IcpState {
   // iteration's select in full)
   uint32_t sel_bin2;  // bits [19:9] of the last limit
   int sel_streak;     // consecutive iterations whose limit stayed in the same 12-bit bin and close in the second level
+  // front rows of the tile kernel: tiles on the spread list as of the last completed iteration (the host sizes the
+  // front of the grid from the copy it fetches with the rest of the state)
+  uint32_t n_spread;
+  uint32_t pad_;
 };
 constexpr int kSelBelowSlots = 64;   // counters of "distance below the predicted bin", hashed by tile ...
 constexpr int kSelBelowStride = 32;  // ... one per 128-byte line (atomics on one line serialise in L2)

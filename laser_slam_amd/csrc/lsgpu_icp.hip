@@ -173,6 +173,9 @@ struct lsgpu_icp {
   DevBuf<GeomDev> geom;      // grid geometry derived on the device (k_ref_stats_final)
   DevBuf<uint32_t> counters;  // [0..16] cell counts, [32] straggler count
   DevBuf<uint32_t> ang_cells; // angular occupancy of the reading (query order decision)
+  uint32_t n_spread_host = 0;   // length of the spread list as of the last state fetch
+  bool n_spread_known = false;
+  DevBuf<uint32_t> spread_flag, spread_list, spread_cnt;  // front rows of the tile kernel (tiles whose queries share no candidates)
   DevBuf<uint32_t> sel_aux;   // predicted select: kSelBelowSlots counters + failure flag
   DevBuf<uint32_t> sel_win;   // committed select: kSelWinRows x 512 window histogram
   DevBuf<uint32_t> work;      // compacted list of searching queries (k_knn_classify -> k_knn_rows)
@@ -327,7 +330,7 @@ void lsgpu_icp_destroy(lsgpu_icp* h) {
   h->ref_in.release(); h->nrm_in.release(); h->keys.release(); h->keys_alt.release();
   h->vals.release(); h->vals_alt.release(); h->sort_tmp.release(); h->sort_hist.release(); h->pts.release();
   h->nrm.release(); h->ref_inv.release(); h->tables.release(); h->flags.release(); h->cidx.release(); h->bounds.release(); h->chunks.release(); h->soa.release(); h->soa_base.release(); h->soa_cnt4.release(); h->soa_first.release(); h->prev.release(); h->state.release(); h->lb.release(); h->cell_cache.release(); h->cell_tags.release(); h->ssn_seg_a.release(); h->ssn_seg_b.release(); h->ssn_seg_of.release(); h->ssn_box_pts.release(); h->ssn_box_base.release(); h->ssn_keep.release(); h->ssn_out_pos.release(); h->ssn_bb.release(); h->ssn_box_normal.release(); h->ssn_draws.release(); h->flt_in.release(); h->flt_ref.release(); h->flt_rd.release(); h->flt_nrm.release(); h->chk_hist.release(); h->trace_dev.release(); h->knn_dbg.release(); h->knn_dbg_wave.release(); h->stat_partials.release(); h->geom.release();
-  h->counters.release(); h->ang_cells.release(); h->sel_aux.release(); h->sel_win.release(); h->work.release(); h->q_in.release(); h->rdq.release(); h->ids.release(); h->d2.release();
+  h->counters.release(); h->ang_cells.release(); h->sel_aux.release(); h->sel_win.release(); h->spread_flag.release(); h->spread_list.release(); h->spread_cnt.release(); h->work.release(); h->q_in.release(); h->rdq.release(); h->ids.release(); h->d2.release();
   h->ids_io.release(); h->d2_io.release(); h->strag.release(); h->hist.release();
   h->sel.release(); h->ne_partials.release(); h->ne_gpartials.release(); h->ne_tickets.release(); h->ne_out.release(); h->limit_dev.release();
   for (auto& e : h->knn_events) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); (void)hipEventDestroy(e.c); (void)hipEventDestroy(e.d); (void)hipEventDestroy(e.e); }
@@ -466,7 +469,7 @@ static KnnArgs knn_args(lsgpu_icp* h, const Mat34& T) {
   a.strag = h->strag.p; a.strag_count = h->counters.p + 32;
   a.r_cap = 1.0f; a.group_r = 0.75f; a.cap2 = INFINITY; a.st = nullptr; a.use_state_cap = 0; a.lb = nullptr;
   a.spread_route_r = 0.f; a.route_chunks = 1 << 30; a.sel_hist2 = nullptr; a.sel_below = nullptr;
-  a.sel_hist3w = nullptr; a.sel_force = 0; a.write_all = 1; a.sparse_lanes = 0;
+  a.sel_hist3w = nullptr; a.sel_force = 0; a.write_all = 1; a.sparse_lanes = 0; a.spread_flag = nullptr; a.spread_list = nullptr; a.spread_cnt = nullptr; a.front_blocks = 0;
   { static const float gap = getenv("LSGPU_GAP") ? (float)atof(getenv("LSGPU_GAP")) : 0.002f; a.gap = gap; }
   a.ntiles = (int)((h->nq + 63) / 64); a.xcd_swizzle = 0; a.pad_index = (int)h->nr;
   { static const int budget = getenv("LSGPU_BUDGET") ? atoi(getenv("LSGPU_BUDGET")) : 128; a.chunk_budget = budget; }
@@ -508,6 +511,24 @@ static int run_knn(lsgpu_icp* h, const Mat34& T, const IcpState* st, bool seed, 
   static const int rowq_blocks = getenv("LSGPU_ROWQ_BLOCKS") ? atoi(getenv("LSGPU_ROWQ_BLOCKS")) : kRowqBlocks;
   static const bool rowq = getenv("LSGPU_NO_ROWQ") == nullptr;
   a.sparse_lanes = settled && rowq ? sparse_lanes : 0;
+  // front rows: spread tiles are remembered from the first searches on and searched row-wise by the first workgroups
+  // of the settled launches themselves -- no hand-over, no second launch (LSGPU_NO_FRONT: the separate row pass)
+  static const bool front_mode = getenv("LSGPU_NO_FRONT") == nullptr && !getenv("LSGPU_KNN_LANE") &&
+                                 !(getenv("LSGPU_KNN_ROWS") && atoi(getenv("LSGPU_KNN_ROWS")) != 0) &&
+                                 !(getenv("LSGPU_TILE_WAVES") && atoi(getenv("LSGPU_TILE_WAVES")) == 4) && sparse_lanes == 0;
+  const bool front = front_mode && st && h->spread_cnt.p;
+  if (front) {
+    a.spread_flag = h->spread_flag.p; a.spread_list = h->spread_list.p; a.spread_cnt = h->spread_cnt.p;
+    // (the front is sized from the list's length as the host last saw it -- it travels with the state every few
+    // iterations --, from a guess before that: surplus workgroups exit at once, a listed tile beyond the front, or one
+    // that turns spread late, searches per lane inside the kernel)
+    static const int front_guess = getenv("LSGPU_FRONT_GUESS") ? atoi(getenv("LSGPU_FRONT_GUESS")) : 2048;
+    if (settled) {
+      const int tiles = h->n_spread_known ? (int)h->n_spread_host : std::min(front_guess, a.ntiles);
+      a.front_blocks = kFrontPerTile * tiles;
+      a.spread_route_r = 0.f;
+    }
+  }
   if (predicted && !wide && capped && st) { a.sel_hist2 = h->hist.p + kHistBins; a.sel_below = h->sel_aux.p; }
   if (committed && a.sel_below) { a.sel_hist3w = h->sel_win.p; a.sel_force = 1; }
   { static const int rc_ = getenv("LSGPU_ROUTE_CHUNKS") ? atoi(getenv("LSGPU_ROUTE_CHUNKS")) : 1024; a.route_chunks = rc_; }
@@ -558,11 +579,13 @@ static int run_knn(lsgpu_icp* h, const Mat34& T, const IcpState* st, bool seed, 
     if (waves_per_block == 4)
       hipLaunchKernelGGL(k_knn_tile<4>, dim3((a.ntiles + 3) / 4), dim3(256), 0, h->stream, a);
     else
-      hipLaunchKernelGGL(k_knn_tile<1>, dim3(a.ntiles), dim3(64), 0, h->stream, a);
+      hipLaunchKernelGGL(k_knn_tile<1>, dim3(a.ntiles + a.front_blocks), dim3(64), 0, h->stream, a);
     if (timed) HIPC(hipEventRecord(ev->b, h->stream));
     // stragglers (balls > r_cap) only exist in uncapped launches
     // (a settled launch routes a few thousand queries at most: a small grid keeps the pass short)
-    if (settled && rowq)   // one DPP row per handed-over query
+    if (a.front_blocks > 0) {
+      // nothing was handed over
+    } else if (settled && rowq)   // one DPP row per handed-over query
       hipLaunchKernelGGL(k_knn_rowq, dim3(rowq_blocks), dim3(256), 0, h->stream, a);
     else if (!capped || a.spread_route_r > 0.f)
       hipLaunchKernelGGL(k_knn_fallback, dim3(settled ? kFallbackBlocksSettled : kFallbackBlocks), dim3(256), 0, h->stream, a);
@@ -1513,6 +1536,10 @@ int lsgpu_icp_align(lsgpu_icp* h, const float* reading_xyz1, int64_t nq, const f
   HIPC(hipMemsetAsync(h->ne_tickets.p, 0, (size_t)(kNeBlocksMax / kNeGroup + 2) * sizeof(uint32_t), h->stream));
   HIPC(h->sel_aux.reserve(kSelFailFlag + 4));
   HIPC(hipMemsetAsync(h->sel_aux.p, 0, (kSelFailFlag + 4) * sizeof(uint32_t), h->stream));
+  HIPC(h->spread_flag.reserve((size_t)((nq + 63) / 64))); HIPC(h->spread_list.reserve(kFrontMax)); HIPC(h->spread_cnt.reserve(2));
+  HIPC(hipMemsetAsync(h->spread_flag.p, 0, (size_t)((nq + 63) / 64) * sizeof(uint32_t), h->stream));
+  HIPC(hipMemsetAsync(h->spread_cnt.p, 0, 2 * sizeof(uint32_t), h->stream));
+  h->n_spread_host = 0; h->n_spread_known = false;
   HIPC(h->sel_win.reserve((size_t)kSelWinRows * 512));
   HIPC(hipMemsetAsync(h->sel_win.p, 0, (size_t)kSelWinRows * 512 * sizeof(uint32_t), h->stream));
 
@@ -1568,7 +1595,7 @@ int lsgpu_icp_align(lsgpu_icp* h, const float* reading_xyz1, int64_t nq, const f
                        h->state.p, h->prev.p, h->d2.p, h->nrm.p, h->hist.p, h->sel.p + 2,
                        h->counters.p + 32, h->ne_tickets.p, h->ne_partials.p, h->ne_gpartials.p, h->ne_out.p,
                        h->chk_hist.p, h->trace_dev.p, max_it, capped ? 1 : 0, (h->comm || split_update) ? 0 : 1,
-                       h->sel_aux.p, h->sel_win.p, committed ? 1 : 0);   // 6d (+6e)
+                       h->sel_aux.p, h->sel_win.p, committed ? 1 : 0, h->spread_cnt.p);   // 6d (+6e)
     if (h->comm || split_update) {   // split scan: every rank gets the sums over all shards (the limit, slot 29, is already global)
       if (h->comm && rccl_api()->AllReduce(h->ne_out.p, h->ne_out.p, kNe, ncclDouble, ncclSum, h->comm, h->stream) != ncclSuccess) {
         h->err = "RCCL all-reduce of the normal equations failed";
@@ -1610,6 +1637,7 @@ int lsgpu_icp_align(lsgpu_icp* h, const float* reading_xyz1, int64_t nq, const f
     if (rc) return rc;
     since_check = 0;
     commit_ok = hst->sel_streak >= 1 && hst->status == 0;  // (a miss below clears it until the streak is rebuilt)
+    h->n_spread_host = hst->n_spread; h->n_spread_known = true;
     if (hst->done && hst->status == kStatusCapFailed) {
       // the cap prediction failed for iteration hst->iter: repeat it uncapped, then carry on
       st.cap_retries++;
@@ -1685,6 +1713,7 @@ int lsgpu_icp_align(lsgpu_icp* h, const float* reading_xyz1, int64_t nq, const f
   }
   st.pad_ = sel_retries;  // (select predictions that missed; informational)
   st.committed_select_iterations = committed_iterations;
+  st.spread_tiles = (int)hst->n_spread;
   st.t_total_ms = wall_ms() - t0;
   if (stats) *stats = st;
   return rc;

@@ -60,6 +60,12 @@ struct KnnArgs {
   float spread_route_r;     // > 0: a spread wave whose largest ball exceeds this hands its lanes to k_knn_fallback
   int route_chunks;         // (with spread_route_r > 0) so does any wave whose cell block holds more chunks than this
   int sparse_lanes;         // > 0: a wave with at most this many searching lanes hands them to k_knn_rowq
+  // front rows (settled launches): tiles found spread in an earlier launch are searched row-wise by the first
+  // `front_blocks` workgroups of the tile kernel itself (8 per tile) -- no hand-over list, no second launch
+  uint32_t* spread_flag;    // per tile: on the list (nullable)
+  uint32_t* spread_list;    // tiles found spread so far
+  uint32_t* spread_cnt;     // [0] entries the front rows may use (committed by k_normal_eq_loop), [1] entries appended
+  int front_blocks;
   uint32_t* sel_hist2;      // predicted select (IcpState::sel_mode): 2048-bin histogram of bits [19:9] inside the bin
   uint32_t* sel_below;      //   kSelBelowSlots counters of distances below the bin (nullable: launch without prediction)
   uint32_t* sel_hist3w;     // committed select: kSelWinRows x 512 histogram of bits [8:0] around the last limit (nullable)
@@ -413,6 +419,222 @@ __device__ __forceinline__ float4 tile_resolve_match(const KnnArgs& a, int grp, 
   return mp;
 }
 
+// ---------------------------------------------------------------- row-per-query search
+// One DPP row of 16 lanes takes one query -- lanes 0..7 probe the <= 2x2x2 cells the ball touches, the cells' chunks
+// are culled 16 at a time (lane = chunk) against the ball itself, a surviving chunk is evaluated one point per lane --
+// and a wave runs four queries side by side.  Exact nearest point inside the cap, smallest index on ties; searches
+// `gap` beyond the current bound like the tile search, so that the second smallest distance found (or the search
+// radius) bounds "every other point" for the next iterations' keep test.  All 16 lanes of a row hold the same inputs.
+constexpr int kRowqList = 64;  // chunk ids staged per row and window
+
+__device__ __forceinline__ void rowq_search(const KnnArgs& a, float cap2s, float gap, uint32_t* list, int row, int k16,
+                                            bool have, float qx, float qy, float qz, float ub, int id_in,
+                                            unsigned long long& bestp_out, float& sec_out) {
+  const GridDev& g = a.g;
+  const int lim = (1 << (g.bits + g.fine)) - 1;
+  unsigned long long bestp = have ? (((unsigned long long)__float_as_uint(ub) << 32) | (uint32_t)id_in) : ~0ull;
+  float bcur = ub;          // the row's smallest distance so far
+  float sec = INFINITY;     // this lane: smallest distance among the points it evaluated other than its own best
+  float best = prune_lim(bcur, gap, cap2s);  // squared search radius
+  // ---- the ball's cells: the level at which it spans at most two cells per axis
+  uint32_t cs = 0, ce = 0;
+  {
+    const float B = sqrtf(best) * (1.0f + 1e-5f) + 1e-7f + kFineSlack * g.hf;
+    const int flx = fine_coord(qx - B, g.ox, g.inv_hf, lim), fhx = fine_coord(qx + B, g.ox, g.inv_hf, lim);
+    const int fly = fine_coord(qy - B, g.oy, g.inv_hf, lim), fhy = fine_coord(qy + B, g.oy, g.inv_hf, lim);
+    const int flz = fine_coord(qz - B, g.oz, g.inv_hf, lim), fhz = fine_coord(qz + B, g.oz, g.inv_hf, lim);
+    int l = 0;
+    for (int sh = g.fine; l < g.bits; ++l, ++sh)
+      if ((fhx >> sh) - (flx >> sh) < 2 && (fhy >> sh) - (fly >> sh) < 2 && (fhz >> sh) - (flz >> sh) < 2) break;
+    unsigned long long todo = __ballot(have);
+    while (todo) {  // rows may sit on different levels: one pass per distinct level keeps table base / mask scalar
+      const int L = __builtin_amdgcn_readlane(l, __ffsll((long long)todo) - 1);
+      const bool mine = have && l == L;
+      todo &= ~__ballot(mine);
+      if (mine && k16 < 8) {
+        const int sh = g.fine + L;
+        const int cx = (flx >> sh) + (k16 & 1), cy = (fly >> sh) + ((k16 >> 1) & 1), cz = (flz >> sh) + (k16 >> 2);
+        if (cx <= (fhx >> sh) && cy <= (fhy >> sh) && cz <= (fhz >> sh))
+          if (!grid_lookup(g, L, (uint32_t)cx, (uint32_t)cy, (uint32_t)cz, cs, ce)) { cs = 0; ce = 0; }
+      }
+    }
+  }
+  const uint32_t nch = ce - cs;
+  const uint32_t incl = row_scan_incl_u32(nch), excl = incl - nch;
+  const uint32_t tot = row_sum_u32(nch);
+  const uint32_t totmax = wave_max_u32(tot);
+  for (uint32_t wbase = 0; wbase < totmax; wbase += (uint32_t)kRowqList) {  // (one window unless the ball is huge)
+    // this lane's chunks whose list position falls into the window
+    for (uint32_t c = 0; c < nch; ++c) {
+      const uint32_t pos = excl + c;
+      if (pos >= wbase && pos < wbase + (uint32_t)kRowqList) list[pos - wbase] = cs + c;
+    }
+    const uint32_t wlen = tot > wbase ? (tot - wbase < (uint32_t)kRowqList ? tot - wbase : (uint32_t)kRowqList) : 0u;
+    const uint32_t wmax = wave_max_u32(wlen);
+    for (uint32_t e0 = 0; e0 < wmax; e0 += 16u) {
+      const uint32_t e = e0 + (uint32_t)k16;
+      float bd = INFINITY;
+      uint32_t st = 0, cnt = 0;
+      if (e < wlen) {
+        const float4* cd = reinterpret_cast<const float4*>(a.chunks + list[e]);
+        const float4 b0 = cd[0], b1 = cd[1];
+        bd = box_dist2(b0.x, b0.y, b0.z, b1.x, b1.y, b1.z, qx, qy, qz) * kPruneShrink;
+        st = __float_as_uint(b0.w); cnt = __float_as_uint(b1.w);
+      }
+      uint32_t m16 = (uint32_t)(__ballot(bd <= best) >> (row * 16)) & 0xFFFFu;
+      while (__ballot(m16 != 0u)) {
+        const bool has = m16 != 0u;
+        const int src = row * 16 + (has ? __ffs((int)m16) - 1 : 0);
+        m16 &= m16 - 1u;
+        const float cbd = __shfl(bd, src, 64);
+        const uint32_t cst = (uint32_t)__shfl((int)st, src, 64), ccnt = (uint32_t)__shfl((int)cnt, src, 64);
+        float dmin = INFINITY;
+        if (has && cbd <= best) {  // (the bound may have shrunk since the cull)
+          for (uint32_t o = (uint32_t)k16; o < ccnt; o += 16u) {
+            const float4 p = a.pts[cst + o];
+            const float d = dist2(qx - p.x, qy - p.y, qz - p.z);
+            const unsigned long long pk = ((unsigned long long)__float_as_uint(d) << 32) | (cst + o);
+            if (pk < bestp) { sec = fminf(sec, __uint_as_float((uint32_t)(bestp >> 32))); bestp = pk; }
+            else if (pk != bestp) sec = fminf(sec, d);   // (pk == bestp: the warm-start point itself)
+            dmin = fminf(dmin, d);
+          }
+        }
+        bcur = fminf(bcur, row_min(dmin));
+        best = prune_lim(bcur, gap, cap2s);
+      }
+    }
+  }
+  // ---- the row's answer: smallest (distance, index) pair over its 16 lanes; every other lane's best is an "other"
+  unsigned long long gb = bestp;
+#pragma unroll
+  for (int o = 8; o > 0; o >>= 1) {
+    const unsigned long long w = __shfl_xor(gb, o, 64);
+    gb = w < gb ? w : gb;
+  }
+  if (bestp != gb) sec = fminf(sec, __uint_as_float((uint32_t)(bestp >> 32)));
+  sec_out = row_min(sec);
+  bestp_out = gb;
+}
+
+__device__ __forceinline__ void sel_count_query(const KnnArgs& a, int j, uint32_t bits) {
+  if (a.sel_below && (a.st->sel_mode || a.sel_force)) {  // predicted select: this query's share (see k_knn_tile)
+    const uint32_t top = bits >> 20, b1 = a.st->sel_bin1;
+    if (top < b1) atomicAdd(&a.sel_below[(j & (kSelBelowSlots - 1)) * kSelBelowStride], 1u);
+    else if (top == b1) sel_count_inside(a, bits);
+  }
+}
+
+// one lane per row: write the query's result, its share of the predicted select, its new lower bound
+__device__ __forceinline__ void rowq_store(const KnnArgs& a, float cap2s, float gap, int j, unsigned long long bestp,
+                                           float sec, int id_in, float lb_carried, bool write_all) {
+  const int id = (int)(uint32_t)(bestp & 0xFFFFFFFFull);
+  const float fd = __uint_as_float((uint32_t)(bestp >> 32));
+  if (write_all || id != id_in) {
+    const float4 p = a.pts[id];
+    a.ids[j] = id;
+    a.prev[j] = make_float4(p.x, p.y, p.z, __int_as_float(id));
+  }
+  a.d2[j] = fd;
+  sel_count_query(a, j, (uint32_t)(bestp >> 32));
+  if (a.lb) {  // every unevaluated point lies beyond the final search radius
+    float nb = sqrtf(fminf(sec, prune_lim(fd, gap, cap2s))) * (1.0f - 1e-5f);
+    if (id == id_in) nb = fmaxf(nb, lb_carried);
+    a.lb[j] = nb;
+  }
+}
+
+// Front rows: workgroup b of the first `front_blocks` takes a quarter (16 queries) of tile spread_list[b / 4] -- the
+// whole per-query work of the tile kernel (transform, keep / far test, search, results) for the tiles whose queries
+// share no candidates.  Every row first runs the prologue of its four queries (loads in flight together); the queries
+// that have to search are packed into an LDS list and searched four at a time, one per row: a quarter with five
+// searching queries costs two rounds of dependent round trips (about 8 us each), not four.  These waves start first,
+// so their latency overlaps the rest of the launch instead of following it as a separate pass.
+constexpr int kFrontMax = 8192;   // tiles the list holds
+constexpr int kFrontPerTile = 4;  // workgroups at the front of the grid per listed tile
+
+__device__ __forceinline__ void tile_front_rows(const KnnArgs& a, uint32_t* lds_words /* >= 4 * kRowqList + 16 * 8 */,
+                                                int lane, uint32_t b) {
+  const uint32_t entry = b / (uint32_t)kFrontPerTile, sub = b % (uint32_t)kFrontPerTile;
+  if (entry >= a.spread_cnt[0]) return;   // (entry < front_blocks / kFrontPerTile by construction)
+  Mat34 T; float cap2;
+  if (!iter_params(a.st, a.T, a.cap2, a.use_state_cap, T, cap2)) return;
+  const float cap2s = cap2 * kCapSearchMargin2;
+  const float gap = a.use_state_cap ? a.gap : 0.f;
+  const int row = lane >> 4, k16 = lane & 15;
+  uint32_t* list = lds_words + row * kRowqList;
+  uint32_t* packed = lds_words + 4 * kRowqList;   // 16 entries x {j, qx, qy, qz, ub, id, lbn, -}
+  const uint32_t tile = a.spread_list[entry];
+  Mat34 To;
+#pragma unroll
+  for (int i = 0; i < 12; ++i) To.m[i] = a.st->T_rows_prev[i];
+  // ---- prologue of the row's four queries (same arithmetic as k_knn_tile's)
+  const int j0 = (int)(tile * 64u + sub * 16u) + row * 4;
+  float4 rraw[4], mp[4];
+  float lb_in[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const bool act = j0 + i < a.nq;
+    rraw[i] = act ? a.rdq[j0 + i] : make_float4(0.f, 0.f, 0.f, 0.f);
+    mp[i] = act ? a.prev[j0 + i] : make_float4(0.f, 0.f, 0.f, __int_as_float(-1));
+    lb_in[i] = act ? a.lb[j0 + i] : 0.f;
+  }
+  uint32_t mine = 0;   // searching queries of this row
+  float qx[4], qy[4], qz[4], ub[4], lbn[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const bool act = j0 + i < a.nq;
+    const float3 q = xform(T, rraw[i].x, rraw[i].y, rraw[i].z);
+    qx[i] = q.x; qy[i] = q.y; qz[i] = q.z;
+    ub[i] = dist2(q.x - mp[i].x, q.y - mp[i].y, q.z - mp[i].z);
+    const float3 qo = xform(To, rraw[i].x, rraw[i].y, rraw[i].z);
+    const float ddx = q.x - qo.x, ddy = q.y - qo.y, ddz = q.z - qo.z;
+    const float delta = sqrtf(ddx * ddx + ddy * ddy + ddz * ddz) * (1.0f + 1e-5f) + 1e-7f;
+    lbn[i] = fmaxf(lb_in[i] * (1.0f - 1e-6f) - delta, 0.f);
+    const float lb2 = lbn[i] * lbn[i];
+    const bool keep = ub[i] * (1.0f + 1e-5f) < lb2;
+    const bool far = fminf(ub[i], lb2) > cap2 * (1.0f + 1e-5f);
+    if (act && (keep || far)) {   // the match stands, only its distance moved
+      if (k16 == 0) {
+        a.d2[j0 + i] = ub[i];
+        a.lb[j0 + i] = lbn[i];
+        sel_count_query(a, j0 + i, __float_as_uint(ub[i]));
+      }
+    } else if (act) {
+      mine |= 1u << i;
+    }
+  }
+  // ---- pack the searching queries (row order, then query order)
+  const uint32_t cnt = (uint32_t)__popc(mine);
+  const uint32_t c0 = rl_u(cnt, 0), c1 = rl_u(cnt, 16), c2 = rl_u(cnt, 32), c3 = rl_u(cnt, 48);
+  const uint32_t total = c0 + c1 + c2 + c3;
+  uint32_t pos = row == 0 ? 0u : row == 1 ? c0 : row == 2 ? c0 + c1 : c0 + c1 + c2;
+  if (k16 == 0) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      if (mine & (1u << i)) {
+        uint32_t* e = packed + pos * 8u;
+        e[0] = (uint32_t)(j0 + i); e[1] = __float_as_uint(qx[i]); e[2] = __float_as_uint(qy[i]); e[3] = __float_as_uint(qz[i]);
+        e[4] = __float_as_uint(ub[i]); e[5] = (uint32_t)__float_as_int(mp[i].w); e[6] = __float_as_uint(lbn[i]);
+        ++pos;
+      }
+    }
+  }
+  __syncthreads();   // (the workgroup is this one wave)
+  for (uint32_t r0 = 0; r0 < total; r0 += 4u) {
+    const uint32_t e_idx = r0 + (uint32_t)row;
+    const bool have = e_idx < total;
+    const uint32_t* e = packed + (have ? e_idx : 0u) * 8u;
+    const int j = (int)e[0];
+    const float sx = __uint_as_float(e[1]), sy = __uint_as_float(e[2]), sz = __uint_as_float(e[3]);
+    const float sub_ = __uint_as_float(e[4]);
+    const int id_in = (int)e[5];
+    const float slbn = __uint_as_float(e[6]);
+    unsigned long long bestp; float sec;
+    rowq_search(a, cap2s, gap, list, row, k16, have, sx, sy, sz, sub_, id_in, bestp, sec);
+    if (have && k16 == 0) rowq_store(a, cap2s, gap, j, bestp, sec, id_in, slbn, a.write_all != 0);
+  }
+}
+
 #ifndef LSGPU_TILE_OCC
 #define LSGPU_TILE_OCC 7   // waves per SIMD the register budget is cut for (7: 72 VGPRs, no spills; 8 spills 48 B per lane)
 #endif
@@ -429,7 +651,13 @@ __global__ __launch_bounds__(WAVES * 64, LSGPU_TILE_OCC) void k_knn_tile(KnnArgs
   // same reference chunks and hash entries, share one L2.
   const uint32_t wpb = blockDim.x >> 6;
   uint32_t blk = blockIdx.x;
-  if (a.xcd_swizzle > 1) {
+  if (WAVES == 1 && a.front_blocks > 0) {
+    if (blk < (uint32_t)a.front_blocks) {
+      tile_front_rows(a, reinterpret_cast<uint32_t*>(lds.slot), lane, blk);
+      return;
+    }
+    blk -= (uint32_t)a.front_blocks;
+  } else if (a.xcd_swizzle > 1) {
     // XCD x takes runs of `xcd_swizzle` consecutive blocks: run index = (i / S) * 8 + x.  Neighbouring
     // tiles share an L2 inside a run, while every XCD still gets an even mix of the whole scan.
     const uint32_t S = (uint32_t)a.xcd_swizzle, nb = gridDim.x, x = blk & 7u, i = blk >> 3;
@@ -453,6 +681,11 @@ __global__ __launch_bounds__(WAVES * 64, LSGPU_TILE_OCC) void k_knn_tile(KnnArgs
     if (a.lb) lb_in = a.lb[j];
   }
   const int id_in = __float_as_int(mp.w);  // the match this query came in with
+  const uint32_t on_list = a.spread_flag ? a.spread_flag[tile] : 0u;   // list position + 1
+  if (on_list && a.front_blocks > 0) {   // the front rows own this tile if its entry is committed and inside this launch's front
+    const uint32_t covered = min(a.spread_cnt[0], (uint32_t)a.front_blocks / (uint32_t)kFrontPerTile);
+    if (on_list - 1u < covered) return;
+  }
   // the tile's cached cell block (tag + 64 probe results) travels with the same round trip: whether it still fits
   // is only known after the reductions below, but waiting until then cost two more dependent loads (40 % of a
   // settled wave's time was this prologue)
@@ -594,6 +827,10 @@ __global__ __launch_bounds__(WAVES * 64, LSGPU_TILE_OCC) void k_knn_tile(KnnArgs
     const float ext = fmaxf(fmaxf(thx - tlx, thy - tly), thz - tlz);
     const uint32_t block_chunks = wave_sum_u32(ce - cs);
     const bool spread = ext > fmaxf(a.group_r, 4.f * Rmax) && block_chunks > (uint32_t)a.chunk_budget;
+    if (spread && a.spread_list && !on_list && lane == 0) {   // remembered: the settled launches search it row-wise, up front
+      const uint32_t idx = atomicAdd(&a.spread_cnt[1], 1u);
+      if (idx < (uint32_t)kFrontMax) { a.spread_list[idx] = tile; a.spread_flag[tile] = idx + 1u; }
+    }
 #ifdef LSGPU_KNN_STATS
     if (spread && (a.dbg_flags & 32)) { /* ablation: drop spread waves */ } else
 #endif

@@ -396,8 +396,6 @@ __global__ __launch_bounds__(64, 4) void k_knn_rows(KnnArgs a) {
 // point per lane -- and a wave runs four queries side by side.  Same results as k_knn_fallback (exact nearest point
 // inside the cap, smallest index on ties, lower bound for the next iterations); three to five dependent memory
 // round trips per query instead of one per chunk and per reduction of a 64-lane wave.
-constexpr int kRowqList = 64;  // chunk ids staged per row and window
-
 __global__ __launch_bounds__(256) void k_knn_rowq(KnnArgs a) {
   __shared__ uint32_t list_sh[16][kRowqList];
   const int lane = threadIdx.x & 63, row = lane >> 4, k16 = lane & 15, wave = threadIdx.x >> 6;
@@ -406,17 +404,12 @@ __global__ __launch_bounds__(256) void k_knn_rowq(KnnArgs a) {
   if (!iter_params(a.st, a.T, a.cap2, a.use_state_cap, T, cap2)) return;
   const float cap2s = cap2 * kCapSearchMargin2;
   const float gap = a.use_state_cap ? a.gap : 0.f;
-  const GridDev& g = a.g;
-  const int lim = (1 << (g.bits + g.fine)) - 1;
   const uint32_t count = *a.strag_count;
-  const uint32_t base0 = (blockIdx.x * 4u + (uint32_t)wave) * 4u, stride = gridDim.x * 16u;
-  const uint32_t* qsrc = a.strag;
-  for (uint32_t base = base0; base < count; base += stride) {
+  for (uint32_t base = (blockIdx.x * 4u + (uint32_t)wave) * 4u; base < count; base += gridDim.x * 16u) {
     const uint32_t s = base + (uint32_t)row;
     const bool have = s < count;
-    const uint32_t j = have ? qsrc[s] : 0u;
+    const uint32_t j = have ? a.strag[s] : 0u;
     float qx = 0.f, qy = 0.f, qz = 0.f, ub = 0.f;
-    unsigned long long bestp = ~0ull;
     int id_in = -1;
     if (have) {
       const float4 r = a.rdq[j];
@@ -424,112 +417,11 @@ __global__ __launch_bounds__(256) void k_knn_rowq(KnnArgs a) {
       qx = q.x; qy = q.y; qz = q.z;
       ub = a.d2[j];  // distance to the warm-start point
       id_in = a.ids[j];
-      bestp = ((unsigned long long)__float_as_uint(ub) << 32) | (uint32_t)id_in;
     }
-    // Search `gap` beyond the current bound (never beyond the cap), like the tile kernel: the second smallest distance
-    // found, or the search radius, then bounds "every other point" well enough for the next iterations' keep test --
-    // with the bare distance to the match as the bound, a query searched here would have to search again every time.
-    float bcur = ub;          // the row's smallest distance so far
-    float sec = INFINITY;     // this lane: smallest distance among the points it evaluated other than its own best
-    float best = prune_lim(bcur, gap, cap2s);  // squared search radius
-    // ---- the ball's cells: the level at which it spans at most two cells per axis
-    uint32_t cs = 0, ce = 0;
-    {
-      const float B = sqrtf(best) * (1.0f + 1e-5f) + 1e-7f + kFineSlack * g.hf;
-      const int flx = fine_coord(qx - B, g.ox, g.inv_hf, lim), fhx = fine_coord(qx + B, g.ox, g.inv_hf, lim);
-      const int fly = fine_coord(qy - B, g.oy, g.inv_hf, lim), fhy = fine_coord(qy + B, g.oy, g.inv_hf, lim);
-      const int flz = fine_coord(qz - B, g.oz, g.inv_hf, lim), fhz = fine_coord(qz + B, g.oz, g.inv_hf, lim);
-      int l = 0;
-      for (int sh = g.fine; l < g.bits; ++l, ++sh)
-        if ((fhx >> sh) - (flx >> sh) < 2 && (fhy >> sh) - (fly >> sh) < 2 && (fhz >> sh) - (flz >> sh) < 2) break;
-      unsigned long long todo = __ballot(have);
-      while (todo) {  // rows may sit on different levels: one pass per distinct level keeps table base / mask scalar
-        const int L = __builtin_amdgcn_readlane(l, __ffsll((long long)todo) - 1);
-        const bool mine = have && l == L;
-        todo &= ~__ballot(mine);
-        if (mine && k16 < 8) {
-          const int sh = g.fine + L;
-          const int cx = (flx >> sh) + (k16 & 1), cy = (fly >> sh) + ((k16 >> 1) & 1), cz = (flz >> sh) + (k16 >> 2);
-          if (cx <= (fhx >> sh) && cy <= (fhy >> sh) && cz <= (fhz >> sh))
-            if (!grid_lookup(g, L, (uint32_t)cx, (uint32_t)cy, (uint32_t)cz, cs, ce)) { cs = 0; ce = 0; }
-        }
-      }
-    }
-    const uint32_t nch = ce - cs;
-    const uint32_t incl = row_scan_incl_u32(nch), excl = incl - nch;
-    const uint32_t tot = row_sum_u32(nch);
-    const uint32_t totmax = wave_max_u32(tot);
-    for (uint32_t wbase = 0; wbase < totmax; wbase += (uint32_t)kRowqList) {  // (one window unless the ball is huge)
-      // this lane's chunks whose list position falls into the window
-      for (uint32_t c = 0; c < nch; ++c) {
-        const uint32_t pos = excl + c;
-        if (pos >= wbase && pos < wbase + (uint32_t)kRowqList) list[pos - wbase] = cs + c;
-      }
-      const uint32_t wlen = tot > wbase ? (tot - wbase < (uint32_t)kRowqList ? tot - wbase : (uint32_t)kRowqList) : 0u;
-      const uint32_t wmax = wave_max_u32(wlen);
-      for (uint32_t e0 = 0; e0 < wmax; e0 += 16u) {
-        const uint32_t e = e0 + (uint32_t)k16;
-        float bd = INFINITY;
-        uint32_t st = 0, cnt = 0;
-        if (e < wlen) {
-          const float4* cd = reinterpret_cast<const float4*>(a.chunks + list[e]);
-          const float4 b0 = cd[0], b1 = cd[1];
-          bd = box_dist2(b0.x, b0.y, b0.z, b1.x, b1.y, b1.z, qx, qy, qz) * kPruneShrink;
-          st = __float_as_uint(b0.w); cnt = __float_as_uint(b1.w);
-        }
-        uint32_t m16 = (uint32_t)(__ballot(bd <= best) >> (row * 16)) & 0xFFFFu;
-        while (__ballot(m16 != 0u)) {
-          const bool has = m16 != 0u;
-          const int src = row * 16 + (has ? __ffs((int)m16) - 1 : 0);
-          m16 &= m16 - 1u;
-          const float cbd = __shfl(bd, src, 64);
-          const uint32_t cst = (uint32_t)__shfl((int)st, src, 64), ccnt = (uint32_t)__shfl((int)cnt, src, 64);
-          float dmin = INFINITY;
-          if (has && cbd <= best) {  // (the bound may have shrunk since the cull)
-            for (uint32_t o = (uint32_t)k16; o < ccnt; o += 16u) {
-              const float4 p = a.pts[cst + o];
-              const float d = dist2(qx - p.x, qy - p.y, qz - p.z);
-              const unsigned long long pk = ((unsigned long long)__float_as_uint(d) << 32) | (cst + o);
-              if (pk < bestp) { sec = fminf(sec, __uint_as_float((uint32_t)(bestp >> 32))); bestp = pk; }
-              else if (pk != bestp) sec = fminf(sec, d);   // (pk == bestp: the warm-start point itself)
-              dmin = fminf(dmin, d);
-            }
-          }
-          bcur = fminf(bcur, row_min(dmin));
-          best = prune_lim(bcur, gap, cap2s);
-        }
-      }
-    }
-    // ---- the row's answer: smallest (distance, index) pair over its 16 lanes; every other lane's best is an "other"
-    {
-      unsigned long long gb = bestp;
-#pragma unroll
-      for (int o = 8; o > 0; o >>= 1) {
-        const unsigned long long w = __shfl_xor(gb, o, 64);
-        gb = w < gb ? w : gb;
-      }
-      if (bestp != gb) sec = fminf(sec, __uint_as_float((uint32_t)(bestp >> 32)));
-      sec = row_min(sec);
-      bestp = gb;
-    }
-    if (have && k16 == 0) {
-      const int id = (int)(uint32_t)(bestp & 0xFFFFFFFFull);
-      const float fd = __uint_as_float((uint32_t)(bestp >> 32));
-      const float4 p = a.pts[id];
-      a.ids[j] = id;
-      a.d2[j] = fd;
-      a.prev[j] = make_float4(p.x, p.y, p.z, __int_as_float(id));
-      if (a.sel_below && (a.st->sel_mode || a.sel_force)) {  // predicted select: this query's share (see k_knn_tile)
-        const uint32_t bits = (uint32_t)(bestp >> 32), top = bits >> 20, b1 = a.st->sel_bin1;
-        if (top < b1) atomicAdd(&a.sel_below[(j & (kSelBelowSlots - 1)) * kSelBelowStride], 1u);
-        else if (top == b1) sel_count_inside(a, bits);
-      }
-      if (a.lb) {  // every unevaluated point lies beyond the final search radius
-        float nb = sqrtf(fminf(sec, prune_lim(fd, gap, cap2s))) * (1.0f - 1e-5f);
-        if (id == id_in) nb = fmaxf(nb, a.lb[j]);  // (the tile kernel left the carried bound there)
-        a.lb[j] = nb;
-      }
-    }
+    unsigned long long bestp; float sec;
+    rowq_search(a, cap2s, gap, list, row, k16, have, qx, qy, qz, ub, id_in, bestp, sec);
+    if (have && k16 == 0)
+      rowq_store(a, cap2s, gap, (int)j, bestp, sec, id_in, a.lb ? a.lb[j] : 0.f /* the tile kernel left the carried bound there */, true);
   }
 }
 

@@ -219,6 +219,13 @@ __global__ __launch_bounds__(256) void k_normal_eq(const float4* __restrict__ rd
 
 constexpr float kCapFactor = 1.1f;  // next search cap = this x the current trim limit (verified each iteration)
 
+#ifdef LSGPU_KNN_STATS
+// stats build only: where k_normal_eq_loop spends its time.  [0] launches, [1..3] sum over blocks of the cycles in
+// {prologue (limit), main loop, wave+block reduce and hand-off}, [4] blocks, [5] first block start (100 MHz wall clock,
+// re-armed by the last block), [6] latest end of a main loop, [7] sum of (last loop end - first start), [8] sum of
+// (kernel end - last loop end), [9] sum of (first loop START - first start) i.e. prologue wall time of the earliest block
+__device__ unsigned long long g_ne_dbg[16] = {0, 0, 0, 0, 0, ~0ull, 0, 0, 0, 0, ~0ull, 0, 0, 0, 0, 0};
+#endif
 // ---------------------------------------------------------------- per-iteration update (device side)
 // One lane: 6x6 float LLT solve, AngleAxis update, T_iter <- dT * T_iter, Counter + Differential
 // checkers, trace record, next cap.  Same code as the host (lsgpu_host_math.h).
@@ -244,6 +251,9 @@ __device__ inline void icp_update_lane(IcpState* st, const double* ne_out, float
     st->done = 1;
     return;
   }
+#ifdef LSGPU_KNN_STATS
+  const long long u0 = clock64();
+#endif
   st->stragglers += nstrag;
   const long long used = (long long)ne_out[27];
   if (used <= 0) { st->status = LSGPU_NO_CONVERGENCE; st->err_code = 1; st->done = 1; return; }
@@ -251,12 +261,18 @@ __device__ inline void icp_update_lane(IcpState* st, const double* ne_out, float
   hostmath::unpack_normal_eq(ne_out, A, b);
   float x[6], dT[16], Tn[16];
   if (!hostmath::llt_solve6(A, b, x)) { st->status = LSGPU_NO_CONVERGENCE; st->err_code = 2; st->done = 1; return; }
+#ifdef LSGPU_KNN_STATS
+  const long long u1 = clock64();
+#endif
   hostmath::delta_from_x(x, dT);
   hostmath::mul4(dT, st->T_iter, Tn);
   for (int i = 0; i < 16; ++i) st->T_iter[i] = Tn[i];
   for (int i = 0; i < 12; ++i) st->T_rows_prev[i] = st->T_rows[i];
   for (int r = 0; r < 3; ++r)
     for (int c = 0; c < 4; ++c) st->T_rows[r * 4 + c] = Tn[c * 4 + r];
+#ifdef LSGPU_KNN_STATS
+  const long long u2 = clock64();
+#endif
   const int it = st->iter;
   if (it < trace_cap) {
     lsgpu_iter_trace& tr = trace[it];
@@ -266,6 +282,9 @@ __device__ inline void icp_update_lane(IcpState* st, const double* ne_out, float
     for (int i = 0; i < 6; ++i) { tr.b[i] = b[i]; tr.x[i] = x[i]; }
     tr.knn_main_us = 0.f; tr.knn_fallback_us = 0.f; tr.stragglers = (uint32_t)nstrag; tr.reserved = (uint32_t)ne_out[31];
   }
+#ifdef LSGPU_KNN_STATS
+  const long long u3 = clock64();
+#endif
   st->prev_limit = limit;
   {
     const uint32_t lb = __float_as_uint(limit), b1 = lb >> 20, b2 = (lb >> 9) & 0x7FFu;
@@ -282,6 +301,13 @@ __device__ inline void icp_update_lane(IcpState* st, const double* ne_out, float
   const bool ok = hostmath::checker_check(&cs, chk_hist, st->max_iter, st->smooth, st->lim_rot,
                                           st->lim_trans, Tn, &iterate, &by_diff);
   st->counter = cs.counter; st->n_hist = cs.n_hist;
+#ifdef LSGPU_KNN_STATS
+  {
+    const long long u4 = clock64();
+    g_ne_dbg[12] += (unsigned long long)(u1 - u0); g_ne_dbg[13] += (unsigned long long)(u2 - u1);
+    g_ne_dbg[14] += (unsigned long long)(u3 - u2); g_ne_dbg[15] += (unsigned long long)(u4 - u3);
+  }
+#endif
   if (!ok) { st->status = LSGPU_NO_CONVERGENCE; st->err_code = 3; st->done = 1; return; }
   if (!iterate) { st->converged = by_diff ? 1 : 0; st->done = 1; }
 }
@@ -302,13 +328,6 @@ __global__ __launch_bounds__(64) void k_icp_update(IcpState* __restrict__ st,
 // LAST block to finish (ticket; partial sums exchanged with agent-scope accesses) reduces the block
 // partials in a fixed order, publishes {29 sums, limit, straggler count} and re-arms the per-iteration
 // scratch (histograms, straggler counter, ticket) so the next iteration needs no memset launches.
-#ifdef LSGPU_KNN_STATS
-// stats build only: where k_normal_eq_loop spends its time.  [0] launches, [1..3] sum over blocks of the cycles in
-// {prologue (limit), main loop, wave+block reduce and hand-off}, [4] blocks, [5] first block start (100 MHz wall clock,
-// re-armed by the last block), [6] latest end of a main loop, [7] sum of (last loop end - first start), [8] sum of
-// (kernel end - last loop end), [9] sum of (first loop START - first start) i.e. prologue wall time of the earliest block
-__device__ unsigned long long g_ne_dbg[16] = {0, 0, 0, 0, 0, ~0ull, 0, 0, 0, 0, ~0ull, 0, 0, 0, 0, 0};
-#endif
 #ifndef LSGPU_NE_UNROLL
 #define LSGPU_NE_UNROLL 8
 #endif
@@ -330,7 +349,8 @@ __global__ __launch_bounds__(256) void k_normal_eq_loop(const float4* __restrict
                                                         int capped_launch, int fuse_update,
                                                         uint32_t* __restrict__ sel_aux,
                                                         uint32_t* __restrict__ hist3w /* committed select: window table */,
-                                                        int committed) {
+                                                        int committed,
+                                                        uint32_t* __restrict__ spread_cnt /* front rows of k_knn_tile (nullable) */) {
   __shared__ uint32_t sc[260];
   __shared__ double fin[32];
   __shared__ double red[8][33];
@@ -528,6 +548,12 @@ __global__ __launch_bounds__(256) void k_normal_eq_loop(const float4* __restrict
     __hip_atomic_store(strag_count, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __hip_atomic_store(strag_count + 2, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // work-list length (k_knn_classify)
     __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (spread_cnt) {  // tiles found spread in this iteration's search join the front rows from the next launch on
+      const uint32_t n = __hip_atomic_load(spread_cnt + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const uint32_t nc = n < (uint32_t)kFrontMax ? n : (uint32_t)kFrontMax;
+      __hip_atomic_store(spread_cnt, nc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (fuse_update) st_sh.n_spread = nc; else ist->n_spread = nc;
+    }
   }
 #ifdef LSGPU_KNN_STATS
   unsigned long long w_pre = 0;
