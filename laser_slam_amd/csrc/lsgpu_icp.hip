@@ -353,6 +353,7 @@ static void radix_pass(lsgpu_icp* h, const uint64_t* kin, const uint32_t* vin, u
                        int shift, uint32_t mask, int nblocks) {
   uint32_t* bh = h->sort_hist.p;
   uint32_t* dtot = bh + (size_t)256 * nblocks;
+  // (the scan as the tail of k_rs_hist -- last block, ticket -- was measured 2 % slower end to end than this launch)
   hipLaunchKernelGGL(k_rs_hist<ITEMS>, dim3(nblocks), dim3(256), 0, h->stream, kin, n, shift, mask, bh, nblocks);
   hipLaunchKernelGGL(k_rs_scan, dim3(256), dim3(256), 0, h->stream, bh, nblocks, dtot);
   hipLaunchKernelGGL(k_rs_scatter<ITEMS>, dim3(nblocks), dim3(256), 0, h->stream, kin, vin, kout, vout, n, shift, mask,
@@ -532,14 +533,13 @@ static int run_knn(lsgpu_icp* h, const Mat34& T, const IcpState* st, bool seed, 
   if (predicted && !wide && capped && st) { a.sel_hist2 = h->hist.p + kHistBins; a.sel_below = h->sel_aux.p; }
   if (committed && a.sel_below) { a.sel_hist3w = h->sel_win.p; a.sel_force = 1; }
   { static const int rc_ = getenv("LSGPU_ROUTE_CHUNKS") ? atoi(getenv("LSGPU_ROUTE_CHUNKS")) : 1024; a.route_chunks = rc_; }
-  if (seed) HIPC(hipMemsetAsync(a.strag_count, 0, sizeof(uint32_t), h->stream));  // later: re-armed by k_normal_eq_loop
+  if (seed && !st) HIPC(hipMemsetAsync(a.strag_count, 0, sizeof(uint32_t), h->stream));  // (align: k_align_init, then re-armed by k_normal_eq_loop)
   if (seed) hipLaunchKernelGGL(k_knn_seed, dim3(nblk(nq)), dim3(256), 0, h->stream, a);
   if (seed && capped && st && seed_rank != 0xFFFFFFFFu) {
     // first iteration of an align: cap = trim quantile of the seed distances (k_knn_seed left them in d2)
-    const int rs = run_select(h, h->d2.p, nq, seed_rank, true, st, true, false);
+    const int rs = run_select(h, h->d2.p, nq, seed_rank, false /* k_align_init armed the tables */, st, true, false);
     if (rs) return rs;
-    hipLaunchKernelGGL(k_seed_cap, dim3(1), dim3(256), 0, h->stream, h->hist.p + 2 * kHistBins, h->sel.p + 2,
-                       h->state.p);
+    hipLaunchKernelGGL(k_seed_cap, dim3(1), dim3(256), 0, h->stream, h->hist.p, h->sel.p + 2, h->state.p);
   }
   lsgpu_icp::KnnEv* ev = nullptr;
   if (timed) {
@@ -1524,26 +1524,27 @@ int lsgpu_icp_align(lsgpu_icp* h, const float* reading_xyz1, int64_t nq, const f
   hst->cap_enabled = h->cfg.reserved[0] == 0 ? 1 : 0;
   hst->max_iter = max_it; hst->smooth = h->cfg.smooth_length;
   hst->lim_rot = h->cfg.min_diff_rot; hst->lim_trans = h->cfg.min_diff_trans;
+  AlignInitArgs ia{};
   {  // checkers.init(T_iter): history starts with the identity
-    float* hh = reinterpret_cast<float*>(h->h_pinned + 48);
     hostmath::CheckerState cs{0, 0};
-    hostmath::checker_push(&cs, hh, hst->T_iter);
+    hostmath::checker_push(&cs, ia.chk0, hst->T_iter);
     hst->counter = cs.counter; hst->n_hist = cs.n_hist;
-    HIPC(hipMemcpyAsync(h->chk_hist.p, hh, 8 * sizeof(float), hipMemcpyHostToDevice, h->stream));
   }
-  HIPC(hipMemcpyAsync(h->state.p, hst, sizeof(IcpState), hipMemcpyHostToDevice, h->stream));
-  HIPC(hipMemsetAsync(h->counters.p + 32, 0, 3 * sizeof(uint32_t), h->stream));  // stragglers, (unused), work-list length
-  HIPC(hipMemsetAsync(h->ne_tickets.p, 0, (size_t)(kNeBlocksMax / kNeGroup + 2) * sizeof(uint32_t), h->stream));
-  HIPC(h->sel_aux.reserve(kSelFailFlag + 4));
-  HIPC(hipMemsetAsync(h->sel_aux.p, 0, (kSelFailFlag + 4) * sizeof(uint32_t), h->stream));
-  HIPC(h->spread_flag.reserve((size_t)((nq + 63) / 64))); HIPC(h->spread_list.reserve(kFrontMax)); HIPC(h->spread_cnt.reserve(2));
-  HIPC(hipMemsetAsync(h->spread_flag.p, 0, (size_t)((nq + 63) / 64) * sizeof(uint32_t), h->stream));
-  HIPC(hipMemsetAsync(h->spread_cnt.p, 0, 2 * sizeof(uint32_t), h->stream));
-  h->n_spread_host = 0; h->n_spread_known = false;
-  HIPC(h->sel_win.reserve((size_t)kSelWinRows * 512));
-  HIPC(hipMemsetAsync(h->sel_win.p, 0, (size_t)kSelWinRows * 512 * sizeof(uint32_t), h->stream));
-
   const uint32_t k = trim_rank(nq_total, h->cfg.trim_ratio);
+  HIPC(h->sel_aux.reserve(kSelFailFlag + 4));
+  HIPC(h->spread_flag.reserve((size_t)((nq + 63) / 64))); HIPC(h->spread_list.reserve(kFrontMax)); HIPC(h->spread_cnt.reserve(2));
+  HIPC(h->sel_win.reserve((size_t)kSelWinRows * 512));
+  h->n_spread_host = 0; h->n_spread_known = false;
+  ia.state = *hst;
+  ia.sel0 = SelState{0u, k};   // sel[0] = {0, rank}: constant during an align
+  ia.state_dev = h->state.p; ia.chk_hist = h->chk_hist.p; ia.sel = h->sel.p;
+  ia.counters3 = h->counters.p + 32;   // stragglers, (unused), work-list length
+  ia.ne_ticket = h->ne_tickets.p; ia.sel_aux = h->sel_aux.p; ia.spread_flag = h->spread_flag.p;
+  ia.spread_cnt = h->spread_cnt.p; ia.sel_win = h->sel_win.p; ia.hist = h->hist.p;
+  ia.n_sel_aux = kSelFailFlag + 4; ia.n_spread_flag = (int)((nq + 63) / 64); ia.n_sel_win = kSelWinRows * 512;
+  hipLaunchKernelGGL(k_align_init, dim3(64), dim3(256), 0, h->stream, ia);
+  HIPC(hipGetLastError());
+
   const int nb = std::min(kNeBlocks, nblk(nq));
   const bool timed = h->cfg.profile_kernels != 0;
   const Mat34 Tdummy = to_mat34(hst->T_iter);
@@ -1583,7 +1584,8 @@ int lsgpu_icp_align(lsgpu_icp* h, const float* reading_xyz1, int64_t nq, const f
       if (api->GroupEnd) RCCLC(api->GroupEnd());
     }
     if (!committed) {
-      r = run_select(h, h->d2.p, (int)nq, k, first_select, h->state.p, true, predicted);       // 6c
+      r = run_select(h, h->d2.p, (int)nq, k, false /* armed by k_align_init / k_seed_cap / the previous k_normal_eq_loop */,
+                     h->state.p, true, predicted);       // 6c
       first_select = false;
       if (r) return r;
     } else {

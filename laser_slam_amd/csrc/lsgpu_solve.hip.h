@@ -142,12 +142,41 @@ __global__ __launch_bounds__(256) void k_limit_out(const uint32_t* __restrict__ 
 
 // First iteration: the select just ran over the SEED distances (upper bounds of the true ones); its result is a
 // valid cap for the first search (limit(true distances) <= limit(upper bounds)).
-__global__ __launch_bounds__(256) void k_seed_cap(const uint32_t* __restrict__ hist3,
+__global__ __launch_bounds__(256) void k_seed_cap(uint32_t* __restrict__ hist /* 3 x kHistBins */,
                                                   const SelState* __restrict__ st, IcpState* __restrict__ ist) {
   __shared__ uint32_t sc[260];
   if (ist->done) return;
-  const float lim = select_limit(hist3, st, sc);
+  const float lim = select_limit(hist + 2 * kHistBins, st, sc);
   if (threadIdx.x == 0) ist->cap2 = lim;
+  for (int i = threadIdx.x; i < 3 * kHistBins; i += 256) hist[i] = 0u;   // re-armed for the iteration's own select
+}
+
+// Start of an align: the loop state, the checker history's first entry, the select's input and every per-iteration
+// scratch table in ONE launch (there used to be two uploads and eight memsets, 4-5 us each on the stream).
+struct AlignInitArgs {
+  IcpState state;
+  float chk0[8];
+  SelState sel0;
+  IcpState* state_dev; float* chk_hist; SelState* sel;
+  uint32_t *counters3, *ne_ticket, *sel_aux, *spread_flag, *spread_cnt, *sel_win, *hist;
+  int n_sel_aux, n_spread_flag, n_sel_win;
+};
+__global__ __launch_bounds__(256) void k_align_init(AlignInitArgs a) {
+  const int t = blockIdx.x * 256 + threadIdx.x, stride = gridDim.x * 256;
+  if (blockIdx.x == 0) {
+    constexpr int kWords = (int)(sizeof(IcpState) / sizeof(uint32_t));
+    const uint32_t* src = reinterpret_cast<const uint32_t*>(&a.state);
+    if ((int)threadIdx.x < kWords) reinterpret_cast<uint32_t*>(a.state_dev)[threadIdx.x] = src[threadIdx.x];
+    if (threadIdx.x < 8) a.chk_hist[threadIdx.x] = a.chk0[threadIdx.x];
+    if (threadIdx.x == 8) a.sel[0] = a.sel0;
+    if (threadIdx.x >= 16 && threadIdx.x < 19) a.counters3[threadIdx.x - 16] = 0u;
+    if (threadIdx.x >= 32 && threadIdx.x < 40) a.ne_ticket[threadIdx.x - 32] = 0u;
+    if (threadIdx.x >= 64 && threadIdx.x < 66) a.spread_cnt[threadIdx.x - 64] = 0u;
+  }
+  for (int i = t; i < a.n_sel_aux; i += stride) a.sel_aux[i] = 0u;
+  for (int i = t; i < a.n_spread_flag; i += stride) a.spread_flag[i] = 0u;
+  for (int i = t; i < a.n_sel_win; i += stride) a.sel_win[i] = 0u;
+  for (int i = t; i < 3 * kHistBins; i += stride) a.hist[i] = 0u;
 }
 
 // ---------------------------------------------------------------- point-to-plane normal equations
