@@ -325,6 +325,43 @@ def test_radius_cap_does_not_change_results(icp_mod, pair64k):
     assert np.array_equal(out[0][0], out[1][0])
 
 
+@pytest.mark.timeout(600)
+def test_experiment_switches_do_not_change_results():
+    """DESIGN.md's claim about the LSGPU_* switches -- they move work between exact paths and never change a result -- on
+    a 14-iteration alignment of a 262 k-point pair: front rows / separate row pass / per-lane search for spread tiles,
+    committed / predicted / plain select, own radix sort / library sort, the row-wise experiment, 4-wave tile blocks, no
+    first-iteration cap.  Every variant runs in its own process (the switches are read once) and must return
+    bit-identical transform, per-iteration limit / inlier count / normal matrix / T, distances and filtered reference.
+    LSGPU_QUERY_ORDER changes the order in which the 29 double sums of the normal equations are added, hence their last
+    bits: for it the search results, the first iteration's limit and inlier count are bit-identical, the transform
+    agrees to 1e-6 and the iteration count is the same."""
+    import json
+    import subprocess
+    import sys
+    variants = [{}, {"LSGPU_NO_FRONT": "1"}, {"LSGPU_NO_FRONT": "1", "LSGPU_NO_ROWQ": "1"},
+                {"LSGPU_NO_FRONT": "1", "LSGPU_NO_ROUTE_ALL": "1"}, {"LSGPU_NO_COMMIT": "1"}, {"LSGPU_NO_PREDICT": "1"},
+                {"LSGPU_ROCPRIM_SORT": "1"}, {"LSGPU_KNN_ROWS": "1"}, {"LSGPU_TILE_WAVES": "4"},
+                {"LSGPU_NO_SEED_CAP": "1"}, {"LSGPU_NO_FRONT": "1", "LSGPU_SPARSE_LANES": "16"}, {"LSGPU_FRONT_GUESS": "8"},
+                {"LSGPU_QUERY_ORDER": "0"}]
+    results = []
+    for env_add in variants:
+        env = dict(os.environ)
+        env.update(env_add)
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "switch_worker.py"), "4096"], env=env,
+                           capture_output=True, text=True, timeout=300)
+        line = [ln for ln in r.stdout.splitlines() if ln.startswith("SWITCH_RESULT ")]
+        assert r.returncode == 0 and line, (env_add, r.stdout[-1500:], r.stderr[-1500:])
+        results.append((env_add, json.loads(line[0][len("SWITCH_RESULT "):])))
+    base = results[0][1]
+    assert base["iterations"] >= 10 and base["committed"] > 0 and base["spread_tiles"] > 0, base
+    for env_add, res in results[1:]:
+        assert res["iterations"] == base["iterations"] and res["digest_order_free"] == base["digest_order_free"], (env_add, res, base)
+        if "LSGPU_QUERY_ORDER" in env_add:
+            assert max(abs(a - b) for a, b in zip(res["T"], base["T"])) < 1e-6, (env_add, res["T"], base["T"])
+        else:
+            assert res["digest"] == base["digest"], (env_add, res, base)
+
+
 def test_full_size_properties(icp_mod):
     """BASELINE configs[1] size (1M-point pair): size-independent properties instead of the oracle.
     (a) kNN distances are self-consistent with the returned ids and no sampled brute-force distance
