@@ -567,63 +567,50 @@ __device__ __forceinline__ void tile_front_rows(const KnnArgs& a, uint32_t* lds_
   Mat34 To;
 #pragma unroll
   for (int i = 0; i < 12; ++i) To.m[i] = a.st->T_rows_prev[i];
-  // ---- prologue of the row's four queries (same arithmetic as k_knn_tile's)
+  // ---- prologue of the row's four queries (same arithmetic as k_knn_tile's), one after the other: this code shares
+  // its register budget with the broadcast search (72 VGPRs, 7 waves per SIMD), arrays of four queries spilled there
   const int j0 = (int)(tile * 64u + sub * 16u) + row * 4;
-  float4 rraw[4], mp[4];
-  float lb_in[4];
-#pragma unroll
+  uint32_t mine = 0;   // searching queries of this row: packed[row * 4 + 0 .. mine)
+#pragma unroll 1
   for (int i = 0; i < 4; ++i) {
-    const bool act = j0 + i < a.nq;
-    rraw[i] = act ? a.rdq[j0 + i] : make_float4(0.f, 0.f, 0.f, 0.f);
-    mp[i] = act ? a.prev[j0 + i] : make_float4(0.f, 0.f, 0.f, __int_as_float(-1));
-    lb_in[i] = act ? a.lb[j0 + i] : 0.f;
-  }
-  uint32_t mine = 0;   // searching queries of this row
-  float qx[4], qy[4], qz[4], ub[4], lbn[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const bool act = j0 + i < a.nq;
-    const float3 q = xform(T, rraw[i].x, rraw[i].y, rraw[i].z);
-    qx[i] = q.x; qy[i] = q.y; qz[i] = q.z;
-    ub[i] = dist2(q.x - mp[i].x, q.y - mp[i].y, q.z - mp[i].z);
-    const float3 qo = xform(To, rraw[i].x, rraw[i].y, rraw[i].z);
+    const int j = j0 + i;
+    if (j >= a.nq) break;
+    const float4 rraw = a.rdq[j], mp = a.prev[j];
+    const float lb_in = a.lb[j];
+    const float3 q = xform(T, rraw.x, rraw.y, rraw.z);
+    const float ub = dist2(q.x - mp.x, q.y - mp.y, q.z - mp.z);
+    const float3 qo = xform(To, rraw.x, rraw.y, rraw.z);
     const float ddx = q.x - qo.x, ddy = q.y - qo.y, ddz = q.z - qo.z;
     const float delta = sqrtf(ddx * ddx + ddy * ddy + ddz * ddz) * (1.0f + 1e-5f) + 1e-7f;
-    lbn[i] = fmaxf(lb_in[i] * (1.0f - 1e-6f) - delta, 0.f);
-    const float lb2 = lbn[i] * lbn[i];
-    const bool keep = ub[i] * (1.0f + 1e-5f) < lb2;
-    const bool far = fminf(ub[i], lb2) > cap2 * (1.0f + 1e-5f);
-    if (act && (keep || far)) {   // the match stands, only its distance moved
+    const float lbn = fmaxf(lb_in * (1.0f - 1e-6f) - delta, 0.f);
+    const float lb2 = lbn * lbn;
+    const bool keep = ub * (1.0f + 1e-5f) < lb2;
+    const bool far = fminf(ub, lb2) > cap2 * (1.0f + 1e-5f);
+    if (keep || far) {   // the match stands, only its distance moved
       if (k16 == 0) {
-        a.d2[j0 + i] = ub[i];
-        a.lb[j0 + i] = lbn[i];
-        sel_count_query(a, j0 + i, __float_as_uint(ub[i]));
+        a.d2[j] = ub;
+        a.lb[j] = lbn;
+        sel_count_query(a, j, __float_as_uint(ub));
       }
-    } else if (act) {
-      mine |= 1u << i;
+    } else {
+      if (k16 == 0) {
+        uint32_t* e = packed + ((uint32_t)row * 4u + mine) * 8u;
+        e[0] = (uint32_t)j; e[1] = __float_as_uint(q.x); e[2] = __float_as_uint(q.y); e[3] = __float_as_uint(q.z);
+        e[4] = __float_as_uint(ub); e[5] = (uint32_t)__float_as_int(mp.w); e[6] = __float_as_uint(lbn);
+      }
+      ++mine;
     }
   }
-  // ---- pack the searching queries (row order, then query order)
-  const uint32_t cnt = (uint32_t)__popc(mine);
-  const uint32_t c0 = rl_u(cnt, 0), c1 = rl_u(cnt, 16), c2 = rl_u(cnt, 32), c3 = rl_u(cnt, 48);
+  // ---- the searching queries in (row, query) order: entry e lives in the segment of the row whose prefix range holds it
+  const uint32_t c0 = rl_u(mine, 0), c1 = rl_u(mine, 16), c2 = rl_u(mine, 32), c3 = rl_u(mine, 48);
   const uint32_t total = c0 + c1 + c2 + c3;
-  uint32_t pos = row == 0 ? 0u : row == 1 ? c0 : row == 2 ? c0 + c1 : c0 + c1 + c2;
-  if (k16 == 0) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      if (mine & (1u << i)) {
-        uint32_t* e = packed + pos * 8u;
-        e[0] = (uint32_t)(j0 + i); e[1] = __float_as_uint(qx[i]); e[2] = __float_as_uint(qy[i]); e[3] = __float_as_uint(qz[i]);
-        e[4] = __float_as_uint(ub[i]); e[5] = (uint32_t)__float_as_int(mp[i].w); e[6] = __float_as_uint(lbn[i]);
-        ++pos;
-      }
-    }
-  }
   __syncthreads();   // (the workgroup is this one wave)
   for (uint32_t r0 = 0; r0 < total; r0 += 4u) {
     const uint32_t e_idx = r0 + (uint32_t)row;
     const bool have = e_idx < total;
-    const uint32_t* e = packed + (have ? e_idx : 0u) * 8u;
+    const uint32_t slot = e_idx < c0 ? e_idx : e_idx < c0 + c1 ? 4u + (e_idx - c0)
+                        : e_idx < c0 + c1 + c2 ? 8u + (e_idx - c0 - c1) : 12u + (e_idx - c0 - c1 - c2);
+    const uint32_t* e = packed + (have ? slot : 0u) * 8u;
     const int j = (int)e[0];
     const float sx = __uint_as_float(e[1]), sy = __uint_as_float(e[2]), sz = __uint_as_float(e[3]);
     const float sub_ = __uint_as_float(e[4]);
