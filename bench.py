@@ -212,7 +212,7 @@ def main():
                                 "per iteration" if args.split else "one scan pair per rank, no collective")},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                     "kernel": "k_knn_tile + k_knn_rowq / k_knn_fallback (exact 1-NN correspondence search: tile pass + the pass for the queries it hands over)",
+                     "kernel": "k_knn_tile (+ k_knn_fallback / k_knn_rowq where a launch hands queries over: the first three iterations) -- exact 1-NN correspondence search",
                      "algorithmic_bytes_per_launch": b_knn,
                      "avg_launch_us": t_knn * 1e6,
                      "avg_main_us": knn_main_ms / max(knn_launches, 1) * 1e3,
