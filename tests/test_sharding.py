@@ -117,6 +117,33 @@ def _split_worker(rank, world, port, q):
         prefix = (prefix << nb) | b
         shift_hi = shift
     limit = np.array([prefix], np.uint32).view(np.float32)[0]
+    # The committed exchange of the settled iterations: with the previous iteration's limit known,
+    # every shard fills {count below its 12-bit bin, 11-bit histogram inside it, 9-bit histograms of a window of 128
+    # second-level bins around it}; ONE all-reduce of the tables, then every rank reads the exact global order statistic.
+    k0 = min(int(np.float32(int(n_total)) * np.float32(0.75)), int(n_total) - 1)
+    last = int(np.array([np.float32(limit) * np.float32(1.0005)], np.float32).view(np.uint32)[0])   # "last iteration's" limit
+    bin1, bin2_last = last >> 20, (last >> 9) & 0x7FF
+    inside = bits >> 20 == bin1
+    tables = np.zeros(1 + 2048 + 128 * 512, np.int64)
+    tables[0] = int((bits >> 20 < bin1).sum())
+    tables[1:2049] = np.bincount((bits[inside] >> 9) & 0x7FF, minlength=2048)
+    drow = ((bits[inside] >> 9) & 0x7FF) - bin2_last + 64
+    inwin = (drow >= 0) & (drow < 128)
+    tables[2049:] = np.bincount(drow[inwin] * 512 + (bits[inside][inwin] & 0x1FF), minlength=128 * 512)
+    tt = torch.from_numpy(tables)
+    dist.all_reduce(tt)
+    tables = tt.numpy()
+    kk = k0 - int(tables[0])
+    assert 0 <= kk < int(tables[1:2049].sum())
+    c2 = np.cumsum(tables[1:2049])
+    b2 = int(np.searchsorted(c2, kk, side="right"))
+    kk -= int(c2[b2 - 1]) if b2 > 0 else 0
+    d = b2 - bin2_last + 64
+    assert 0 <= d < 128
+    c3 = np.cumsum(tables[2049 + d * 512: 2049 + (d + 1) * 512])
+    b3 = int(np.searchsorted(c3, kk, side="right"))
+    committed_limit = np.array([(bin1 << 20) | (b2 << 9) | b3], np.uint32).view(np.float32)[0]
+    assert np.float32(committed_limit) == np.float32(limit), (committed_limit, limit)
     rc, A, b_, x, dT, used = O.point_to_plane(qs, rf, rn, ids, d2, float(limit), 1)
     t = torch.from_numpy(np.concatenate([A.ravel(), b_, [float(used)]]))
     dist.all_reduce(t)
