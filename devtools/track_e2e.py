@@ -6,7 +6,7 @@ sys.path.insert(0, ROOT)
 import numpy as np
 from laser_slam_amd import synth
 n_az = int(sys.argv[1]) if len(sys.argv) > 1 else 16384
-n = 6
+n = 12
 d = tempfile.mkdtemp()
 exe = os.path.join(d, "track_driver")
 subprocess.check_call(["g++", "-std=c++17", "-O2", "-I", ROOT + "/include", "-I", ROOT + "/laser_slam_amd/cpp/include",
