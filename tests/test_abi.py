@@ -173,6 +173,18 @@ def test_draw_stream_is_the_glibc_rand_sequence():
     assert np.array_equal(icp.random_sampling(777, 0.5, -1), libc_keep(777, 0.5))             # continues after it
 
 
+def test_draw_stream_speculative_use_and_parallel_path(tmp_path):
+    """begin(kmax) / commit(k < kmax) / continue, as the device filters use the stream, for small requests and for the
+    large ones that are produced in parallel segments -- against glibc's rand() (tests/cpp/draw_stream_check.cpp)."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "draw_stream_check")
+    subprocess.check_call(["g++", "-std=c++17", "-O2", "-I", os.path.join(root, "laser_slam_amd", "csrc"),
+                           os.path.join(root, "tests", "cpp", "draw_stream_check.cpp"), "-o", exe, "-lpthread"])
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "DRAWS_OK" in r.stdout, r.stdout + r.stderr
+
+
 def test_header_is_c99_and_the_c_example_links(tmp_path):
     """include/lsgpu_icp.h must stay a plain C header (the reference's maintainers would bind it from C++ or through
     an FFI), and examples/compute_pair.c must build against it and the shared library."""
