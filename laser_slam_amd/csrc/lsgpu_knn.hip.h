@@ -550,7 +550,13 @@ __device__ __forceinline__ void rowq_store(const KnnArgs& a, float cap2s, float 
 // searching queries costs two rounds of dependent round trips (about 8 us each), not four.  These waves start first,
 // so their latency overlaps the rest of the launch instead of following it as a separate pass.
 constexpr int kFrontMax = 8192;   // tiles the list holds
-constexpr int kFrontPerTile = 4;  // workgroups at the front of the grid per listed tile
+#ifndef LSGPU_FRONT_PER_TILE
+#define LSGPU_FRONT_PER_TILE 4
+#endif
+// workgroups at the front of the grid per listed tile; measured on the benchmark pair: 1: 191, 2: 212, 4: 212, 8: 210,
+// 16: 208 scans/s
+constexpr int kFrontPerTile = LSGPU_FRONT_PER_TILE;
+constexpr int kFrontRowQ = 16 / kFrontPerTile;       // queries per row of such a workgroup
 
 __device__ __forceinline__ void tile_front_rows(const KnnArgs& a, uint32_t* lds_words /* >= 4 * kRowqList + 16 * 8 */,
                                                 int lane, uint32_t b) {
@@ -569,10 +575,10 @@ __device__ __forceinline__ void tile_front_rows(const KnnArgs& a, uint32_t* lds_
   for (int i = 0; i < 12; ++i) To.m[i] = a.st->T_rows_prev[i];
   // ---- prologue of the row's four queries (same arithmetic as k_knn_tile's), one after the other: this code shares
   // its register budget with the broadcast search (72 VGPRs, 7 waves per SIMD), arrays of four queries spilled there
-  const int j0 = (int)(tile * 64u + sub * 16u) + row * 4;
+  const int j0 = (int)(tile * 64u + sub * (uint32_t)(4 * kFrontRowQ)) + row * kFrontRowQ;
   uint32_t mine = 0;   // searching queries of this row: packed[row * 4 + 0 .. mine)
 #pragma unroll 1
-  for (int i = 0; i < 4; ++i) {
+  for (int i = 0; i < kFrontRowQ; ++i) {
     const int j = j0 + i;
     if (j >= a.nq) break;
     const float4 rraw = a.rdq[j], mp = a.prev[j];
@@ -594,7 +600,7 @@ __device__ __forceinline__ void tile_front_rows(const KnnArgs& a, uint32_t* lds_
       }
     } else {
       if (k16 == 0) {
-        uint32_t* e = packed + ((uint32_t)row * 4u + mine) * 8u;
+        uint32_t* e = packed + ((uint32_t)row * (uint32_t)kFrontRowQ + mine) * 8u;
         e[0] = (uint32_t)j; e[1] = __float_as_uint(q.x); e[2] = __float_as_uint(q.y); e[3] = __float_as_uint(q.z);
         e[4] = __float_as_uint(ub); e[5] = (uint32_t)__float_as_int(mp.w); e[6] = __float_as_uint(lbn);
       }
@@ -608,8 +614,9 @@ __device__ __forceinline__ void tile_front_rows(const KnnArgs& a, uint32_t* lds_
   for (uint32_t r0 = 0; r0 < total; r0 += 4u) {
     const uint32_t e_idx = r0 + (uint32_t)row;
     const bool have = e_idx < total;
-    const uint32_t slot = e_idx < c0 ? e_idx : e_idx < c0 + c1 ? 4u + (e_idx - c0)
-                        : e_idx < c0 + c1 + c2 ? 8u + (e_idx - c0 - c1) : 12u + (e_idx - c0 - c1 - c2);
+    constexpr uint32_t Q = (uint32_t)kFrontRowQ;
+    const uint32_t slot = e_idx < c0 ? e_idx : e_idx < c0 + c1 ? Q + (e_idx - c0)
+                        : e_idx < c0 + c1 + c2 ? 2u * Q + (e_idx - c0 - c1) : 3u * Q + (e_idx - c0 - c1 - c2);
     const uint32_t* e = packed + (have ? slot : 0u) * 8u;
     const int j = (int)e[0];
     const float sx = __uint_as_float(e[1]), sy = __uint_as_float(e[2]), sz = __uint_as_float(e[3]);
