@@ -176,7 +176,8 @@ int lsgpu_transform_points(lsgpu_icp* h, const float T[16], const float* xyz1, i
  * glibc (csrc/lsgpu_rand.h); seed >= 0 reseeds it, seed < 0 continues it.  The device filters, the host
  * filters below and the oracle produce the same points, in the same order, with the same normals. */
 typedef struct lsgpu_chain_config {
-  float   reading_prob;     /* RandomSamplingDataPointsFilter.prob            yaml:2-3 (0.5)  */
+  float   reading_prob;     /* RandomSamplingDataPointsFilter.prob            yaml:2-3 (0.5); < 0: NO reading filter
+                             * module (a yaml without readingDataPointsFilters): every point, no draw consumed */
   int     ssn_knn;          /* SamplingSurfaceNormalDataPointsFilter.knn      yaml:6-7 (10)   */
   float   ssn_ratio;        /* SamplingSurfaceNormalDataPointsFilter.ratio    yaml:6-7 (0.5)  */
   int     pad_;
@@ -234,8 +235,8 @@ int lsgpu_filter_voxel_grid(lsgpu_icp* h, const float* xyz1, int64_t n, const fl
  * laser_track.cpp:24-30, LOG(FATAL) if the file cannot be opened) and applies it to every incoming scan before the
  * scan is stored or matched (laser_track.cpp:81, :146: input_filters_.apply(scan.scan)).  The filters below run on the
  * device, one after the other, each on the output of the previous one, order of the surviving points preserved:
- *   MaxDistDataPointsFilter      dim -1: keep |p| <  maxDist          dim 0..2: keep |p[dim]| <  maxDist
- *   MinDistDataPointsFilter      dim -1: keep |p| >  minDist          dim 0..2: keep |p[dim]| >  minDist
+ *   MaxDistDataPointsFilter      dim -1: keep |p| <  |maxDist|        dim 0..2: keep  p[dim]  <  maxDist (SIGNED, as upstream)
+ *   MinDistDataPointsFilter      dim -1: keep |p| >  |minDist|        dim 0..2: keep |p[dim]| >  minDist
  *   BoundingBoxDataPointsFilter  inside = xMin < x < xMax && ...;     keeps inside (removeInside 0) or outside (1)
  *   FixStepSamplingDataPointsFilter  keeps points phase, phase + step, ...; phase = rand() % step; afterwards
  *                                step *= stepMult, clamped at endStep (the step persists from scan to scan: `state`)

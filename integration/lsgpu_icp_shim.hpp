@@ -159,7 +159,7 @@ class LsgpuDataPointsFilters {
   void apply(DataPoints& cloud) {
     if (filters_.empty()) return;
     const int64_t n = Traits::size(cloud);
-    if (n == 0) return;
+    if (n == 0) throw typename PM::ConvergenceError("no points to filter");   // as DataPointsFilters::apply does upstream
     if (!h_) {
       lsgpu_icp_config c;
       lsgpu_icp_config_default(&c);

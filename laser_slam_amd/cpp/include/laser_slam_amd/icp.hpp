@@ -258,7 +258,7 @@ class ICP {
     // without are required.
     bool has_reading = false, has_reference = false, has_matcher = false, has_outlier = false, has_minimizer = false,
          has_counter = false, has_differential = false;
-    prob = 1.0f;
+    prob = -1.0f;   // no reading filter module: lsgpu_chain_config::reading_prob < 0 (every point, no draws)
     c.trim_ratio = 1.0f;
     for (const auto& m : mods) {
       const std::string& sec = m.section;

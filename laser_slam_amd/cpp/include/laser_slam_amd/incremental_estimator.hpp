@@ -29,6 +29,54 @@ struct EstimatorParams {  // laser_slam/include/laser_slam/parameters.hpp:25-34
   LaserTrackParams laser_track_params;
 };
 
+// Which prior goes when two robots' graphs first link (incremental_estimator.cpp:176-241, 276-283): every worker
+// registers a prior and starts as its own group; the factor index of that prior is remembered for every worker but 0.
+// The first loop closure between two groups merges them into the group that holds worker 0 (the second worker's group if
+// neither does) and hands back the ONE prior index of the absorbed group, which the caller removes from its graph while
+// it adds the first-association factor instead of the loop-closure factor.  Graph-agnostic (indices are whatever the
+// graph returned), so the GTSAM-typed overlay (integration/gtsam/) runs the same, tested, bookkeeping over gtsam::ISAM2.
+class WorkerLinks {
+ public:
+  void registerPrior(unsigned int worker_id, size_t factor_index) {
+    if (worker_id > 0u) factor_indices_to_remove_.emplace(worker_id, factor_index);   // (insert semantics: the first index stays)
+    linked_workers_.push_back({worker_id});
+  }
+  // indices to remove for a loop closure between the two workers: none (same worker / already linked) or exactly one
+  std::vector<size_t> link(const std::vector<unsigned int>& affected_worker_ids) {
+    if (affected_worker_ids.size() != 2u) throw std::logic_error("two affected workers expected");
+    std::vector<size_t> to_remove;
+    const unsigned int first = affected_worker_ids[0], second = affected_worker_ids[1];
+    if (first == second) return to_remove;
+    int group_first = -1, group_second = -1;
+    for (size_t g = 0; g < linked_workers_.size(); ++g) {
+      const auto& grp = linked_workers_[g];
+      if (std::find(grp.begin(), grp.end(), first) != grp.end()) group_first = (int)g;
+      if (std::find(grp.begin(), grp.end(), second) != grp.end()) group_second = (int)g;
+    }
+    if (group_first < 0 || group_second < 0) throw std::logic_error("worker without a registered prior");
+    if (group_first == group_second) return to_remove;
+    const auto& gf = linked_workers_[(size_t)group_first];
+    const bool keep_first = std::find(gf.begin(), gf.end(), 0u) != gf.end();
+    const int keep = keep_first ? group_first : group_second, drop = keep_first ? group_second : group_first;
+    for (unsigned int worker : linked_workers_[(size_t)drop]) {
+      auto it = factor_indices_to_remove_.find(worker);
+      if (it != factor_indices_to_remove_.end()) {
+        to_remove.push_back(it->second);
+        factor_indices_to_remove_.erase(it);
+      }
+      linked_workers_[(size_t)keep].push_back(worker);
+    }
+    if (to_remove.size() != 1u) throw std::logic_error("exactly one prior must be removed");
+    linked_workers_.erase(linked_workers_.begin() + drop);
+    return to_remove;
+  }
+  const std::vector<std::vector<unsigned int>>& groups() const { return linked_workers_; }
+
+ private:
+  std::unordered_map<unsigned int, size_t> factor_indices_to_remove_;
+  std::vector<std::vector<unsigned int>> linked_workers_;
+};
+
 class IncrementalEstimator {
  public:
   explicit IncrementalEstimator(const EstimatorParams& parameters, unsigned int n_laser_slam_workers = 1u)
@@ -117,33 +165,7 @@ class IncrementalEstimator {
                            const Values& new_values, const std::vector<unsigned int>& affected_worker_ids,
                            Time /*timestamp_ns*/ = 0) {
     std::lock_guard<std::recursive_mutex> lock(full_class_mutex_);
-    if (affected_worker_ids.size() != 2u) throw std::logic_error("two affected workers expected");
-    std::vector<size_t> factor_indices_to_remove;
-    const unsigned int first = affected_worker_ids[0], second = affected_worker_ids[1];
-    if (first != second) {
-      int group_first = -1, group_second = -1;
-      for (size_t g = 0; g < linked_workers_.size(); ++g) {
-        const auto& grp = linked_workers_[g];
-        if (std::find(grp.begin(), grp.end(), first) != grp.end()) group_first = (int)g;
-        if (std::find(grp.begin(), grp.end(), second) != grp.end()) group_second = (int)g;
-      }
-      if (group_first < 0 || group_second < 0) throw std::logic_error("worker without a registered prior");
-      if (group_first != group_second) {  // not linked yet: keep the group that holds worker 0
-        const auto& gf = linked_workers_[group_first];
-        const bool keep_first = std::find(gf.begin(), gf.end(), 0u) != gf.end();
-        const int keep = keep_first ? group_first : group_second, drop = keep_first ? group_second : group_first;
-        for (unsigned int worker : linked_workers_[drop]) {
-          auto it = factor_indices_to_remove_.find(worker);
-          if (it != factor_indices_to_remove_.end()) {
-            factor_indices_to_remove.push_back(it->second);
-            factor_indices_to_remove_.erase(it);
-          }
-          linked_workers_[keep].push_back(worker);
-        }
-        if (factor_indices_to_remove.size() != 1u) throw std::logic_error("exactly one prior must be removed");
-        linked_workers_.erase(linked_workers_.begin() + drop);
-      }
-    }
+    const std::vector<size_t> factor_indices_to_remove = links_.link(affected_worker_ids);
     graph_.insert(new_values);
     for (size_t idx : factor_indices_to_remove) graph_.removeFactor(idx);
     for (const Factor& f : (factor_indices_to_remove.empty() ? new_factors : new_associations_factors))
@@ -158,15 +180,14 @@ class IncrementalEstimator {
     if (new_factors.size() != 1u) throw std::logic_error("registerPrior expects exactly one factor");
     graph_.insert(new_values);
     const size_t index = graph_.addFactor(new_factors[0]);
-    if (worker_id > 0u) factor_indices_to_remove_[worker_id] = index;
-    linked_workers_.push_back({worker_id});
+    links_.registerPrior(worker_id, index);
     graph_.optimize(3);
     return graph_.values();
   }
 
   ICP& loopClosureIcp() { return icp_; }  // configuration access (seed, test seam)
   const PoseGraph& graph() const { return graph_; }
-  const std::vector<std::vector<unsigned int>>& linkedWorkers() const { return linked_workers_; }
+  const std::vector<std::vector<unsigned int>>& linkedWorkers() const { return links_.groups(); }
   const RelativePose& lastLoopClosure() const { return last_loop_closure_; }
   const lsgpu_icp_stats& lastLoopClosureIcpStats() const { return last_loop_closure_icp_stats_; }
 
@@ -178,8 +199,7 @@ class IncrementalEstimator {
   PoseGraph graph_;
   ICP icp_;
   std::array<double, 6> first_association_sigmas_{};
-  std::unordered_map<unsigned int, size_t> factor_indices_to_remove_;
-  std::vector<std::vector<unsigned int>> linked_workers_;
+  WorkerLinks links_;
   RelativePose last_loop_closure_;
   lsgpu_icp_stats last_loop_closure_icp_stats_{};
 };

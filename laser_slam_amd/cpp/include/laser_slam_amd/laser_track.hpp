@@ -195,6 +195,44 @@ class LaserTrack {
     for (Time t : times) trajectory->emplace(t, trajectory_.evaluate(t));
   }
 
+  // laser_track.cpp:310-316: the pose MEASUREMENTS as they came in (odometry only, no ICP, no graph), by time stamp.
+  // laser_slam_ros publishes it beside the estimated trajectory (laser_slam_worker.cpp:519).
+  void getOdometryTrajectory(TrajectoryMap* trajectory) const {
+    std::lock_guard<std::recursive_mutex> lock(mutex_);
+    if (!trajectory) throw std::logic_error("null output");
+    trajectory->clear();
+    for (const Pose& pose : pose_measurements_) trajectory->emplace(pose.time_ns, pose.T_w);  // (emplace: first one wins)
+  }
+
+  Pose getPreviousPose() const {  // :302-312: the node before the last one, default Pose while there is none
+    std::lock_guard<std::recursive_mutex> lock(mutex_);
+    Pose p;
+    std::vector<Time> times;
+    trajectory_.getCurveTimes(&times);
+    if (times.size() > 1u) { p.time_ns = times[times.size() - 2]; p.T_w = trajectory_.evaluate(p.time_ns); }
+    return p;
+  }
+
+  void getLaserScansTimes(std::vector<Time>* out_times_ns) const {  // :328-334
+    std::lock_guard<std::recursive_mutex> lock(mutex_);
+    if (!out_times_ns) throw std::logic_error("null output");
+    out_times_ns->clear();
+    for (const LaserScan& s : laser_scans_) out_times_ns->push_back(s.time_ns);
+  }
+
+  // :557-572: the trajectory evaluated at the requested time (despite the name), which must not be later than the
+  // latest pose measurement; the key is not filled in
+  Pose findNearestPose(const Time& timestamp_ns) const {
+    std::lock_guard<std::recursive_mutex> lock(mutex_);
+    if (pose_measurements_.empty()) throw std::logic_error("Cannot find nearest pose as no pose was registered.");
+    if (timestamp_ns > pose_measurements_.back().time_ns)
+      throw std::logic_error("The requested time is later than the latest pose time.");
+    Pose p;
+    p.time_ns = timestamp_ns;
+    p.T_w = trajectory_.evaluate(timestamp_ns);
+    return p;
+  }
+
   Pose getCurrentPose() const {  // :292-300
     std::lock_guard<std::recursive_mutex> lock(mutex_);
     Pose p;

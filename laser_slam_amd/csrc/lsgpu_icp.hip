@@ -1144,13 +1144,21 @@ int lsgpu_icp_compute(lsgpu_icp* h, const float* reading_xyz1, int64_t nq, const
   // step 4: reading filter (yaml:1-3)
   rc = stage_points(h, reading_xyz1, nq, h->flt_in, &src);
   if (rc) return rc;
-  HIPC(h->flt_rd.reserve(nq));
-  rc = random_sampling_device(h, src, nq, chain->reading_prob, -1, h->flt_rd.p, &nqf);
-  if (rc) return rc;
+  const float4* rd_dev = src;
+  if (chain->reading_prob < 0.f) {
+    // no readingDataPointsFilters section: upstream runs no module at all -- every point, NO rand() call (a
+    // RandomSampling module with prob 1 would consume nq draws and drop the points whose draw rounds to 1.0f)
+    nqf = nq;
+  } else {
+    HIPC(h->flt_rd.reserve(nq));
+    rc = random_sampling_device(h, src, nq, chain->reading_prob, -1, h->flt_rd.p, &nqf);
+    if (rc) return rc;
+    rd_dev = h->flt_rd.p;
+  }
   const double t_filters = wall_ms() - t0;
   if (nqf <= 0) { h->err = "compute: the reading filter left no point"; return LSGPU_NO_CONVERGENCE; }
   // steps 5-7
-  rc = lsgpu_icp_align(h, reinterpret_cast<const float*>(h->flt_rd.p), nqf, T_init, T_out, stats);
+  rc = lsgpu_icp_align(h, reinterpret_cast<const float*>(rd_dev), nqf, T_init, T_out, stats);
   if (stats) stats->t_reserved[0] = t_filters;
   return rc;
 }
@@ -1265,7 +1273,13 @@ int lsgpu_apply_point_filters(lsgpu_icp* h, lsgpu_point_filter* filters, int n_f
     if (!ok) { h->err = "apply_point_filters: unknown filter type or parameter out of range"; return LSGPU_BAD_CONFIG; }
   }
   if (seed >= 0) DrawStream::global().take(seed, 0, nullptr);
-  if (n == 0) return LSGPU_OK;  // DataPointsFilters::apply returns at once on an empty cloud
+  // DataPointsFilters::apply: an empty CHAIN is a no-op; otherwise the first filter that is handed an empty cloud throws
+  // ConvergenceError("no points to filter") -- also when the cloud came in empty
+  if (n == 0) {
+    if (n_filters == 0) return LSGPU_OK;
+    h->err = "apply_point_filters: no points to filter";
+    return LSGPU_NO_CONVERGENCE;
+  }
   HIPC(hipSetDevice(h->device));
   const float4* cur = nullptr;
   int rc = stage_points(h, xyz1, n, h->flt_in, &cur);

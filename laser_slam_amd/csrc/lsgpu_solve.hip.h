@@ -502,7 +502,15 @@ __global__ __launch_bounds__(256) void k_normal_eq_loop(const float4* __restrict
   // one ticket and one load round trip after the last block's own loop.  (A two-level variant -- groups of 16 blocks,
   // then the groups -- paid two more dependent agent-scope round trips; measured 24 us from the last loop end to the
   // kernel's end, of which 8 us in the update lane, before this and the LDS staging below.)
+  // The fence-free form leans on gfx9 behaviour (stores are counted in vmcnt, sc1 accesses are served by the memory
+  // side of the L2): it is compiled for gfx942 / gfx950 only, any other target gets the release / acquire pair of the
+  // HIP memory model (tests/test_gpu_parity.py::test_ne_handoff_matches_fenced_build compares the two builds).
+#if (defined(__gfx950__) || defined(__gfx942__)) && !defined(LSGPU_NE_FENCED)
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#else
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
   __syncthreads();
   if (threadIdx.x == 0) {
     const uint32_t t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -515,6 +523,9 @@ __global__ __launch_bounds__(256) void k_normal_eq_loop(const float4* __restrict
   }
   __syncthreads();
   if (!is_last) return;
+#if !((defined(__gfx950__) || defined(__gfx942__)) && !defined(LSGPU_NE_FENCED))
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+#endif
   // the loop state and the select's failure flag travel with the same round trip as the partials: the update lane
   // then works on an LDS copy (a dozen dependent global round trips of one lane otherwise)
   __shared__ IcpState st_sh;

@@ -473,9 +473,16 @@ __global__ __launch_bounds__(256) void k_point_filter_select(const float4* __res
   const float4 p = src[i];
   bool k = true;
   if (f.type == 1 || f.type == 2) {  // Max / MinDist
-    const float val = f.dim < 0 ? sqrtf(__fmaf_rn(p.z, p.z, __fmaf_rn(p.y, p.y, p.x * p.x)))
-                                : fabsf(f.dim == 0 ? p.x : f.dim == 1 ? p.y : p.z);
-    k = f.type == 1 ? val < f.v[0] : val > f.v[0];
+    // upstream asymmetry (libpointmatcher MaxDist.cpp / MinDist.cpp, from knowledge): the radial branch of both compares
+    // the norm with |limit|; on ONE axis MaxDist compares the SIGNED coordinate (x < maxDist keeps every negative x),
+    // MinDist the absolute one
+    const float c = f.dim == 0 ? p.x : f.dim == 1 ? p.y : p.z;
+    if (f.dim < 0) {
+      const float val = sqrtf(__fmaf_rn(p.z, p.z, __fmaf_rn(p.y, p.y, p.x * p.x)));
+      k = f.type == 1 ? val < fabsf(f.v[0]) : val > fabsf(f.v[0]);
+    } else {
+      k = f.type == 1 ? c < f.v[0] : fabsf(c) > f.v[0];
+    }
   } else if (f.type == 3) {          // BoundingBox
     const bool in = p.x > f.v[0] && p.x < f.v[1] && p.y > f.v[2] && p.y < f.v[3] && p.z > f.v[4] && p.z < f.v[5];
     k = f.flag ? !in : in;

@@ -506,9 +506,9 @@ class ICP:
         if not isinstance(doc, dict):
             raise LsgpuError(_lib.BAD_CONFIG, "load_from_yaml", "not a YAML mapping")
         # libpointmatcher's loadFromYaml starts from EMPTY chains: a section the file does not mention means "no such
-        # module".  No reading filter = every point (prob 1), no outlier filter = every pair (ratio 1), no differential
+        # module".  No reading filter = every point and no draw (reading_prob < 0), no outlier filter = every pair (ratio 1), no differential
         # checker = only the counter stops the loop; the modules the device loop cannot run without are required.
-        ch = ChainConfig(reading_sampling_prob=1.0, surface_normal_knn=7, trim_ratio=1.0,
+        ch = ChainConfig(reading_sampling_prob=-1.0, surface_normal_knn=7, trim_ratio=1.0,
                          min_diff_rot=-1.0, min_diff_trans=-1.0, smooth_length=1)
         seen = set()
 

@@ -861,7 +861,13 @@ int lso_icp_compute_full(const lso_config* cfg, const float* reading_xyz1, int64
                                                   cfg->surface_normal_ratio, -1, rf, rn);
   /* step 4: reading filters (K1) */
   int64_t* keep = (int64_t*)malloc(sizeof(int64_t) * (size_t)nq);
-  const int64_t nqf = lso_random_sampling(nq, cfg->reading_sampling_prob, -1, keep);
+  int64_t nqf;
+  if (cfg->reading_sampling_prob < 0.f) { /* no readingDataPointsFilters module: every point, no rand() call */
+    nqf = nq;
+    for (int64_t i = 0; i < nq; ++i) keep[i] = i;
+  } else {
+    nqf = lso_random_sampling(nq, cfg->reading_sampling_prob, -1, keep);
+  }
   float* qf = (float*)malloc(sizeof(float) * 4 * (size_t)(nqf > 0 ? nqf : 1));
   for (int64_t i = 0; i < nqf; ++i) memcpy(qf + 4 * i, reading_xyz1 + 4 * keep[i], 16);
   const double tf = now_ms() - t0;
@@ -949,7 +955,7 @@ int64_t lso_voxel_grid(const float* xyz1, int64_t n, const float leaf[3], int mi
 int64_t lso_apply_point_filters(lso_point_filter* filters, int n_filters, const float* xyz1, int64_t n,
                                 int64_t seed, float* out_xyz1) {
   if (seed >= 0) srand((unsigned)seed);
-  if (n <= 0) return 0;
+  if (n <= 0) return n_filters > 0 ? -1 : 0;  /* empty cloud into a non-empty chain: ConvergenceError upstream */
   float* cur = (float*)malloc(sizeof(float) * 4 * (size_t)n);
   memcpy(cur, xyz1, sizeof(float) * 4 * (size_t)n);
   int64_t m = n;
@@ -973,8 +979,15 @@ int64_t lso_apply_point_filters(lso_point_filter* filters, int n_filters, const 
       const float x = cur[4 * i], y = cur[4 * i + 1], z = cur[4 * i + 2];
       int keep = 1;
       if (f->type == 1 || f->type == 2) {
-        const float val = f->dim < 0 ? sqrtf(fmaf(z, z, fmaf(y, y, x * x))) : fabsf(f->dim == 0 ? x : f->dim == 1 ? y : z);
-        keep = f->type == 1 ? (val < f->v[0]) : (val > f->v[0]);
+        /* MaxDist / MinDist (upstream, from knowledge): radial branch = norm against |limit| for both; single-axis
+         * branch = SIGNED coordinate < maxDist for MaxDist, |coordinate| > minDist for MinDist */
+        const float c = f->dim == 0 ? x : f->dim == 1 ? y : z;
+        if (f->dim < 0) {
+          const float val = sqrtf(fmaf(z, z, fmaf(y, y, x * x)));
+          keep = f->type == 1 ? (val < fabsf(f->v[0])) : (val > fabsf(f->v[0]));
+        } else {
+          keep = f->type == 1 ? (c < f->v[0]) : (fabsf(c) > f->v[0]);
+        }
       } else if (f->type == 3) {
         const int in = x > f->v[0] && x < f->v[1] && y > f->v[2] && y < f->v[3] && z > f->v[4] && z < f->v[5];
         keep = f->flag ? !in : in;

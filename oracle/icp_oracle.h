@@ -37,7 +37,7 @@ extern "C" {
 
 /* icp_default.yaml:1-29 (values) / ICP::setDefault (laser_track.cpp:18-21). */
 typedef struct lso_config {
-  float reading_sampling_prob;  /* RandomSamplingDataPointsFilter prob   (yaml 0.5, default 0.75) */
+  float reading_sampling_prob;  /* RandomSamplingDataPointsFilter prob   (yaml 0.5, default 0.75); < 0: no reading filter module */
   int   surface_normal_knn;     /* SamplingSurfaceNormal knn             (yaml 10,  default 7)    */
   float surface_normal_ratio;   /* SamplingSurfaceNormal ratio           (default 0.5)            */
   float trim_ratio;             /* TrimmedDistOutlierFilter ratio        (yaml 0.75, default .85) */

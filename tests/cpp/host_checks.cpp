@@ -119,6 +119,41 @@ int main(int argc, char** argv) {
     TrajectoryMap tm;
     track.getTrajectory(&tm);
     CHECK(tm.size() == 3);
+    // getOdometryTrajectory (laser_track.cpp:310-316; caller laser_slam_worker.cpp:519): the pose MEASUREMENTS by time
+    // stamp -- untouched by a graph update of the trajectory, and a pose registered without a scan is part of it
+    Values moved; moved[track.getValueKey(100)] = SE3({1, 0, 0, 0}, {5.0, 0, 0});
+    track.updateFromValues(moved);
+    Pose extra; extra.time_ns = 250; extra.T_w = SE3({1, 0, 0, 0}, {2.0, 0, 0});
+    track.processPose(extra);
+    TrajectoryMap odo;
+    track.getOdometryTrajectory(&odo);
+    CHECK(odo.size() == 4 && std::fabs(odo.at(100).position()[0] - 0.8) < 1e-12 && std::fabs(odo.at(250).position()[0] - 2.0) < 1e-12);
+    track.getTrajectory(&tm);
+    CHECK(tm.size() == 3 && std::fabs(tm.at(100).position()[0] - 5.0) < 1e-12);
+    // getPreviousPose (:302-312), getLaserScansTimes (:328-334), findNearestPose (:557-572)
+    CHECK(track.getPreviousPose().time_ns == 100 && std::fabs(track.getPreviousPose().T_w.position()[0] - 5.0) < 1e-12);
+    std::vector<Time> times;
+    track.getLaserScansTimes(&times);
+    CHECK(times.size() == 3 && times[0] == 0 && times[2] == 200);
+    CHECK(track.findNearestPose(200).time_ns == 200 && std::fabs(track.findNearestPose(200).T_w.position()[0] - 1.6) < 1e-12);
+    bool late = false;
+    try { track.findNearestPose(251); } catch (const std::logic_error&) { late = true; }   // later than the latest pose
+    CHECK(late);
+  }
+  // --- WorkerLinks: which prior goes when two robots' graphs first link (incremental_estimator.cpp:176-241, 276-283)
+  {
+    WorkerLinks links;
+    links.registerPrior(0u, 10); links.registerPrior(1u, 11); links.registerPrior(2u, 12);
+    CHECK(links.groups().size() == 3);
+    CHECK(links.link({1u, 1u}).empty());                           // same worker: nothing to remove
+    std::vector<size_t> r = links.link({2u, 1u});                  // neither group holds worker 0: the SECOND worker's group stays
+    CHECK(r.size() == 1 && r[0] == 12 && links.groups().size() == 2);
+    CHECK(links.link({1u, 2u}).empty());                           // already linked
+    r = links.link({1u, 0u});                                      // worker 0's group is kept, {1, 2} loses its remaining prior
+    CHECK(r.size() == 1 && r[0] == 11 && links.groups().size() == 1 && links.groups()[0].size() == 3);
+    bool threw2 = false;
+    try { links.link({0u, 7u}); } catch (const std::logic_error&) { threw2 = true; }   // a worker that never registered
+    CHECK(threw2);
   }
   // --- SE3 chart: retract / localCoordinates are inverse of each other
   {
@@ -344,7 +379,7 @@ int main(int argc, char** argv) {
                          "matcher:\n  KDTreeMatcher: {knn: 1}\nerrorMinimizer: PointToPlaneErrorMinimizer\n"
                          "transformationCheckers:\n  - CounterTransformationChecker: {maxIterationCount: 12}\n");
     icp.loadFromYaml(y);
-    CHECK(icp.readingSamplingProb() == 1.0f);        // no reading filter: every point
+    CHECK(icp.readingSamplingProb() < 0.f);        // no reading filter: every point
     CHECK(icp.config().trim_ratio == 1.0f);          // no outlier filter: every pair
     CHECK(icp.surfaceNormalKnn() == 9 && icp.config().max_iterations == 12);
     CHECK(icp.config().min_diff_rot < 0.f);          // no differential checker: only the counter stops the loop

@@ -123,7 +123,7 @@ def test_yaml_loader_accepts_the_reference_chain_and_rejects_others():
     assert o.chain.trim_ratio == 0.85 and o.chain.surface_normal_knn == 7
     # an absent section is "no module" (libpointmatcher clears the chains first), not the default module
     o.load_from_yaml(io.StringIO(base))
-    assert o.chain.reading_sampling_prob == 1.0 and o.chain.trim_ratio == 1.0 and o.chain.min_diff_rot < 0
+    assert o.chain.reading_sampling_prob < 0 and o.chain.trim_ratio == 1.0 and o.chain.min_diff_rot < 0
     with pytest.raises(_lib.LsgpuError):
         o.load_from_yaml(io.StringIO("matcher:\n  KDTreeMatcher: {}\n"))      # no normals, no minimizer, no stop
     for bad in ("outlierFilters:\n  - MaxDistOutlierFilter: {maxDist: 1}\n",

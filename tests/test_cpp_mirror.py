@@ -30,6 +30,31 @@ def test_cpp_host_checks(tmp_path):
     assert r.returncode == 0 and "host_checks: ok" in r.stdout, r.stdout + r.stderr
 
 
+def test_gtsam_overlay_parses_and_resolves_the_ros_worker_calls():
+    """PARSE check of integration/gtsam/laser_slam_gtsam_overlay.hpp (the `namespace laser_slam` types laser_slam_ros
+    compiles against): g++ -fsyntax-only against the declaration-only stand-ins of tests/cpp/mock/ (GTSAM, minkindr,
+    libpointmatcher, Eigen are not installed here), together with tests/cpp/overlay_worker_calls.cpp, which makes every
+    call of laser_slam_ros/src/laser_slam_worker.cpp:47-600 plus the rest of the public surface of laser_track.hpp:20-144 /
+    incremental_estimator.hpp:20-53 under the include names laser_slam_ros uses.  It pins NO behaviour: what the overlay
+    delegates to (LaserTrack, WorkerLinks, ICP of the mirror) is tested by test_cpp_host_checks and the GPU tests."""
+    cmd = ["g++", "-std=c++17", "-fsyntax-only", "-Wall", "-I", os.path.join(ROOT, "tests", "cpp", "mock"),
+           "-I", os.path.join(ROOT, "integration", "gtsam"), "-I", os.path.join(ROOT, "include"),
+           "-I", os.path.join(ROOT, "laser_slam_amd", "cpp", "include"),
+           os.path.join(ROOT, "tests", "cpp", "overlay_worker_calls.cpp")]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr[-3000:]
+    # the reference's public members, by name, must all be declared by the overlay
+    src = open(os.path.join(ROOT, "integration", "gtsam", "laser_slam_gtsam_overlay.hpp")).read()
+    for name in ("processPose", "processLaserScan", "processPoseAndLaserScan", "getLastPointCloud", "getPointCloudOfTimeInterval",
+                 "getLocalCloudInWorldFrame", "getLaserScans", "getTrajectory", "getOdometryTrajectory", "getCovariances",
+                 "getCurrentPose", "getPreviousPose", "getMinTime", "getMaxTime", "getLaserScansTimes", "appendPriorFactors",
+                 "appendOdometryFactors", "appendICPFactors", "appendLoopClosureFactors", "initializeGTSAMValues",
+                 "updateFromGTSAMValues", "updateCovariancesFromGTSAMValues", "getNumScans", "printTrajectory", "findNearestPose",
+                 "buildSubMapAroundTime", "getValueExpression", "evaluate", "getScanMatchingTimes", "saveTrajectory",
+                 "processLoopClosure", "getLaserTrack", "getAllLaserTracks", "estimate", "estimateAndRemove", "registerPrior"):
+        assert name + "(" in src, name
+
+
 @pytest.mark.gpu
 def test_cpp_laser_track_registers_scans(tmp_path):
     """Four scans along a straight drive: LaserTrack must emit prior / odometry / ICP factors with the

@@ -849,6 +849,14 @@ def test_input_filter_chain_matches_oracle(icp_mod, oracle):
             h.apply_point_filters(_chain(_lib, empty_after), scans[0])
         assert oracle.apply_point_filters(_chain(oracle, empty_after), scans[0]) is None
         assert h.apply_point_filters(_chain(_lib, empty_after[:1]), scans[0]).shape[0] == 0     # ... the last one may empty it
+        with pytest.raises(_lib.ConvergenceError):                                              # an empty cloud into a non-empty chain
+            h.apply_point_filters(_chain(_lib, empty_after[:1]), scans[0][:0])
+        assert h.apply_point_filters(_chain(_lib, []), scans[0][:0]).shape[0] == 0              # empty chain: no-op
+        # MaxDist on one axis is SIGNED (keeps every negative coordinate), MinDist absolute; radial limits by magnitude
+        for sp in ((_lib.FILTER_MAX_DIST, 0, 0, [3.0]), (_lib.FILTER_MIN_DIST, 1, 0, [3.0]), (_lib.FILTER_MAX_DIST, -1, 0, [-20.0])):
+            got = h.apply_point_filters(_chain(_lib, [sp]), scans[0])
+            assert np.array_equal(got, oracle.apply_point_filters(_chain(oracle, [sp]), scans[0]))
+        assert (h.apply_point_filters(_chain(_lib, [(_lib.FILTER_MAX_DIST, 0, 0, [3.0])]), scans[0])[:, 0] < -3.0).any()
         with pytest.raises(_lib.LsgpuError):
             h.apply_point_filters(_chain(_lib, [(77, 0, 0, [1.0])]), scans[0])
 

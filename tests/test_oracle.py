@@ -213,3 +213,26 @@ def test_filter_golden_vectors_reproduce(oracle):
     assert np.array_equal(oracle.cylinder_filter(scan, [0.5, -0.5, 0.0], 10.0, 40.0, False), g["cyl_in"])
     assert np.array_equal(oracle.cylinder_filter(scan, [0.5, -0.5, 0.0], 10.0, 40.0, True), g["cyl_out"])
     assert len(g["cyl_in"]) + len(g["cyl_out"]) == len(scan) and 0 < len(g["voxel_1p0_min3"]) < len(g["voxel_0p5"])
+
+
+def test_input_filters_upstream_asymmetries(oracle):
+    """Choices of the input-filter restatement that a shared misreading would hide: MaxDist on ONE axis
+    compares the SIGNED coordinate (x < maxDist keeps every negative x), MinDist the absolute one; the radial branches
+    compare the norm with |limit|; an empty cloud handed to a non-empty chain is "no points to filter" (None here,
+    ConvergenceError upstream), an empty chain is a no-op."""
+    pts = np.array([[-5, 0, 0, 1], [-1, 0, 0, 1], [0.5, 0, 0, 1], [2, 0, 0, 1], [0, 3, 0, 1]], np.float32)
+
+    def chain(typ, dim, v):
+        arr = (oracle.PointFilter * 1)()
+        arr[0].type, arr[0].dim, arr[0].flag, arr[0].state = typ, dim, 0, 0.0
+        arr[0].v[0] = v
+        return arr
+
+    keep = lambda a: [float(x) for x in a[:, 0] + 10 * a[:, 1]]
+    assert keep(oracle.apply_point_filters(chain(1, 0, 1.0), pts)) == [-5.0, -1.0, 0.5, 30.0]    # MaxDist x < 1: signed
+    assert keep(oracle.apply_point_filters(chain(2, 0, 1.0), pts)) == [-5.0, 2.0]                 # MinDist |x| > 1
+    assert keep(oracle.apply_point_filters(chain(1, -1, -2.5), pts)) == [-1.0, 0.5, 2.0]          # radial: |p| < |-2.5|
+    assert keep(oracle.apply_point_filters(chain(2, -1, -2.5), pts)) == [-5.0, 30.0]              # radial: |p| > |-2.5|
+    assert oracle.apply_point_filters(chain(1, 0, 1.0), pts[:0]) is None                          # empty cloud, non-empty chain
+    empty_chain = (oracle.PointFilter * 0)()
+    assert oracle.apply_point_filters(empty_chain, pts).shape[0] == 5 and oracle.apply_point_filters(empty_chain, pts[:0]).shape[0] == 0
