@@ -306,7 +306,9 @@ class ICP {
   // T with p_reference = T * p_reading.  Throws ConvergenceError exactly where PointMatcher would.
   TransformationParameters compute(const DataPoints& reading, const DataPoints& reference,
                                    const TransformationParameters& T_init) {
+#ifdef LSGPU_TEST_SEAMS
     if (override_) return override_(*this, reading, reference, T_init);
+#endif
     ensureHandle();
     const int64_t nr = reference.getNbPoints(), nq = reading.getNbPoints();
     if (nr <= 0 || nq <= 0) throw ConvergenceError("empty cloud");
@@ -318,7 +320,9 @@ class ICP {
     TransformationParameters T = T_init;
     check(lsgpu_icp_compute(h_, reading.features.data(), nq, reference.features.data(), nr, T_init.data(),
                             &chain, T.data(), &stats_), "lsgpu_icp_compute");
+#ifdef LSGPU_TEST_SEAMS
     if (observer_) observer_(*this, reading, reference, T_init, T);
+#endif
     return T;
   }
 
@@ -358,6 +362,8 @@ class ICP {
   void setSeed(int64_t seed) { seed_ = seed; }
   int64_t seed() const { return seed_; }
 
+#ifdef LSGPU_TEST_SEAMS
+  // (compiled only into the parity-test drivers, tests/cpp/*: -DLSGPU_TEST_SEAMS; the shipped header has no hook)
   // Test seam: replaces compute() by another implementation of the same call (the parity tests inject the CPU
   // oracle here, so that LaserTrack / IncrementalEstimator run unchanged on either ICP).  Never set by the
   // product; with an override in place nothing touches the GPU (no handle is created).
@@ -365,12 +371,15 @@ class ICP {
                                                                  const DataPoints& reference,
                                                                  const TransformationParameters& T_init)>;
   void setComputeOverride(ComputeOverride f) { override_ = std::move(f); }
-  bool hasComputeOverride() const { return (bool)override_; }
   // Test seam: called after every successful device compute() with its inputs and its result (the parity tests run
   // the CPU oracle on exactly the clouds the facade handed to the device).  Never set by the product.
   using ComputeObserver = std::function<void(const ICP&, const DataPoints& reading, const DataPoints& reference,
                                              const TransformationParameters& T_init, const TransformationParameters& T)>;
   void setComputeObserver(ComputeObserver f) { observer_ = std::move(f); }
+  bool hasComputeOverride() const { return (bool)override_; }
+#else
+  bool hasComputeOverride() const { return false; }
+#endif
 
   // Steps 2-7 on already filtered clouds (device or host pointers).
   TransformationParameters computeFiltered(const float* reading_xyz1, int64_t nq, const float* ref_xyz1,
@@ -456,8 +465,10 @@ class ICP {
   int knn_ = 7;
   int64_t seed_ = -1;
   unsigned generation_ = 0;
+#ifdef LSGPU_TEST_SEAMS
   ComputeOverride override_;
   ComputeObserver observer_;
+#endif
 };
 
 inline void DataPointsFilters::apply(DataPoints& cloud) {

@@ -23,8 +23,11 @@
 
 #include "../../include/lsgpu_icp.h"
 #include "lsgpu_grid.hip.h"
+#include "lsgpu_tuning.h"
 #include "lsgpu_knn.hip.h"
-#include "lsgpu_knn_rows.hip.h"
+#ifdef LSGPU_EXPERIMENTS
+#include "lsgpu_knn_rows.hip.h"   // measured-slower variants, kept as the record of what was tried
+#endif
 #include "lsgpu_solve.hip.h"
 #include "lsgpu_host_math.h"
 #include "lsgpu_ssn.hip.h"
@@ -178,7 +181,9 @@ struct lsgpu_icp {
   DevBuf<uint32_t> spread_flag, spread_list, spread_cnt;  // front rows of the tile kernel (tiles whose queries share no candidates)
   DevBuf<uint32_t> sel_aux;   // predicted select: kSelBelowSlots counters + failure flag
   DevBuf<uint32_t> sel_win;   // committed select: kSelWinRows x 512 window histogram
+#ifdef LSGPU_EXPERIMENTS
   DevBuf<uint32_t> work;      // compacted list of searching queries (k_knn_classify -> k_knn_rows)
+#endif
 
   // device filters (lsgpu_ssn.hip.h)
   DevBuf<SsnSeg> ssn_seg_a, ssn_seg_b;
@@ -218,7 +223,7 @@ struct lsgpu_icp {
 // communicator is aborted and the caller gets LSGPU_HIP_ERROR instead of a hang.
 static int wait_stream(lsgpu_icp* h) {
   if (!h->comm) { HIPC(hipStreamSynchronize(h->stream)); return LSGPU_OK; }
-  static const double limit_ms = getenv("LSGPU_COMM_TIMEOUT_MS") ? atof(getenv("LSGPU_COMM_TIMEOUT_MS")) : 30000.0;
+  const double limit_ms = tuning().comm_timeout_ms;
   const double t0 = wall_ms();
   for (int spin = 0;; ++spin) {
     const hipError_t e = hipStreamQuery(h->stream);
@@ -237,12 +242,10 @@ static int wait_stream(lsgpu_icp* h) {
 }
 
 static constexpr int kNeBlocksMax = 2048;
-static const int kNeBlocks = [] { const char* e = getenv("LSGPU_NE_BLOCKS"); const int v = e ? atoi(e) : 256;
-                                  return v < 64 ? 64 : v > kNeBlocksMax ? kNeBlocksMax : v; }();
+static const int kNeBlocks = tuning().ne_blocks;   // 64 .. kNeBlocksMax (lsgpu_tuning.h)
 static constexpr int kStatBlocks = 512;
 static constexpr int kHistBlocks = 256;
 static constexpr int kFallbackBlocksSettled = 1024;
-static constexpr int kRowqBlocks = 2048;  // x 16 rows side by side, round robin beyond (512 -> 2048: 24.7 -> 20.8 us per pass)
 static constexpr int kFallbackBlocks = 8192;  // x 4 waves: one query per wave for up to 32 k stragglers, round robin beyond
 
 extern "C" {
@@ -328,9 +331,12 @@ void lsgpu_icp_destroy(lsgpu_icp* h) {
   for (auto& c : h->clouds) c.release();
   h->submap.release();
   h->ref_in.release(); h->nrm_in.release(); h->keys.release(); h->keys_alt.release();
+#ifdef LSGPU_EXPERIMENTS
+  h->work.release();
+#endif
   h->vals.release(); h->vals_alt.release(); h->sort_tmp.release(); h->sort_hist.release(); h->pts.release();
   h->nrm.release(); h->ref_inv.release(); h->tables.release(); h->flags.release(); h->cidx.release(); h->bounds.release(); h->chunks.release(); h->soa.release(); h->soa_base.release(); h->soa_cnt4.release(); h->soa_first.release(); h->prev.release(); h->state.release(); h->lb.release(); h->cell_cache.release(); h->cell_tags.release(); h->ssn_seg_a.release(); h->ssn_seg_b.release(); h->ssn_seg_of.release(); h->ssn_box_pts.release(); h->ssn_box_base.release(); h->ssn_keep.release(); h->ssn_out_pos.release(); h->ssn_bb.release(); h->ssn_box_normal.release(); h->ssn_draws.release(); h->flt_in.release(); h->flt_ref.release(); h->flt_rd.release(); h->flt_nrm.release(); h->chk_hist.release(); h->trace_dev.release(); h->knn_dbg.release(); h->knn_dbg_wave.release(); h->stat_partials.release(); h->geom.release();
-  h->counters.release(); h->ang_cells.release(); h->sel_aux.release(); h->sel_win.release(); h->spread_flag.release(); h->spread_list.release(); h->spread_cnt.release(); h->work.release(); h->q_in.release(); h->rdq.release(); h->ids.release(); h->d2.release();
+  h->counters.release(); h->ang_cells.release(); h->sel_aux.release(); h->sel_win.release(); h->spread_flag.release(); h->spread_list.release(); h->spread_cnt.release(); h->q_in.release(); h->rdq.release(); h->ids.release(); h->d2.release();
   h->ids_io.release(); h->d2_io.release(); h->strag.release(); h->hist.release();
   h->sel.release(); h->ne_partials.release(); h->ne_gpartials.release(); h->ne_tickets.release(); h->ne_out.release(); h->limit_dev.release();
   for (auto& e : h->knn_events) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); (void)hipEventDestroy(e.c); (void)hipEventDestroy(e.d); (void)hipEventDestroy(e.e); }
@@ -365,9 +371,9 @@ static void radix_pass(lsgpu_icp* h, const uint64_t* kin, const uint32_t* vin, u
 static int sort_pairs(lsgpu_icp* h, int64_t n, int nbits) {
   HIPC(h->keys_alt.reserve(n));
   HIPC(h->vals_alt.reserve(n));
-  static const bool lib_sort = getenv("LSGPU_ROCPRIM_SORT") != nullptr;
+  const bool lib_sort = tuning().rocprim_sort;
   if (!lib_sort && n >= 8192 && nbits > 0) {   // own radix sort (lsgpu_sort.hip.h); tiny inputs stay with the library
-    static const int items_env = getenv("LSGPU_SORT_ITEMS") ? atoi(getenv("LSGPU_SORT_ITEMS")) : 0;
+    const int items_env = tuning().sort_items;
     const int items = items_env ? items_env : n >= (1 << 21) ? 16 : n >= (1 << 19) ? 8 : 4;
     const int nblocks = (int)((n + 256 * items - 1) / (256 * items));
     HIPC(h->sort_hist.reserve((size_t)256 * nblocks + 256));
@@ -431,11 +437,12 @@ static int prepare_queries(lsgpu_icp* h, const float* q_xyz1, int64_t nq, const 
   HIPC(h->rdq.reserve(nq));
   HIPC(h->prev.reserve(nq));
   HIPC(h->lb.reserve(nq));
+#ifdef LSGPU_EXPERIMENTS
   HIPC(h->work.reserve(nq));
+#endif
   // order of the queries inside the waves: chosen on the device from the cloud's angular sampling density
-  static const int qorder = getenv("LSGPU_QUERY_ORDER") ? atoi(getenv("LSGPU_QUERY_ORDER")) : -1;   // -1: automatic
-  static const float qelev = getenv("LSGPU_Q_ELEV") ? (float)atof(getenv("LSGPU_Q_ELEV")) : 0.f;   // 0: automatic
-  static const float qsect = getenv("LSGPU_Q_SECT") ? (float)atof(getenv("LSGPU_Q_SECT")) : 0.f;
+  const int qorder = tuning().query_order;   // -1: automatic
+  const float qelev = tuning().q_elev, qsect = tuning().q_sect;   // 0: automatic
   HIPC(h->ang_cells.reserve(kDecCells + 8));
   HIPC(hipMemsetAsync(h->ang_cells.p, 0, (kDecCells + 8) * sizeof(uint32_t), h->stream));
   if (qorder != 0) hipLaunchKernelGGL(k_query_ang_hist, dim3(nblk(nq)), dim3(256), 0, h->stream, src, nq, h->ang_cells.p);
@@ -470,15 +477,17 @@ static KnnArgs knn_args(lsgpu_icp* h, const Mat34& T) {
   a.strag = h->strag.p; a.strag_count = h->counters.p + 32;
   a.r_cap = 1.0f; a.group_r = 0.75f; a.cap2 = INFINITY; a.st = nullptr; a.use_state_cap = 0; a.lb = nullptr;
   a.spread_route_r = 0.f; a.route_chunks = 1 << 30; a.sel_hist2 = nullptr; a.sel_below = nullptr;
-  a.sel_hist3w = nullptr; a.sel_force = 0; a.write_all = 1; a.sparse_lanes = 0; a.spread_flag = nullptr; a.spread_list = nullptr; a.spread_cnt = nullptr; a.front_blocks = 0;
-  { static const float gap = getenv("LSGPU_GAP") ? (float)atof(getenv("LSGPU_GAP")) : 0.002f; a.gap = gap; }
-  a.ntiles = (int)((h->nq + 63) / 64); a.xcd_swizzle = 0; a.pad_index = (int)h->nr;
-  { static const int budget = getenv("LSGPU_BUDGET") ? atoi(getenv("LSGPU_BUDGET")) : 128; a.chunk_budget = budget; }
+  a.sel_hist3w = nullptr; a.sel_force = 0; a.write_all = 1; a.spread_flag = nullptr; a.spread_list = nullptr; a.spread_cnt = nullptr; a.front_blocks = 0;
+  a.gap = tuning().gap;
+  a.ntiles = (int)((h->nq + 63) / 64); a.pad_index = (int)h->nr;
+  a.chunk_budget = tuning().chunk_budget;
   a.cell_cache = h->cell_cache.p; a.cell_tags = h->cell_tags.p; a.cache_gen = h->cache_gen;
-  a.work = h->work.p; a.work_count = h->counters.p + 34;
+#ifdef LSGPU_EXPERIMENTS
+  a.sparse_lanes = 0; a.xcd_swizzle = 0; a.work = h->work.p; a.work_count = h->counters.p + 34;
+#endif
   a.dbg = h->knn_dbg.p;
   a.dbg_wave = h->knn_dbg_wave.p;
-  { const char* e = getenv("LSGPU_KNN_DBG"); a.dbg_flags = e ? atoi(e) : 0;
+  { a.dbg_flags = tuning().knn_dbg;
     if ((a.dbg_flags & (64 | 128 | 256 | 512 | 1024 | 2048)) && h->dbg_launch_no < 6) a.dbg_flags = 0; }  // early-exit ablations from launch 6 on
   return a;
 }
@@ -502,37 +511,31 @@ static int run_knn(lsgpu_icp* h, const Mat34& T, const IcpState* st, bool seed, 
   if (capped) a.r_cap = INFINITY;  // capped balls are never larger than the cap: no straggler by radius
   // `wide`: the balls may still be large (first iterations of an align, retries, kernel-level API): spread
   // waves with wide balls go to the wave-per-query pass, which is launched after the tile kernel
-  static const float route_r = getenv("LSGPU_ROUTE_R") ? (float)atof(getenv("LSGPU_ROUTE_R")) : 0.02f;
-  // settled launches (capped, balls already small): EVERY spread wave hands its lanes to the wave-per-query pass --
-  // 64 divergent per-lane searches held single waves for 190 k cycles, the tail of a 46 k-cycle launch
-  static const bool route_all = getenv("LSGPU_NO_ROUTE_ALL") == nullptr;
-  const bool settled = capped && !wide && st && route_all;
-  a.spread_route_r = wide ? route_r : settled ? 1e-30f : 0.f;
-  static const int sparse_lanes = getenv("LSGPU_SPARSE_LANES") ? atoi(getenv("LSGPU_SPARSE_LANES")) : 0;
-  static const int rowq_blocks = getenv("LSGPU_ROWQ_BLOCKS") ? atoi(getenv("LSGPU_ROWQ_BLOCKS")) : kRowqBlocks;
-  static const bool rowq = getenv("LSGPU_NO_ROWQ") == nullptr;
-  a.sparse_lanes = settled && rowq ? sparse_lanes : 0;
+  const Tuning& tn = tuning();
+  // settled launches (capped, balls already small): EVERY spread wave hands its lanes on -- 64 divergent per-lane
+  // searches held single waves for 190 k cycles, the tail of a 46 k-cycle launch
+  const bool settled = capped && !wide && st && tn.route_all;
+  a.spread_route_r = wide ? tn.route_r : settled ? 1e-30f : 0.f;
+#ifdef LSGPU_EXPERIMENTS
+  a.sparse_lanes = settled && tn.rowq ? tn.sparse_lanes : 0;
+#endif
   // front rows: spread tiles are remembered from the first searches on and searched row-wise by the first workgroups
   // of the settled launches themselves -- no hand-over, no second launch (LSGPU_NO_FRONT: the separate row pass)
-  static const bool front_mode = getenv("LSGPU_NO_FRONT") == nullptr && !getenv("LSGPU_KNN_LANE") &&
-                                 !(getenv("LSGPU_KNN_ROWS") && atoi(getenv("LSGPU_KNN_ROWS")) != 0) &&
-                                 !(getenv("LSGPU_TILE_WAVES") && atoi(getenv("LSGPU_TILE_WAVES")) == 4) && sparse_lanes == 0;
-  const bool front = front_mode && st && h->spread_cnt.p;
+  const bool front = tn.front && st && h->spread_cnt.p;
   if (front) {
     a.spread_flag = h->spread_flag.p; a.spread_list = h->spread_list.p; a.spread_cnt = h->spread_cnt.p;
     // (the front is sized from the list's length as the host last saw it -- it travels with the state every few
     // iterations --, from a guess before that: surplus workgroups exit at once, a listed tile beyond the front, or one
     // that turns spread late, searches per lane inside the kernel)
-    static const int front_guess = getenv("LSGPU_FRONT_GUESS") ? atoi(getenv("LSGPU_FRONT_GUESS")) : 2048;
     if (settled) {
-      const int tiles = h->n_spread_known ? (int)h->n_spread_host : std::min(front_guess, a.ntiles);
+      const int tiles = h->n_spread_known ? (int)h->n_spread_host : std::min(tn.front_guess, a.ntiles);
       a.front_blocks = kFrontPerTile * tiles;
       a.spread_route_r = 0.f;
     }
   }
   if (predicted && !wide && capped && st) { a.sel_hist2 = h->hist.p + kHistBins; a.sel_below = h->sel_aux.p; }
   if (committed && a.sel_below) { a.sel_hist3w = h->sel_win.p; a.sel_force = 1; }
-  { static const int rc_ = getenv("LSGPU_ROUTE_CHUNKS") ? atoi(getenv("LSGPU_ROUTE_CHUNKS")) : 1024; a.route_chunks = rc_; }
+  a.route_chunks = tn.route_chunks;
   if (seed && !st) HIPC(hipMemsetAsync(a.strag_count, 0, sizeof(uint32_t), h->stream));  // (align: k_align_init, then re-armed by k_normal_eq_loop)
   if (seed) hipLaunchKernelGGL(k_knn_seed, dim3(nblk(nq)), dim3(256), 0, h->stream, a);
   if (seed && capped && st && seed_rank != 0xFFFFFFFFu) {
@@ -552,45 +555,49 @@ static int run_knn(lsgpu_icp* h, const Mat34& T, const IcpState* st, bool seed, 
     ev = &h->knn_events[h->knn_events_used++];
     HIPC(hipEventRecord(ev->a, h->stream));
   }
-  static const bool lane_mode = getenv("LSGPU_KNN_LANE") != nullptr;  // experiment switch
-  // 0: k_knn_tile everywhere; 1 (default): settled launches (capped, no wave-per-query pass, lower bounds
-  // carried) classify first and search row-wise on the compacted list; 2: k_knn_rows also stands in for
-  // k_knn_tile everywhere else (validation of the row-wise search against the whole parity suite)
-  static const int rows_mode = getenv("LSGPU_KNN_ROWS") ? atoi(getenv("LSGPU_KNN_ROWS")) : 0;
-  if (rows_mode >= 1 && capped && !wide && st && !lane_mode) {
+#ifdef LSGPU_EXPERIMENTS
+  // measured-slower variants (DESIGN.md "Rejected after measurement"), compiled only into the experiments build:
+  //   knn_rows 1: settled launches classify first and search row-wise on the compacted list; 2: k_knn_rows also stands
+  //   in for k_knn_tile everywhere else; knn_lane: one lane per query in capped launches; tile_waves 4; xcd_swizzle
+  if (tn.knn_rows >= 1 && capped && !wide && st && !tn.knn_lane) {
     hipLaunchKernelGGL(k_knn_classify, dim3((nq + kClassifyPerBlock - 1) / kClassifyPerBlock), dim3(256), 0, h->stream, a);
     hipLaunchKernelGGL(k_knn_rows<true>, dim3(a.ntiles), dim3(64), 0, h->stream, a);
     if (timed) { HIPC(hipEventRecord(ev->b, h->stream)); HIPC(hipEventRecord(ev->c, h->stream)); }
-  } else if (rows_mode >= 2 && !lane_mode) {
+    HIPC(hipGetLastError());
+    return LSGPU_OK;
+  }
+  if (tn.knn_rows >= 2 && !tn.knn_lane) {
     a.spread_route_r = 0.f;  // (no routing in the row-wise kernel; stragglers by radius still go to the fallback)
     hipLaunchKernelGGL(k_knn_rows<false>, dim3(a.ntiles), dim3(64), 0, h->stream, a);
     if (timed) HIPC(hipEventRecord(ev->b, h->stream));
     if (!capped) hipLaunchKernelGGL(k_knn_fallback, dim3(kFallbackBlocks), dim3(256), 0, h->stream, a);
     if (timed) HIPC(hipEventRecord(ev->c, h->stream));
-  } else if (capped && lane_mode) {
+    HIPC(hipGetLastError());
+    return LSGPU_OK;
+  }
+  if (capped && tn.knn_lane) {
     hipLaunchKernelGGL(k_knn_lane, dim3(nblk(nq)), dim3(256), 0, h->stream, a);
     if (timed) { HIPC(hipEventRecord(ev->b, h->stream)); HIPC(hipEventRecord(ev->c, h->stream)); }
-  } else {
-    static const int tile_waves = getenv("LSGPU_TILE_WAVES") ? atoi(getenv("LSGPU_TILE_WAVES")) : 1;
-    const int tile_threads = tile_waves == 4 ? 256 : 64;
-    static const int swz = getenv("LSGPU_XCD_SWIZZLE") ? atoi(getenv("LSGPU_XCD_SWIZZLE")) : 0;
-    a.xcd_swizzle = swz;
-    const int waves_per_block = tile_threads / 64;
-    if (waves_per_block == 4)
-      hipLaunchKernelGGL(k_knn_tile<4>, dim3((a.ntiles + 3) / 4), dim3(256), 0, h->stream, a);
-    else
-      hipLaunchKernelGGL(k_knn_tile<1>, dim3(a.ntiles + a.front_blocks), dim3(64), 0, h->stream, a);
-    if (timed) HIPC(hipEventRecord(ev->b, h->stream));
-    // stragglers (balls > r_cap) only exist in uncapped launches
-    // (a settled launch routes a few thousand queries at most: a small grid keeps the pass short)
-    if (a.front_blocks > 0) {
-      // nothing was handed over
-    } else if (settled && rowq)   // one DPP row per handed-over query
-      hipLaunchKernelGGL(k_knn_rowq, dim3(rowq_blocks), dim3(256), 0, h->stream, a);
-    else if (!capped || a.spread_route_r > 0.f)
-      hipLaunchKernelGGL(k_knn_fallback, dim3(settled ? kFallbackBlocksSettled : kFallbackBlocks), dim3(256), 0, h->stream, a);
-    if (timed) HIPC(hipEventRecord(ev->c, h->stream));
+    HIPC(hipGetLastError());
+    return LSGPU_OK;
   }
+  a.xcd_swizzle = tn.xcd_swizzle;
+  if (tn.tile_waves == 4)
+    hipLaunchKernelGGL(k_knn_tile<4>, dim3((a.ntiles + 3) / 4), dim3(256), 0, h->stream, a);
+  else
+#endif
+  hipLaunchKernelGGL(k_knn_tile<1>, dim3(a.ntiles + a.front_blocks), dim3(64), 0, h->stream, a);
+  if (timed) HIPC(hipEventRecord(ev->b, h->stream));
+  // stragglers (balls > r_cap) only exist in uncapped launches; a settled launch without front rows hands a few
+  // thousand queries at most to the row pass (one DPP row per query)
+  if (a.front_blocks > 0) {
+    // nothing was handed over
+  } else if (settled && tn.rowq) {
+    hipLaunchKernelGGL(k_knn_rowq, dim3(tn.rowq_blocks), dim3(256), 0, h->stream, a);
+  } else if (!capped || a.spread_route_r > 0.f) {
+    hipLaunchKernelGGL(k_knn_fallback, dim3(settled ? kFallbackBlocksSettled : kFallbackBlocks), dim3(256), 0, h->stream, a);
+  }
+  if (timed) HIPC(hipEventRecord(ev->c, h->stream));
   HIPC(hipGetLastError());
   return LSGPU_OK;
 }
@@ -987,7 +994,7 @@ static int ssn_device(lsgpu_icp* h, const float4* src, int64_t n, int knn, float
   // its LDS (<= kSsnLdsMax points, <= kSsnLdsLevels levels to go)
   int glevels = 0;
   {
-    static const bool lds_finish = getenv("LSGPU_SSN_GLOBAL") == nullptr;
+    const bool lds_finish = !tuning().ssn_global;
     int64_t c = n;
     while (glevels < levels && !(lds_finish && c <= kSsnLdsMax && levels - glevels <= kSsnLdsLevels)) { c -= c / 2; ++glevels; }
   }
@@ -1564,12 +1571,10 @@ int lsgpu_icp_align(lsgpu_icp* h, const float* reading_xyz1, int64_t nq, const f
   const Mat34 Tdummy = to_mat34(hst->T_iter);
   bool first_select = true;
   std::vector<size_t> ev_of_launch;  // event index of every enqueued iteration
-  static const bool split_update = getenv("LSGPU_SPLIT_UPDATE") != nullptr;  // (profiling: the update as its own launch)
-  static const bool predict_select = getenv("LSGPU_NO_PREDICT") == nullptr && !split_update;
-  // committed select (device reports a steady limit): no select kernels at all, see IcpState::sel_streak
-  static const bool commit_select = getenv("LSGPU_NO_COMMIT") == nullptr &&
-                                    !(getenv("LSGPU_KNN_ROWS") && atoi(getenv("LSGPU_KNN_ROWS")) != 0);  // (the experimental row-wise path does not fill the window table)
-  static const bool comm_commit = getenv("LSGPU_NO_COMM_COMMIT") == nullptr;
+  const bool split_update = tuning().split_update;  // (profiling: the update as its own launch)
+  const bool predict_select = tuning().predict_select;
+  const bool commit_select = tuning().commit_select;
+  const bool comm_commit = tuning().comm_commit;
   bool commit_ok = false;
   int committed_iterations = 0;
   auto enqueue_iteration = [&](bool seed, bool capped, bool wide, bool knn = true) -> int {
@@ -1629,9 +1634,9 @@ int lsgpu_icp_align(lsgpu_icp* h, const float* reading_xyz1, int64_t nq, const f
   };
 
   // the first launches still have wide balls: their spread waves go to the wave-per-query pass
-  static const int wide_iters = getenv("LSGPU_WIDE_ITERS") ? atoi(getenv("LSGPU_WIDE_ITERS")) : 3;
+  const int wide_iters = tuning().wide_iters;
   // iteration 0: seeded; capped by the trim quantile of the seed distances (a guaranteed bound: no retry can follow)
-  static const bool seed_cap = getenv("LSGPU_NO_SEED_CAP") == nullptr;
+  const bool seed_cap = tuning().seed_cap;
   rc = enqueue_iteration(true, seed_cap && h->cfg.reserved[0] == 0, true);
   if (rc) return rc;
   int enq = 1, since_check = 1, sel_retries = 0;

@@ -12,10 +12,9 @@
 //     needs it are its <= 64 points staged through LDS and broadcast to all lanes.
 //   * lanes whose ball is larger than r_cap go to k_knn_fallback: one wave per query, chunks culled
 //     lane-parallel against the single ball, surviving chunks evaluated one point per lane.
-//   * k_knn_lane: one LANE per query, used once the balls are small (later ICP iterations): each
-//     lane looks up the <= 2x2x2 cells its ball touches and walks their chunks with the same box
-//     test.  Neighbouring lanes read the same cells / chunks, so the loads coalesce.
-//     TrimmedDistOutlierFilter (yaml:14-16) gives every pair beyond the trim limit weight 0, so in
+//   * (k_knn_lane, one LANE per query with lane_ball_search, was measured slower and lives in the -DLSGPU_EXPERIMENTS
+//     build only; lane_ball_search itself serves the rare tie and late-spread paths.)
+//   * TrimmedDistOutlierFilter (yaml:14-16) gives every pair beyond the trim limit weight 0, so in
 //     the ICP loop a lane needs an exact neighbour only if it is closer than cap = sqrt(cap2), a
 //     bound the host derives from the previous iteration's limit and verifies after the select
 //     (a violated bound repeats the iteration uncapped).  Lanes with nothing inside the cap keep an
@@ -59,7 +58,12 @@ struct KnnArgs {
   float gap;                // capped launches search `gap` metres beyond the current best (keep-match bound)
   float spread_route_r;     // > 0: a spread wave whose largest ball exceeds this hands its lanes to k_knn_fallback
   int route_chunks;         // (with spread_route_r > 0) so does any wave whose cell block holds more chunks than this
+#ifdef LSGPU_EXPERIMENTS
   int sparse_lanes;         // > 0: a wave with at most this many searching lanes hands them to k_knn_rowq
+  int xcd_swizzle;          // 1: block b -> XCD (b % 8) gets a contiguous eighth of the tiles
+  uint32_t* work;           // compacted list of the queries that have to search (k_knn_classify -> k_knn_rows)
+  uint32_t* work_count;     //   its length; re-armed by the last block of k_normal_eq_loop
+#endif
   // front rows (settled launches): tiles found spread in an earlier launch are searched row-wise by the first
   // `front_blocks` workgroups of the tile kernel itself (8 per tile) -- no hand-over list, no second launch
   uint32_t* spread_flag;    // per tile: on the list (nullable)
@@ -82,9 +86,6 @@ struct KnnArgs {
   uint2* cell_cache;        // per tile: the 64 (chunk_start, chunk_end) probe results of its cell block
   ulonglong2* cell_tags;    // per tile: which block (generation, level, origin, extent) the cache holds
   uint32_t cache_gen;       // bumped by every set_reference / align: older entries never match
-  int xcd_swizzle;          // 1: block b -> XCD (b % 8) gets a contiguous eighth of the tiles
-  uint32_t* work;           // compacted list of the queries that have to search (k_knn_classify -> k_knn_rows)
-  uint32_t* work_count;     //   its length; re-armed by the last block of k_normal_eq_loop
   int dbg_flags;            // LSGPU_KNN_STATS builds: ablation switches (1 no eval, 2 no refine, 4 no search)
 };
 
@@ -651,7 +652,9 @@ __global__ __launch_bounds__(WAVES * 64, LSGPU_TILE_OCC) void k_knn_tile(KnnArgs
       return;
     }
     blk -= (uint32_t)a.front_blocks;
-  } else if (a.xcd_swizzle > 1) {
+  }
+#ifdef LSGPU_EXPERIMENTS
+  else if (a.xcd_swizzle > 1) {
     // XCD x takes runs of `xcd_swizzle` consecutive blocks: run index = (i / S) * 8 + x.  Neighbouring
     // tiles share an L2 inside a run, while every XCD still gets an even mix of the whole scan.
     const uint32_t S = (uint32_t)a.xcd_swizzle, nb = gridDim.x, x = blk & 7u, i = blk >> 3;
@@ -662,6 +665,7 @@ __global__ __launch_bounds__(WAVES * 64, LSGPU_TILE_OCC) void k_knn_tile(KnnArgs
     const uint32_t nb = gridDim.x, q = nb >> 3, r = nb & 7u, x = blk & 7u, i = blk >> 3;
     blk = (x < r ? x * (q + 1u) : r * (q + 1u) + (x - r) * q) + i;  // bijective for any grid size
   }
+#endif
   const uint32_t tile = blk * wpb + w;
   if (tile >= (uint32_t)a.ntiles) return;
   // the wave's three coalesced loads go out before anything waits on the loop state (scalar loads + early exit)
@@ -746,15 +750,17 @@ __global__ __launch_bounds__(WAVES * 64, LSGPU_TILE_OCC) void k_knn_tile(KnnArgs
   const bool ing = act && !straggler && !skip;
   bool routed = false;
   const unsigned long long ing_mask = __ballot(ing);
-  // Experiment (LSGPU_SPARSE_LANES, default off): a wave with few searching lanes evaluates every candidate of its
-  // region for all 64 lanes (about 1400 vector instructions whatever the number of lanes that need them), so hand
-  // those lanes to the row-per-query pass.  Measured: the tile kernel does get shorter (79 -> 57 us with <= 48 lanes
-  // handed over), but the row pass pays ~11 us of dependent round trips per query and row, and thousands of waves
-  // appending to one list counter serialise in the L2 -- a net loss at every threshold (kNN section).
+#ifdef LSGPU_EXPERIMENTS
+  // Experiment (LSGPU_SPARSE_LANES): a wave with few searching lanes evaluates every candidate of its region for all 64
+  // lanes (about 1400 vector instructions whatever the number of lanes that need them), so hand those lanes to the
+  // row-per-query pass.  Measured: the tile kernel does get shorter (79 -> 57 us with <= 48 lanes handed over), but the
+  // row pass pays ~11 us of dependent round trips per query and row, and thousands of waves appending to one list
+  // counter serialise in the L2 -- a net loss at every threshold (kNN section).
   const bool sparse = a.sparse_lanes > 0 && __popcll(ing_mask) <= a.sparse_lanes;
   if (sparse) {
     routed = ing;
   } else
+#endif
 #ifdef LSGPU_KNN_STATS
   if (ing_mask && !(a.dbg_flags & 4)) {
 #else
@@ -954,6 +960,7 @@ __global__ __launch_bounds__(WAVES * 64, LSGPU_TILE_OCC) void k_knn_tile(KnnArgs
 #endif
 }
 
+#ifdef LSGPU_EXPERIMENTS
 // ---------------------------------------------------------------- lane-per-query search
 __global__ __launch_bounds__(256) void k_knn_lane(KnnArgs a) {
   const int j = blockIdx.x * 256 + threadIdx.x;
@@ -973,6 +980,8 @@ __global__ __launch_bounds__(256) void k_knn_lane(KnnArgs a) {
   a.prev[j] = mp;
   if (a.lb) a.lb[j] = best <= cap2 ? sqrtf(best) * (1.0f - 1e-6f) : sqrtf(cap2) * (1.0f - 1e-5f);
 }
+
+#endif  // LSGPU_EXPERIMENTS
 
 // ---------------------------------------------------------------- exact fallback, one wave per query
 __global__ __launch_bounds__(256) void k_knn_fallback(KnnArgs a) {
@@ -1066,6 +1075,42 @@ __global__ __launch_bounds__(256) void k_knn_fallback(KnnArgs a) {
         a.lb[j] = fd <= cap2s ? sqrtf(fd) * (1.0f - 1e-6f) : fmaxf(a.lb[j], sqrtf(cap2s) * (1.0f - 1e-5f));
       }
     }
+  }
+}
+
+// ---------------------------------------------------------------- row-per-query pass (settled launches)
+// The queries a settled launch hands over (lanes of spread waves: a few thousand, small balls) do not need a whole
+// wave each: one DPP row of 16 lanes takes one query -- lanes 0..7 probe the <= 2x2x2 cells the ball touches, the
+// cells' chunks are culled 16 at a time (lane = chunk) against the ball itself, a surviving chunk is evaluated one
+// point per lane -- and a wave runs four queries side by side.  Same results as k_knn_fallback (exact nearest point
+// inside the cap, smallest index on ties, lower bound for the next iterations); three to five dependent memory
+// round trips per query instead of one per chunk and per reduction of a 64-lane wave.
+__global__ __launch_bounds__(256) void k_knn_rowq(KnnArgs a) {
+  __shared__ uint32_t list_sh[16][kRowqList];
+  const int lane = threadIdx.x & 63, row = lane >> 4, k16 = lane & 15, wave = threadIdx.x >> 6;
+  uint32_t* list = list_sh[wave * 4 + row];
+  Mat34 T; float cap2;
+  if (!iter_params(a.st, a.T, a.cap2, a.use_state_cap, T, cap2)) return;
+  const float cap2s = cap2 * kCapSearchMargin2;
+  const float gap = a.use_state_cap ? a.gap : 0.f;
+  const uint32_t count = *a.strag_count;
+  for (uint32_t base = (blockIdx.x * 4u + (uint32_t)wave) * 4u; base < count; base += gridDim.x * 16u) {
+    const uint32_t s = base + (uint32_t)row;
+    const bool have = s < count;
+    const uint32_t j = have ? a.strag[s] : 0u;
+    float qx = 0.f, qy = 0.f, qz = 0.f, ub = 0.f;
+    int id_in = -1;
+    if (have) {
+      const float4 r = a.rdq[j];
+      const float3 q = xform(T, r.x, r.y, r.z);
+      qx = q.x; qy = q.y; qz = q.z;
+      ub = a.d2[j];  // distance to the warm-start point
+      id_in = a.ids[j];
+    }
+    unsigned long long bestp; float sec;
+    rowq_search(a, cap2s, gap, list, row, k16, have, qx, qy, qz, ub, id_in, bestp, sec);
+    if (have && k16 == 0)
+      rowq_store(a, cap2s, gap, (int)j, bestp, sec, id_in, a.lb ? a.lb[j] : 0.f /* the tile kernel left the carried bound there */, true);
   }
 }
 

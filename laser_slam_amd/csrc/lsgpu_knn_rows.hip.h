@@ -389,40 +389,4 @@ __global__ __launch_bounds__(64, 4) void k_knn_rows(KnnArgs a) {
 #endif
 }
 
-// ---------------------------------------------------------------- row-per-query pass (settled launches)
-// The queries a settled launch hands over (lanes of spread waves: a few thousand, small balls) do not need a whole
-// wave each: one DPP row of 16 lanes takes one query -- lanes 0..7 probe the <= 2x2x2 cells the ball touches, the
-// cells' chunks are culled 16 at a time (lane = chunk) against the ball itself, a surviving chunk is evaluated one
-// point per lane -- and a wave runs four queries side by side.  Same results as k_knn_fallback (exact nearest point
-// inside the cap, smallest index on ties, lower bound for the next iterations); three to five dependent memory
-// round trips per query instead of one per chunk and per reduction of a 64-lane wave.
-__global__ __launch_bounds__(256) void k_knn_rowq(KnnArgs a) {
-  __shared__ uint32_t list_sh[16][kRowqList];
-  const int lane = threadIdx.x & 63, row = lane >> 4, k16 = lane & 15, wave = threadIdx.x >> 6;
-  uint32_t* list = list_sh[wave * 4 + row];
-  Mat34 T; float cap2;
-  if (!iter_params(a.st, a.T, a.cap2, a.use_state_cap, T, cap2)) return;
-  const float cap2s = cap2 * kCapSearchMargin2;
-  const float gap = a.use_state_cap ? a.gap : 0.f;
-  const uint32_t count = *a.strag_count;
-  for (uint32_t base = (blockIdx.x * 4u + (uint32_t)wave) * 4u; base < count; base += gridDim.x * 16u) {
-    const uint32_t s = base + (uint32_t)row;
-    const bool have = s < count;
-    const uint32_t j = have ? a.strag[s] : 0u;
-    float qx = 0.f, qy = 0.f, qz = 0.f, ub = 0.f;
-    int id_in = -1;
-    if (have) {
-      const float4 r = a.rdq[j];
-      const float3 q = xform(T, r.x, r.y, r.z);
-      qx = q.x; qy = q.y; qz = q.z;
-      ub = a.d2[j];  // distance to the warm-start point
-      id_in = a.ids[j];
-    }
-    unsigned long long bestp; float sec;
-    rowq_search(a, cap2s, gap, list, row, k16, have, qx, qy, qz, ub, id_in, bestp, sec);
-    if (have && k16 == 0)
-      rowq_store(a, cap2s, gap, (int)j, bestp, sec, id_in, a.lb ? a.lb[j] : 0.f /* the tile kernel left the carried bound there */, true);
-  }
-}
-
 }  // namespace lsgpu

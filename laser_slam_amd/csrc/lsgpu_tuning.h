@@ -1,0 +1,155 @@
+// lsgpu_tuning.h -- the ONE place where liblsgpu_icp.so looks at its environment.
+//
+// Every LSGPU_* variable is read once per process by tuning(), range-checked (an out-of-range or unparsable value is
+// reported on stderr and replaced by the default -- it never aborts a registration), and kept in this struct; the rest
+// of the library reads the struct.  None of the switches changes a result: they move work between exact paths
+// (tests/test_gpu_parity.py::test_experiment_switches_do_not_change_results) or size scratch resources.  A variable
+// that starts with LSGPU_ and is not listed here is reported once (a typo would otherwise silently run the default).
+//
+// Product switches (defaults are the measured optima, DESIGN.md "switches"):
+//   LSGPU_QUERY_ORDER      -1   order of the queries inside the waves: -1 automatic, 0 Morton, 1 spherical cells
+//   LSGPU_Q_ELEV / _Q_SECT  0   elevation bin / azimuth sector of the spherical cells in degrees (0: from the density)
+//   LSGPU_GAP             0.002 metres searched beyond the current best in capped launches (keep-match bound)
+//   LSGPU_BUDGET           128  chunks in a spread wave's cell block above which its lanes search on their own
+//   LSGPU_WIDE_ITERS         3  first iterations of an align whose wide-ball spread waves go to the wave-per-query pass
+//   LSGPU_ROUTE_R         0.02  ... if their largest ball exceeds this (metres)
+//   LSGPU_ROUTE_CHUNKS    1024  ... or the cell block holds more chunks than this
+//   LSGPU_NO_PREDICT            always the three-pass select (no first two passes in the search epilogue)
+//   LSGPU_NO_COMMIT             keep launching the select kernels when the limit is steady
+//   LSGPU_NO_COMM_COMMIT        the same, only for handles with a communicator (split-scan mode)
+//   LSGPU_NO_SEED_CAP           first search uncapped (no quantile of the seed distances)
+//   LSGPU_NO_FRONT              spread tiles go through the separate row pass instead of the front of the tile launch
+//   LSGPU_FRONT_GUESS     2048  tiles the front of the grid is sized for before the host has seen the list
+//   LSGPU_NO_ROUTE_ALL          (with NO_FRONT) settled spread waves search per lane inside the tile kernel
+//   LSGPU_NO_ROWQ               (with NO_FRONT) handed-over queries go to the wave-per-query kernel
+//   LSGPU_ROWQ_BLOCKS     2048  (with NO_FRONT) grid of the row pass
+//   LSGPU_ROCPRIM_SORT          rocPRIM's radix sort instead of lsgpu_sort.hip.h
+//   LSGPU_SORT_ITEMS         0  keys per thread of the radix passes (0: by size; 4, 8, 16)
+//   LSGPU_SSN_GLOBAL            every level of the reference filter as a global sort (no in-LDS finish)
+//   LSGPU_NE_BLOCKS        256  blocks of k_normal_eq_loop (64 .. 2048)
+//   LSGPU_SPLIT_UPDATE          the per-iteration update as its own launch (profiling)
+//   LSGPU_COMM_TIMEOUT_MS 30000 bound on every stream wait of the split-scan mode
+//   LSGPU_KNN_DBG            0  ablation flags of the -DLSGPU_KNN_STATS build (ignored by the product build)
+// Experiment switches, compiled in only with -DLSGPU_EXPERIMENTS (measured-slower variants kept as the record of what was
+// tried: DESIGN.md "Rejected after measurement"); the product build reports them as unknown:
+//   LSGPU_KNN_ROWS (0/1/2), LSGPU_KNN_LANE, LSGPU_SPARSE_LANES, LSGPU_TILE_WAVES (1/4), LSGPU_XCD_SWIZZLE
+#pragma once
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+
+extern char** environ;
+
+namespace lsgpu {
+
+struct Tuning {
+  int query_order = -1;
+  float q_elev = 0.f, q_sect = 0.f;
+  float gap = 0.002f;
+  int chunk_budget = 128;
+  int wide_iters = 3;
+  float route_r = 0.02f;
+  int route_chunks = 1024;
+  bool predict_select = true, commit_select = true, comm_commit = true, seed_cap = true;
+  bool front = true;
+  int front_guess = 2048;
+  bool route_all = true, rowq = true;
+  int rowq_blocks = 2048;
+  bool rocprim_sort = false;
+  int sort_items = 0;
+  bool ssn_global = false;
+  int ne_blocks = 256;
+  bool split_update = false;
+  double comm_timeout_ms = 30000.0;
+  int knn_dbg = 0;
+#ifdef LSGPU_EXPERIMENTS
+  int knn_rows = 0;
+  bool knn_lane = false;
+  int sparse_lanes = 0;
+  int tile_waves = 1;
+  int xcd_swizzle = 0;
+#endif
+};
+
+namespace tuning_detail {
+inline bool flag(const char* name) { return getenv(name) != nullptr; }
+inline double number(const char* name, double def, double lo, double hi) {
+  const char* e = getenv(name);
+  if (!e) return def;
+  char* end = nullptr;
+  const double v = strtod(e, &end);
+  if (end == e || *end != '\0' || !(v >= lo && v <= hi)) {
+    fprintf(stderr, "liblsgpu_icp: %s=%s is not a number in [%g, %g]; using the default %g\n", name, e, lo, hi, def);
+    return def;
+  }
+  return v;
+}
+inline Tuning read() {
+  Tuning t;
+  t.query_order = (int)number("LSGPU_QUERY_ORDER", -1, -1, 1);
+  t.q_elev = (float)number("LSGPU_Q_ELEV", 0, 0, 45);
+  t.q_sect = (float)number("LSGPU_Q_SECT", 0, 0, 45);
+  t.gap = (float)number("LSGPU_GAP", 0.002, 0, 1);
+  t.chunk_budget = (int)number("LSGPU_BUDGET", 128, 1, 1 << 20);
+  t.wide_iters = (int)number("LSGPU_WIDE_ITERS", 3, 0, 1 << 20);
+  t.route_r = (float)number("LSGPU_ROUTE_R", 0.02, 1e-6, 1e6);
+  t.route_chunks = (int)number("LSGPU_ROUTE_CHUNKS", 1024, 1, 1 << 30);
+  t.split_update = flag("LSGPU_SPLIT_UPDATE");
+  t.predict_select = !flag("LSGPU_NO_PREDICT") && !t.split_update;
+  t.commit_select = !flag("LSGPU_NO_COMMIT");
+  t.comm_commit = !flag("LSGPU_NO_COMM_COMMIT");
+  t.seed_cap = !flag("LSGPU_NO_SEED_CAP");
+  t.front = !flag("LSGPU_NO_FRONT");
+  t.front_guess = (int)number("LSGPU_FRONT_GUESS", 2048, 0, 8192);
+  t.route_all = !flag("LSGPU_NO_ROUTE_ALL");
+  t.rowq = !flag("LSGPU_NO_ROWQ");
+  t.rowq_blocks = (int)number("LSGPU_ROWQ_BLOCKS", 2048, 1, 65535);
+  t.rocprim_sort = flag("LSGPU_ROCPRIM_SORT");
+  t.sort_items = (int)number("LSGPU_SORT_ITEMS", 0, 0, 16);
+  if (t.sort_items != 0 && t.sort_items != 4 && t.sort_items != 8 && t.sort_items != 16) {
+    fprintf(stderr, "liblsgpu_icp: LSGPU_SORT_ITEMS must be 4, 8 or 16; choosing by size\n");
+    t.sort_items = 0;
+  }
+  t.ssn_global = flag("LSGPU_SSN_GLOBAL");
+  t.ne_blocks = (int)number("LSGPU_NE_BLOCKS", 256, 64, 2048);
+  t.comm_timeout_ms = number("LSGPU_COMM_TIMEOUT_MS", 30000, 1, 1e9);
+  t.knn_dbg = (int)number("LSGPU_KNN_DBG", 0, 0, 1 << 20);
+  static const char* known[] = {"LSGPU_QUERY_ORDER", "LSGPU_Q_ELEV", "LSGPU_Q_SECT", "LSGPU_GAP", "LSGPU_BUDGET", "LSGPU_WIDE_ITERS",
+                                "LSGPU_ROUTE_R", "LSGPU_ROUTE_CHUNKS", "LSGPU_SPLIT_UPDATE", "LSGPU_NO_PREDICT", "LSGPU_NO_COMMIT",
+                                "LSGPU_NO_COMM_COMMIT", "LSGPU_NO_SEED_CAP", "LSGPU_NO_FRONT", "LSGPU_FRONT_GUESS", "LSGPU_NO_ROUTE_ALL",
+                                "LSGPU_NO_ROWQ", "LSGPU_ROWQ_BLOCKS", "LSGPU_ROCPRIM_SORT", "LSGPU_SORT_ITEMS", "LSGPU_SSN_GLOBAL",
+                                "LSGPU_NE_BLOCKS", "LSGPU_COMM_TIMEOUT_MS", "LSGPU_KNN_DBG",
+                                // read by the Python / C++ hosts and the test drivers, not by this library:
+                                "LSGPU_SO", "LSGPU_STATS_SO", "LSGPU_GOLDEN_DIR", "LSGPU_SEQ_PERTURB", "LSGPU_SEQ_POSES", "LSGPU_TEST_INPUT_FILTERS",
+#ifdef LSGPU_EXPERIMENTS
+                                "LSGPU_KNN_ROWS", "LSGPU_KNN_LANE", "LSGPU_SPARSE_LANES", "LSGPU_TILE_WAVES", "LSGPU_XCD_SWIZZLE",
+#endif
+                                nullptr};
+#ifdef LSGPU_EXPERIMENTS
+  t.knn_rows = (int)number("LSGPU_KNN_ROWS", 0, 0, 2);
+  t.knn_lane = flag("LSGPU_KNN_LANE");
+  t.sparse_lanes = (int)number("LSGPU_SPARSE_LANES", 0, 0, 64);
+  t.tile_waves = (int)number("LSGPU_TILE_WAVES", 1, 1, 4) == 4 ? 4 : 1;
+  t.xcd_swizzle = (int)number("LSGPU_XCD_SWIZZLE", 0, 0, 1 << 16);
+  // the front rows only exist in the one-wave tile kernel; the row-wise experiment does not fill the window table
+  if (t.knn_lane || t.knn_rows != 0 || t.tile_waves == 4 || t.sparse_lanes != 0) t.front = false;
+  if (t.knn_rows != 0) t.commit_select = false;
+#endif
+  for (char** e = environ; e && *e; ++e) {
+    if (strncmp(*e, "LSGPU_", 6) != 0) continue;
+    const char* eq = strchr(*e, '=');
+    const size_t len = eq ? (size_t)(eq - *e) : strlen(*e);
+    bool ok = false;
+    for (const char** k = known; *k; ++k) ok = ok || (strlen(*k) == len && strncmp(*k, *e, len) == 0);
+    if (!ok) fprintf(stderr, "liblsgpu_icp: unknown switch %.*s ignored (see csrc/lsgpu_tuning.h)\n", (int)len, *e);
+  }
+  return t;
+}
+}  // namespace tuning_detail
+
+inline const Tuning& tuning() {
+  static const Tuning t = tuning_detail::read();
+  return t;
+}
+
+}  // namespace lsgpu

@@ -13,7 +13,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def _build(tmp_path, src, name):
     out = str(tmp_path / name)
-    cmd = ["g++", "-std=c++17", "-O1", "-Wall", "-I", os.path.join(ROOT, "include"),
+    cmd = ["g++", "-std=c++17", "-O1", "-Wall", "-DLSGPU_TEST_SEAMS", "-I", os.path.join(ROOT, "include"),
            "-I", os.path.join(ROOT, "laser_slam_amd", "cpp", "include"), os.path.join(ROOT, "tests", "cpp", src),
            "-o", out, "-L", os.path.join(ROOT, "laser_slam_amd"), "-llsgpu_icp",
            "-Wl,-rpath," + os.path.join(ROOT, "laser_slam_amd")]

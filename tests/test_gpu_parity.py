@@ -340,9 +340,17 @@ def test_experiment_switches_do_not_change_results():
     import sys
     variants = [{}, {"LSGPU_NO_FRONT": "1"}, {"LSGPU_NO_FRONT": "1", "LSGPU_NO_ROWQ": "1"},
                 {"LSGPU_NO_FRONT": "1", "LSGPU_NO_ROUTE_ALL": "1"}, {"LSGPU_NO_COMMIT": "1"}, {"LSGPU_NO_PREDICT": "1"},
-                {"LSGPU_ROCPRIM_SORT": "1"}, {"LSGPU_KNN_ROWS": "1"}, {"LSGPU_TILE_WAVES": "4"},
-                {"LSGPU_NO_SEED_CAP": "1"}, {"LSGPU_NO_FRONT": "1", "LSGPU_SPARSE_LANES": "16"}, {"LSGPU_FRONT_GUESS": "8"},
+                {"LSGPU_ROCPRIM_SORT": "1"}, {"LSGPU_NO_SEED_CAP": "1"}, {"LSGPU_FRONT_GUESS": "8"}, {"LSGPU_SSN_GLOBAL": "1"},
                 {"LSGPU_QUERY_ORDER": "0"}]
+    # the measured-slower variants only exist in the -DLSGPU_EXPERIMENTS build (devtools/build.sh); when that build is
+    # around it has to give the same bits as the product, switch by switch
+    fenced_so = os.path.join(ROOT, "tests", "liblsgpu_icp_fenced.so")   # built by `make -C laser_slam_amd/csrc` (build())
+    assert os.path.exists(fenced_so), "run __graft_entry__.build() first"
+    variants.append({"LSGPU_SO": fenced_so})        # release / acquire fences instead of the fence-free hand-off: same bits
+    exp_so = os.path.join(ROOT, "devtools", "liblsgpu_exp.so")
+    if os.path.exists(exp_so):
+        variants += [dict(v, LSGPU_SO=exp_so) for v in ({}, {"LSGPU_KNN_ROWS": "1"}, {"LSGPU_TILE_WAVES": "4"},
+                                                        {"LSGPU_NO_FRONT": "1", "LSGPU_SPARSE_LANES": "16"})]
     results = []
     for env_add in variants:
         env = dict(os.environ)

@@ -22,7 +22,7 @@ def _build(tmp_path):
     from oracle import oracle_py
     oracle_py.build()
     out = str(tmp_path / "sequence_driver")
-    cmd = ["g++", "-std=c++17", "-O2", "-Wall", "-I", os.path.join(ROOT, "include"),
+    cmd = ["g++", "-std=c++17", "-O2", "-Wall", "-DLSGPU_TEST_SEAMS", "-I", os.path.join(ROOT, "include"),
            "-I", os.path.join(ROOT, "laser_slam_amd", "cpp", "include"),
            os.path.join(ROOT, "tests", "cpp", "sequence_driver.cpp"), "-o", out,
            "-L", os.path.join(ROOT, "laser_slam_amd"), "-llsgpu_icp", "-L", os.path.join(ROOT, "oracle"), "-llsoracle",
