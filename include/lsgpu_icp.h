@@ -289,6 +289,10 @@ int64_t lsgpu_filter_sampling_surface_normal(const float* xyz1, int64_t n, int k
 /* RigidTransformation::checkParameters / correctParameters (common.hpp:136-149). */
 int  lsgpu_check_rigid(const float T[16]);
 void lsgpu_correct_rigid(const float T[16], float out[16]);
+/* The rotation metric of DifferentialTransformationChecker (yaml:24-27) between two 4x4 transforms (column major):
+ * Quaternion(R_a).angularDistance(Quaternion(R_b)) = 2 atan2(|vec|, |w|) of q_a * conj(q_b), in float -- the same code
+ * the device-side checker runs (csrc/lsgpu_host_math.h). */
+float lsgpu_rotation_distance(const float Ta[16], const float Tb[16]);
 
 const char* lsgpu_strerror(int code);
 const char* lsgpu_last_error(lsgpu_icp* h); /* detail of the last failure on this handle */

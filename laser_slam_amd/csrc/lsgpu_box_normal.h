@@ -1,7 +1,7 @@
 // lsgpu_box_normal.h -- the per-box arithmetic of SamplingSurfaceNormalDataPointsFilter
 // (laser_slam/configurations/icp_default.yaml:5-7, run inside icp_.compute,
 // laser_slam/src/laser_track.cpp:496), shared by the host filter (lsgpu_host_filters.cpp) and the
-// device filter (lsgpu_ssn.hip.h): mean and covariance of the box in float, rank test (FullPivLU
+// device filter (lsgpu_ssn.hip.h): mean and covariance of the box in float, rank test (FullPivHouseholderQR,
 // default threshold), eigenvector of the smallest eigenvalue by cyclic Jacobi rotations in double.
 // Compiled with -ffp-contract=off; only IEEE + - * / sqrt fabs are used, so host and device agree
 // bit for bit when they visit the box's points in the same order.
@@ -49,30 +49,53 @@ LSGPU_BN_HD void eig3(double a[3][3], double w[3], double v[3][3]) {
   for (int i = 0; i < 3; ++i) w[i] = a[i][i];
 }
 
-// rank with full pivoting, threshold = max pivot * eps * 3 (Eigen FullPivLU default)
+// Numerical rank as Eigen's FullPivHouseholderQR reports it -- upstream's fuseRange tests
+// C.fullPivHouseholderQr().rank() + 1 >= dim (libpointmatcher SamplingSurfaceNormal.cpp, from knowledge; rounds 1-2 used
+// FullPivLU pivots here, same threshold, different pivot values -- they differ only on borderline boxes).  Per step: the
+// largest |entry| of the remaining corner is brought to (k, k) by a row and a column swap, the corner is declared
+// negligible if it is <= eps * 3 times the very first one, a Householder reflection zeroes the column below the
+// diagonal and |beta| (the column's norm) is the pivot; rank = pivots > max pivot * eps * 3.
 LSGPU_BN_HD int rank3(const float c[3][3]) {
   float m[3][3];
   for (int i = 0; i < 3; ++i)
     for (int j = 0; j < 3; ++j) m[i][j] = c[i][j];
-  float piv[3] = {0.f, 0.f, 0.f}, maxpiv = 0.f;
+  const float prec = FLT_EPSILON * 3.0f;
+  float piv[3] = {0.f, 0.f, 0.f}, maxpiv = 0.f, biggest = 0.f;
+  int nonzero = 3;
   for (int k = 0; k < 3; ++k) {
     int pr = k, pc = k;
-    float best = -1.f;
+    float corner = -1.f;
     for (int i = k; i < 3; ++i)
       for (int j = k; j < 3; ++j)
-        if (fabsf(m[i][j]) > best) { best = fabsf(m[i][j]); pr = i; pc = j; }
-    if (best <= 0.f) break;
+        if (fabsf(m[i][j]) > corner) { corner = fabsf(m[i][j]); pr = i; pc = j; }
+    if (k == 0) biggest = corner;
+    if (corner <= biggest * prec) { nonzero = k; break; }   // isMuchSmallerThan(corner, biggest, precision)
     for (int j = 0; j < 3; ++j) { const float t = m[k][j]; m[k][j] = m[pr][j]; m[pr][j] = t; }
     for (int i = 0; i < 3; ++i) { const float t = m[i][k]; m[i][k] = m[i][pc]; m[i][pc] = t; }
-    piv[k] = fabsf(m[k][k]);
+    // makeHouseholderInPlace on rows k..2 of column k
+    float tail2 = 0.f;
+    for (int i = k + 1; i < 3; ++i) tail2 += m[i][k] * m[i][k];
+    const float c0 = m[k][k];
+    float beta = c0, tau = 0.f, v[3] = {0.f, 0.f, 0.f};
+    if (tail2 > FLT_MIN) {
+      beta = sqrtf(c0 * c0 + tail2);
+      if (c0 >= 0.f) beta = -beta;
+      for (int i = k + 1; i < 3; ++i) v[i] = m[i][k] / (c0 - beta);
+      tau = (beta - c0) / beta;
+    }
+    piv[k] = fabsf(beta);
     maxpiv = piv[k] > maxpiv ? piv[k] : maxpiv;
-    for (int i = k + 1; i < 3; ++i) {
-      const float f = m[i][k] / m[k][k];
-      for (int j = k; j < 3; ++j) m[i][j] -= f * m[k][j];
+    for (int j = k + 1; j < 3; ++j) {     // apply (I - tau v v^T), v = (1, essential part), to the rest of the corner
+      float sdot = m[k][j];
+      for (int i = k + 1; i < 3; ++i) sdot += v[i] * m[i][j];
+      m[k][j] -= tau * sdot;
+      for (int i = k + 1; i < 3; ++i) m[i][j] -= tau * sdot * v[i];
     }
   }
-  const float thr = maxpiv * FLT_EPSILON * 3.0f;
-  return (piv[0] > thr) + (piv[1] > thr) + (piv[2] > thr);
+  const float thr = maxpiv * prec;
+  int r = 0;
+  for (int k = 0; k < nonzero; ++k) r += (piv[k] > thr);
+  return r;
 }
 
 // Normal of one box.  point(i, d) -> coordinate d of the box's i-th point, in the box's order.

@@ -14,6 +14,8 @@
 #include <utility>
 #include <vector>
 
+#include "lsgpu_host_math.h"
+
 #include "../../include/lsgpu_icp.h"
 #include "lsgpu_box_normal.h"
 #include "lsgpu_rand.h"
@@ -133,6 +135,13 @@ void lsgpu_correct_rigid(const float T[16], float out[16]) {
                        c[2][0] * c0[1] - c[2][1] * c0[0]};
   std::memcpy(out, T, 16 * sizeof(float));
   for (int r = 0; r < 3; ++r) { out[r] = c0[r]; out[4 + r] = c1[r]; out[8 + r] = c[2][r]; }
+}
+
+float lsgpu_rotation_distance(const float Ta[16], const float Tb[16]) {
+  float qa[4], qb[4];
+  lsgpu::hostmath::quat_from_rotation(Ta, qa);
+  lsgpu::hostmath::quat_from_rotation(Tb, qb);
+  return lsgpu::hostmath::angular_distance(qa, qb);
 }
 
 }  // extern "C"

@@ -441,6 +441,11 @@ def check_rigid(T) -> bool:
     return bool(_lib.lib().lsgpu_check_rigid(_fp(_t16(T))))
 
 
+def rotation_distance(Ta, Tb) -> float:
+    """DifferentialTransformationChecker's rotation metric between two transforms (Eigen angularDistance, float)."""
+    return float(_lib.lib().lsgpu_rotation_distance(_fp(_t16(Ta)), _fp(_t16(Tb))))
+
+
 def correct_rigid(T) -> np.ndarray:
     out = np.empty(16, np.float32)
     _lib.lib().lsgpu_correct_rigid(_fp(_t16(T)), _fp(out))

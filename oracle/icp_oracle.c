@@ -266,32 +266,50 @@ static void jacobi3(double a[3][3], double w[3], double v[3][3]) {
   w[0] = a[0][0]; w[1] = a[1][1]; w[2] = a[2][2];
 }
 
-/* Numerical rank of a 3x3 float matrix, full pivoting, Eigen FullPivLU default threshold
- * (eps * diagonalSize). */
+/* Numerical rank of a 3x3 float matrix the way Eigen::FullPivHouseholderQR::rank() counts it: upstream's
+ * fuseRange drops a box unless C.fullPivHouseholderQr().rank() + 1 >= 3 (libpointmatcher, from knowledge -- see
+ * "restatement choices" in icp_oracle.h).  Threshold: |pivot| > max |pivot| * eps * 3; a remaining corner whose
+ * largest entry is <= eps * 3 times the first one ends the factorisation. */
 static int rank3f(const float c[3][3]) {
   float m[3][3];
   memcpy(m, c, sizeof(m));
-  float maxpiv = 0.f;
-  float piv[3] = {0, 0, 0};
+  const float prec = FLT_EPSILON * 3.0f;
+  float pivots[3] = {0, 0, 0};
+  float max_pivot = 0.f, first_corner = 0.f;
+  int n_pivots = 3;
   for (int k = 0; k < 3; ++k) {
-    int pr = k, pc = k;
-    float best = -1.f;
+    /* full pivoting: the largest remaining entry goes to (k, k) */
+    int br = k, bc = k;
+    float big = -1.f;
     for (int i = k; i < 3; ++i)
       for (int j = k; j < 3; ++j)
-        if (fabsf(m[i][j]) > best) { best = fabsf(m[i][j]); pr = i; pc = j; }
-    if (best <= 0.f) break;
-    for (int j = 0; j < 3; ++j) { float t = m[k][j]; m[k][j] = m[pr][j]; m[pr][j] = t; }
-    for (int i = 0; i < 3; ++i) { float t = m[i][k]; m[i][k] = m[i][pc]; m[i][pc] = t; }
-    piv[k] = fabsf(m[k][k]);
-    if (piv[k] > maxpiv) maxpiv = piv[k];
-    for (int i = k + 1; i < 3; ++i) {
-      const float f = m[i][k] / m[k][k];
-      for (int j = k; j < 3; ++j) m[i][j] -= f * m[k][j];
+        if (fabsf(m[i][j]) > big) { big = fabsf(m[i][j]); br = i; bc = j; }
+    if (k == 0) first_corner = big;
+    if (big <= first_corner * prec) { n_pivots = k; break; }
+    for (int j = 0; j < 3; ++j) { float t = m[k][j]; m[k][j] = m[br][j]; m[br][j] = t; }
+    for (int i = 0; i < 3; ++i) { float t = m[i][k]; m[i][k] = m[i][bc]; m[i][bc] = t; }
+    /* Householder reflector of column k (rows k..2): beta = -sign(x0) |x| */
+    float below = 0.f;
+    for (int i = k + 1; i < 3; ++i) below += m[i][k] * m[i][k];
+    const float x0 = m[k][k];
+    float beta = x0, tau = 0.f, ess[3] = {0, 0, 0};
+    if (below > FLT_MIN) {
+      beta = sqrtf(x0 * x0 + below);
+      if (x0 >= 0.f) beta = -beta;
+      for (int i = k + 1; i < 3; ++i) ess[i] = m[i][k] / (x0 - beta);
+      tau = (beta - x0) / beta;
+    }
+    pivots[k] = fabsf(beta);
+    if (pivots[k] > max_pivot) max_pivot = pivots[k];
+    for (int j = k + 1; j < 3; ++j) {
+      float dot = m[k][j];
+      for (int i = k + 1; i < 3; ++i) dot += ess[i] * m[i][j];
+      m[k][j] -= tau * dot;
+      for (int i = k + 1; i < 3; ++i) m[i][j] -= tau * dot * ess[i];
     }
   }
-  const float thr = maxpiv * FLT_EPSILON * 3.0f;
   int r = 0;
-  for (int k = 0; k < 3; ++k) r += (piv[k] > thr);
+  for (int k = 0; k < n_pivots; ++k) r += (pivots[k] > max_pivot * prec);
   return r;
 }
 
@@ -706,6 +724,16 @@ static float quat_angular_distance(const float a[4], const float b[4]) {
   const float y = a[0] * by + a[2] * bw + a[3] * bx - a[1] * bz;
   const float z = a[0] * bz + a[3] * bw + a[1] * by - a[2] * bx;
   return 2.0f * atan2f(sqrtf(x * x + y * y + z * z), fabsf(w));
+}
+
+/* Test hook: the rotation metric of DifferentialTransformationChecker between two 4x4 transforms (column major),
+ * i.e. Eigen's Quaternion(R_a).angularDistance(Quaternion(R_b)) as restated above.  Pinned against scipy's
+ * Rotation.magnitude() by tests/golden/make_golden_independent.py. */
+float lso_rotation_distance(const float Ta[16], const float Tb[16]) {
+  float qa[4], qb[4];
+  quat_from_R(Ta, qa);
+  quat_from_R(Tb, qb);
+  return quat_angular_distance(qa, qb);
 }
 
 typedef struct checkers {

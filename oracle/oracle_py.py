@@ -143,6 +143,15 @@ def check_rigid(T16) -> bool:
     return bool(lib().lso_check_rigid(Tp))
 
 
+def rotation_distance(Ta16, Tb16) -> float:
+    L = lib()
+    L.lso_rotation_distance.argtypes = [C.POINTER(C.c_float), C.POINTER(C.c_float)]
+    L.lso_rotation_distance.restype = C.c_float
+    a, ap = _f(Ta16)
+    b, bp = _f(Tb16)
+    return float(L.lso_rotation_distance(ap, bp))
+
+
 def correct_rigid(T16):
     T, Tp = _f(T16)
     out = np.empty(16, np.float32)

@@ -806,6 +806,34 @@ def test_config3_full_size_submap_vs_scan(icp_mod):
         assert np.array_equal(Tc, Tg)                              # same clouds, same chain: the same transform
 
 
+def test_independent_known_answers_on_device(icp_mod):
+    """tests/golden/independent_kat.npz (numpy / scipy only, tests/golden/make_golden_independent.py) replayed on the
+    DEVICE path: box normals of the device surface-normal filter against numpy.linalg.eigh, the device radix select
+    against numpy.partition, the 6x6 solve of the device-side update lane against numpy's Cholesky, and the differential
+    checker's rotation metric (shared host / device source) against scipy.  The oracle is not involved."""
+    import os
+    import torch
+    from test_oracle import _check_box_normals
+    gold = os.path.join(os.path.dirname(__file__), "golden")
+    kat, g = np.load(os.path.join(gold, "independent_kat.npz")), np.load(os.path.join(gold, "icp_pair4k.npz"))
+    with icp_mod.IcpHandle() as h:
+        pts, nrm = h.filter_reference(torch.from_numpy(kat["box_cloud"]).cuda(), 8, 1.0, 0)
+        _check_box_normals(kat, pts.cpu().numpy(), nrm.cpu().numpy())
+        for i in range(int(kat["trim_n"])):
+            d2 = kat[f"trim{i}_d2"]
+            # the kernel-level select takes the distances of the matched pairs (the loop never produces infinities: an
+            # unmatched query does not exist with maxDist = inf, yaml:9-12)
+            lim = h.trim_limit(d2[np.isfinite(d2)], float(kat[f"trim{i}_ratio"]))
+            assert np.float32(lim) == kat[f"trim{i}_limit"], i
+        h.set_reference(g["ref"], g["nrm"])
+        T, st = h.align(g["rd"], g["T_init"])
+        x0 = np.asarray(h.trace()[0]["x"], np.float64)          # first iteration: the matches of the fixture, device solve
+        assert np.allclose(x0, kat["solve_x_f32"], rtol=2e-4, atol=1e-9) and np.allclose(x0, kat["solve_x_f64"], rtol=2e-3, atol=1e-8)
+    for Ta, Tb, want in zip(kat["rot_Ta"], kat["rot_Tb"], kat["rot_angle"]):
+        got = icp_mod.rotation_distance(Ta.reshape(4, 4).T, Tb.reshape(4, 4).T)
+        assert abs(got - want) <= 5e-7 + 2e-6 * want, (got, want)
+
+
 def _chain(mod, specs):
     arr = (mod.PointFilter * len(specs))()
     for a, (typ, dim, flag, v) in zip(arr, specs):

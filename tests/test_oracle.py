@@ -236,3 +236,44 @@ def test_input_filters_upstream_asymmetries(oracle):
     assert oracle.apply_point_filters(chain(1, 0, 1.0), pts[:0]) is None                          # empty cloud, non-empty chain
     empty_chain = (oracle.PointFilter * 0)()
     assert oracle.apply_point_filters(empty_chain, pts).shape[0] == 5 and oracle.apply_point_filters(empty_chain, pts[:0]).shape[0] == 0
+
+
+def _check_box_normals(kat, pts, nrm):
+    """Output of a SamplingSurfaceNormal filter (knn 8, ratio 1) on the KAT cloud against the numpy eigh normals."""
+    cloud, cl_of, want, kept = kat["box_cloud"], kat["box_cluster_of_point"], kat["box_normals"], kat["box_kept"]
+    key = {tuple(p[:3].tobytes() for p in [row])[0]: i for i, row in enumerate(cloud)}
+    idx = np.array([key[row[:3].tobytes()] for row in pts])
+    assert len(set(idx.tolist())) == idx.size                              # every output point is an input point, once
+    cl = cl_of[idx]
+    assert kept[cl].all() and idx.size == int(kept.sum()) * 8              # collinear boxes dropped, all others whole
+    dots = np.abs((nrm.astype(np.float64) * want[cl]).sum(1))
+    assert dots.min() > 1.0 - 1e-5, dots.min()                             # same normal up to sign
+    assert np.allclose(np.linalg.norm(nrm, axis=1), 1.0, atol=1e-5)
+
+
+def test_independent_known_answers(oracle):
+    """tests/golden/independent_kat.npz (numpy / scipy only, make_golden_independent.py) replayed on the oracle AND on the
+    product's host-side code: box normals, the 6x6 solve, the checker's rotation metric, the trim index.  The oracle and
+    the product share the restatement of this arithmetic; these vectors do not."""
+    from laser_slam_amd import icp
+    kat = np.load(os.path.join(os.path.dirname(GOLD), "independent_kat.npz"))
+    g = np.load(GOLD)
+    # box normals: oracle filter, product host filter
+    _check_box_normals(kat, *oracle.sampling_surface_normal(kat["box_cloud"], 8, 1.0, 0))
+    _check_box_normals(kat, *icp.sampling_surface_normal(kat["box_cloud"], 8, 1.0, 0))
+    # 6x6 solve: the oracle's x on the committed matches against numpy's Cholesky (float32 and float64)
+    mean = g["mean"]
+    ref_c = g["ref"].copy(); ref_c[:, :3] -= mean
+    Tm = g["T_init"].copy(); Tm[12:15] -= mean
+    q = oracle.transform_points(Tm, g["rd"])
+    rc, A, b, x, dT, used = oracle.point_to_plane(q, ref_c, g["nrm"], g["nn_ids"], g["nn_d2"], float(g["limit0"]), 1)
+    assert rc == 0 and np.allclose(A, g["A0"], rtol=1e-12)
+    assert np.allclose(x, kat["solve_x_f32"], rtol=2e-4, atol=1e-9) and np.allclose(x, kat["solve_x_f64"], rtol=2e-3, atol=1e-8)
+    # rotation metric of the differential checker
+    for Ta, Tb, want in zip(kat["rot_Ta"], kat["rot_Tb"], kat["rot_angle"]):
+        for got in (oracle.rotation_distance(Ta, Tb), icp.rotation_distance(Ta.reshape(4, 4).T, Tb.reshape(4, 4).T)):
+            assert abs(got - want) <= 5e-7 + 2e-6 * want, (got, want)
+    # trim index floor(n * ratio) over the matched pairs
+    for i in range(int(kat["trim_n"])):
+        rc, lim = oracle.trim_limit(kat[f"trim{i}_d2"], float(kat[f"trim{i}_ratio"]))
+        assert rc == 0 and np.float32(lim) == kat[f"trim{i}_limit"], i
