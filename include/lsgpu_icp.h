@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define LSGPU_ABI_VERSION 2
+#define LSGPU_ABI_VERSION 3
 
 /* Return codes.  NO_CONVERGENCE is PointMatcher::ConvergenceError: laser_track.cpp:499-502 catches it
  * and keeps the odometry guess; incremental_estimator.cpp:108 lets it propagate. */
@@ -81,6 +81,8 @@ typedef struct lsgpu_icp_stats {
   double  t_ne_ms;           /* sum over the iterations: normal equations + solve + checkers (profile_kernels=1) */
   int     committed_select_iterations;  /* iterations whose trim limit came from the search kernels' own tables (no select launch) */
   int     spread_tiles;                 /* 64-query tiles whose queries share no candidates (searched row-wise by the front of the tile kernel) */
+  int     reference_reused;             /* lsgpu_icp_align_batch: 1 if this pair kept the previous pair's reference structures (no set_reference) */
+  int     pad2_;
 } lsgpu_icp_stats;
 
 /* One record per iteration (optional parity/debug trace; replaces the VTKFileInspector dump of
@@ -117,7 +119,10 @@ int lsgpu_icp_align(lsgpu_icp* h, const float* reading_xyz1, int64_t nq, const f
  * must live on the same device.  rc[i] receives pair i's return code (LSGPU_NO_CONVERGENCE leaves
  * T_out[i] = T_init[i], like lsgpu_icp_align); the function returns the first non-OK, non-NO_CONVERGENCE
  * code, else LSGPU_NO_CONVERGENCE if any pair failed to converge, else LSGPU_OK.
- * T_init / T_out: 16 floats per pair, column major.  stats and rc may be NULL. */
+ * T_init / T_out: 16 floats per pair, column major.  stats and rc may be NULL.
+ * Reference reuse: a pair whose reference_xyz1[i], reference_normals[i] and n_reference[i] equal those of the previous
+ * pair of the same handle (pair i - n_handles) skips set_reference -- the sorted reference, chunks and cell tables depend
+ * on the reference alone (stats[i].reference_reused = 1 for such a pair).  Results are bit-identical either way. */
 int lsgpu_icp_align_batch(lsgpu_icp* const* handles, int n_handles, int64_t n_pairs,
                           const float* const* reference_xyz1, const float* const* reference_normals,
                           const int64_t* n_reference, const float* const* reading_xyz1,

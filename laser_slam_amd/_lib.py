@@ -71,6 +71,8 @@ class IcpStats(C.Structure):
         ("t_ne_ms", C.c_double),
         ("committed_select_iterations", C.c_int),
         ("spread_tiles", C.c_int),
+        ("reference_reused", C.c_int),
+        ("pad2_", C.c_int),
     ]
 
 

@@ -376,6 +376,11 @@ class ICP {
   using ComputeObserver = std::function<void(const ICP&, const DataPoints& reading, const DataPoints& reference,
                                              const TransformationParameters& T_init, const TransformationParameters& T)>;
   void setComputeObserver(ComputeObserver f) { observer_ = std::move(f); }
+  bool hasComputeObserver() const { return (bool)observer_; }
+  // the resident-scan path (computeClouds) never sees the assembled sub-map on the host; LaserTrack assembles it for the
+  // observer's benefit when (and only when) one is set
+  void notifyObserver(const DataPoints& reading, const DataPoints& reference, const TransformationParameters& T_init,
+                      const TransformationParameters& T) const { if (observer_) observer_(*this, reading, reference, T_init, T); }
   bool hasComputeOverride() const { return (bool)override_; }
 #else
   bool hasComputeOverride() const { return false; }

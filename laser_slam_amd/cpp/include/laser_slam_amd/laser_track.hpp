@@ -360,6 +360,14 @@ class LaserTrack {
         std::vector<int> slots;
         for (size_t m : members) slots.push_back(deviceSlot(m));
         solution = icp_.computeClouds(deviceSlot(n - 1), slots, member_T, T_init);
+#ifdef LSGPU_TEST_SEAMS
+        if (icp_.hasComputeObserver()) {   // parity drivers: hand the observer the clouds the device just matched
+          DataPoints sub_map = laser_scans_[members[0]].scan;
+          for (size_t i = 1; i < members.size(); ++i)
+            sub_map.concatenate(RigidTransformation::compute(laser_scans_[members[i]].scan, member_T[i]));
+          icp_.notifyObserver(last_scan.scan, sub_map, T_init, solution);
+        }
+#endif
       } else {
         DataPoints sub_map = laser_scans_[members[0]].scan;
         for (size_t i = 1; i < members.size(); ++i)

@@ -1757,13 +1757,25 @@ int lsgpu_icp_align_batch(lsgpu_icp* const* handles, int n_handles, int64_t n_pa
   // deterministic {set_reference, align} on that handle's stream
   auto worker = [&](int k) {
     lsgpu_icp* h = handles[k];
+    // Reference reuse (the part that is exact): a pair that names the SAME reference buffers as the
+    // previous pair of this handle (same pointers, same size -- many readings against one map, loop-closure candidates
+    // against one sub-map) keeps the centred, sorted reference, its chunks and its cell tables: steps 2-3 of ICP::compute
+    // depend on the reference alone.  Bit-identical with rebuilding (tests/test_gpu_parity.py::
+    // test_align_batch_reuses_a_shared_reference).
+    const float* have_ref = nullptr; const float* have_nrm = nullptr; int64_t have_n = -1;
     for (int64_t i = k; i < n_pairs; i += n_handles) {
       float* To = T_out + 16 * i;
       const float* Ti = T_init + 16 * i;
       std::memcpy(To, Ti, 16 * sizeof(float));
       if (stats) std::memset(&stats[i], 0, sizeof(lsgpu_icp_stats));
-      int c = lsgpu_icp_set_reference(h, reference_xyz1[i], reference_normals[i], n_reference[i]);
+      int c = LSGPU_OK;
+      const bool same = have_n > 0 && reference_xyz1[i] == have_ref && reference_normals[i] == have_nrm && n_reference[i] == have_n;
+      if (!same) {
+        c = lsgpu_icp_set_reference(h, reference_xyz1[i], reference_normals[i], n_reference[i]);
+        have_ref = reference_xyz1[i]; have_nrm = reference_normals[i]; have_n = c == LSGPU_OK ? n_reference[i] : -1;
+      }
       if (c == LSGPU_OK) c = lsgpu_icp_align(h, reading_xyz1[i], n_reading[i], Ti, To, stats ? &stats[i] : nullptr);
+      if (stats) stats[i].reference_reused = same ? 1 : 0;
       codes[(size_t)i] = c;
     }
   };

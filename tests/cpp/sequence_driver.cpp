@@ -6,7 +6,13 @@
 // 133-176); loop closures go through IncrementalEstimator::processLoopClosure with the ICP step
 // (incremental_estimator.cpp:89-115).
 //
-//   usage: sequence_driver <icp_yaml> <nscan_in_sub_map> <lc_radius> <backends: dev|ora|both|shadow> <oracle_threads> < stream
+//   usage: sequence_driver <icp_yaml> <nscan_in_sub_map> <lc_radius> <backends: dev|ora|both|shadow> <oracle_threads>
+//                          [scans_on_device (default: 16, 0 in shadow mode)] [draws: reseed (default) | continue] < stream
+// scans_on_device > 0 keeps the track's scans in HBM and assembles the sub-maps there (lsgpu_icp_compute_clouds), also in
+// shadow mode (the oracle is then fed a host assembly of the same scans and transforms).  draws = continue: the filters'
+// draw stream is seeded ONCE, before the first ICP call, and then runs on across all calls of the sequence -- track ICP
+// and loop-closure ICP alike -- the way consecutive rand() calls do in the reference process; the oracle's libc stream
+// is seeded the same way and consumes the same draws call by call (shadow / single-backend modes only).
 // "both": two independent runs (each feeds its own estimates back into its sub-maps and initial guesses).  "shadow":
 // the device run drives; at every ICP call the oracle aligns the SAME clouds from the SAME guess ("call" lines), and a
 // second pose graph receives the device run's factors with the oracle's transforms in place of the device's
@@ -85,6 +91,8 @@ int main(int argc, char** argv) {
   if (argc < 6) { std::fprintf(stderr, "usage: see the header comment\n"); return 2; }
   const std::string yaml = argv[1], which = argv[4];
   g_oracle_threads = std::atoi(argv[5]);
+  const int scans_on_device_arg = argc > 6 ? std::atoi(argv[6]) : -1;
+  const bool continue_draws = argc > 7 && std::string(argv[7]) == "continue";
   if (const char* e = std::getenv("LSGPU_SEQ_PERTURB")) std::sscanf(e, "%ld:%lf", &g_perturb_call, &g_perturb_eps);
   EstimatorParams ep;
   LaserTrackParams& p = ep.laser_track_params;
@@ -108,6 +116,7 @@ int main(int argc, char** argv) {
       r.name = name;
       EstimatorParams e = ep;
       if (oracle || which == "shadow") e.laser_track_params.scans_on_device = 0;  // host sub-map assembly (bit-identical results)
+      if (!oracle && scans_on_device_arg >= 0) e.laser_track_params.scans_on_device = scans_on_device_arg;
       r.est.reset(new IncrementalEstimator(e, 1u));
       r.track = r.est->getLaserTrack(0);
       r.track->icp().setSeed(7);             // every compute() reseeds the filters' draw stream: both back ends
@@ -135,6 +144,10 @@ int main(int argc, char** argv) {
                          const TransformationParameters& T_init, const TransformationParameters& T_dev) {
         sha_T = oracleCompute(self, reading, reference, T_init);
         sha_have = true;
+        if (continue_draws) {   // both streams were seeded by this first pair of calls; from here on they run on
+          runs[0].track->icp().setSeed(-1);
+          runs[0].est->loopClosureIcp().setSeed(-1);
+        }
         const SE3 a = SE3::fromTransformationMatrix(T_dev.data()), b = SE3::fromTransformationMatrix(sha_T.data());
         printPose("call", "dev", n_calls, self.lastStats().iterations, g_last_oracle_iterations, a);
         printPose("call", "ora", n_calls, self.lastStats().iterations, g_last_oracle_iterations, b);

@@ -506,6 +506,84 @@ def test_align_batch_matches_sequential(icp_mod, oracle):
     assert dt <= TOL_T and dr <= TOL_R, (dt, dr)
 
 
+def test_align_batch_reuses_a_shared_reference(icp_mod):
+    """SURVEY.md §8f N1, the reuse that is exact: several readings against ONE filtered reference (loop-closure candidates
+    against one sub-map, several robots against one map).  Pairs that name the same reference buffers as the previous
+    pair of their handle skip set_reference (stats.reference_reused) and give bit-identical transforms, iteration
+    counts and limits to rebuilding the reference for every pair."""
+    ref, rd0, _Tt, Ti0 = synth.scan_pair(512)
+    rf, rn = icp_mod.sampling_surface_normal(ref, 10, 1.0, 0)
+    rds, Tis = [rd0], [Ti0]
+    for i in range(1, 6):                                  # five more readings of the same scene, other noise / guesses
+        _r, rd, _t, Ti = synth.scan_pair(512, noise_seeds=(1, 50 + i), guess_seed=90 + i)
+        rds.append(rd); Tis.append(Ti)
+    seq = []
+    with icp_mod.IcpHandle() as h:
+        for rd, Ti in zip(rds, Tis):
+            h.set_reference(rf, rn)                        # rebuilt every time
+            T, st = h.align(rd, Ti)
+            seq.append((T, st.iterations, st.final_limit, st.final_n_used))
+    for pool in (1, 2):
+        hs = [icp_mod.IcpHandle() for _ in range(pool)]
+        T, st, rc = icp_mod.align_batch(hs, [rf] * 6, [rn] * 6, rds, Tis)
+        for h in hs:
+            h.close()
+        assert list(rc) == [0] * 6
+        assert [s.reference_reused for s in st] == [0] * pool + [1] * (6 - pool)
+        for i in range(6):
+            assert np.array_equal(T[i], seq[i][0]) and (st[i].iterations, st[i].final_limit, st[i].final_n_used) == seq[i][1:], (pool, i)
+    # a different buffer with the same content is NOT assumed equal (the library compares pointers, never contents)
+    hs = [icp_mod.IcpHandle()]
+    T2, st2, _ = icp_mod.align_batch(hs, [rf, rf.copy()], [rn, rn], rds[:2], Tis[:2])
+    hs[0].close()
+    assert [s.reference_reused for s in st2] == [0, 0] and np.array_equal(T2[1], seq[1][0])
+
+
+@pytest.mark.timeout(900)
+def test_config2_batch_at_size(icp_mod):
+    """BASELINE configs[2] at its real pair size on one GPU: 32 independent pairs of 200 k-point scans (64 x 3125 rays)
+    through lsgpu_icp_align_batch on a pool of 8 handles == the same pairs one after the other on one handle, bit for
+    bit (transform, iteration count, final limit and inlier count); every pair recovers the synthetic motion; and a
+    sampled brute-force check of one pair's first correspondence search (no oracle at this size)."""
+    import torch
+    B, n_az = 32, 3125
+    refs, nrms, rds, Tis, truths = [], [], [], [], []
+    with icp_mod.IcpHandle() as hf:
+        for i in range(B):
+            ref, rd, Tt, Ti = synth.scan_pair(n_az, noise_seeds=(1000 + i, 2000 + i), guess_seed=1000 + i)
+            rf, rn = hf.filter_reference(torch.from_numpy(ref).cuda(), 10, 1.0, 0)      # device filter == host filter == oracle
+            refs.append(rf.contiguous().clone()); nrms.append(rn.contiguous().clone())
+            rds.append(torch.from_numpy(rd).cuda()); Tis.append(Ti); truths.append(Tt)
+    torch.cuda.synchronize()
+    assert 150_000 < rds[0].shape[0] < 210_000
+    seq = []
+    with icp_mod.IcpHandle() as h:
+        for i in range(B):
+            h.set_reference(refs[i], nrms[i])
+            T, st = h.align(rds[i], Tis[i])
+            seq.append((T, st.iterations, st.final_limit, st.final_n_used))
+        # sampled brute force on pair 0's search at the initial guess
+        h.set_reference(refs[0], nrms[0])
+        mean = h.reference_mean()
+        Tm = synth.colmajor(Tis[0]).copy(); Tm[12:15] -= mean
+        rd0 = rds[0].cpu().numpy()
+        ids, d2 = h.knn(rd0, Tm)
+        q = h.transform_points(Tm, rd0)
+        ref_c = refs[0].cpu().numpy()[:, :3] - mean
+        pick = np.random.default_rng(0).choice(rd0.shape[0], 128, replace=False)
+        D = ((q[pick, None, :3].astype(np.float64) - ref_c[None, :, :]) ** 2).sum(-1)
+        assert (D.min(1) >= d2[pick] * (1 - 1e-5)).all() and np.allclose(D[np.arange(128), ids[pick]], d2[pick], rtol=1e-5, atol=1e-12)
+    hs = [icp_mod.IcpHandle() for _ in range(8)]
+    T, st, rc = icp_mod.align_batch(hs, refs, nrms, rds, Tis)
+    for h in hs:
+        h.close()
+    assert list(rc) == [0] * B
+    for i in range(B):
+        assert np.array_equal(T[i], seq[i][0]) and (st[i].iterations, st[i].final_limit, st[i].final_n_used) == seq[i][1:], i
+        dt, dr = synth.pose_error(T[i].astype(np.float64), truths[i])
+        assert dt < 0.03 and dr < 2e-3, (i, dt, dr)            # the scene's own accuracy (2 cm range noise), not a parity bound
+
+
 # ---- SURVEY.md §8f N1 / N3: the sampling filters and the whole of ICP::compute on the device
 
 @pytest.mark.parametrize("n_az,knn,ratio,seed", [(64, 10, 0.5, 3), (256, 10, 1.0, 0), (1024, 7, 0.5, 11),

@@ -84,10 +84,10 @@ def _T(v):
     return T
 
 
-def run_driver(exe, stream, nscan, lc_radius, backends, threads, timeout, yaml=YAML):
+def run_driver(exe, stream, nscan, lc_radius, backends, threads, timeout, yaml=YAML, extra=()):
     with open(stream, "rb") as f:
-        r = subprocess.run([exe, yaml, str(nscan), str(lc_radius), backends, str(threads)], stdin=f, capture_output=True,
-                           text=True, timeout=timeout)
+        r = subprocess.run([exe, yaml, str(nscan), str(lc_radius), backends, str(threads), *[str(e) for e in extra]], stdin=f,
+                           capture_output=True, text=True, timeout=timeout)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     out = {}
     for line in r.stdout.splitlines():
@@ -190,3 +190,37 @@ def test_config4_sequence_gpu_icp_vs_oracle_icp(tmp_path):
     assert len(beyond) <= 0.005 * len(ce) and report["max_call_dt_m"] <= 1e-3, report
     assert between <= 1e-3, report
     assert e_dev < e_dead / 5 and e_sha < e_dead / 5, report
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(900)
+def test_config4_resident_scans_and_continuing_draws(tmp_path):
+    """What the 2000-pose run above does not exercise: the track's scans RESIDENT in HBM with the
+    sub-maps assembled on the device (scans_on_device = 16, lsgpu_icp_compute_clouds), and ONE draw stream that runs on
+    across every ICP call of the sequence -- lidar odometry and loop closures alike -- like consecutive rand() calls in
+    the reference process, instead of a reseed per call.  400 poses with the yaml chain (RandomSampling 0.5 /
+    SamplingSurfaceNormal ratio 0.5: every call consumes draws), 3-scan sub-maps, two loop closures, shadow mode: the
+    oracle aligns a host assembly of the same scans from the same guess with its own libc stream seeded the same way.
+    A single draw out of step would change every later filter output; asserted per call as in the long run."""
+    exe = _build(tmp_path)
+    n = 400
+    lcs = {n // 2: [0], n - 1: [n // 2 - 1]}
+    stream = str(tmp_path / "stream.bin")
+    truth, odom = make_stream(stream, n, 256, lcs, min(32, os.cpu_count() or 1))
+    out = run_driver(exe, stream, 3, 2, "shadow", min(32, os.cpu_count() or 1), 800, YAML_TIGHT, extra=(16, "continue"))
+    calls_d, calls_o = out["dev"]["call"], out["ora"]["call"]
+    assert len(calls_d) == len(calls_o) == (n - 1) + len(lcs)
+    ce = [synth.pose_error(d[3], o[3]) for d, o in zip(calls_d, calls_o)]
+    beyond = [e for e in ce if e[0] > 1e-4 or e[1] > 1e-5]
+    dev, sha = [p[3] for p in out["dev"]["pose"]], [p[3] for p in out["sha"]["pose"]]
+    report = {"poses": n, "icp_calls": len(ce), "n_calls_beyond": len(beyond), "max_call_dt_m": max(e[0] for e in ce),
+              "max_call_dr_rad": max(e[1] for e in ce), "calls_with_different_iteration_count": sum(1 for d in calls_d if d[1] != d[2]),
+              "rmse_gpu_vs_cpu_reference_m": _rmse(dev, sha), "rmse_gpu_vs_truth_m": _rmse(dev, truth),
+              "rmse_dead_reckoning_m": _rmse(odom, truth), "scans_on_device": 16, "draws": "one continuing stream"}
+    print("config4 (resident scans, continuing draws):", report)
+    import json
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    with open(os.path.join(ROOT, "gpurun_out", "config4_resident_continue.json"), "w") as f:
+        json.dump(report, f, indent=1)
+    assert len(beyond) <= 0.005 * len(ce) and report["max_call_dt_m"] <= 1e-3, report
+    assert report["rmse_gpu_vs_cpu_reference_m"] <= 1e-3, report
