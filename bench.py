@@ -3,15 +3,24 @@
 
     python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
-        --master-port P bench.py --gpus N --steps K --warmup W
+        --master-port P bench.py --gpus N --steps K --warmup W [--batch | --split]
 
-A step = one pass of the hot path over one scan pair: steps 2-7 of PointMatcher::ICP::compute as
-called at laser_slam/src/laser_track.cpp:496 -- centre the reference + build the voxel grid, then
-iterate {transform, exact 1-NN, trimmed weights, point-to-plane 6x6} until the (tightened, 1e-4 m /
-1e-5 rad) differential checker stops it.  Inputs (filtered reading, filtered reference + normals) are
-resident in HBM when the timed region starts.  Workload = BASELINE.json configs[1]: one synthetic
-HDL-64E pair of 64 x 16384 rays, full-density chain (F).  With N > 1 every rank
-registers its own pair (embarrassingly parallel, no data-path collective; "weak" scaling).
+Default workload = BASELINE.json configs[1]: one synthetic HDL-64E pair of 64 x 16384 rays, full-density chain (F)
+(SURVEY.md §8d).  A step = one WHOLE `icp_.compute(reading, reference, T_init)` as laser_slam calls it
+(laser_slam/src/laser_track.cpp:496) = lsgpu_icp_compute: reference filter (SamplingSurfaceNormal), centring + voxel
+grid, reading filter, then {transform, exact 1-NN, trimmed weights, point-to-plane 6x6} until the (tightened, 1e-4 m /
+1e-5 rad) differential checker stops it -- on RAW clouds that are resident in HBM when the timed region starts.
+`value` = scans/s of that step.  Reported beside it in the same line:
+  value_loop  the resident loop alone (set_reference + align on already filtered clouds: the north-star kernels)
+  value_e2e   the same compute handed HOST buffers (H2D + D2H inclusive; pageable / pinned) -- never `value`
+With N > 1 every rank registers its own pair (embarrassingly parallel, no data-path collective; "weak" scaling).
+
+--batch  BASELINE configs[2]: ONE step = 256 independent 200 k-point pairs (64 x 3125 rays), pair i -> rank i mod N
+         (sharding.pairs_of_rank), each rank runs its share through lsgpu_icp_align_batch on a pool of handles; no
+         collective; value = pairs/s over all ranks ("strong": the batch is fixed).
+--split  BASELINE configs[3]: ONE 8.4 M-point local map (8 scans in one frame) vs ONE 1 M-point scan per step, the
+         reading sharded over the ranks, RCCL all-reduce of the select tables + 29 f64 per iteration; value = scans/s
+         ("strong").  --split-pair uses the configs[1] pair instead (what round 2 measured on one rank).
 
 Prints ONE JSON line on rank 0.
 """
@@ -19,6 +28,7 @@ from __future__ import annotations
 
 import argparse
 import ctypes as C
+import hashlib
 import json
 import os
 import sys
@@ -32,6 +42,17 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s peak
 
 
+def csrc_digest() -> str:
+    """sha256 over the kernel sources: artifacts measured out of band (PMC passes) carry it and are refused if stale."""
+    d = hashlib.sha256()
+    base = os.path.join(ROOT, "laser_slam_amd", "csrc")
+    for name in sorted(os.listdir(base)):
+        if name.endswith((".h", ".hip", ".cpp")):
+            d.update(name.encode())
+            d.update(open(os.path.join(base, name), "rb").read())
+    return d.hexdigest()[:16]
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -41,11 +62,13 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=1)
     ap.add_argument("--no-compute-e2e", action="store_true",
-                    help="skip the compute_with_filters section (used for the rocprofv3 run, so that the kernel\n"
-                         "averages of the profile cover the benchmark workload only)")
-    ap.add_argument("--split", action="store_true",
-                    help="BASELINE config 4 layout: ONE scan pair per step, its reading sharded over the ranks, "
-                         "RCCL all-reduce of the select histograms + 6x6 sums (strong scaling)")
+                    help="skip the value_loop / value_e2e sections (used for the rocprofv3 runs, so that the kernel\n"
+                         "averages of the profile cover the timed workload only)")
+    ap.add_argument("--batch", action="store_true", help="BASELINE configs[2]: 256 x 200 k-point pairs sharded over the ranks")
+    ap.add_argument("--batch-pairs", type=int, default=256)
+    ap.add_argument("--batch-handles", type=int, default=16)
+    ap.add_argument("--split", action="store_true", help="BASELINE configs[3]: one 8.4 M local map vs one 1 M scan, reading sharded, RCCL")
+    ap.add_argument("--split-pair", action="store_true", help="(with --split) the configs[1] pair instead of the 8-scan local map")
     args = ap.parse_args()
 
     import torch
@@ -61,29 +84,113 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
-    from laser_slam_amd import synth, icp
+    from laser_slam_amd import synth, icp, sharding
     from laser_slam_amd._lib import IcpConfig, lib
 
-    # ---- synthetic workload (host), then resident in HBM
-    data_rank = 0 if args.split else rank   # split: every rank works on the SAME pair
-    ref, rd, T_true, T_init = synth.scan_pair(args.n_az, noise_seeds=(1 + 2 * data_rank, 2 + 2 * data_rank),
-                                              guess_seed=7 + data_rank)
-    raw_ref, raw_rd = ref, rd
-    with icp.IcpHandle(None, local_rank) as hf:               # chain (F): ratio 1.0, knn 10; the device filter
-        d_ref, d_nrm = hf.filter_reference(torch.from_numpy(ref).cuda(), 10, 1.0, 0)  # == host filter == oracle
-    d_ref, d_nrm = d_ref.contiguous().clone(), d_nrm.contiguous().clone()
-    rf, rn = d_ref.cpu().numpy(), d_nrm.cpu().numpy()
-    if args.split:
-        from laser_slam_amd import sharding
-        rd = rd[sharding.split_shard(rd.shape[0], rank, world)]
-    d_rd = torch.from_numpy(rd).cuda()
-    torch.cuda.synchronize()
-    nq, nr = rd.shape[0], rf.shape[0]
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def max_over_ranks(x):
+        if world == 1:
+            return x
+        t = torch.tensor([x], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
 
     cfg = IcpConfig()
     lib().lsgpu_icp_config_yaml(C.byref(cfg))
     cfg.min_diff_rot, cfg.min_diff_trans = 1e-5, 1e-4        # configs[1]: "to 1e-4 m tolerance"
     cfg.profile_kernels = 0
+
+    base = {"n_gpus": world, "steps": args.steps, "warmup": args.warmup, "higher_is_better": True, "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic", "csrc_sha": csrc_digest()}
+
+    # ------------------------------------------------------------------------------------------ configs[2]: --batch
+    if args.batch:
+        cfgy = IcpConfig()
+        lib().lsgpu_icp_config_yaml(C.byref(cfgy))          # the yaml checker (1e-3 rad / 1e-2 m), as configs[2] does not tighten it
+        mine = sharding.pairs_of_rank(args.batch_pairs, rank, world)
+        uniq = {}
+        with icp.IcpHandle(None, local_rank) as hf:
+            for u in sorted({i % 16 for i in mine}):        # 16 distinct scenes' worth of scans, cycled over the batch
+                ref, rd, Tt, Ti = synth.scan_pair(3125, noise_seeds=(1000 + u, 2000 + u), guess_seed=1000 + u)
+                rf, rn = hf.filter_reference(torch.from_numpy(ref).cuda(), 10, 1.0, 0)
+                uniq[u] = (rf.contiguous().clone(), rn.contiguous().clone(), torch.from_numpy(rd).cuda(), Ti, Tt)
+        # every pair owns its buffers: equal POINTERS would let align_batch keep a shared reference's structures, which
+        # independent pairs do not have
+        pairs = [(uniq[i % 16][0].clone(), uniq[i % 16][1].clone(), uniq[i % 16][2].clone(), uniq[i % 16][3], uniq[i % 16][4]) for i in mine]
+        refs, nrms, rds, Tis, Tts = map(list, zip(*pairs)) if pairs else ([], [], [], [], [])
+        hs = [icp.IcpHandle(cfgy, local_rank) for _ in range(args.batch_handles)]
+        torch.cuda.synchronize()
+
+        def step_batch():
+            return icp.align_batch(hs, refs, nrms, rds, Tis) if pairs else (None, [], np.zeros(0, np.int32))
+
+        for _ in range(args.warmup):
+            step_batch()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            T, st, rc = step_batch()
+        barrier()
+        elapsed = max_over_ranks(time.perf_counter() - t0)
+        err = max((synth.pose_error(T[i].astype(np.float64), Tts[i])[0] for i in range(len(pairs))), default=0.0)
+        out = dict(base, metric="scan_pairs_per_sec", value=args.batch_pairs * args.steps / elapsed, unit="pairs/s",
+                   ms_per_step=elapsed / args.steps * 1e3, scaling="strong",
+                   config={"workload": "configs[2]: batch of %d independent 200 k-point scan pairs (64 x 3125 rays, chain F clouds "
+                                       "resident in HBM, yaml checker), lsgpu_icp_align_batch on %d handles per rank"
+                                       % (args.batch_pairs, args.batch_handles),
+                           "pairs_per_rank": len(mine), "points_per_cloud": int(rds[0].shape[0]) if pairs else 0,
+                           "distinct_scan_pairs": 16, "sharding": "pair i -> rank i mod N (sharding.pairs_of_rank), no collective"},
+                   iterations_per_pair=float(np.mean([s.iterations for s in st])) if pairs else 0.0,
+                   max_trans_err_m_rank0=err, not_converged_rank0=int((rc != 0).sum()))
+        if rank == 0:
+            print(json.dumps(out))
+        for h in hs:
+            h.close()
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    # ------------------------------------------------------------------------------------------ workload clouds (host)
+    data_rank = 0 if args.split else rank   # split: every rank works on the SAME pair
+    ref, rd, T_true, T_init = synth.scan_pair(args.n_az, noise_seeds=(1 + 2 * data_rank, 2 + 2 * data_rank),
+                                              guess_seed=7 + data_rank)
+    raw_ref, raw_rd = ref, rd
+    workload = ("configs[1]: single 1M-point HDL-64E scan pair (64x%d rays), full-density chain F, point-to-plane ICP, "
+                "differential checker 1e-4 m / 1e-5 rad" % args.n_az)
+    if args.split and not args.split_pair:
+        # configs[3]: the local map = 8 scans along the trajectory in the frame of the newest one, the reading = the next scan
+        scene = synth.Scene(1234)
+        step_T = synth.se3(0.8, 0.05, 0.0, yaw=np.deg2rad(2.0), pitch=np.deg2rad(0.2))
+        poses = [synth.se3(0.0, 0.0, synth.SENSOR_HEIGHT)]
+        for _ in range(8):
+            poses.append(poses[-1] @ step_T)
+        clouds = []
+        for i in range(8):
+            s = synth.hdl64_scan(scene, poses[i], args.n_az, 100 + i)
+            Trel = np.linalg.inv(poses[7]) @ poses[i]
+            s[:, :3] = (s[:, :3].astype(np.float64) @ Trel[:3, :3].T + Trel[:3, 3]).astype(np.float32)
+            clouds.append(s)
+        ref = np.concatenate(clouds)
+        rd = synth.hdl64_scan(scene, poses[8], args.n_az, 200)
+        T_true = step_T
+        T_init = synth.scan_pair(64)[3]   # the same perturbed guess as configs[1] (same step between the poses)
+        raw_ref, raw_rd = ref, rd
+        workload = ("configs[3]: 8-scan local map (%d points after the reference filter's input) vs one 64x%d-ray scan, reading "
+                    "sharded over the ranks" % (ref.shape[0], args.n_az))
+    with icp.IcpHandle(None, local_rank) as hf:               # chain (F): ratio 1.0, knn 10; the device filter
+        d_ref, d_nrm = hf.filter_reference(torch.from_numpy(ref).cuda(), 10, 1.0, 0)  # == host filter == oracle
+    d_ref, d_nrm = d_ref.contiguous().clone(), d_nrm.contiguous().clone()
+    if args.split:
+        rd = rd[sharding.split_shard(rd.shape[0], rank, world)]
+    d_rd = torch.from_numpy(rd).cuda()
+    d_raw_ref, d_raw_rd = torch.from_numpy(raw_ref).cuda(), torch.from_numpy(raw_rd).cuda()
+    torch.cuda.synchronize()
+    nq, nr = rd.shape[0], int(d_ref.shape[0])
+
     h = icp.IcpHandle(cfg, local_rank)
     # second handle, identical but with a HIP-event pair around every kNN launch: used for a few extra
     # steps right after the timed region (event records inside the timed region cost ~5 % throughput)
@@ -95,37 +202,51 @@ def main():
         for hh in (h, hp):
             sharding.init_split_comm(hh, device="cuda")
 
-    def step(hh=h):
+    def step_loop(hh=h):       # the resident loop: steps 2-7 of ICP::compute on filtered clouds
         hh.set_reference(d_ref, d_nrm)
         return hh.align(d_rd, T_init)
 
-    def barrier():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
+    def step_compute():        # the whole ICP::compute on raw clouds resident in HBM (both filters included)
+        return h.compute(d_raw_rd, d_raw_ref, T_init, 1.0, 10, 1.0, seed=0)
 
+    step = step_loop if args.split else step_compute
     for _ in range(args.warmup):
         step()
     barrier()
     t0 = time.perf_counter()
     iters = 0
-    sel_ms = ne_ms = 0.0
-    knn_ms = knn_main_ms = knn_fb_ms = 0.0
-    knn_launches = 0
-    align_ms = 0.0
-    strag = 0
+    filt_ms = 0.0
     T = None
     for _ in range(args.steps):
         T, st = step()
         iters += st.iterations
-        align_ms += st.t_total_ms
+        filt_ms += st.t_reserved[0]
     barrier()
-    elapsed = time.perf_counter() - t0
-    # kernel timing for the roofline: same workload, same kernels, HIP events on the handle's stream
+    elapsed = max_over_ranks(time.perf_counter() - t0)
+
+    # ---- the resident loop alone (value_loop), then the profiled steps for the rooflines
+    loop_steps = max(1, min(args.steps, 10))
+    value_loop = None
+    align_ms, loop_iters = 0.0, 0
+    if not args.split and not args.no_compute_e2e:
+        step_loop(); step_loop()
+        torch.cuda.synchronize()
+        tl = time.perf_counter()
+        for _ in range(loop_steps):
+            Tl, stl = step_loop()
+            align_ms += stl.t_total_ms
+            loop_iters += stl.iterations
+        torch.cuda.synchronize()
+        tl = time.perf_counter() - tl
+        value_loop = {"value": loop_steps / tl, "unit": "scans/s", "ms_per_scan": tl / loop_steps * 1e3,
+                      "ms_per_icp_iteration": align_ms / max(loop_iters, 1), "iterations": loop_iters / loop_steps,
+                      "workload": "set_reference + align on the FILTERED clouds resident in HBM (steps 2-7 of ICP::compute: the north-star kernels)"}
     prof_steps = max(1, min(args.steps, 3))
-    step(hp)
+    sel_ms = ne_ms = knn_ms = knn_main_ms = knn_fb_ms = 0.0
+    knn_launches = strag = 0
+    step_loop(hp)
     for _ in range(prof_steps):
-        Tp, stp = step(hp)
+        Tp, stp = step_loop(hp)
         knn_ms += stp.t_knn_ms
         knn_main_ms += stp.t_knn_main_ms
         knn_fb_ms += stp.t_knn_fallback_ms
@@ -133,32 +254,24 @@ def main():
         strag += stp.stragglers
         sel_ms += stp.t_select_ms
         ne_ms += stp.t_ne_ms
-    assert np.array_equal(Tp, T)
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    loop_equals_compute = bool(np.array_equal(Tp, T))   # (chain F keeps every point: the loop on filtered clouds is the same alignment)
 
-    # ---- the whole ICP::compute (both filters + set_reference + align) on the raw clouds, SURVEY.md §8d
-    # variants P (icp_default.yaml chain: prob 0.5 / ratio 0.5) and F (full density): reported, not `value`
-    end_to_end = None
+    # ---- the same compute handed HOST buffers (H2D + D2H inclusive), chains F and P, pageable and pinned
     value_e2e = None
+    variants = None
     if not args.split and not args.no_compute_e2e:
-        d_raw_ref, d_raw_rd = torch.from_numpy(raw_ref).cuda(), torch.from_numpy(raw_rd).cuda()
-        torch.cuda.synchronize()
-        end_to_end = {}
-        for name, prob, ratio in (("P_yaml_chain", 0.5, 0.5), ("F_full_density", 1.0, 1.0)):
+        variants = {}
+        for name, prob, ratio in (("P_yaml_chain", 0.5, 0.5),):
             ts = []
             for rep in range(4):
                 tc0 = time.perf_counter()
                 Te, ste = h.compute(d_raw_rd, d_raw_ref, T_init, prob, 10, ratio, seed=0)
                 ts.append((time.perf_counter() - tc0) * 1e3)
-            end_to_end[name] = {"ms_per_compute": float(np.median(ts[1:])), "filters_and_grid_ms": ste.t_reserved[0],
-                                "iterations": ste.iterations, "n_reference_after_filter": int(h.info().n_reference),
-                                "trans_err_m": synth.pose_error(Te.astype(np.float64), T_true)[0]}
-        # SURVEY.md §8d's inclusive figure: the whole ICP::compute (lsgpu_icp_compute) handed HOST buffers, i.e. H2D of
-        # both raw clouds + both filters + grid + loop + D2H of the transform, from pageable and from pinned memory
-        value_e2e = {"workload": "lsgpu_icp_compute on host buffers (raw 1M-point clouds): H2D + reference filter + grid + "
+            variants[name] = {"ms_per_compute": float(np.median(ts[1:])), "scans_per_s": 1e3 / float(np.median(ts[1:])),
+                              "filters_and_grid_ms": ste.t_reserved[0], "iterations": ste.iterations,
+                              "n_reference_after_filter": int(h.info().n_reference),
+                              "trans_err_m": synth.pose_error(Te.astype(np.float64), T_true)[0]}
+        value_e2e = {"workload": "lsgpu_icp_compute on HOST buffers (raw 1M-point clouds): H2D + reference filter + grid + "
                                  "reading filter + loop + D2H", "unit": "scans/s"}
         p_ref, p_rd = torch.from_numpy(raw_ref).pin_memory(), torch.from_numpy(raw_rd).pin_memory()
         for chain, prob, ratio in (("F_full_density", 1.0, 1.0), ("P_yaml_chain", 0.5, 0.5)):
@@ -179,52 +292,60 @@ def main():
     b_knn = 24 * nq + 16 * nr + 8 * ncell
     t_knn = knn_ms / max(knn_launches, 1) * 1e-3
     achieved = b_knn / t_knn / 1e9 if t_knn > 0 else 0.0
-    traffic = None
+    # HBM traffic of the kernel: PMC counters cannot be read from inside the process, so the figure comes from the
+    # artifact of the separate rocprofv3 --pmc passes (devtools/gpu_check.sh pmc) -- only if it was measured on THESE
+    # kernel sources (csrc_sha) and this workload; otherwise null
+    traffic, traffic_note = None, "no PMC artifact for these kernel sources (profiles/knn_traffic.json csrc_sha mismatch or absent)"
     tpath = os.path.join(ROOT, "profiles", "knn_traffic.json")
-    if os.path.exists(tpath):
+    if os.path.exists(tpath) and not args.split:
         try:
             tj = json.load(open(tpath))
-            if tj.get("n_az") == args.n_az:
+            if tj.get("n_az") == args.n_az and tj.get("csrc_sha") == base["csrc_sha"]:
                 traffic = tj.get("hbm_bytes_per_launch")
+                traffic_note = "profiles/knn_traffic.json (separate --pmc FETCH_SIZE / WRITE_SIZE passes on these kernel sources)"
         except Exception:
             traffic = None
 
     et, er = synth.pose_error(T.astype(np.float64), T_true)
-    out = {
-        "metric": "scans_per_sec",
-        "value": (1 if args.split else world) * args.steps / elapsed,
-        "unit": "scans/s",
-        "n_gpus": world,
-        "steps": args.steps,
-        "warmup": args.warmup,
-        "ms_per_step": elapsed / args.steps * 1e3,
-        "ms_per_icp_iteration": align_ms / max(iters, 1),
-        "icp_iterations_per_scan": iters / args.steps,
-        "higher_is_better": True,
-        "scaling": "strong" if args.split else "weak",
-        "vs_baseline": None,
-        "dtype": "f32",
-        "data": "synthetic",
-        "config": {"workload": "configs[1]: single 1M-point HDL-64E scan pair (64x%d rays), full-density "
-                               "chain F, point-to-plane ICP, differential checker 1e-4 m / 1e-5 rad" % args.n_az,
-                   "n_reading": nq, "n_reference": nr, "pairs_per_gpu_per_step": 1,
-                   "sharding": ("one scan pair per step, reading sharded over ranks, RCCL all-reduce of 3x2048 u32 + 29 f64 "
-                                "per iteration" if args.split else "one scan pair per rank, no collective")},
-        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                     "kernel": "k_knn_tile (+ k_knn_fallback / k_knn_rowq where a launch hands queries over: the first three iterations) -- exact 1-NN correspondence search",
-                     "algorithmic_bytes_per_launch": b_knn,
-                     "avg_launch_us": t_knn * 1e6,
-                     "avg_main_us": knn_main_ms / max(knn_launches, 1) * 1e3,
-                     "avg_fallback_us": knn_fb_ms / max(knn_launches, 1) * 1e3,
-                     "launches": knn_launches, "timed_in": "%d extra profiled steps after the timed region" % prof_steps,
-                     "occupied_cells": ncell,
-                     "stragglers_per_launch": strag / max(knn_launches, 1)},
-        "final_error_vs_truth": {"trans_m": et, "rot_rad": er},
-    }
-    out["value_is"] = ("resident-input loop: set_reference + align on filtered clouds already in HBM (the north_star kernels); "
-                       "value_e2e = the whole ICP::compute from host buffers")
-    # the other two per-iteration kernels groups against the same HBM roofline (B_trim = 4 Nq, B_ne = 52 Nq)
+    units = 1 if args.split else world
+    out = dict(base, metric="scans_per_sec", value=units * args.steps / elapsed, unit="scans/s",
+               ms_per_step=elapsed / args.steps * 1e3, icp_iterations_per_scan=iters / args.steps,
+               scaling="strong" if args.split else "weak")
+    if args.split:
+        out["ms_per_icp_iteration"] = elapsed / max(iters, 1) * 1e3
+        out["value_is"] = "set_reference + align of one pair whose reading is sharded over the ranks (filtered clouds resident in HBM)"
+    else:
+        out["filters_and_grid_ms_per_step"] = filt_ms / args.steps
+        out["ms_per_icp_iteration"] = (elapsed / args.steps * 1e3 - filt_ms / args.steps) / max(iters / args.steps, 1)
+        out["value_is"] = ("the whole ICP::compute (lsgpu_icp_compute: reference filter + grid + reading filter + loop) on RAW clouds "
+                           "resident in HBM; value_loop = the loop alone on filtered clouds; value_e2e = the same compute from host "
+                           "buffers (PCIe inclusive)")
+    out["config"] = {"workload": workload, "n_reading": nq, "n_reference": nr, "pairs_per_gpu_per_step": 1,
+                     "sharding": ("one scan pair per step, reading sharded over ranks, RCCL all-reduce of the select tables + 29 f64 "
+                                  "per iteration" if args.split else "one scan pair per rank, no collective")}
+    out["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                       "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_note,
+                       "kernel": "k_knn_tile (+ k_knn_fallback / k_knn_rowq where a launch hands queries over: the first three iterations) -- exact 1-NN correspondence search",
+                       "algorithmic_bytes_per_launch": b_knn,
+                       "avg_launch_us": t_knn * 1e6,
+                       "avg_main_us": knn_main_ms / max(knn_launches, 1) * 1e3,
+                       "avg_fallback_us": knn_fb_ms / max(knn_launches, 1) * 1e3,
+                       "launches": knn_launches, "timed_in": "%d extra profiled steps of the resident loop after the timed region (HIP events on the handle's stream)" % prof_steps,
+                       "occupied_cells": ncell,
+                       "stragglers_per_launch": strag / max(knn_launches, 1)}
+    # second yardstick for a kernel that is vector-issue bound, not byte bound: the distance evaluations an ideal
+    # per-query search would need (a libnabo kd-tree with bucket size 8 visits 20-30 points per query) x the
+    # 7.75 vector operations one evaluation costs (6 for the defined arithmetic, 1.75 for minimum / runner-up / index),
+    # against what the chip's vector units could issue during the launch (256 CUs x 4 SIMDs x 16 lanes at 2.4 GHz)
+    if t_knn > 0:
+        ideal_ops = nq * 25 * 7.75
+        peak_lane_ops = 256 * 4 * 16 * 2.4e9
+        out["roofline"]["valu_frac"] = ideal_ops / (t_knn * peak_lane_ops)
+        out["roofline"]["valu_frac_is"] = ("(Nq x 25 kd-tree-equivalent distance evaluations x 7.75 lane-ops) / (launch time x 256 CUs x 4 SIMDs x "
+                                           "16 lanes x 2.4 GHz): the share of the launch's vector issue slots an ideal search would need")
+    out["final_error_vs_truth"] = {"trans_m": et, "rot_rad": er}
+    out["profiled_loop_transform_equals_timed_compute"] = loop_equals_compute
+    # the other two per-iteration kernel groups against the same HBM roofline (B_trim = 4 Nq, B_ne = 52 Nq)
     n_it = max(knn_launches, 1)
     t_sel, t_ne = sel_ms / n_it * 1e-3, ne_ms / n_it * 1e-3
     if t_sel > 0 and t_ne > 0:
@@ -236,25 +357,28 @@ def main():
                               "algorithmic_bytes_per_iteration": 52 * nq, "avg_us": t_ne * 1e6,
                               "achieved": 52 * nq / t_ne / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                               "frac": 52 * nq / t_ne / 1e9 / HBM_PEAK_GBS}
+    if value_loop is not None:
+        out["value_loop"] = value_loop
     if value_e2e is not None:
         out["value_e2e"] = value_e2e
-    if end_to_end is not None:
-        out["compute_with_filters"] = end_to_end
+    if variants is not None:
+        out["compute_variants"] = variants
 
-    # ---- CPU baseline: the oracle (port) on this box's host cores, same workload, rank 0, N=1 only
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    # ---- CPU baseline: the oracle (port) on this box's host cores, same workload and SAME region as `value`
+    # (both filters + kd-tree build + loop), rank 0, N=1 only
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and not args.split:
         from oracle import oracle_py as O
-        ocfg = O.config_yaml(accum_double=0, min_diff_rot=1e-5, min_diff_trans=1e-4,
-                             num_threads=args.cpu_threads)
+        ocfg = O.config_yaml(accum_double=0, min_diff_rot=1e-5, min_diff_trans=1e-4, num_threads=args.cpu_threads,
+                             reading_sampling_prob=1.0, surface_normal_knn=10, surface_normal_ratio=1.0)
         tc = time.perf_counter()
-        rc, To, sto, _ = O.icp_compute(ocfg, rd, rf, rn, synth.colmajor(T_init), 0)
+        rc, To, sto = O.icp_compute_full(ocfg, raw_rd, raw_ref, synth.colmajor(T_init), seed=0)
         cpu_s = time.perf_counter() - tc
         dt, dr = synth.pose_error(synth.from_colmajor(To), T.astype(np.float64))
         out["cpu_baseline"] = {
             "value": 1.0 / cpu_s, "unit": "scans/s", "cores": args.cpu_threads, "kind": "port",
-            "sample": "1 scan pair of the same workload (kd-tree build + %d ICP iterations), "
+            "sample": "1 scan pair of the same workload, same region as `value` (both filters + kd-tree build + %d ICP iterations); "
                       "host has %d cores" % (sto.iterations, os.cpu_count()),
-            "ms_per_icp_iteration": sto.t_loop_ms / max(sto.iterations, 1),
+            "ms_filters": sto.t_filter_ms, "ms_per_icp_iteration": sto.t_loop_ms / max(sto.iterations, 1),
             "iterations": sto.iterations,
             "gpu_vs_cpu_transform": {"trans_m": dt, "rot_rad": dr},
         }
@@ -262,9 +386,9 @@ def main():
         # libnabo built with OpenMP does); reported next to the single-thread figure, never as the baseline value
         nthr = min(os.cpu_count() or 1, 64)
         if nthr > args.cpu_threads:
-            ocfg_mt = O.config_yaml(accum_double=0, min_diff_rot=1e-5, min_diff_trans=1e-4, num_threads=nthr)
+            ocfg.num_threads = nthr
             tc = time.perf_counter()
-            rc_mt, _To, sto_mt, _ = O.icp_compute(ocfg_mt, rd, rf, rn, synth.colmajor(T_init), 0)
+            rc_mt, _To, sto_mt = O.icp_compute_full(ocfg, raw_rd, raw_ref, synth.colmajor(T_init), seed=0)
             out["cpu_baseline"]["all_threads"] = {"value": 1.0 / (time.perf_counter() - tc), "unit": "scans/s", "cores": nthr,
                                                   "iterations": sto_mt.iterations}
     if rank == 0:

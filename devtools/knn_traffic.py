@@ -1,6 +1,8 @@
 """dev helper: profiles/knn_traffic.json from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) of bench.py.
 usage: knn_traffic.py <fetch_counter_collection.csv> <write_counter_collection.csv> <out.json> <tag>"""
-import csv, json, sys
+import csv, json, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from bench import csrc_digest
 def mean_counter(path, name):
     vals = {}
     for r in csv.DictReader(open(path)):
@@ -13,7 +15,7 @@ def mean_counter(path, name):
     return (sum(tile) + sum(fb)) / max(len(tile), 1), len(tile), len(fb)
 f, nt, nf = mean_counter(sys.argv[1], "FETCH_SIZE")
 w, _, _ = mean_counter(sys.argv[2], "WRITE_SIZE")
-out = {"n_az": 16384, "kernel": "k_knn_tile (+ the wave-per-query / row-per-query pass that follows it)",
+out = {"n_az": 16384, "csrc_sha": csrc_digest(), "kernel": "k_knn_tile (+ the wave-per-query / row-per-query pass that follows it)",
        "fetch_size_kb_per_launch": f, "write_size_kb_per_launch": w,
        "hbm_bytes_per_launch": (2 * f + w) * 1024,
        "dispatches": {"k_knn_tile": nt, "k_knn_fallback + k_knn_rowq": nf},

@@ -49,6 +49,9 @@ struct KnnArgs {
   int* ids;                 // out: sorted-reference index of the NN
   float* d2;                // out: squared distance
   float4* prev;             // in/out: warm start = the query's current match {x,y,z, sorted index bits}
+  const float4* nrm;        // normals of the sorted reference (nullable)
+  float4* prevn;            // out (nullable): normal of the query's current match, written wherever prev is -- the
+                            // normal-equation pass then reads it coalesced instead of gathering nrm[match]
   uint32_t* strag;          // out: straggler list
   uint32_t* strag_count;
   float r_cap;              // lanes with a larger ball go to the fallback
@@ -157,6 +160,7 @@ __global__ __launch_bounds__(256) void k_knn_seed(KnnArgs a) {
     break;
   }
   a.prev[j] = make_float4(bp.x, bp.y, bp.z, __int_as_float(bi));
+  if (a.prevn) a.prevn[j] = a.nrm[bi];
   // the seed distance bounds the nearest-neighbour distance from above, query by query, hence so does every order
   // statistic: the trim quantile of the seed distances is a guaranteed search cap for the first iteration
   a.d2[j] = bd;
@@ -534,6 +538,7 @@ __device__ __forceinline__ void rowq_store(const KnnArgs& a, float cap2s, float 
     const float4 p = a.pts[id];
     a.ids[j] = id;
     a.prev[j] = make_float4(p.x, p.y, p.z, __int_as_float(id));
+    if (a.prevn) a.prevn[j] = a.nrm[id];
   }
   a.d2[j] = fd;
   sel_count_query(a, j, (uint32_t)(bestp >> 32));
@@ -917,6 +922,7 @@ __global__ __launch_bounds__(WAVES * 64, LSGPU_TILE_OCC) void k_knn_tile(KnnArgs
     if (a.write_all || __float_as_int(mp.w) != id_in) {
       a.ids[j] = __float_as_int(mp.w);
       a.prev[j] = mp;
+      if (a.prevn) a.prevn[j] = a.nrm[__float_as_int(mp.w)];
     }
     a.d2[j] = best;
     if (a.lb) a.lb[j] = nb;
@@ -978,6 +984,7 @@ __global__ __launch_bounds__(256) void k_knn_lane(KnnArgs a) {
   a.ids[j] = bi;
   a.d2[j] = best;
   a.prev[j] = mp;
+  if (a.prevn) a.prevn[j] = a.nrm[bi];
   if (a.lb) a.lb[j] = best <= cap2 ? sqrtf(best) * (1.0f - 1e-6f) : sqrtf(cap2) * (1.0f - 1e-5f);
 }
 
@@ -1068,6 +1075,7 @@ __global__ __launch_bounds__(256) void k_knn_fallback(KnnArgs a) {
         else if (top == b1) sel_count_inside(a, bits);
       }
       a.prev[j] = make_float4(p.x, p.y, p.z, __int_as_float(id));
+      if (a.prevn) a.prevn[j] = a.nrm[id];
       if (a.lb) {
         // every other point is at least as far as the neighbour found, or beyond the verified radius
         // (nothing inside the cap: the match did not change, its old bound still holds)
