@@ -172,7 +172,6 @@ struct lsgpu_icp {
   DevBuf<float> chk_hist;    // checker history: 8 floats x (max_iterations + 2)
   DevBuf<lsgpu_iter_trace> trace_dev;
   DevBuf<float4> prev;       // warm start of every query: its current match {xyz, sorted index}
-  DevBuf<float4> prevn;      // ... and that match's normal (read coalesced by k_normal_eq_loop)
   DevBuf<RefStats> stat_partials;
   DevBuf<GeomDev> geom;      // grid geometry derived on the device (k_ref_stats_final)
   DevBuf<uint32_t> counters;  // [0..16] cell counts, [32] straggler count
@@ -336,7 +335,7 @@ void lsgpu_icp_destroy(lsgpu_icp* h) {
   h->work.release();
 #endif
   h->vals.release(); h->vals_alt.release(); h->sort_tmp.release(); h->sort_hist.release(); h->pts.release();
-  h->nrm.release(); h->ref_inv.release(); h->tables.release(); h->flags.release(); h->cidx.release(); h->bounds.release(); h->chunks.release(); h->soa.release(); h->soa_base.release(); h->soa_cnt4.release(); h->soa_first.release(); h->prev.release(); h->prevn.release(); h->state.release(); h->lb.release(); h->cell_cache.release(); h->cell_tags.release(); h->ssn_seg_a.release(); h->ssn_seg_b.release(); h->ssn_seg_of.release(); h->ssn_box_pts.release(); h->ssn_box_base.release(); h->ssn_keep.release(); h->ssn_out_pos.release(); h->ssn_bb.release(); h->ssn_box_normal.release(); h->ssn_draws.release(); h->flt_in.release(); h->flt_ref.release(); h->flt_rd.release(); h->flt_nrm.release(); h->chk_hist.release(); h->trace_dev.release(); h->knn_dbg.release(); h->knn_dbg_wave.release(); h->stat_partials.release(); h->geom.release();
+  h->nrm.release(); h->ref_inv.release(); h->tables.release(); h->flags.release(); h->cidx.release(); h->bounds.release(); h->chunks.release(); h->soa.release(); h->soa_base.release(); h->soa_cnt4.release(); h->soa_first.release(); h->prev.release(); h->state.release(); h->lb.release(); h->cell_cache.release(); h->cell_tags.release(); h->ssn_seg_a.release(); h->ssn_seg_b.release(); h->ssn_seg_of.release(); h->ssn_box_pts.release(); h->ssn_box_base.release(); h->ssn_keep.release(); h->ssn_out_pos.release(); h->ssn_bb.release(); h->ssn_box_normal.release(); h->ssn_draws.release(); h->flt_in.release(); h->flt_ref.release(); h->flt_rd.release(); h->flt_nrm.release(); h->chk_hist.release(); h->trace_dev.release(); h->knn_dbg.release(); h->knn_dbg_wave.release(); h->stat_partials.release(); h->geom.release();
   h->counters.release(); h->ang_cells.release(); h->sel_aux.release(); h->sel_win.release(); h->spread_flag.release(); h->spread_list.release(); h->spread_cnt.release(); h->q_in.release(); h->rdq.release(); h->ids.release(); h->d2.release();
   h->ids_io.release(); h->d2_io.release(); h->strag.release(); h->hist.release();
   h->sel.release(); h->ne_partials.release(); h->ne_gpartials.release(); h->ne_tickets.release(); h->ne_out.release(); h->limit_dev.release();
@@ -437,7 +436,6 @@ static int prepare_queries(lsgpu_icp* h, const float* q_xyz1, int64_t nq, const 
   HIPC(h->vals.reserve(nq));
   HIPC(h->rdq.reserve(nq));
   HIPC(h->prev.reserve(nq));
-  HIPC(h->prevn.reserve(nq));
   HIPC(h->lb.reserve(nq));
 #ifdef LSGPU_EXPERIMENTS
   HIPC(h->work.reserve(nq));
@@ -476,12 +474,12 @@ static KnnArgs knn_args(lsgpu_icp* h, const Mat34& T) {
   KnnArgs a;
   a.rdq = h->rdq.p; a.nq = (int)h->nq; a.T = T; a.g = h->grid; a.pts = h->pts.p;
   a.chunks = h->chunks.p; a.soa = reinterpret_cast<const float4*>(h->soa.p); a.chunk_soa = h->soa_base.p; a.ids = h->ids.p; a.d2 = h->d2.p; a.prev = h->prev.p;
-  a.nrm = h->nrm.p; a.prevn = h->nrm.p ? h->prevn.p : nullptr;
   a.strag = h->strag.p; a.strag_count = h->counters.p + 32;
   a.r_cap = 1.0f; a.group_r = 0.75f; a.cap2 = INFINITY; a.st = nullptr; a.use_state_cap = 0; a.lb = nullptr;
   a.spread_route_r = 0.f; a.route_chunks = 1 << 30; a.sel_hist2 = nullptr; a.sel_below = nullptr;
   a.sel_hist3w = nullptr; a.sel_force = 0; a.write_all = 1; a.spread_flag = nullptr; a.spread_list = nullptr; a.spread_cnt = nullptr; a.front_blocks = 0;
   a.gap = tuning().gap;
+  a.rep_rows = tuning().rep_rows ? 1 : 0;
   a.ntiles = (int)((h->nq + 63) / 64); a.pad_index = (int)h->nr;
   a.chunk_budget = tuning().chunk_budget;
   a.cell_cache = h->cell_cache.p; a.cell_tags = h->cell_tags.p; a.cache_gen = h->cache_gen;
@@ -1616,7 +1614,7 @@ int lsgpu_icp_align(lsgpu_icp* h, const float* reading_xyz1, int64_t nq, const f
     lsgpu_icp::KnnEv* ev = (timed && knn && h->knn_events_used) ? &h->knn_events[h->knn_events_used - 1] : nullptr;
     if (ev) HIPC(hipEventRecord(ev->d, h->stream));
     hipLaunchKernelGGL(k_normal_eq_loop, dim3(nb), dim3(256), 0, h->stream, h->rdq.p, (int)nq,
-                       h->state.p, h->prev.p, h->d2.p, h->prevn.p, h->hist.p, h->sel.p + 2,
+                       h->state.p, h->prev.p, h->d2.p, h->nrm.p, h->hist.p, h->sel.p + 2,
                        h->counters.p + 32, h->ne_tickets.p, h->ne_partials.p, h->ne_gpartials.p, h->ne_out.p,
                        h->chk_hist.p, h->trace_dev.p, max_it, capped ? 1 : 0, (h->comm || split_update) ? 0 : 1,
                        h->sel_aux.p, h->sel_win.p, committed ? 1 : 0, h->spread_cnt.p);   // 6d (+6e)

@@ -49,9 +49,6 @@ struct KnnArgs {
   int* ids;                 // out: sorted-reference index of the NN
   float* d2;                // out: squared distance
   float4* prev;             // in/out: warm start = the query's current match {x,y,z, sorted index bits}
-  const float4* nrm;        // normals of the sorted reference (nullable)
-  float4* prevn;            // out (nullable): normal of the query's current match, written wherever prev is -- the
-                            // normal-equation pass then reads it coalesced instead of gathering nrm[match]
   uint32_t* strag;          // out: straggler list
   uint32_t* strag_count;
   float r_cap;              // lanes with a larger ball go to the fallback
@@ -73,6 +70,7 @@ struct KnnArgs {
   uint32_t* spread_list;    // tiles found spread so far
   uint32_t* spread_cnt;     // [0] entries the front rows may use (committed by k_normal_eq_loop), [1] entries appended
   int front_blocks;
+  int rep_rows;             // 1: tiles with <= 32 / <= 16 searching lanes evaluate 2 / 4 chunks at a time (replicated queries)
   uint32_t* sel_hist2;      // predicted select (IcpState::sel_mode): 2048-bin histogram of bits [19:9] inside the bin
   uint32_t* sel_below;      //   kSelBelowSlots counters of distances below the bin (nullable: launch without prediction)
   uint32_t* sel_hist3w;     // committed select: kSelWinRows x 512 histogram of bits [8:0] around the last limit (nullable)
@@ -160,7 +158,6 @@ __global__ __launch_bounds__(256) void k_knn_seed(KnnArgs a) {
     break;
   }
   a.prev[j] = make_float4(bp.x, bp.y, bp.z, __int_as_float(bi));
-  if (a.prevn) a.prevn[j] = a.nrm[bi];
   // the seed distance bounds the nearest-neighbour distance from above, query by query, hence so does every order
   // statistic: the trim quantile of the seed distances is a guaranteed search cap for the first iteration
   a.d2[j] = bd;
@@ -250,9 +247,12 @@ __device__ __forceinline__ float4 canonical_tie(const KnnArgs& a, float qx, floa
 constexpr int kListCap = 128;        // chunk ids queued per wave (LDS)
 constexpr uint32_t kChunkBudget = 1024;  // a whole-wave group is accepted up to this many chunks
 
+constexpr int kSlotStride = 65;     // float4s between two slots: 64 + 1, so that the four slots start on different LDS banks
+                                    // (the replicated evaluation reads all four at the same offset in one instruction)
 struct TileLds {
-  float4 slot[4][64];            // 4 chunks in flight: filled by LDS-DMA (global_load_lds, 16 B per lane)
+  float4 slot[4][kSlotStride];   // 4 chunks in flight: filled by LDS-DMA (global_load_lds, 16 B per lane)
   uint32_t list[kListCap];       // flattened chunk ids of the region's cells
+  float qpack[3][32];            // replicated evaluation: the searching queries' coordinates, packed by rank
 };
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -292,6 +292,29 @@ __device__ __forceinline__ void tile_eval_slot(const float4* __restrict__ slot, 
   }
 }
 
+// Replicated evaluation (tiles with few searching lanes).  The broadcast evaluation costs the same whether 64 or 6 lanes
+// search: every candidate of the tile's union is evaluated by all 64 lanes.  When at most 16 (32) lanes search, the wave
+// holds 4 (2) COPIES of the searching queries -- copy c in lanes [c W, (c + 1) W), W = 64 / copies, query of rank r in lane
+// c W + r -- and every copy evaluates a DIFFERENT chunk: `copies` chunks per pass of the same inner loop, each group of
+// lanes reading its own LDS slot.  Afterwards the copies' (minimum, runner-up, group) triples are merged per query, which
+// is exact: the runner-up of the union is the second smallest of the copies' two smallest group minima, and equal minima
+// in two copies leave runner-up == minimum, i.e. the same tie signal as inside one copy (canonical_tie settles it).
+__device__ __forceinline__ void tile_eval_slot_groups(const float4* __restrict__ slot, uint32_t st, uint32_t cnt, uint32_t c4max,
+                                                      float qx, float qy, float qz, float& best, float& sec, int& grp) {
+  const uint32_t c4 = (cnt + 3u) >> 2;   // this lane group's chunk (0: none this round)
+  const f32x2 q2x = {qx, qx}, q2y = {qy, qy}, q2z = {qz, qz};
+  for (uint32_t t = 0; t < c4max; ++t) {
+    if (t < c4) {
+      const float4 x = slot[t], y = slot[c4 + t], z = slot[2u * c4 + t];
+      const f32x2 d0 = dist2_pair(q2x, q2y, q2z, f32x2{x.x, x.y}, f32x2{y.x, y.y}, f32x2{z.x, z.y});
+      const f32x2 d1 = dist2_pair(q2x, q2y, q2z, f32x2{x.z, x.w}, f32x2{y.z, y.w}, f32x2{z.z, z.w});
+      const float m4 = fminf(fminf(fminf(d0.x, d0.y), d1.x), d1.y);
+      sec = __builtin_amdgcn_fmed3f(best, m4, sec);
+      if (m4 < best) { best = m4; grp = (int)(st + 4u * t); }
+    }
+  }
+}
+
 // Cull 64 queued chunks (one per lane) against the group's query box, test the survivors per lane
 // against each lane's own bound, then fetch the needed chunks FOUR AT A TIME with LDS-DMA (one memory
 // latency per four chunks, no staging registers) and broadcast-evaluate them.
@@ -300,7 +323,8 @@ __device__ __forceinline__ void tile_process_batch(const KnnArgs& a, float cap2,
                                                    float tlx, float tly, float tlz, float thx, float thy,
                                                    float thz, float& maxbest, float ub, float gap, float& best,
                                                    float& sec, int& grp, uint32_t& n_eval, uint32_t& n_surv,
-                                                   uint32_t& c_eval /* stats builds: cycles spent fetching + evaluating */) {
+                                                   uint32_t& c_eval /* stats builds: cycles spent fetching + evaluating */,
+                                                   int copies, unsigned long long ing_mask) {
   float4 b0 = make_float4(0.f, 0.f, 0.f, 0.f), b1 = b0;
   uint32_t sbase = 0;
   bool pass = false;
@@ -353,13 +377,70 @@ __device__ __forceinline__ void tile_process_batch(const KnnArgs& a, float cap2,
 #ifdef LSGPU_KNN_STATS
   if (a.dbg_flags & (1 | 256)) { n_eval += __popcll(needm); return; }
 #endif
-  // ---- fetch + evaluate: two chunks per round, double buffered -- the LDS-DMA of the next pair is in
-  // flight while the current pair is evaluated (slots 0,1 <-> 2,3)
   typedef __attribute__((address_space(1))) const void* gptr_t;
   typedef __attribute__((address_space(3))) void* lptr_t;
 #ifdef LSGPU_KNN_STATS
   const long long t_ev0 = clock64();
 #endif
+  if (copies > 1) {
+    // ---- replicated evaluation: `copies` chunks per round, one per lane group (see tile_eval_slot_groups)
+    const int W = 64 / copies, gi = lane / W;
+    // this lane's copy of a searching query (packed by rank in LDS by the caller); a lane without one sits far from
+    // everything, pad points included
+    const uint32_t ns = (uint32_t)__popcll(ing_mask), slotq = (uint32_t)(lane % W);
+    const uint32_t rank = (uint32_t)__popcll(ing_mask & ((1ull << lane) - 1ull));
+    float eqx = -kPadCoord, eqy = -kPadCoord, eqz = -kPadCoord;
+    if (slotq < ns) { eqx = lds.qpack[0][slotq]; eqy = lds.qpack[1][slotq]; eqz = lds.qpack[2][slotq]; }
+    float eb = INFINITY, es = INFINITY;
+    int eg = -1;
+    while (needm) {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the slots are no longer being read
+      uint32_t st_l = 0, cnt_l = 0, cmax = 0;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        if (c < copies && needm) {
+          const int k = __ffsll((long long)needm) - 1;
+          needm &= needm - 1;
+          const uint32_t st = rl_u(__float_as_uint(b0.w), k), cnt = rl_u(__float_as_uint(b1.w), k);
+          const uint32_t nf4 = 3u * ((cnt + 3u) >> 2);
+          const float4* src = a.soa + rl_u(sbase, k) + (uint32_t)lane;
+          if ((uint32_t)lane < nf4) __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)&lds.slot[c][0], 16, 0, 0);
+          if (gi == c) { st_l = st; cnt_l = cnt; }
+          cmax = cnt > cmax ? cnt : cmax;
+          ++n_eval;
+        }
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      tile_eval_slot_groups(lds.slot[gi], st_l, cnt_l, (cmax + 3u) >> 2, eqx, eqy, eqz, eb, es, eg);
+    }
+    // ---- merge the copies into the query's own lane: query of rank r sits in lanes r, W + r, ...
+    {
+      const int src0 = ing ? (int)rank : lane;
+      float mb = best, ms = sec;
+      int mg = grp;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        if (c < copies) {
+          const int srcl = ing ? src0 + c * W : lane;
+          const float cb = __shfl(eb, srcl, 64), cs = __shfl(es, srcl, 64);
+          const int cg = __shfl(eg, srcl, 64);
+          const float hi = fmaxf(mb, cb);
+          ms = fminf(hi, fminf(ms, cs));
+          if (cb < mb) { mb = cb; mg = cg; }
+        }
+      }
+      if (ing) { best = mb; sec = ms; grp = mg; }
+    }
+    maxbest = wave_max(ing ? prune_lim(fminf(best, ub), gap, cap2) : 0.f);
+#ifdef LSGPU_KNN_STATS
+    c_eval += (uint32_t)(clock64() - t_ev0);
+#else
+    (void)c_eval;
+#endif
+    return;
+  }
+  // ---- fetch + evaluate: two chunks per round, double buffered -- the LDS-DMA of the next pair is in
+  // flight while the current pair is evaluated (slots 0,1 <-> 2,3)
   uint32_t sa0 = 0, sa1 = 0, ca0 = 0, ca1 = 0, sb0 = 0, sb1 = 0, cb0 = 0, cb1 = 0;
   auto issue = [&](int slot, uint32_t& st, uint32_t& cnt) -> int {
     if (!needm) return 0;
@@ -538,7 +619,6 @@ __device__ __forceinline__ void rowq_store(const KnnArgs& a, float cap2s, float 
     const float4 p = a.pts[id];
     a.ids[j] = id;
     a.prev[j] = make_float4(p.x, p.y, p.z, __int_as_float(id));
-    if (a.prevn) a.prevn[j] = a.nrm[id];
   }
   a.d2[j] = fd;
   sel_count_query(a, j, (uint32_t)(bestp >> 32));
@@ -856,6 +936,13 @@ __global__ __launch_bounds__(WAVES * 64, LSGPU_TILE_OCC) void k_knn_tile(KnnArgs
 #ifdef LSGPU_KNN_STATS
       if (a.dbg_flags & 64) return;
 #endif
+      // ---- few searching lanes: 2 or 4 copies of them evaluate 2 or 4 chunks at a time (tile_eval_slot_groups)
+      const uint32_t ns_tile = (uint32_t)__popcll(ing_mask);
+      const int copies = (WAVES == 1 && a.rep_rows) ? (ns_tile <= 16u ? 4 : ns_tile <= 32u ? 2 : 1) : 1;
+      if (copies > 1 && ing) {
+        const uint32_t rank = (uint32_t)__popcll(ing_mask & ((1ull << lane) - 1ull));
+        lds.qpack[0][rank] = qx; lds.qpack[1][rank] = qy; lds.qpack[2][rank] = qz;
+      }
       // ---- flatten the cells' chunk ranges into the LDS list, 64 at a time into the cull
       unsigned long long cells = __ballot(ce > cs);
       uint32_t fill = 0;
@@ -871,7 +958,7 @@ __global__ __launch_bounds__(WAVES * 64, LSGPU_TILE_OCC) void k_knn_tile(KnnArgs
             fill -= 64u;
             const uint32_t ch = lds.list[fill + lane];
             tile_process_batch(a, cap2s, lds, lane, true, ch, ing, qx, qy, qz, tlx, tly, tlz, thx, thy, thz,
-                               maxbest, ub, gap, best, sec, grp, n_eval, n_surv, c_eval);
+                               maxbest, ub, gap, best, sec, grp, n_eval, n_surv, c_eval, copies, ing_mask);
           }
         }
       }
@@ -879,7 +966,7 @@ __global__ __launch_bounds__(WAVES * 64, LSGPU_TILE_OCC) void k_knn_tile(KnnArgs
         const bool v = (uint32_t)lane < fill;
         const uint32_t ch = v ? lds.list[lane] : 0u;
         tile_process_batch(a, cap2s, lds, lane, v, ch, ing, qx, qy, qz, tlx, tly, tlz, thx, thy, thz,
-                           maxbest, ub, gap, best, sec, grp, n_eval, n_surv, c_eval);
+                           maxbest, ub, gap, best, sec, grp, n_eval, n_surv, c_eval, copies, ing_mask);
       }
     }
   }
@@ -922,7 +1009,6 @@ __global__ __launch_bounds__(WAVES * 64, LSGPU_TILE_OCC) void k_knn_tile(KnnArgs
     if (a.write_all || __float_as_int(mp.w) != id_in) {
       a.ids[j] = __float_as_int(mp.w);
       a.prev[j] = mp;
-      if (a.prevn) a.prevn[j] = a.nrm[__float_as_int(mp.w)];
     }
     a.d2[j] = best;
     if (a.lb) a.lb[j] = nb;
@@ -984,7 +1070,6 @@ __global__ __launch_bounds__(256) void k_knn_lane(KnnArgs a) {
   a.ids[j] = bi;
   a.d2[j] = best;
   a.prev[j] = mp;
-  if (a.prevn) a.prevn[j] = a.nrm[bi];
   if (a.lb) a.lb[j] = best <= cap2 ? sqrtf(best) * (1.0f - 1e-6f) : sqrtf(cap2) * (1.0f - 1e-5f);
 }
 
@@ -1075,7 +1160,6 @@ __global__ __launch_bounds__(256) void k_knn_fallback(KnnArgs a) {
         else if (top == b1) sel_count_inside(a, bits);
       }
       a.prev[j] = make_float4(p.x, p.y, p.z, __int_as_float(id));
-      if (a.prevn) a.prevn[j] = a.nrm[id];
       if (a.lb) {
         // every other point is at least as far as the neighbour found, or beyond the verified radius
         // (nothing inside the cap: the match did not change, its old bound still holds)

@@ -368,7 +368,6 @@ __global__ __launch_bounds__(64, 4) void k_knn_rows(KnnArgs a) {
     a.ids[j] = __float_as_int(mp.w);
     a.d2[j] = best;
     a.prev[j] = mp;
-    if (a.prevn) a.prevn[j] = a.nrm[__float_as_int(mp.w)];
     if (a.lb) a.lb[j] = nb;
     if (straggler) a.strag[atomicAdd(a.strag_count, 1u)] = (uint32_t)j;
   }

@@ -352,9 +352,8 @@ __global__ __launch_bounds__(64) void k_icp_update(IcpState* __restrict__ st,
 }
 
 
-// The align loop's variant: the matched point AND its normal come coalesced from the warm-start arrays (xyz + sorted
-// index of every query's neighbour and that neighbour's normal, written by the kNN kernels whenever a match changes):
-// 52 B per query, no gather.  The
+// The align loop's variant: the matched point comes coalesced from the warm-start array (xyz + sorted
+// index of every query's neighbour, written by the kNN kernels), only the normal is gathered.  The
 // LAST block to finish (ticket; partial sums exchanged with agent-scope accesses) reduces the block
 // partials in a fixed order, publishes {29 sums, limit, straggler count} and re-arms the per-iteration
 // scratch (histograms, straggler counter, ticket) so the next iteration needs no memset launches.
@@ -366,7 +365,7 @@ __global__ __launch_bounds__(256) void k_normal_eq_loop(const float4* __restrict
                                                         IcpState* __restrict__ ist,
                                                         const float4* __restrict__ match,
                                                         const float* __restrict__ d2,
-                                                        const float4* __restrict__ matchn,  // normal of every query's match
+                                                        const float4* __restrict__ nrm,
                                                         uint32_t* __restrict__ hist,  // 3 x kHistBins
                                                         const SelState* __restrict__ st,
                                                         uint32_t* __restrict__ strag_count,
@@ -450,8 +449,10 @@ __global__ __launch_bounds__(256) void k_normal_eq_loop(const float4* __restrict
       use[u] = use[u] && __float_as_int(qq[u].w) >= 0;
     }
 #pragma unroll
-    for (int u = 0; u < kNeUnroll; ++u)   // the match's normal sits next to the match (written by the search kernels): coalesced
-      nn[u] = use[u] ? matchn[j0 + u * stride] : make_float4(0.f, 0.f, 0.f, 0.f);
+    // (the normal is gathered: the 16 MB normal array stays in the L2s / Infinity Cache over an alignment, and a copy of
+    // the match's normal kept next to the match -- coalesced 16 B per query, written by the search kernels -- measured
+    // SLOWER: 31.5 -> 34.6 us per launch, profiles/r03b_bench.json; it adds 16 MB of HBM stream to save cache hits)
+    for (int u = 0; u < kNeUnroll; ++u) nn[u] = use[u] ? nrm[__float_as_int(qq[u].w)] : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
     for (int u = 0; u < kNeUnroll; ++u) {
     if (!use[u]) continue;
