@@ -172,6 +172,11 @@ int lsgpu_normal_eq(lsgpu_icp* h, const float* query_xyz1, int64_t nq, const flo
                     const int32_t* ids, const float* d2, float limit, double out[29]);
 /* RigidTransformation::compute on features (laser_track.cpp:265,485): out = T * xyz1. */
 int lsgpu_transform_points(lsgpu_icp* h, const float T[16], const float* xyz1, int64_t n, float* out);
+/* RigidTransformation::compute on a 3-row descriptor of the cloud (`normals`, `observationDirections`: the descriptors
+ * upstream rotates, laser_track.cpp:265,485,630,643 when stored scans carry them): out = R * d, 3 floats per point
+ * (a 3 x N column-major matrix), same fma chain as the points without the translation.  LSGPU_BAD_ARG if T is not rigid
+ * (TransformationError upstream). */
+int lsgpu_rotate_descriptors(lsgpu_icp* h, const float T[16], const float* desc3, int64_t n, float* out);
 
 /* ---- the whole of ICP::compute on the device ----------------------------------
  * The sampling filters of icp_default.yaml:1-7 as device kernels, and the complete call

@@ -22,7 +22,7 @@ ABI_SYMBOLS = [
     "lsgpu_icp_filter_reading", "lsgpu_icp_compute", "lsgpu_cloud_upload", "lsgpu_cloud_release",
     "lsgpu_cloud_size", "lsgpu_icp_compute_clouds", "lsgpu_filter_cylinder", "lsgpu_filter_voxel_grid",
     "lsgpu_icp_get_reference_mean", "lsgpu_icp_get_info", "lsgpu_comm_get_unique_id", "lsgpu_icp_comm_init", "lsgpu_knn", "lsgpu_trim_limit", "lsgpu_normal_eq",
-    "lsgpu_transform_points", "lsgpu_filter_random_sampling",
+    "lsgpu_transform_points", "lsgpu_rotate_descriptors", "lsgpu_filter_random_sampling",
     "lsgpu_filter_sampling_surface_normal", "lsgpu_check_rigid", "lsgpu_correct_rigid", "lsgpu_rotation_distance",
     "lsgpu_strerror", "lsgpu_last_error", "lsgpu_abi_version", "lsgpu_apply_point_filters",
     "lsgpu_cloud_from_pointcloud2", "lsgpu_cloud_to_pointxyz",
@@ -180,6 +180,7 @@ def lib() -> C.CDLL:
     L.lsgpu_normal_eq.argtypes = [vp, fp, i64, C.POINTER(C.c_float), fp, fp, C.c_float,
                                   C.POINTER(C.c_double)]
     L.lsgpu_transform_points.argtypes = [vp, C.POINTER(C.c_float), fp, i64, fp]
+    L.lsgpu_rotate_descriptors.argtypes = [vp, C.POINTER(C.c_float), fp, i64, fp]
     L.lsgpu_filter_random_sampling.argtypes = [i64, C.c_float, i64, C.POINTER(C.c_int64)]
     L.lsgpu_filter_random_sampling.restype = i64
     L.lsgpu_filter_sampling_surface_normal.argtypes = [fp, i64, C.c_int, C.c_float, i64, fp, fp]

@@ -274,6 +274,17 @@ __global__ __launch_bounds__(256) void k_transform(const float4* __restrict__ in
   out[i] = make_float4(q.x, q.y, q.z, p.w);
 }
 
+// RigidTransformation::compute on a 3-row descriptor (`normals`, `observationDirections`): d' = R d, rows of T without the
+// translation, same fma chain as the points (laser_track.cpp:265, 485, 630, 643 rotate the descriptors of stored scans)
+__global__ __launch_bounds__(256) void k_rotate3(const float* __restrict__ in, int64_t n, Mat34 T, float* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const float x = in[3 * i], y = in[3 * i + 1], z = in[3 * i + 2];
+  out[3 * i + 0] = __fmaf_rn(T.m[2], z, __fmaf_rn(T.m[1], y, T.m[0] * x));
+  out[3 * i + 1] = __fmaf_rn(T.m[6], z, __fmaf_rn(T.m[5], y, T.m[4] * x));
+  out[3 * i + 2] = __fmaf_rn(T.m[10], z, __fmaf_rn(T.m[9], y, T.m[8] * x));
+}
+
 // ---------------------------------------------------------------- chunks
 // A chunk starts at every level-0 cell boundary and at every 64th sorted point.
 __global__ __launch_bounds__(256) void k_chunk_flags(const uint64_t* __restrict__ keys, int64_t n,

@@ -480,6 +480,7 @@ static KnnArgs knn_args(lsgpu_icp* h, const Mat34& T) {
   a.sel_hist3w = nullptr; a.sel_force = 0; a.write_all = 1; a.spread_flag = nullptr; a.spread_list = nullptr; a.spread_cnt = nullptr; a.front_blocks = 0;
   a.gap = tuning().gap;
   a.rep_rows = tuning().rep_rows ? 1 : 0;
+  a.lazy_need = 0;
   a.ntiles = (int)((h->nq + 63) / 64); a.pad_index = (int)h->nr;
   a.chunk_budget = tuning().chunk_budget;
   a.cell_cache = h->cell_cache.p; a.cell_tags = h->cell_tags.p; a.cache_gen = h->cache_gen;
@@ -517,6 +518,7 @@ static int run_knn(lsgpu_icp* h, const Mat34& T, const IcpState* st, bool seed, 
   // searches held single waves for 190 k cycles, the tail of a 46 k-cycle launch
   const bool settled = capped && !wide && st && tn.route_all;
   a.spread_route_r = wide ? tn.route_r : settled ? 1e-30f : 0.f;
+  a.lazy_need = (wide && tn.lazy_need) ? 1 : 0;   // balls still as wide as the last ICP step: re-test chunks right before they are fetched
 #ifdef LSGPU_EXPERIMENTS
   a.sparse_lanes = settled && tn.rowq ? tn.sparse_lanes : 0;
 #endif
@@ -913,6 +915,29 @@ int lsgpu_transform_points(lsgpu_icp* h, const float T[16], const float* xyz1, i
   hipLaunchKernelGGL(k_transform, dim3(nblk(n)), dim3(256), 0, h->stream, src, n, to_mat34(T), dst);
   HIPC(hipGetLastError());
   if (!dev_out) HIPC(hipMemcpyAsync(out, dst, (size_t)n * 16, hipMemcpyDeviceToHost, h->stream));
+  HIPC(hipStreamSynchronize(h->stream));
+  return LSGPU_OK;
+}
+
+int lsgpu_rotate_descriptors(lsgpu_icp* h, const float T[16], const float* desc3, int64_t n, float* out) {
+  if (!h || !T || !out) return LSGPU_BAD_ARG;
+  h->err.clear();
+  if (n == 0) return LSGPU_OK;
+  if (!desc3 || n < 0 || n > 0x7FFFFFF0ll) return LSGPU_BAD_ARG;
+  if (!lsgpu_check_rigid(T)) { h->err = "rotate_descriptors: the matrix is not rigid"; return LSGPU_BAD_ARG; }   // TransformationError upstream
+  HIPC(hipSetDevice(h->device));
+  const float* src = desc3;
+  if (!is_device_ptr(desc3)) {
+    HIPC(h->flt_nrm.reserve(3 * n));
+    HIPC(hipMemcpyAsync(h->flt_nrm.p, desc3, (size_t)n * 12, hipMemcpyHostToDevice, h->stream));
+    src = h->flt_nrm.p;
+  }
+  const bool dev_out = is_device_ptr(out);
+  float* dst = out;
+  if (!dev_out) { HIPC(h->ssn_box_normal.reserve(3 * n)); dst = h->ssn_box_normal.p; }
+  hipLaunchKernelGGL(k_rotate3, dim3(nblk(n)), dim3(256), 0, h->stream, src, n, to_mat34(T), dst);
+  HIPC(hipGetLastError());
+  if (!dev_out) HIPC(hipMemcpyAsync(out, dst, (size_t)n * 12, hipMemcpyDeviceToHost, h->stream));
   HIPC(hipStreamSynchronize(h->stream));
   return LSGPU_OK;
 }

@@ -70,6 +70,7 @@ struct KnnArgs {
   uint32_t* spread_list;    // tiles found spread so far
   uint32_t* spread_cnt;     // [0] entries the front rows may use (committed by k_normal_eq_loop), [1] entries appended
   int front_blocks;
+  int lazy_need;            // 1 (launches whose balls are still wide): re-test a chunk against the lanes' CURRENT bounds right before it is fetched
   int rep_rows;             // 1: tiles with <= 32 / <= 16 searching lanes evaluate 2 / 4 chunks at a time (replicated queries)
   uint32_t* sel_hist2;      // predicted select (IcpState::sel_mode): 2048-bin histogram of bits [19:9] inside the bin
   uint32_t* sel_below;      //   kSelBelowSlots counters of distances below the bin (nullable: launch without prediction)
@@ -327,7 +328,7 @@ __device__ __forceinline__ void tile_process_batch(const KnnArgs& a, float cap2,
                                                    int copies, unsigned long long ing_mask) {
   float4 b0 = make_float4(0.f, 0.f, 0.f, 0.f), b1 = b0;
   uint32_t sbase = 0;
-  bool pass = false;
+  bool pass = false, near = false;
   if (valid) {
     const float4* cd = reinterpret_cast<const float4*>(a.chunks + ch);
     b0 = cd[0]; b1 = cd[1];
@@ -335,18 +336,23 @@ __device__ __forceinline__ void tile_process_batch(const KnnArgs& a, float cap2,
     const float gx = fmaxf(fmaxf(b0.x - thx, tlx - b1.x), 0.f);
     const float gy = fmaxf(fmaxf(b0.y - thy, tly - b1.y), 0.f);
     const float gz = fmaxf(fmaxf(b0.z - thz, tlz - b1.z), 0.f);
-    pass = (gx * gx + gy * gy + gz * gz) * kPruneShrink <= maxbest;
+    const float gd = gx * gx + gy * gy + gz * gz;
+    pass = gd * kPruneShrink <= maxbest;
+    near = gd == 0.f;   // the chunk's box overlaps the box of the tile's own queries
   }
   unsigned long long m = __ballot(pass);
   if (!m) return;
+  const unsigned long long nearm = __ballot(pass && near);
 #ifdef LSGPU_KNN_STATS
   if (a.dbg_flags & 128) { n_surv += __popcll(m); return; }
 #endif
   const float lim = ing ? prune_lim(fminf(best, ub), gap, cap2) : 0.f;  // bounds as of now; they only tighten
   bool refined = false;
-  if (__popcll(m) > kRefineMin) {
-    // Many boxes passed the group-level test: refine lane-parallel (lane = chunk) against every
-    // query's own bound before the serial walk, which costs a broadcast + branch per chunk.
+  // which way round the (searching query, surviving box) tests are cheaper: lane = box, one step per searching query
+  // (about 22 instructions each), or lane = query, one step per surviving box (about 26 each)
+  if (__popcll(m) > kRefineMin || 22 * __popcll(ing_mask) < 26 * __popcll(m)) {
+    // Many boxes passed the group-level test, or few lanes search: refine lane-parallel (lane = chunk) against every
+    // searching query's own bound instead of the serial walk, which costs a broadcast + branch per chunk.
     bool needed = false;
     unsigned long long qm = __ballot(ing);
     while (qm) {
@@ -442,10 +448,25 @@ __device__ __forceinline__ void tile_process_batch(const KnnArgs& a, float cap2,
   // ---- fetch + evaluate: two chunks per round, double buffered -- the LDS-DMA of the next pair is in
   // flight while the current pair is evaluated (slots 0,1 <-> 2,3)
   uint32_t sa0 = 0, sa1 = 0, ca0 = 0, ca1 = 0, sb0 = 0, sb1 = 0, cb0 = 0, cb1 = 0;
+  // Order: chunks that overlap the tile's own query box first -- they hold most of the answers.  In launches whose balls
+  // are still wide (first iterations of an align: the balls are as large as the last ICP step, the neighbours a few
+  // centimetres away) every chunk is RE-TESTED against the lanes' current bounds right before it is fetched: once the
+  // near chunks are evaluated most of the others are no longer needed by anybody.  Skipping them is exact (the bounds are
+  // upper bounds of the final distances; the unevaluated points stay beyond the final search radius).
   auto issue = [&](int slot, uint32_t& st, uint32_t& cnt) -> int {
-    if (!needm) return 0;
-    const int k = __ffsll((long long)needm) - 1;
-    needm &= needm - 1;
+    int k;
+    for (;;) {
+      unsigned long long pick = needm & nearm;
+      if (!pick) pick = needm;
+      if (!pick) return 0;
+      k = __ffsll((long long)pick) - 1;
+      needm &= ~(1ull << k);
+      if (!a.lazy_need) break;
+      const float lx = rl_f(b0.x, k), ly = rl_f(b0.y, k), lz = rl_f(b0.z, k);
+      const float hx = rl_f(b1.x, k), hy = rl_f(b1.y, k), hz = rl_f(b1.z, k);
+      const bool need = ing && box_dist2(lx, ly, lz, hx, hy, hz, qx, qy, qz) * kPruneShrink <= prune_lim(fminf(best, ub), gap, cap2);
+      if (__ballot(need)) break;
+    }
     st = rl_u(__float_as_uint(b0.w), k);
     cnt = rl_u(__float_as_uint(b1.w), k);
     // the chunk's SoA block is 3 * cnt4 / 4 float4s (<= 48): one per lane, the other lanes stay out of it (nothing

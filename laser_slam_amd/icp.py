@@ -373,6 +373,19 @@ class IcpHandle:
         return out
 
 
+def _rotate_descriptors(self, T, desc3):
+    """RigidTransformation::compute on a 3-row descriptor (normals / observationDirections): R * d on the device."""
+    p, _k, n = _as_f32(desc3, 3)
+    out = np.empty((n, 3), np.float32)
+    rc = _lib.lib().lsgpu_rotate_descriptors(self._h, _fp(_t16(T)), p, n, out.ctypes.data if n else None)
+    if rc != _lib.OK:
+        _raise(rc, "lsgpu_rotate_descriptors", self._h)
+    return out
+
+
+IcpHandle.rotate_descriptors = _rotate_descriptors
+
+
 def align_batch(handles, references, normals, readings, T_inits):
     """BASELINE config 3: many independent pairs on one GPU (``lsgpu_icp_align_batch``).
 

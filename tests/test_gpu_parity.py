@@ -340,7 +340,7 @@ def test_experiment_switches_do_not_change_results():
     import sys
     variants = [{}, {"LSGPU_NO_FRONT": "1"}, {"LSGPU_NO_FRONT": "1", "LSGPU_NO_ROWQ": "1"},
                 {"LSGPU_NO_FRONT": "1", "LSGPU_NO_ROUTE_ALL": "1"}, {"LSGPU_NO_COMMIT": "1"}, {"LSGPU_NO_PREDICT": "1"},
-                {"LSGPU_ROCPRIM_SORT": "1"}, {"LSGPU_NO_SEED_CAP": "1"}, {"LSGPU_NO_REP": "1"}, {"LSGPU_FRONT_GUESS": "8"}, {"LSGPU_SSN_GLOBAL": "1"},
+                {"LSGPU_ROCPRIM_SORT": "1"}, {"LSGPU_NO_SEED_CAP": "1"}, {"LSGPU_NO_REP": "1"}, {"LSGPU_NO_LAZY": "1"}, {"LSGPU_FRONT_GUESS": "8"}, {"LSGPU_SSN_GLOBAL": "1"},
                 {"LSGPU_QUERY_ORDER": "0"}]
     # the measured-slower variants only exist in the -DLSGPU_EXPERIMENTS build (devtools/build.sh); when that build is
     # around it has to give the same bits as the product, switch by switch
@@ -886,6 +886,31 @@ def test_config3_full_size_submap_vs_scan(icp_mod):
         Tc, stc = h2.compute_clouds(8, list(range(8)), [synth.colmajor(r) for r in rel], T_init, 1.0, 10, 1.0, seed=0)
         assert int(h2.info().n_reference) == ref.shape[0]
         assert np.array_equal(Tc, Tg)                              # same clouds, same chain: the same transform
+
+
+def test_descriptor_rotation_matches_oracle(icp_mod, oracle):
+    """RigidTransformation::compute rotates the `normals` / `observationDirections` descriptors of a cloud beside its
+    features (laser_track.cpp:265, 485, 630, 643): lsgpu_rotate_descriptors against the oracle, bit for bit, host and
+    device buffers; a non-rigid matrix is refused like upstream's TransformationError."""
+    import torch
+    rng = np.random.default_rng(5)
+    nrm = rng.normal(size=(70001, 3)).astype(np.float32)
+    nrm /= np.linalg.norm(nrm, axis=1, keepdims=True)
+    T = synth.se3(1.0, -2.0, 0.5, yaw=0.7, pitch=-0.2, roll=0.1)
+    with icp_mod.IcpHandle() as h:
+        got = h.rotate_descriptors(T, nrm)
+        want = oracle.rotate_normals(synth.colmajor(T), nrm)
+        assert np.array_equal(got, want)
+        d_out = torch.empty((nrm.shape[0], 3), dtype=torch.float32, device="cuda")
+        from laser_slam_amd import _lib
+        import ctypes as C
+        rc = _lib.lib().lsgpu_rotate_descriptors(h._h, synth.colmajor(T).ctypes.data_as(C.POINTER(C.c_float)),
+                                                 C.c_void_p(torch.from_numpy(nrm).cuda().data_ptr()), nrm.shape[0], C.c_void_p(d_out.data_ptr()))
+        assert rc == 0 and np.array_equal(d_out.cpu().numpy(), want)
+        bad = T.copy(); bad[:3, :3] *= 1.1
+        with pytest.raises(_lib.LsgpuError):
+            h.rotate_descriptors(bad, nrm)
+        assert h.rotate_descriptors(T, nrm[:0]).shape == (0, 3)
 
 
 def test_independent_known_answers_on_device(icp_mod):
