@@ -479,8 +479,6 @@ static KnnArgs knn_args(lsgpu_icp* h, const Mat34& T) {
   a.spread_route_r = 0.f; a.route_chunks = 1 << 30; a.sel_hist2 = nullptr; a.sel_below = nullptr;
   a.sel_hist3w = nullptr; a.sel_force = 0; a.write_all = 1; a.spread_flag = nullptr; a.spread_list = nullptr; a.spread_cnt = nullptr; a.front_blocks = 0;
   a.gap = tuning().gap;
-  a.rep_rows = tuning().rep_rows ? 1 : 0;
-  a.lazy_need = 0;
   a.ntiles = (int)((h->nq + 63) / 64); a.pad_index = (int)h->nr;
   a.chunk_budget = tuning().chunk_budget;
   a.cell_cache = h->cell_cache.p; a.cell_tags = h->cell_tags.p; a.cache_gen = h->cache_gen;
@@ -518,7 +516,6 @@ static int run_knn(lsgpu_icp* h, const Mat34& T, const IcpState* st, bool seed, 
   // searches held single waves for 190 k cycles, the tail of a 46 k-cycle launch
   const bool settled = capped && !wide && st && tn.route_all;
   a.spread_route_r = wide ? tn.route_r : settled ? 1e-30f : 0.f;
-  a.lazy_need = (wide && tn.lazy_need) ? 1 : 0;   // balls still as wide as the last ICP step: re-test chunks right before they are fetched
 #ifdef LSGPU_EXPERIMENTS
   a.sparse_lanes = settled && tn.rowq ? tn.sparse_lanes : 0;
 #endif

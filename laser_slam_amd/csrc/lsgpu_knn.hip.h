@@ -70,8 +70,6 @@ struct KnnArgs {
   uint32_t* spread_list;    // tiles found spread so far
   uint32_t* spread_cnt;     // [0] entries the front rows may use (committed by k_normal_eq_loop), [1] entries appended
   int front_blocks;
-  int lazy_need;            // 1 (launches whose balls are still wide): re-test a chunk against the lanes' CURRENT bounds right before it is fetched
-  int rep_rows;             // 1: tiles with <= 32 / <= 16 searching lanes evaluate 2 / 4 chunks at a time (replicated queries)
   uint32_t* sel_hist2;      // predicted select (IcpState::sel_mode): 2048-bin histogram of bits [19:9] inside the bin
   uint32_t* sel_below;      //   kSelBelowSlots counters of distances below the bin (nullable: launch without prediction)
   uint32_t* sel_hist3w;     // committed select: kSelWinRows x 512 histogram of bits [8:0] around the last limit (nullable)
@@ -248,12 +246,9 @@ __device__ __forceinline__ float4 canonical_tie(const KnnArgs& a, float qx, floa
 constexpr int kListCap = 128;        // chunk ids queued per wave (LDS)
 constexpr uint32_t kChunkBudget = 1024;  // a whole-wave group is accepted up to this many chunks
 
-constexpr int kSlotStride = 65;     // float4s between two slots: 64 + 1, so that the four slots start on different LDS banks
-                                    // (the replicated evaluation reads all four at the same offset in one instruction)
 struct TileLds {
-  float4 slot[4][kSlotStride];   // 4 chunks in flight: filled by LDS-DMA (global_load_lds, 16 B per lane)
+  float4 slot[4][64];            // 4 chunks in flight: filled by LDS-DMA (global_load_lds, 16 B per lane)
   uint32_t list[kListCap];       // flattened chunk ids of the region's cells
-  float qpack[3][32];            // replicated evaluation: the searching queries' coordinates, packed by rank
 };
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -293,29 +288,6 @@ __device__ __forceinline__ void tile_eval_slot(const float4* __restrict__ slot, 
   }
 }
 
-// Replicated evaluation (tiles with few searching lanes).  The broadcast evaluation costs the same whether 64 or 6 lanes
-// search: every candidate of the tile's union is evaluated by all 64 lanes.  When at most 16 (32) lanes search, the wave
-// holds 4 (2) COPIES of the searching queries -- copy c in lanes [c W, (c + 1) W), W = 64 / copies, query of rank r in lane
-// c W + r -- and every copy evaluates a DIFFERENT chunk: `copies` chunks per pass of the same inner loop, each group of
-// lanes reading its own LDS slot.  Afterwards the copies' (minimum, runner-up, group) triples are merged per query, which
-// is exact: the runner-up of the union is the second smallest of the copies' two smallest group minima, and equal minima
-// in two copies leave runner-up == minimum, i.e. the same tie signal as inside one copy (canonical_tie settles it).
-__device__ __forceinline__ void tile_eval_slot_groups(const float4* __restrict__ slot, uint32_t st, uint32_t cnt, uint32_t c4max,
-                                                      float qx, float qy, float qz, float& best, float& sec, int& grp) {
-  const uint32_t c4 = (cnt + 3u) >> 2;   // this lane group's chunk (0: none this round)
-  const f32x2 q2x = {qx, qx}, q2y = {qy, qy}, q2z = {qz, qz};
-  for (uint32_t t = 0; t < c4max; ++t) {
-    if (t < c4) {
-      const float4 x = slot[t], y = slot[c4 + t], z = slot[2u * c4 + t];
-      const f32x2 d0 = dist2_pair(q2x, q2y, q2z, f32x2{x.x, x.y}, f32x2{y.x, y.y}, f32x2{z.x, z.y});
-      const f32x2 d1 = dist2_pair(q2x, q2y, q2z, f32x2{x.z, x.w}, f32x2{y.z, y.w}, f32x2{z.z, z.w});
-      const float m4 = fminf(fminf(fminf(d0.x, d0.y), d1.x), d1.y);
-      sec = __builtin_amdgcn_fmed3f(best, m4, sec);
-      if (m4 < best) { best = m4; grp = (int)(st + 4u * t); }
-    }
-  }
-}
-
 // Cull 64 queued chunks (one per lane) against the group's query box, test the survivors per lane
 // against each lane's own bound, then fetch the needed chunks FOUR AT A TIME with LDS-DMA (one memory
 // latency per four chunks, no staging registers) and broadcast-evaluate them.
@@ -324,11 +296,10 @@ __device__ __forceinline__ void tile_process_batch(const KnnArgs& a, float cap2,
                                                    float tlx, float tly, float tlz, float thx, float thy,
                                                    float thz, float& maxbest, float ub, float gap, float& best,
                                                    float& sec, int& grp, uint32_t& n_eval, uint32_t& n_surv,
-                                                   uint32_t& c_eval /* stats builds: cycles spent fetching + evaluating */,
-                                                   int copies, unsigned long long ing_mask) {
+                                                   uint32_t& c_eval /* stats builds: cycles spent fetching + evaluating */) {
   float4 b0 = make_float4(0.f, 0.f, 0.f, 0.f), b1 = b0;
   uint32_t sbase = 0;
-  bool pass = false, near = false;
+  bool pass = false;
   if (valid) {
     const float4* cd = reinterpret_cast<const float4*>(a.chunks + ch);
     b0 = cd[0]; b1 = cd[1];
@@ -336,23 +307,18 @@ __device__ __forceinline__ void tile_process_batch(const KnnArgs& a, float cap2,
     const float gx = fmaxf(fmaxf(b0.x - thx, tlx - b1.x), 0.f);
     const float gy = fmaxf(fmaxf(b0.y - thy, tly - b1.y), 0.f);
     const float gz = fmaxf(fmaxf(b0.z - thz, tlz - b1.z), 0.f);
-    const float gd = gx * gx + gy * gy + gz * gz;
-    pass = gd * kPruneShrink <= maxbest;
-    near = gd == 0.f;   // the chunk's box overlaps the box of the tile's own queries
+    pass = (gx * gx + gy * gy + gz * gz) * kPruneShrink <= maxbest;
   }
   unsigned long long m = __ballot(pass);
   if (!m) return;
-  const unsigned long long nearm = __ballot(pass && near);
 #ifdef LSGPU_KNN_STATS
   if (a.dbg_flags & 128) { n_surv += __popcll(m); return; }
 #endif
   const float lim = ing ? prune_lim(fminf(best, ub), gap, cap2) : 0.f;  // bounds as of now; they only tighten
   bool refined = false;
-  // which way round the (searching query, surviving box) tests are cheaper: lane = box, one step per searching query
-  // (about 22 instructions each), or lane = query, one step per surviving box (about 26 each)
-  if (__popcll(m) > kRefineMin || 22 * __popcll(ing_mask) < 26 * __popcll(m)) {
-    // Many boxes passed the group-level test, or few lanes search: refine lane-parallel (lane = chunk) against every
-    // searching query's own bound instead of the serial walk, which costs a broadcast + branch per chunk.
+  if (__popcll(m) > kRefineMin) {
+    // Many boxes passed the group-level test: refine lane-parallel (lane = chunk) against every
+    // query's own bound before the serial walk, which costs a broadcast + branch per chunk.
     bool needed = false;
     unsigned long long qm = __ballot(ing);
     while (qm) {
@@ -383,90 +349,18 @@ __device__ __forceinline__ void tile_process_batch(const KnnArgs& a, float cap2,
 #ifdef LSGPU_KNN_STATS
   if (a.dbg_flags & (1 | 256)) { n_eval += __popcll(needm); return; }
 #endif
+  // ---- fetch + evaluate: two chunks per round, double buffered -- the LDS-DMA of the next pair is in
+  // flight while the current pair is evaluated (slots 0,1 <-> 2,3)
   typedef __attribute__((address_space(1))) const void* gptr_t;
   typedef __attribute__((address_space(3))) void* lptr_t;
 #ifdef LSGPU_KNN_STATS
   const long long t_ev0 = clock64();
 #endif
-  if (copies > 1) {
-    // ---- replicated evaluation: `copies` chunks per round, one per lane group (see tile_eval_slot_groups)
-    const int W = 64 / copies, gi = lane / W;
-    // this lane's copy of a searching query (packed by rank in LDS by the caller); a lane without one sits far from
-    // everything, pad points included
-    const uint32_t ns = (uint32_t)__popcll(ing_mask), slotq = (uint32_t)(lane % W);
-    const uint32_t rank = (uint32_t)__popcll(ing_mask & ((1ull << lane) - 1ull));
-    float eqx = -kPadCoord, eqy = -kPadCoord, eqz = -kPadCoord;
-    if (slotq < ns) { eqx = lds.qpack[0][slotq]; eqy = lds.qpack[1][slotq]; eqz = lds.qpack[2][slotq]; }
-    float eb = INFINITY, es = INFINITY;
-    int eg = -1;
-    while (needm) {
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the slots are no longer being read
-      uint32_t st_l = 0, cnt_l = 0, cmax = 0;
-#pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        if (c < copies && needm) {
-          const int k = __ffsll((long long)needm) - 1;
-          needm &= needm - 1;
-          const uint32_t st = rl_u(__float_as_uint(b0.w), k), cnt = rl_u(__float_as_uint(b1.w), k);
-          const uint32_t nf4 = 3u * ((cnt + 3u) >> 2);
-          const float4* src = a.soa + rl_u(sbase, k) + (uint32_t)lane;
-          if ((uint32_t)lane < nf4) __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)&lds.slot[c][0], 16, 0, 0);
-          if (gi == c) { st_l = st; cnt_l = cnt; }
-          cmax = cnt > cmax ? cnt : cmax;
-          ++n_eval;
-        }
-      }
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      tile_eval_slot_groups(lds.slot[gi], st_l, cnt_l, (cmax + 3u) >> 2, eqx, eqy, eqz, eb, es, eg);
-    }
-    // ---- merge the copies into the query's own lane: query of rank r sits in lanes r, W + r, ...
-    {
-      const int src0 = ing ? (int)rank : lane;
-      float mb = best, ms = sec;
-      int mg = grp;
-#pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        if (c < copies) {
-          const int srcl = ing ? src0 + c * W : lane;
-          const float cb = __shfl(eb, srcl, 64), cs = __shfl(es, srcl, 64);
-          const int cg = __shfl(eg, srcl, 64);
-          const float hi = fmaxf(mb, cb);
-          ms = fminf(hi, fminf(ms, cs));
-          if (cb < mb) { mb = cb; mg = cg; }
-        }
-      }
-      if (ing) { best = mb; sec = ms; grp = mg; }
-    }
-    maxbest = wave_max(ing ? prune_lim(fminf(best, ub), gap, cap2) : 0.f);
-#ifdef LSGPU_KNN_STATS
-    c_eval += (uint32_t)(clock64() - t_ev0);
-#else
-    (void)c_eval;
-#endif
-    return;
-  }
-  // ---- fetch + evaluate: two chunks per round, double buffered -- the LDS-DMA of the next pair is in
-  // flight while the current pair is evaluated (slots 0,1 <-> 2,3)
   uint32_t sa0 = 0, sa1 = 0, ca0 = 0, ca1 = 0, sb0 = 0, sb1 = 0, cb0 = 0, cb1 = 0;
-  // Order: chunks that overlap the tile's own query box first -- they hold most of the answers.  In launches whose balls
-  // are still wide (first iterations of an align: the balls are as large as the last ICP step, the neighbours a few
-  // centimetres away) every chunk is RE-TESTED against the lanes' current bounds right before it is fetched: once the
-  // near chunks are evaluated most of the others are no longer needed by anybody.  Skipping them is exact (the bounds are
-  // upper bounds of the final distances; the unevaluated points stay beyond the final search radius).
   auto issue = [&](int slot, uint32_t& st, uint32_t& cnt) -> int {
-    int k;
-    for (;;) {
-      unsigned long long pick = needm & nearm;
-      if (!pick) pick = needm;
-      if (!pick) return 0;
-      k = __ffsll((long long)pick) - 1;
-      needm &= ~(1ull << k);
-      if (!a.lazy_need) break;
-      const float lx = rl_f(b0.x, k), ly = rl_f(b0.y, k), lz = rl_f(b0.z, k);
-      const float hx = rl_f(b1.x, k), hy = rl_f(b1.y, k), hz = rl_f(b1.z, k);
-      const bool need = ing && box_dist2(lx, ly, lz, hx, hy, hz, qx, qy, qz) * kPruneShrink <= prune_lim(fminf(best, ub), gap, cap2);
-      if (__ballot(need)) break;
-    }
+    if (!needm) return 0;
+    const int k = __ffsll((long long)needm) - 1;
+    needm &= needm - 1;
     st = rl_u(__float_as_uint(b0.w), k);
     cnt = rl_u(__float_as_uint(b1.w), k);
     // the chunk's SoA block is 3 * cnt4 / 4 float4s (<= 48): one per lane, the other lanes stay out of it (nothing
@@ -957,13 +851,6 @@ __global__ __launch_bounds__(WAVES * 64, LSGPU_TILE_OCC) void k_knn_tile(KnnArgs
 #ifdef LSGPU_KNN_STATS
       if (a.dbg_flags & 64) return;
 #endif
-      // ---- few searching lanes: 2 or 4 copies of them evaluate 2 or 4 chunks at a time (tile_eval_slot_groups)
-      const uint32_t ns_tile = (uint32_t)__popcll(ing_mask);
-      const int copies = (WAVES == 1 && a.rep_rows) ? (ns_tile <= 16u ? 4 : ns_tile <= 32u ? 2 : 1) : 1;
-      if (copies > 1 && ing) {
-        const uint32_t rank = (uint32_t)__popcll(ing_mask & ((1ull << lane) - 1ull));
-        lds.qpack[0][rank] = qx; lds.qpack[1][rank] = qy; lds.qpack[2][rank] = qz;
-      }
       // ---- flatten the cells' chunk ranges into the LDS list, 64 at a time into the cull
       unsigned long long cells = __ballot(ce > cs);
       uint32_t fill = 0;
@@ -979,7 +866,7 @@ __global__ __launch_bounds__(WAVES * 64, LSGPU_TILE_OCC) void k_knn_tile(KnnArgs
             fill -= 64u;
             const uint32_t ch = lds.list[fill + lane];
             tile_process_batch(a, cap2s, lds, lane, true, ch, ing, qx, qy, qz, tlx, tly, tlz, thx, thy, thz,
-                               maxbest, ub, gap, best, sec, grp, n_eval, n_surv, c_eval, copies, ing_mask);
+                               maxbest, ub, gap, best, sec, grp, n_eval, n_surv, c_eval);
           }
         }
       }
@@ -987,7 +874,7 @@ __global__ __launch_bounds__(WAVES * 64, LSGPU_TILE_OCC) void k_knn_tile(KnnArgs
         const bool v = (uint32_t)lane < fill;
         const uint32_t ch = v ? lds.list[lane] : 0u;
         tile_process_batch(a, cap2s, lds, lane, v, ch, ing, qx, qy, qz, tlx, tly, tlz, thx, thy, thz,
-                           maxbest, ub, gap, best, sec, grp, n_eval, n_surv, c_eval, copies, ing_mask);
+                           maxbest, ub, gap, best, sec, grp, n_eval, n_surv, c_eval);
       }
     }
   }

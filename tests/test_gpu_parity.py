@@ -340,7 +340,7 @@ def test_experiment_switches_do_not_change_results():
     import sys
     variants = [{}, {"LSGPU_NO_FRONT": "1"}, {"LSGPU_NO_FRONT": "1", "LSGPU_NO_ROWQ": "1"},
                 {"LSGPU_NO_FRONT": "1", "LSGPU_NO_ROUTE_ALL": "1"}, {"LSGPU_NO_COMMIT": "1"}, {"LSGPU_NO_PREDICT": "1"},
-                {"LSGPU_ROCPRIM_SORT": "1"}, {"LSGPU_NO_SEED_CAP": "1"}, {"LSGPU_NO_REP": "1"}, {"LSGPU_NO_LAZY": "1"}, {"LSGPU_FRONT_GUESS": "8"}, {"LSGPU_SSN_GLOBAL": "1"},
+                {"LSGPU_ROCPRIM_SORT": "1"}, {"LSGPU_NO_SEED_CAP": "1"}, {"LSGPU_FRONT_GUESS": "8"}, {"LSGPU_SSN_GLOBAL": "1"},
                 {"LSGPU_QUERY_ORDER": "0"}]
     # the measured-slower variants only exist in the -DLSGPU_EXPERIMENTS build (devtools/build.sh); when that build is
     # around it has to give the same bits as the product, switch by switch
@@ -348,7 +348,7 @@ def test_experiment_switches_do_not_change_results():
     assert os.path.exists(fenced_so), "run __graft_entry__.build() first"
     variants.append({"LSGPU_SO": fenced_so})        # release / acquire fences instead of the fence-free hand-off: same bits
     exp_so = os.path.join(ROOT, "devtools", "liblsgpu_exp.so")
-    if os.path.exists(exp_so):
+    if os.path.exists(exp_so) and os.path.getmtime(exp_so) >= os.path.getmtime(os.path.join(ROOT, "laser_slam_amd", "liblsgpu_icp.so")) - 600:   # (a stale build says nothing)
         variants += [dict(v, LSGPU_SO=exp_so) for v in ({}, {"LSGPU_KNN_ROWS": "1"}, {"LSGPU_TILE_WAVES": "4"},
                                                         {"LSGPU_NO_FRONT": "1", "LSGPU_SPARSE_LANES": "16"})]
     results = []
