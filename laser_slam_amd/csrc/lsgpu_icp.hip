@@ -137,6 +137,8 @@ struct lsgpu_icp {
   lsgpu_icp_config cfg;
   int device = 0;
   hipStream_t stream = nullptr;
+  hipStream_t copy_stream = nullptr;   // lsgpu_icp_compute: the reading's H2D, overlapped with the reference filter
+  hipEvent_t copy_done = nullptr;
   std::string err;
 
   // reference (steps 2-3)
@@ -189,7 +191,7 @@ struct lsgpu_icp {
   DevBuf<SsnSeg> ssn_seg_a, ssn_seg_b;
   DevBuf<uint32_t> ssn_seg_of, ssn_box_pts, ssn_box_base, ssn_keep, ssn_out_pos, ssn_bb;
   DevBuf<float> ssn_box_normal, ssn_draws;
-  DevBuf<float4> flt_in, flt_ref, flt_rd;
+  DevBuf<float4> flt_in, flt_in2, flt_ref, flt_rd;
   DevBuf<float> flt_nrm;
   float* draws_pinned = nullptr;  // host staging of the filter draws (pinned: async H2D)
   std::vector<DevBuf<float4>> clouds;  // lsgpu_cloud_upload slots
@@ -335,7 +337,7 @@ void lsgpu_icp_destroy(lsgpu_icp* h) {
   h->work.release();
 #endif
   h->vals.release(); h->vals_alt.release(); h->sort_tmp.release(); h->sort_hist.release(); h->pts.release();
-  h->nrm.release(); h->ref_inv.release(); h->tables.release(); h->flags.release(); h->cidx.release(); h->bounds.release(); h->chunks.release(); h->soa.release(); h->soa_base.release(); h->soa_cnt4.release(); h->soa_first.release(); h->prev.release(); h->state.release(); h->lb.release(); h->cell_cache.release(); h->cell_tags.release(); h->ssn_seg_a.release(); h->ssn_seg_b.release(); h->ssn_seg_of.release(); h->ssn_box_pts.release(); h->ssn_box_base.release(); h->ssn_keep.release(); h->ssn_out_pos.release(); h->ssn_bb.release(); h->ssn_box_normal.release(); h->ssn_draws.release(); h->flt_in.release(); h->flt_ref.release(); h->flt_rd.release(); h->flt_nrm.release(); h->chk_hist.release(); h->trace_dev.release(); h->knn_dbg.release(); h->knn_dbg_wave.release(); h->stat_partials.release(); h->geom.release();
+  h->nrm.release(); h->ref_inv.release(); h->tables.release(); h->flags.release(); h->cidx.release(); h->bounds.release(); h->chunks.release(); h->soa.release(); h->soa_base.release(); h->soa_cnt4.release(); h->soa_first.release(); h->prev.release(); h->state.release(); h->lb.release(); h->cell_cache.release(); h->cell_tags.release(); h->ssn_seg_a.release(); h->ssn_seg_b.release(); h->ssn_seg_of.release(); h->ssn_box_pts.release(); h->ssn_box_base.release(); h->ssn_keep.release(); h->ssn_out_pos.release(); h->ssn_bb.release(); h->ssn_box_normal.release(); h->ssn_draws.release(); h->flt_in.release(); h->flt_in2.release(); h->flt_ref.release(); h->flt_rd.release(); h->flt_nrm.release(); h->chk_hist.release(); h->trace_dev.release(); h->knn_dbg.release(); h->knn_dbg_wave.release(); h->stat_partials.release(); h->geom.release();
   h->counters.release(); h->ang_cells.release(); h->sel_aux.release(); h->sel_win.release(); h->spread_flag.release(); h->spread_list.release(); h->spread_cnt.release(); h->q_in.release(); h->rdq.release(); h->ids.release(); h->d2.release();
   h->ids_io.release(); h->d2_io.release(); h->strag.release(); h->hist.release();
   h->sel.release(); h->ne_partials.release(); h->ne_gpartials.release(); h->ne_tickets.release(); h->ne_out.release(); h->limit_dev.release();
@@ -344,6 +346,8 @@ void lsgpu_icp_destroy(lsgpu_icp* h) {
   if (h->ev1) (void)hipEventDestroy(h->ev1);
   if (h->h_pinned) (void)hipHostFree(h->h_pinned);
   if (h->draws_pinned) (void)hipHostFree(h->draws_pinned);
+  if (h->copy_done) (void)hipEventDestroy(h->copy_done);
+  if (h->copy_stream) (void)hipStreamDestroy(h->copy_stream);
   if (h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
 }
@@ -1158,6 +1162,24 @@ int lsgpu_icp_compute(lsgpu_icp* h, const float* reading_xyz1, int64_t nq, const
   if (nq > 0x7FFFFFF0ll || nr > 0x7FFFFFF0ll) return LSGPU_BAD_ARG;
   HIPC(hipSetDevice(h->device));
   const double t0 = wall_ms();
+  // A reading handed over in HOST memory crosses PCIe while the reference is being filtered: its own stream, and its own
+  // host thread, because a copy from pageable memory keeps the calling thread until the last chunk is staged
+  // (SURVEY.md §8d counts H2D in scans/s).  The loop's stream waits for it right before the reading filter.
+  std::thread uploader;
+  hipError_t upload_err = hipSuccess;
+  const bool overlap_upload = !is_device_ptr(reading_xyz1);
+  if (overlap_upload) {
+    if (!h->copy_stream) HIPC(hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking));
+    if (!h->copy_done) HIPC(hipEventCreateWithFlags(&h->copy_done, hipEventDisableTiming));
+    HIPC(h->flt_in2.reserve(nq));
+    uploader = std::thread([&] {
+      hipError_t e = hipSetDevice(h->device);
+      if (e == hipSuccess) e = hipMemcpyAsync(h->flt_in2.p, reading_xyz1, (size_t)nq * 16, hipMemcpyHostToDevice, h->copy_stream);
+      if (e == hipSuccess) e = hipEventRecord(h->copy_done, h->copy_stream);
+      upload_err = e;
+    });
+  }
+  struct Joiner { std::thread& t; ~Joiner() { if (t.joinable()) t.join(); } } joiner{uploader};   // every return path joins
   // step 1: reference filter (yaml:5-7)
   const float4* src = nullptr;
   int rc = stage_points(h, reference_xyz1, nr, h->flt_in, &src);
@@ -1172,8 +1194,14 @@ int lsgpu_icp_compute(lsgpu_icp* h, const float* reading_xyz1, int64_t nq, const
   rc = lsgpu_icp_set_reference(h, reinterpret_cast<const float*>(h->flt_ref.p), h->flt_nrm.p, nrf);
   if (rc) return rc;
   // step 4: reading filter (yaml:1-3)
-  rc = stage_points(h, reading_xyz1, nq, h->flt_in, &src);
-  if (rc) return rc;
+  if (overlap_upload) {
+    uploader.join();
+    if (upload_err != hipSuccess) { h->err = std::string("compute: reading upload: ") + hipGetErrorString(upload_err); (void)hipGetLastError(); return LSGPU_HIP_ERROR; }
+    HIPC(hipStreamWaitEvent(h->stream, h->copy_done, 0));
+    src = h->flt_in2.p;
+  } else {
+    src = reinterpret_cast<const float4*>(reading_xyz1);
+  }
   const float4* rd_dev = src;
   if (chain->reading_prob < 0.f) {
     // no readingDataPointsFilters section: upstream runs no module at all -- every point, NO rand() call (a
