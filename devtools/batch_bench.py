@@ -14,7 +14,8 @@ for i in range(4):
     rf, rn = icp.sampling_surface_normal(ref, 10, 1.0, 0)
     uniq.append((torch.from_numpy(rf).cuda(), torch.from_numpy(rn).cuda(), torch.from_numpy(rd).cuda(), Ti, Tt))
 torch.cuda.synchronize()
-pairs = [uniq[i % 4] for i in range(B)]
+# every pair owns its buffers (equal pointers would let align_batch keep a shared reference's structures)
+pairs = [(uniq[i % 4][0].clone(), uniq[i % 4][1].clone(), uniq[i % 4][2].clone(), uniq[i % 4][3], uniq[i % 4][4]) for i in range(B)]
 refs, nrms, rds, Tis, Tts = map(list, zip(*pairs))
 print("points per cloud", rds[0].shape[0], "pairs", B)
 rows = []

@@ -26,7 +26,7 @@ for s in $steps; do
              gzip -c $f > gpurun_out/${tag}_pmc_fetch.csv.gz; gzip -c $w > gpurun_out/${tag}_pmc_write.csv.gz ;;
     batch)   timeout 600 python devtools/batch_bench.py 3125 32 gpurun_out/${tag}_batch200k.json 2>&1 | tail -6
              timeout 600 python bench.py --batch --steps 3 --warmup 1 > gpurun_out/${tag}_bench_batch.json 2> gpurun_out/${tag}_bench_batch.err; echo "bench --batch rc=$?"; cut -c1-900 gpurun_out/${tag}_bench_batch.json ;;
-    split)   timeout 900 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 1 --split --steps 5 --warmup 1 > gpurun_out/${tag}_bench_split.json 2> gpurun_out/${tag}_bench_split.err; echo "bench --split rc=$?"; cut -c1-900 gpurun_out/${tag}_bench_split.json ;;
+    split)   timeout 900 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 1 --split --steps 5 --warmup 1 2> gpurun_out/${tag}_bench_split.err | grep '^{' > gpurun_out/${tag}_bench_split.json; echo "bench --split rc=$?"; cut -c1-900 gpurun_out/${tag}_bench_split.json ;;
     cfg3)    timeout 600 python devtools/config4_shape.py 16384 - gpurun_out/${tag}_config3_1gpu.json 2>&1 | tail -3 ;;
     sq)      rm -rf gpurun_out/sq_${tag}
              (cd /tmp && timeout 600 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS -d $OLDPWD/gpurun_out/sq_${tag} --output-format csv -- python $OLDPWD/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-compute-e2e > /dev/null 2> $OLDPWD/gpurun_out/${tag}_sq.err)

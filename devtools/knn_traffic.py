@@ -20,7 +20,7 @@ out = {"n_az": 16384, "csrc_sha": csrc_digest(), "kernel": "k_knn_tile (+ the wa
        "hbm_bytes_per_launch": (2 * f + w) * 1024,
        "dispatches": {"k_knn_tile": nt, "k_knn_fallback + k_knn_rowq": nf},
        "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes with --kernel-trace, mean over all "
-                 "kNN launches of `python bench.py --steps 2 --warmup 1 --no-cpu-baseline`; bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 "
+                 "kNN launches of `python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-compute-e2e` (the timed compute steps + the profiled loop steps of configs[1]); bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 "
                  "(gfx950 FETCH_SIZE counts 128-B requests as 64 B: MI355X_MICROARCH.md HBM section; WRITE_SIZE uncalibrated)",
        "source": ["profiles/%s_pmc_fetch.csv.gz" % sys.argv[4], "profiles/%s_pmc_write.csv.gz" % sys.argv[4]]}
 json.dump(out, open(sys.argv[3], "w"), indent=1)

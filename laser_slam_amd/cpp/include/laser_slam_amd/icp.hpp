@@ -478,7 +478,6 @@ class ICP {
 
 inline void DataPointsFilters::apply(DataPoints& cloud) {
   if (filters_.empty()) return;
-  if (!cloud.normals.empty()) throw std::logic_error("DataPointsFilters: descriptors are not carried through the input filters");
   if (!h_) {
     lsgpu_icp_config c;
     lsgpu_icp_config_default(&c);
@@ -487,12 +486,31 @@ inline void DataPointsFilters::apply(DataPoints& cloud) {
   const int64_t n = cloud.getNbPoints();
   std::vector<float> out((size_t)std::max<int64_t>(n, 1) * 4);
   int64_t m = 0;
-  const int rc = lsgpu_apply_point_filters(h_, filters_.data(), (int)filters_.size(), cloud.features.data(), n, seed_,
-                                           out.data(), &m);
+  // A cloud with descriptors (normals): the device filters look at x, y, z only and carry the 4th component through, so
+  // the point's index travels in it and the descriptor columns of the survivors are picked afterwards -- the filters keep
+  // or drop whole columns, features and descriptors alike, as upstream's do.
+  const bool tagged = !cloud.normals.empty();
+  std::vector<float> in_tagged;
+  if (tagged) {
+    in_tagged = cloud.features;
+    for (int64_t i = 0; i < n; ++i) { const uint32_t tag = (uint32_t)i; std::memcpy(&in_tagged[(size_t)(4 * i + 3)], &tag, 4); }
+  }
+  const int rc = lsgpu_apply_point_filters(h_, filters_.data(), (int)filters_.size(), tagged ? in_tagged.data() : cloud.features.data(),
+                                           n, seed_, out.data(), &m);
   if (rc == LSGPU_NO_CONVERGENCE) throw ConvergenceError("no points to filter");
   if (rc == LSGPU_BAD_CONFIG) throw ConfigError(std::string("input filters: ") + lsgpu_last_error(h_));
   if (rc != LSGPU_OK) throw DeviceError(std::string("lsgpu_apply_point_filters: ") + lsgpu_strerror(rc) + " [" + lsgpu_last_error(h_) + "]");
   out.resize((size_t)m * 4);
+  if (tagged) {
+    std::vector<float> nrm((size_t)m * 3);
+    for (int64_t j = 0; j < m; ++j) {
+      uint32_t tag;
+      std::memcpy(&tag, &out[(size_t)(4 * j + 3)], 4);
+      out[(size_t)(4 * j + 3)] = cloud.features[(size_t)(4 * (int64_t)tag + 3)];
+      for (int d = 0; d < 3; ++d) nrm[(size_t)(3 * j + d)] = cloud.normals[(size_t)(3 * (int64_t)tag + d)];
+    }
+    cloud.normals.swap(nrm);
+  }
   cloud.features.swap(out);
 }
 

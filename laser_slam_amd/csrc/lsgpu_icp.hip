@@ -921,10 +921,10 @@ int lsgpu_transform_points(lsgpu_icp* h, const float T[16], const float* xyz1, i
 }
 
 int lsgpu_rotate_descriptors(lsgpu_icp* h, const float T[16], const float* desc3, int64_t n, float* out) {
-  if (!h || !T || !out) return LSGPU_BAD_ARG;
+  if (!h || !T) return LSGPU_BAD_ARG;
   h->err.clear();
   if (n == 0) return LSGPU_OK;
-  if (!desc3 || n < 0 || n > 0x7FFFFFF0ll) return LSGPU_BAD_ARG;
+  if (!desc3 || !out || n < 0 || n > 0x7FFFFFF0ll) return LSGPU_BAD_ARG;
   if (!lsgpu_check_rigid(T)) { h->err = "rotate_descriptors: the matrix is not rigid"; return LSGPU_BAD_ARG; }   // TransformationError upstream
   HIPC(hipSetDevice(h->device));
   const float* src = desc3;

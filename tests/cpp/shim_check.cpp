@@ -69,6 +69,21 @@ int main(int argc, char** argv) {
   }
   CHECK(same);
   CHECK(desc_ok);
+  {  // the mirror's own DataPointsFilters carries a cloud's normals through as well: same survivors, their own descriptors
+    std::ifstream fy3(argv[2]);
+    DataPointsFilters mf2(fy3);
+    mf2.setSeed(11);
+    DataPoints c = rd;
+    c.normals.resize((size_t)c.getNbPoints() * 3);
+    for (int64_t i = 0; i < c.getNbPoints(); ++i) { c.normals[3 * i] = (float)i; c.normals[3 * i + 1] = c.features[4 * i]; c.normals[3 * i + 2] = 7.f; }
+    mf2.apply(c);
+    CHECK(c.getNbPoints() == b.getNbPoints() && c.normals.size() == (size_t)c.getNbPoints() * 3);
+    bool ok = true;
+    for (int64_t i = 0; i < c.getNbPoints() && i < b.getNbPoints(); ++i)
+      ok = ok && std::memcmp(&c.features[4 * i], &b.features[4 * i], 16) == 0 && c.normals[3 * i + 1] == c.features[4 * i] &&
+           c.normals[3 * i + 2] == 7.f && rd.features[4 * (int64_t)c.normals[3 * i]] == c.features[4 * i];
+    CHECK(ok);
+  }
   {  // ROS message surface: a Velodyne-style PointCloud2 (x,y,z,intensity,ring: 22-byte records) -> DataPoints -> back
     PointCloud2 msg;
     const int64_t n = rd.getNbPoints();
