@@ -587,10 +587,13 @@ static int run_knn(lsgpu_icp* h, const Mat34& T, const IcpState* st, bool seed, 
   }
   a.xcd_swizzle = tn.xcd_swizzle;
   if (tn.tile_waves == 4)
-    hipLaunchKernelGGL(k_knn_tile<4>, dim3((a.ntiles + 3) / 4), dim3(256), 0, h->stream, a);
+    hipLaunchKernelGGL((k_knn_tile<4, false>), dim3((a.ntiles + 3) / 4), dim3(256), 0, h->stream, a);
   else
 #endif
-  hipLaunchKernelGGL(k_knn_tile<1>, dim3(a.ntiles + a.front_blocks), dim3(64), 0, h->stream, a);
+  if (wide && tn.lazy_need)   // balls still as wide as the last ICP step: the instantiation that re-tests chunks before fetching them
+    hipLaunchKernelGGL((k_knn_tile<1, true>), dim3(a.ntiles + a.front_blocks), dim3(64), 0, h->stream, a);
+  else
+    hipLaunchKernelGGL((k_knn_tile<1, false>), dim3(a.ntiles + a.front_blocks), dim3(64), 0, h->stream, a);
   if (timed) HIPC(hipEventRecord(ev->b, h->stream));
   // stragglers (balls > r_cap) only exist in uncapped launches; a settled launch without front rows hands a few
   // thousand queries at most to the row pass (one DPP row per query)

@@ -291,6 +291,14 @@ __device__ __forceinline__ void tile_eval_slot(const float4* __restrict__ slot, 
 // Cull 64 queued chunks (one per lane) against the group's query box, test the survivors per lane
 // against each lane's own bound, then fetch the needed chunks FOUR AT A TIME with LDS-DMA (one memory
 // latency per four chunks, no staging registers) and broadcast-evaluate them.
+// LAZY (launches whose balls are still WIDE -- the first iterations of an align: a ball is as large as the last ICP step,
+// 15 cm in the median of iteration 1, while the neighbour sits 2-5 cm from the query): the chunks that overlap the tile's own
+// query box are fetched first, and every chunk is RE-TESTED against the lanes' current bounds right before it is fetched --
+// once the near chunks are evaluated most of the others are needed by nobody.  Exact: the bounds are upper bounds of the
+// final distances, a skipped chunk lies beyond the final search radius.  Worth 35-40 us in each of the first two launches;
+// compiled into its own instantiation of the kernel, because the same code in the settled launches costs them 8 % (it
+// lengthens the live ranges of a kernel that sits at its register budget; profiles/r03_knn_variants.txt).
+template <bool LAZY>
 __device__ __forceinline__ void tile_process_batch(const KnnArgs& a, float cap2, TileLds& lds, int lane, bool valid,
                                                    uint32_t ch, bool ing, float qx, float qy, float qz,
                                                    float tlx, float tly, float tlz, float thx, float thy,
@@ -299,7 +307,7 @@ __device__ __forceinline__ void tile_process_batch(const KnnArgs& a, float cap2,
                                                    uint32_t& c_eval /* stats builds: cycles spent fetching + evaluating */) {
   float4 b0 = make_float4(0.f, 0.f, 0.f, 0.f), b1 = b0;
   uint32_t sbase = 0;
-  bool pass = false;
+  bool pass = false, near = false;
   if (valid) {
     const float4* cd = reinterpret_cast<const float4*>(a.chunks + ch);
     b0 = cd[0]; b1 = cd[1];
@@ -307,10 +315,13 @@ __device__ __forceinline__ void tile_process_batch(const KnnArgs& a, float cap2,
     const float gx = fmaxf(fmaxf(b0.x - thx, tlx - b1.x), 0.f);
     const float gy = fmaxf(fmaxf(b0.y - thy, tly - b1.y), 0.f);
     const float gz = fmaxf(fmaxf(b0.z - thz, tlz - b1.z), 0.f);
-    pass = (gx * gx + gy * gy + gz * gz) * kPruneShrink <= maxbest;
+    const float gd = gx * gx + gy * gy + gz * gz;
+    pass = gd * kPruneShrink <= maxbest;
+    if (LAZY) near = gd == 0.f;   // the chunk's box overlaps the box of the tile's own queries
   }
   unsigned long long m = __ballot(pass);
   if (!m) return;
+  const unsigned long long nearm = LAZY ? __ballot(pass && near) : 0ull;
 #ifdef LSGPU_KNN_STATS
   if (a.dbg_flags & 128) { n_surv += __popcll(m); return; }
 #endif
@@ -358,9 +369,24 @@ __device__ __forceinline__ void tile_process_batch(const KnnArgs& a, float cap2,
 #endif
   uint32_t sa0 = 0, sa1 = 0, ca0 = 0, ca1 = 0, sb0 = 0, sb1 = 0, cb0 = 0, cb1 = 0;
   auto issue = [&](int slot, uint32_t& st, uint32_t& cnt) -> int {
-    if (!needm) return 0;
-    const int k = __ffsll((long long)needm) - 1;
-    needm &= needm - 1;
+    int k;
+    if (LAZY) {
+      for (;;) {
+        unsigned long long pick = needm & nearm;
+        if (!pick) pick = needm;
+        if (!pick) return 0;
+        k = __ffsll((long long)pick) - 1;
+        needm &= ~(1ull << k);
+        const float lx = rl_f(b0.x, k), ly = rl_f(b0.y, k), lz = rl_f(b0.z, k);
+        const float hx = rl_f(b1.x, k), hy = rl_f(b1.y, k), hz = rl_f(b1.z, k);
+        const bool need = ing && box_dist2(lx, ly, lz, hx, hy, hz, qx, qy, qz) * kPruneShrink <= prune_lim(fminf(best, ub), gap, cap2);
+        if (__ballot(need)) break;
+      }
+    } else {
+      if (!needm) return 0;
+      k = __ffsll((long long)needm) - 1;
+      needm &= needm - 1;
+    }
     st = rl_u(__float_as_uint(b0.w), k);
     cnt = rl_u(__float_as_uint(b1.w), k);
     // the chunk's SoA block is 3 * cnt4 / 4 float4s (<= 48): one per lane, the other lanes stay out of it (nothing
@@ -633,7 +659,7 @@ __device__ __forceinline__ void tile_front_rows(const KnnArgs& a, uint32_t* lds_
 #ifndef LSGPU_TILE_OCC
 #define LSGPU_TILE_OCC 7   // waves per SIMD the register budget is cut for (7: 72 VGPRs, no spills; 8 spills 48 B per lane)
 #endif
-template <int WAVES>
+template <int WAVES, bool LAZY = false>
 __global__ __launch_bounds__(WAVES * 64, LSGPU_TILE_OCC) void k_knn_tile(KnnArgs a) {
   __shared__ TileLds lds_all[WAVES];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -865,7 +891,7 @@ __global__ __launch_bounds__(WAVES * 64, LSGPU_TILE_OCC) void k_knn_tile(KnnArgs
           while (fill >= 64u) {  // a full batch is ready
             fill -= 64u;
             const uint32_t ch = lds.list[fill + lane];
-            tile_process_batch(a, cap2s, lds, lane, true, ch, ing, qx, qy, qz, tlx, tly, tlz, thx, thy, thz,
+            tile_process_batch<LAZY>(a, cap2s, lds, lane, true, ch, ing, qx, qy, qz, tlx, tly, tlz, thx, thy, thz,
                                maxbest, ub, gap, best, sec, grp, n_eval, n_surv, c_eval);
           }
         }
@@ -873,7 +899,7 @@ __global__ __launch_bounds__(WAVES * 64, LSGPU_TILE_OCC) void k_knn_tile(KnnArgs
       if (fill) {
         const bool v = (uint32_t)lane < fill;
         const uint32_t ch = v ? lds.list[lane] : 0u;
-        tile_process_batch(a, cap2s, lds, lane, v, ch, ing, qx, qy, qz, tlx, tly, tlz, thx, thy, thz,
+        tile_process_batch<LAZY>(a, cap2s, lds, lane, v, ch, ing, qx, qy, qz, tlx, tly, tlz, thx, thy, thz,
                            maxbest, ub, gap, best, sec, grp, n_eval, n_surv, c_eval);
       }
     }
