@@ -520,6 +520,7 @@ static int run_knn(lsgpu_icp* h, const Mat34& T, const IcpState* st, bool seed, 
   // searches held single waves for 190 k cycles, the tail of a 46 k-cycle launch
   const bool settled = capped && !wide && st && tn.route_all;
   a.spread_route_r = wide ? tn.route_r : settled ? 1e-30f : 0.f;
+  a.chunk_budget = wide ? tn.chunk_budget_wide : tn.chunk_budget;
 #ifdef LSGPU_EXPERIMENTS
   a.sparse_lanes = settled && tn.rowq ? tn.sparse_lanes : 0;
 #endif

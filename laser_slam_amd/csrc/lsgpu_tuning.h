@@ -10,7 +10,9 @@
 //   LSGPU_QUERY_ORDER      -1   order of the queries inside the waves: -1 automatic, 0 Morton, 1 spherical cells
 //   LSGPU_Q_ELEV / _Q_SECT  0   elevation bin / azimuth sector of the spherical cells in degrees (0: from the density)
 //   LSGPU_GAP             0.002 metres searched beyond the current best in capped launches (keep-match bound)
-//   LSGPU_BUDGET           128  chunks in a spread wave's cell block above which its lanes search on their own
+//   LSGPU_BUDGET           512  chunks in a spread wave's cell block above which its lanes search on their own (settled launches;
+//                               measured 128 / 256 / 512 / 1024: 89.9 / 88.3 / 86.4 / 91.5 us per launch, profiles/r03_knn_variants.txt)
+//   LSGPU_BUDGET_WIDE     1024  the same threshold in the wide launches (first iterations)
 //   LSGPU_WIDE_ITERS         3  first iterations of an align whose wide-ball spread waves go to the wave-per-query pass
 //   LSGPU_ROUTE_R         0.02  ... if their largest ball exceeds this (metres)
 //   LSGPU_ROUTE_CHUNKS    1024  ... or the cell block holds more chunks than this
@@ -47,7 +49,7 @@ struct Tuning {
   int query_order = -1;
   float q_elev = 0.f, q_sect = 0.f;
   float gap = 0.002f;
-  int chunk_budget = 128;
+  int chunk_budget = 512, chunk_budget_wide = 1024;
   int wide_iters = 3;
   float route_r = 0.02f;
   int route_chunks = 1024;
@@ -92,7 +94,8 @@ inline Tuning read() {
   t.q_elev = (float)number("LSGPU_Q_ELEV", 0, 0, 45);
   t.q_sect = (float)number("LSGPU_Q_SECT", 0, 0, 45);
   t.gap = (float)number("LSGPU_GAP", 0.002, 0, 1);
-  t.chunk_budget = (int)number("LSGPU_BUDGET", 128, 1, 1 << 20);
+  t.chunk_budget = (int)number("LSGPU_BUDGET", 512, 1, 1 << 20);
+  t.chunk_budget_wide = (int)number("LSGPU_BUDGET_WIDE", 1024, 1, 1 << 20);
   t.wide_iters = (int)number("LSGPU_WIDE_ITERS", 3, 0, 1 << 20);
   t.route_r = (float)number("LSGPU_ROUTE_R", 0.02, 1e-6, 1e6);
   t.route_chunks = (int)number("LSGPU_ROUTE_CHUNKS", 1024, 1, 1 << 30);
@@ -117,7 +120,7 @@ inline Tuning read() {
   t.ne_blocks = (int)number("LSGPU_NE_BLOCKS", 256, 64, 2048);
   t.comm_timeout_ms = number("LSGPU_COMM_TIMEOUT_MS", 30000, 1, 1e9);
   t.knn_dbg = (int)number("LSGPU_KNN_DBG", 0, 0, 1 << 20);
-  static const char* known[] = {"LSGPU_QUERY_ORDER", "LSGPU_Q_ELEV", "LSGPU_Q_SECT", "LSGPU_GAP", "LSGPU_BUDGET", "LSGPU_WIDE_ITERS",
+  static const char* known[] = {"LSGPU_QUERY_ORDER", "LSGPU_Q_ELEV", "LSGPU_Q_SECT", "LSGPU_GAP", "LSGPU_BUDGET", "LSGPU_BUDGET_WIDE", "LSGPU_WIDE_ITERS",
                                 "LSGPU_ROUTE_R", "LSGPU_ROUTE_CHUNKS", "LSGPU_SPLIT_UPDATE", "LSGPU_NO_PREDICT", "LSGPU_NO_COMMIT",
                                 "LSGPU_NO_COMM_COMMIT", "LSGPU_NO_SEED_CAP", "LSGPU_NO_FRONT", "LSGPU_NO_LAZY", "LSGPU_FRONT_GUESS", "LSGPU_NO_ROUTE_ALL",
                                 "LSGPU_NO_ROWQ", "LSGPU_ROWQ_BLOCKS", "LSGPU_ROCPRIM_SORT", "LSGPU_SORT_ITEMS", "LSGPU_SSN_GLOBAL",
