@@ -11,9 +11,11 @@
 //   k_rs_scan     one block per digit: exclusive prefix over the blocks (in place) + the digit's total
 //   k_rs_scatter  every block ranks its keys again -- wave by wave, 64 consecutive keys at a time: the lanes holding the
 //                 same digit find each other with 8 ballots, the lowest of them advances the wave's counter of that digit
-//                 in LDS -- and writes each pair to  digit base + blocks before + waves before + rank,
-//                 which keeps equal digits in input order (stable), hence the whole sort stable and identical to any
-//                 other stable sort of the same keys.
+//                 in LDS -- which gives each pair its slot  digit base + blocks before + waves before + rank  and keeps
+//                 equal digits in input order (stable), hence the whole sort stable and identical to any other stable
+//                 sort of the same keys.  The block's pairs go through LDS in digit order first, so that consecutive
+//                 threads store to consecutive addresses of each digit's run (round 3; straight from the registers every
+//                 lane of a store hit its own cache line).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -79,12 +81,18 @@ __global__ __launch_bounds__(256) void k_rs_scatter(const uint64_t* __restrict__
                                                     const uint32_t* __restrict__ blockpref,
                                                     const uint32_t* __restrict__ dtot, int nblocks) {
   __shared__ uint32_t cnt[4][256];   // per wave and digit: keys seen so far, then: keys of the waves before
-  __shared__ uint32_t base_sh[256];  // per digit: first output position of this block's keys
-  __shared__ uint32_t wtot[4];
+  __shared__ uint32_t base_sh[256];  // per digit: first output position of this block's keys, minus their first local slot
+  __shared__ uint32_t dstart[256];   // per digit: first local slot of this block's keys (exclusive prefix of the block's digit counts)
+  __shared__ uint32_t wtot[4], wtot2[4];
+  // the block's pairs in digit order: stores straight from the registers hit a different cache line per lane (the digits of
+  // 64 consecutive keys are unrelated); staged through LDS, consecutive threads write consecutive addresses of each digit's run
+  __shared__ uint64_t skey[256 * ITEMS];
+  __shared__ uint32_t sval[256 * ITEMS];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
 #pragma unroll
   for (int i = 0; i < 4; ++i) cnt[i][threadIdx.x] = 0u;
-  const int64_t base = (int64_t)blockIdx.x * (256 * ITEMS) + (int64_t)w * (64 * ITEMS) + lane;
+  const int64_t blk0 = (int64_t)blockIdx.x * (256 * ITEMS);
+  const int64_t base = blk0 + (int64_t)w * (64 * ITEMS) + lane;
   uint64_t key[ITEMS];
   uint32_t val[ITEMS], rank[ITEMS];
 #pragma unroll
@@ -129,22 +137,40 @@ __global__ __launch_bounds__(256) void k_rs_scatter(const uint64_t* __restrict__
       cnt[ww][d] = run;
       run += t;
     }
+    // two block-wide exclusive scans over the digits: the digit totals of the whole input (global base) and of this block
+    // (local slot of the digit's run)
     const uint32_t tot = dtot[d];
     const uint32_t incl = wave_scan_incl_u32(tot, lane);
-    if (lane == 63) wtot[w] = incl;
+    const uint32_t incl2 = wave_scan_incl_u32(run, lane);
+    if (lane == 63) { wtot[w] = incl; wtot2[w] = incl2; }
     __syncthreads();
-    uint32_t before = 0u;
-    for (int ww = 0; ww < w; ++ww) before += wtot[ww];
-    base_sh[d] = before + incl - tot + blockpref[(size_t)d * nblocks + blockIdx.x];
+    uint32_t before = 0u, before2 = 0u;
+    for (int ww = 0; ww < w; ++ww) { before += wtot[ww]; before2 += wtot2[ww]; }
+    const uint32_t ds = before2 + incl2 - run;
+    dstart[d] = ds;
+    base_sh[d] = before + incl - tot + blockpref[(size_t)d * nblocks + blockIdx.x] - ds;   // (+ local slot = output position; wraps harmlessly)
   }
   __syncthreads();
 #pragma unroll
   for (int i = 0; i < ITEMS; ++i) {
     if (base + i * 64 < n) {
       const uint32_t dig = (uint32_t)(key[i] >> shift) & mask;
-      const uint32_t pos = base_sh[dig] + cnt[w][dig] + rank[i];
-      kout[pos] = key[i];
-      vout[pos] = val[i];
+      const uint32_t slot = dstart[dig] + cnt[w][dig] + rank[i];
+      skey[slot] = key[i];
+      sval[slot] = val[i];
+    }
+  }
+  __syncthreads();
+  const int64_t left = n - blk0;
+  const uint32_t nloc = left >= (int64_t)(256 * ITEMS) ? (uint32_t)(256 * ITEMS) : (uint32_t)left;
+#pragma unroll
+  for (int i = 0; i < ITEMS; ++i) {
+    const uint32_t slot = (uint32_t)i * 256u + threadIdx.x;
+    if (slot < nloc) {
+      const uint64_t k = skey[slot];
+      const uint32_t pos = base_sh[(uint32_t)(k >> shift) & mask] + slot;
+      kout[pos] = k;
+      vout[pos] = sval[slot];
     }
   }
 }
