@@ -977,6 +977,52 @@ static int upload_draws_begin(lsgpu_icp* h, int64_t seed, size_t kmax) {
   return LSGPU_OK;
 }
 
+// The same, produced AHEAD on a helper thread while the calling thread enqueues the kernels that come before the draws
+// are needed (the ~1.3 ns a draw costs used to sit on the stream's critical path: the device idled ~0.3 ms per 200 k
+// points in front of k_ssn_select and again in front of k_draw_select, profiles/r03_bench.stats.txt).  begin() locks
+// the stream and starts the helper, ready() joins it and enqueues the H2D of all draws on the handle's stream, the
+// destructor consumes `used` draws -- what the sequential filters would have made -- and unlocks.  One DrawAhead can
+// serve consecutive filters: lsgpu_icp_compute draws for the reference filter and the reading filter in one go, the
+// reading filter's draws start where the reference filter's end (known once its kernels ran).
+struct DrawAhead {
+  lsgpu_icp* h = nullptr;
+  size_t kmax = 0, used = 0;
+  bool open = false, uploaded = false;
+  std::thread worker;
+  DrawAhead() = default;
+  DrawAhead(const DrawAhead&) = delete;
+  DrawAhead& operator=(const DrawAhead&) = delete;
+  int begin(lsgpu_icp* hh, int64_t seed, size_t k) {
+    h = hh; kmax = k;
+    if (kmax + 1 > h->draws_pinned_cap) {
+      if (h->draws_pinned) (void)hipHostFree(h->draws_pinned);
+      h->draws_pinned = nullptr; h->draws_pinned_cap = 0;
+      HIPC(hipHostMalloc((void**)&h->draws_pinned, (kmax + 1) * sizeof(float), hipHostMallocDefault));
+      h->draws_pinned_cap = kmax + 1;
+    }
+    HIPC(h->ssn_draws.reserve(kmax + 1));
+    DrawStream::global().lock(seed);
+    open = true;
+    float* dst = h->draws_pinned;
+    if (kmax) worker = std::thread([dst, k] { DrawStream::global().generate(k, dst); });
+    return LSGPU_OK;
+  }
+  int ready() {
+    if (worker.joinable()) worker.join();
+    if (!uploaded && kmax) {
+      HIPC(hipMemcpyAsync(h->ssn_draws.p, h->draws_pinned, kmax * sizeof(float), hipMemcpyHostToDevice, h->stream));
+      uploaded = true;
+    }
+    return LSGPU_OK;
+  }
+  void finish() {   // consume + unlock now (the stream must not stay locked while the ICP loop runs)
+    if (worker.joinable()) worker.join();
+    if (open) DrawStream::global().commit(std::min(used, kmax));
+    open = false;
+  }
+  ~DrawAhead() { finish(); }
+};
+
 // totals of two exclusive scans (last scanned value + last input) in one D2H, synchronises the stream
 static int scan_totals(lsgpu_icp* h, const uint32_t* in_a, const uint32_t* sc_a, size_t na,
                        const uint32_t* in_b, const uint32_t* sc_b, size_t nb, uint32_t* tot_a, uint32_t* tot_b) {
@@ -997,9 +1043,17 @@ static int scan_totals(lsgpu_icp* h, const uint32_t* in_a, const uint32_t* sc_a,
 }
 
 // SamplingSurfaceNormal on device memory: src (n points) -> out_xyz1 / out_nrm (device, room for n)
+// (`ahead`: draws begun by the caller, this filter's first at ahead->used; nullptr: the filter draws for itself)
 static int ssn_device(lsgpu_icp* h, const float4* src, int64_t n, int knn, float ratio, int64_t seed,
-                      float4* out_xyz1, float* out_nrm, int64_t* n_out) {
+                      float4* out_xyz1, float* out_nrm, int64_t* n_out, DrawAhead* ahead = nullptr) {
   *n_out = 0;
+  DrawAhead own;
+  if (!ahead) {   // at most one draw per point, produced while the levels below are enqueued and run
+    const int rc0 = own.begin(h, seed, (size_t)n);
+    if (rc0) return rc0;
+    ahead = &own;
+  }
+  const size_t first_draw = ahead->used;
   int levels = 0;
   for (int64_t c = n; c > knn; c -= c / 2) ++levels;  // the largest child keeps count - count / 2 points
   const size_t nseg = (size_t)1 << levels;
@@ -1061,11 +1115,11 @@ static int ssn_device(lsgpu_icp* h, const float4* src, int64_t n, int knn, float
   HIPC(hipGetLastError());
   int rc = scan_u32(h, h->ssn_box_pts.p, h->ssn_box_base.p, nseg);
   if (rc) return rc;
-  // the draws: at most one per point; produced on the host while the kernels above run
-  rc = upload_draws_begin(h, seed, (size_t)n);
+  // the draws: at most one per point; produced on the helper thread while the kernels above were enqueued
+  rc = ahead->ready();
   if (rc) return rc;
   hipLaunchKernelGGL(k_ssn_select, dim3(nblk(n)), dim3(256), 0, h->stream, (int)n, h->ssn_seg_of.p, cur,
-                     h->ssn_box_pts.p, h->ssn_box_base.p, h->ssn_draws.p, ratio, h->ssn_keep.p);
+                     h->ssn_box_pts.p, h->ssn_box_base.p, h->ssn_draws.p + first_draw, ratio, h->ssn_keep.p);
   rc = scan_u32(h, h->ssn_keep.p, h->ssn_out_pos.p, (size_t)n);
   if (rc == LSGPU_OK) {
     hipLaunchKernelGGL(k_ssn_emit, dim3(nblk(n)), dim3(256), 0, h->stream, src, (int)n, idx, h->ssn_seg_of.p,
@@ -1074,8 +1128,8 @@ static int ssn_device(lsgpu_icp* h, const float4* src, int64_t n, int knn, float
   uint32_t n_draws = 0, kept = 0;
   if (rc == LSGPU_OK)
     rc = scan_totals(h, h->ssn_box_pts.p, h->ssn_box_base.p, nseg, h->ssn_keep.p, h->ssn_out_pos.p, (size_t)n, &n_draws, &kept);
-  DrawStream::global().commit(rc == LSGPU_OK ? (size_t)n_draws : 0);  // dropped boxes drew nothing
   if (rc) return rc;
+  ahead->used = first_draw + (size_t)n_draws;  // dropped boxes drew nothing
   HIPC(hipGetLastError());
   *n_out = kept;
   return LSGPU_OK;
@@ -1083,14 +1137,22 @@ static int ssn_device(lsgpu_icp* h, const float4* src, int64_t n, int knn, float
 
 // RandomSampling on device memory (order preserved)
 static int random_sampling_device(lsgpu_icp* h, const float4* src, int64_t n, float prob, int64_t seed,
-                                  float4* out_xyz1, int64_t* n_out) {
+                                  float4* out_xyz1, int64_t* n_out, DrawAhead* ahead = nullptr) {
   *n_out = 0;
   HIPC(h->ssn_keep.reserve(n));
   HIPC(h->ssn_out_pos.reserve(n));
-  int rc = upload_draws_begin(h, seed, (size_t)n);
+  DrawAhead own;
+  int rc = LSGPU_OK;
+  if (!ahead) {
+    rc = own.begin(h, seed, (size_t)n);
+    if (rc) return rc;
+    ahead = &own;
+  }
+  const size_t first_draw = ahead->used;
+  ahead->used = first_draw + (size_t)n;  // one draw per point, whatever happens next
+  rc = ahead->ready();
   if (rc) return rc;
-  DrawStream::global().commit((size_t)n);  // one draw per point, whatever happens next
-  hipLaunchKernelGGL(k_draw_select, dim3(nblk(n)), dim3(256), 0, h->stream, (int)n, h->ssn_draws.p, prob, h->ssn_keep.p);
+  hipLaunchKernelGGL(k_draw_select, dim3(nblk(n)), dim3(256), 0, h->stream, (int)n, h->ssn_draws.p + first_draw, prob, h->ssn_keep.p);
   rc = scan_u32(h, h->ssn_keep.p, h->ssn_out_pos.p, (size_t)n);
   if (rc) return rc;
   hipLaunchKernelGGL(k_compact_points, dim3(nblk(n)), dim3(256), 0, h->stream, src, (int)n, h->ssn_keep.p,
@@ -1184,6 +1246,13 @@ int lsgpu_icp_compute(lsgpu_icp* h, const float* reading_xyz1, int64_t nq, const
     });
   }
   struct Joiner { std::thread& t; ~Joiner() { if (t.joinable()) t.join(); } } joiner{uploader};   // every return path joins
+  // the draws of both filters, produced on a helper thread from now on: at most one per reference point, then one per
+  // reading point
+  DrawAhead draws;
+  {
+    const int rc0 = draws.begin(h, -1, (size_t)nr + (chain->reading_prob < 0.f ? (size_t)0 : (size_t)nq));
+    if (rc0) return rc0;
+  }
   // step 1: reference filter (yaml:5-7)
   const float4* src = nullptr;
   int rc = stage_points(h, reference_xyz1, nr, h->flt_in, &src);
@@ -1191,7 +1260,7 @@ int lsgpu_icp_compute(lsgpu_icp* h, const float* reading_xyz1, int64_t nq, const
   HIPC(h->flt_ref.reserve(nr));
   HIPC(h->flt_nrm.reserve(3 * nr));
   int64_t nrf = 0, nqf = 0;
-  rc = ssn_device(h, src, nr, chain->ssn_knn, chain->ssn_ratio, -1, h->flt_ref.p, h->flt_nrm.p, &nrf);
+  rc = ssn_device(h, src, nr, chain->ssn_knn, chain->ssn_ratio, -1, h->flt_ref.p, h->flt_nrm.p, &nrf, &draws);
   if (rc) return rc;
   if (nrf <= 0) { h->err = "compute: the reference filter left no point"; h->nr = 0; return LSGPU_NO_CONVERGENCE; }
   // steps 2-3
@@ -1213,10 +1282,11 @@ int lsgpu_icp_compute(lsgpu_icp* h, const float* reading_xyz1, int64_t nq, const
     nqf = nq;
   } else {
     HIPC(h->flt_rd.reserve(nq));
-    rc = random_sampling_device(h, src, nq, chain->reading_prob, -1, h->flt_rd.p, &nqf);
+    rc = random_sampling_device(h, src, nq, chain->reading_prob, -1, h->flt_rd.p, &nqf, &draws);
     if (rc) return rc;
     rd_dev = h->flt_rd.p;
   }
+  draws.finish();
   const double t_filters = wall_ms() - t0;
   if (nqf <= 0) { h->err = "compute: the reading filter left no point"; return LSGPU_NO_CONVERGENCE; }
   // steps 5-7

@@ -58,6 +58,13 @@ class DrawStream {
     commit_locked(k);
     mu_.unlock();
   }
+  // The same in two steps, for draws produced on a helper thread: the OWNER calls lock() and later commit(); generate()
+  // may run on any one thread in between (the owner joins it before commit()).
+  void lock(int64_t seed) {
+    mu_.lock();
+    if (seed >= 0) reseed_locked((unsigned)seed);
+  }
+  void generate(size_t kmax, float* out) { generate_locked(kmax, out); }
 
   static DrawStream& global() {
     static DrawStream s;
@@ -115,7 +122,7 @@ class DrawStream {
   // raw_[0..31) = the last 31 raw words (oldest first), raw_[31 + i] = the i-th not yet consumed word
   void generate_locked(size_t k, float* out) {
     seg_states_.clear();
-    if (out && k >= 4 * kSeg) {   // large request: segment start states by jump-ahead, segments filled in parallel
+    if (out && k >= 16 * kSeg) {   // large request (a sub-map of several scans): segment start states by jump-ahead, segments filled in parallel
       const size_t nseg = (k + kSeg - 1) / kSeg;
       const Mat& J = jump();
       seg_states_.resize((nseg + 1) * 31);
