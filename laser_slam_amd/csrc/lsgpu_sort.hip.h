@@ -9,6 +9,10 @@
 // Per pass, three launches on the handle's stream:
 //   k_rs_hist     per block (256 threads x ITEMS keys) the histogram of the pass's digit -> blockhist[digit][block]
 //   k_rs_scan     one block per digit: exclusive prefix over the blocks (in place) + the digit's total
+//                 (Leaving this launch out was tried twice and measured slower both times: as the tail of k_rs_hist -- last
+//                 block, ticket -- 2 %; and with two-level counts -- k_rs_hist adds to per-group-of-32-blocks totals,
+//                 the scatter's thread d sums <= 32 groups + <= 31 blocks with 16 16-byte loads -- filters + grid
+//                 1.94 -> 2.13 ms per 1 M-point compute, profiles/r03_knn_variants.txt r03r.)
 //   k_rs_scatter  every block ranks its keys again -- wave by wave, 64 consecutive keys at a time: the lanes holding the
 //                 same digit find each other with 8 ballots, the lowest of them advances the wave's counter of that digit
 //                 in LDS -- which gives each pair its slot  digit base + blocks before + waves before + rank  and keeps
