@@ -12,6 +12,7 @@
 #include <string>
 #include <vector>
 #include <chrono>
+#include <functional>
 #include <thread>
 
 #include <dlfcn.h>
@@ -148,10 +149,24 @@ struct lsgpu_icp {
   int ls = 0;  // start level of the main kNN pass
   lsgpu_icp_info info;
   DevBuf<float4> ref_in;   DevBuf<float> nrm_in;
-  DevBuf<uint64_t> keys, keys_alt;
-  DevBuf<uint32_t> vals, vals_alt;
-  DevBuf<char> sort_tmp;
-  DevBuf<uint32_t> sort_hist;  // radix sort: 256 x blocks digit histograms + 256 digit totals
+  // Scratch of the sorts and scans.  Two sets: lsgpu_icp_compute orders the queries on a second stream while the
+  // reference grid is built on the first (`sc` / `cur` = the set and the stream the helpers below enqueue on).
+  struct SortScratch {
+    DevBuf<uint64_t> keys, keys_alt;
+    DevBuf<uint32_t> vals, vals_alt;
+    DevBuf<char> sort_tmp;
+    DevBuf<uint32_t> sort_hist;  // radix sort: 256 x blocks digit histograms + 256 digit totals
+    void release() { keys.release(); keys_alt.release(); vals.release(); vals_alt.release(); sort_tmp.release(); sort_hist.release(); }
+  };
+  SortScratch scr_main, scr_side;
+  SortScratch* sc = &scr_main;
+  hipStream_t cur = nullptr;           // == stream except while lsgpu_icp_compute enqueues its side work
+  hipStream_t side_stream = nullptr;   // lsgpu_icp_compute: reading filter + query order, beside the grid build
+  hipEvent_t side_done = nullptr;
+  int side_totals_slot = 0;            // scan_totals staging: the side path uses its own words of h_pinned
+  std::function<int()> hook_before_ref_sync, hook_after_ref_sync;   // set by lsgpu_icp_compute around set_reference
+  const float* prepared_rd = nullptr;  // queries already ordered by the side path (consumed by the next align)
+  int64_t prepared_nq = 0;
   DevBuf<float4> pts, nrm;
   DevBuf<uint32_t> ref_inv;
   DevBuf<HashEntry> tables;
@@ -320,6 +335,7 @@ int lsgpu_icp_create(const lsgpu_icp_config* cfg, int device, lsgpu_icp** out) {
     delete h;
     return LSGPU_HIP_ERROR;
   }
+  h->cur = h->stream;
   *out = h;
   return LSGPU_OK;
 }
@@ -332,11 +348,11 @@ void lsgpu_icp_destroy(lsgpu_icp* h) {
   h->comm_tmp.release();
   for (auto& c : h->clouds) c.release();
   h->submap.release();
-  h->ref_in.release(); h->nrm_in.release(); h->keys.release(); h->keys_alt.release();
+  h->ref_in.release(); h->nrm_in.release(); h->scr_main.release(); h->scr_side.release();
 #ifdef LSGPU_EXPERIMENTS
   h->work.release();
 #endif
-  h->vals.release(); h->vals_alt.release(); h->sort_tmp.release(); h->sort_hist.release(); h->pts.release();
+  h->pts.release();
   h->nrm.release(); h->ref_inv.release(); h->tables.release(); h->flags.release(); h->cidx.release(); h->bounds.release(); h->chunks.release(); h->soa.release(); h->soa_base.release(); h->soa_cnt4.release(); h->soa_first.release(); h->prev.release(); h->state.release(); h->lb.release(); h->cell_cache.release(); h->cell_tags.release(); h->ssn_seg_a.release(); h->ssn_seg_b.release(); h->ssn_seg_of.release(); h->ssn_box_pts.release(); h->ssn_box_base.release(); h->ssn_keep.release(); h->ssn_out_pos.release(); h->ssn_bb.release(); h->ssn_box_normal.release(); h->ssn_draws.release(); h->flt_in.release(); h->flt_in2.release(); h->flt_ref.release(); h->flt_rd.release(); h->flt_nrm.release(); h->chk_hist.release(); h->trace_dev.release(); h->knn_dbg.release(); h->knn_dbg_wave.release(); h->stat_partials.release(); h->geom.release();
   h->counters.release(); h->ang_cells.release(); h->sel_aux.release(); h->sel_win.release(); h->spread_flag.release(); h->spread_list.release(); h->spread_cnt.release(); h->q_in.release(); h->rdq.release(); h->ids.release(); h->d2.release();
   h->ids_io.release(); h->d2_io.release(); h->strag.release(); h->hist.release();
@@ -347,6 +363,8 @@ void lsgpu_icp_destroy(lsgpu_icp* h) {
   if (h->h_pinned) (void)hipHostFree(h->h_pinned);
   if (h->draws_pinned) (void)hipHostFree(h->draws_pinned);
   if (h->copy_done) (void)hipEventDestroy(h->copy_done);
+  if (h->side_done) (void)hipEventDestroy(h->side_done);
+  if (h->side_stream) { (void)hipStreamSynchronize(h->side_stream); (void)hipStreamDestroy(h->side_stream); }
   if (h->copy_stream) (void)hipStreamDestroy(h->copy_stream);
   if (h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
@@ -361,29 +379,29 @@ static int scan_u32(lsgpu_icp* h, const uint32_t* in, uint32_t* out, size_t n);
 template <int ITEMS>
 static void radix_pass(lsgpu_icp* h, const uint64_t* kin, const uint32_t* vin, uint64_t* kout, uint32_t* vout, int64_t n,
                        int shift, uint32_t mask, int nblocks) {
-  uint32_t* bh = h->sort_hist.p;
+  uint32_t* bh = h->sc->sort_hist.p;
   uint32_t* dtot = bh + (size_t)256 * nblocks;
   // (the scan as the tail of k_rs_hist -- last block, ticket -- was measured 2 % slower end to end than this launch)
-  hipLaunchKernelGGL(k_rs_hist<ITEMS>, dim3(nblocks), dim3(256), 0, h->stream, kin, n, shift, mask, bh, nblocks);
-  hipLaunchKernelGGL(k_rs_scan, dim3(256), dim3(256), 0, h->stream, bh, nblocks, dtot);
-  hipLaunchKernelGGL(k_rs_scatter<ITEMS>, dim3(nblocks), dim3(256), 0, h->stream, kin, vin, kout, vout, n, shift, mask,
+  hipLaunchKernelGGL(k_rs_hist<ITEMS>, dim3(nblocks), dim3(256), 0, h->cur, kin, n, shift, mask, bh, nblocks);
+  hipLaunchKernelGGL(k_rs_scan, dim3(256), dim3(256), 0, h->cur, bh, nblocks, dtot);
+  hipLaunchKernelGGL(k_rs_scatter<ITEMS>, dim3(nblocks), dim3(256), 0, h->cur, kin, vin, kout, vout, n, shift, mask,
                      bh, dtot, nblocks);
 }
 
-// Stable sort of (h->keys, h->vals)[0..n) by the low `nbits` key bits; the result is in h->keys_alt / h->vals_alt
+// Stable sort of (h->sc->keys, h->sc->vals)[0..n) by the low `nbits` key bits; the result is in h->sc->keys_alt / h->sc->vals_alt
 // (callers re-read those members: the two buffer pairs may have changed places).
 static int sort_pairs(lsgpu_icp* h, int64_t n, int nbits) {
-  HIPC(h->keys_alt.reserve(n));
-  HIPC(h->vals_alt.reserve(n));
+  HIPC(h->sc->keys_alt.reserve(n));
+  HIPC(h->sc->vals_alt.reserve(n));
   const bool lib_sort = tuning().rocprim_sort;
   if (!lib_sort && n >= 8192 && nbits > 0) {   // own radix sort (lsgpu_sort.hip.h); tiny inputs stay with the library
     const int items_env = tuning().sort_items;
     const int items = items_env ? items_env : n >= (1 << 21) ? 16 : n >= (1 << 19) ? 8 : 4;
     const int nblocks = (int)((n + 256 * items - 1) / (256 * items));
-    HIPC(h->sort_hist.reserve((size_t)256 * nblocks + 256));
+    HIPC(h->sc->sort_hist.reserve((size_t)256 * nblocks + 256));
     const int passes = (nbits + 7) / 8;
-    uint64_t *kin = h->keys.p, *kout = h->keys_alt.p;
-    uint32_t *vin = h->vals.p, *vout = h->vals_alt.p;
+    uint64_t *kin = h->sc->keys.p, *kout = h->sc->keys_alt.p;
+    uint32_t *vin = h->sc->vals.p, *vout = h->sc->vals_alt.p;
     for (int p = 0; p < passes; ++p) {
       const int shift = 8 * p, width = std::min(8, nbits - shift);
       const uint32_t mask = (1u << width) - 1u;
@@ -393,16 +411,16 @@ static int sort_pairs(lsgpu_icp* h, int64_t n, int nbits) {
       std::swap(kin, kout); std::swap(vin, vout);
     }
     HIPC(hipGetLastError());
-    if ((passes & 1) == 0) { std::swap(h->keys, h->keys_alt); std::swap(h->vals, h->vals_alt); }  // result is in `keys`
+    if ((passes & 1) == 0) { std::swap(h->sc->keys, h->sc->keys_alt); std::swap(h->sc->vals, h->sc->vals_alt); }  // result is in `keys`
     return LSGPU_OK;
   }
   size_t bytes = 0;
-  HIPC(rocprim::radix_sort_pairs(nullptr, bytes, h->keys.p, h->keys_alt.p, h->vals.p,
-                                 h->vals_alt.p, (size_t)n, 0, nbits, h->stream));
-  HIPC(h->sort_tmp.reserve(bytes));
-  bytes = h->sort_tmp.cap;
-  HIPC(rocprim::radix_sort_pairs((void*)h->sort_tmp.p, bytes, h->keys.p, h->keys_alt.p, h->vals.p,
-                                 h->vals_alt.p, (size_t)n, 0, nbits, h->stream));
+  HIPC(rocprim::radix_sort_pairs(nullptr, bytes, h->sc->keys.p, h->sc->keys_alt.p, h->sc->vals.p,
+                                 h->sc->vals_alt.p, (size_t)n, 0, nbits, h->cur));
+  HIPC(h->sc->sort_tmp.reserve(bytes));
+  bytes = h->sc->sort_tmp.cap;
+  HIPC(rocprim::radix_sort_pairs((void*)h->sc->sort_tmp.p, bytes, h->sc->keys.p, h->sc->keys_alt.p, h->sc->vals.p,
+                                 h->sc->vals_alt.p, (size_t)n, 0, nbits, h->cur));
   return LSGPU_OK;  // sorted: keys_alt / vals_alt
 }
 
@@ -411,7 +429,7 @@ static int stage_points(lsgpu_icp* h, const float* src, int64_t n, DevBuf<float4
                         const float4** out) {
   if (is_device_ptr(src)) { *out = reinterpret_cast<const float4*>(src); return LSGPU_OK; }
   HIPC(buf.reserve(n));
-  HIPC(hipMemcpyAsync(buf.p, src, (size_t)n * 16, hipMemcpyHostToDevice, h->stream));
+  HIPC(hipMemcpyAsync(buf.p, src, (size_t)n * 16, hipMemcpyHostToDevice, h->cur));
   *out = buf.p;
   return LSGPU_OK;
 }
@@ -432,12 +450,14 @@ static int ensure_loop_buffers(lsgpu_icp* h, int64_t nq) {
 }
 
 // Sort the reading coarsely (own frame), move it by T (rows) -> h->rdq (w = caller index).
-static int prepare_queries(lsgpu_icp* h, const float* q_xyz1, int64_t nq, const Mat34& T) {
+// (gather == false: everything but the last kernel, which needs T -- lsgpu_icp_compute launches it once the reference's
+// mean is known)
+static int prepare_queries(lsgpu_icp* h, const float* q_xyz1, int64_t nq, const Mat34& T, bool gather = true) {
   const float4* src = nullptr;
   int rc = stage_points(h, q_xyz1, nq, h->q_in, &src);
   if (rc) return rc;
-  HIPC(h->keys.reserve(nq));
-  HIPC(h->vals.reserve(nq));
+  HIPC(h->sc->keys.reserve(nq));
+  HIPC(h->sc->vals.reserve(nq));
   HIPC(h->rdq.reserve(nq));
   HIPC(h->prev.reserve(nq));
   HIPC(h->lb.reserve(nq));
@@ -448,23 +468,25 @@ static int prepare_queries(lsgpu_icp* h, const float* q_xyz1, int64_t nq, const 
   const int qorder = tuning().query_order;   // -1: automatic
   const float qelev = tuning().q_elev, qsect = tuning().q_sect;   // 0: automatic
   HIPC(h->ang_cells.reserve(kDecCells + 8));
-  HIPC(hipMemsetAsync(h->ang_cells.p, 0, (kDecCells + 8) * sizeof(uint32_t), h->stream));
-  if (qorder != 0) hipLaunchKernelGGL(k_query_ang_hist, dim3(nblk(nq)), dim3(256), 0, h->stream, src, nq, h->ang_cells.p);
-  hipLaunchKernelGGL(k_query_order, dim3(1), dim3(1024), 0, h->stream, h->ang_cells.p, qorder, qelev, qsect);
-  hipLaunchKernelGGL(k_query_keys, dim3(nblk(nq)), dim3(256), 0, h->stream, src, nq, h->keys.p, h->vals.p,
+  HIPC(hipMemsetAsync(h->ang_cells.p, 0, (kDecCells + 8) * sizeof(uint32_t), h->cur));
+  if (qorder != 0) hipLaunchKernelGGL(k_query_ang_hist, dim3(nblk(nq)), dim3(256), 0, h->cur, src, nq, h->ang_cells.p);
+  hipLaunchKernelGGL(k_query_order, dim3(1), dim3(1024), 0, h->cur, h->ang_cells.p, qorder, qelev, qsect);
+  hipLaunchKernelGGL(k_query_keys, dim3(nblk(nq)), dim3(256), 0, h->cur, src, nq, h->sc->keys.p, h->sc->vals.p,
                      h->ang_cells.p + kDecCells + 2);
   rc = sort_pairs(h, nq, 48);
   if (rc) return rc;
-  hipLaunchKernelGGL(k_query_gather, dim3(nblk(nq)), dim3(256), 0, h->stream, src, nq,
-                     h->vals_alt.p, T, h->rdq.p);
-  HIPC(hipGetLastError());
+  if (gather) {
+    hipLaunchKernelGGL(k_query_gather, dim3(nblk(nq)), dim3(256), 0, h->cur, src, nq,
+                       h->sc->vals_alt.p, T, h->rdq.p);
+    HIPC(hipGetLastError());
+  }
   h->nq = nq;
   {  // per-tile probe cache: new generation, tags cleared when (re)allocated
     const size_t nt = (size_t)((nq + 63) / 64);
     const bool grow = nt > h->cell_tags.cap;
     HIPC(h->cell_cache.reserve(nt * 64));
     HIPC(h->cell_tags.reserve(nt));
-    if (grow) HIPC(hipMemsetAsync(h->cell_tags.p, 0, h->cell_tags.cap * sizeof(ulonglong2), h->stream));
+    if (grow) HIPC(hipMemsetAsync(h->cell_tags.p, 0, h->cell_tags.cap * sizeof(ulonglong2), h->cur));
     if (++h->cache_gen == 0) h->cache_gen = 1;
   }
   h->dbg_launch_no = 0;
@@ -688,30 +710,30 @@ int lsgpu_icp_set_reference(lsgpu_icp* h, const float* ref_xyz1, const float* re
                      h->stat_partials.p + kStatBlocks, nr, h->cfg.cell_size, h->geom.p);
   // ---- keys, sort, gather: 16 key bits per axis in total (`bits` address level-0 cells, `fine` order points inside
   // a cell; the split is chosen by k_ref_stats_final), i.e. always 48 key bits
-  HIPC(h->keys.reserve(nr)); HIPC(h->vals.reserve(nr));
+  HIPC(h->sc->keys.reserve(nr)); HIPC(h->sc->vals.reserve(nr));
   HIPC(h->pts.reserve(nr + 8)); HIPC(h->nrm.reserve(nr)); HIPC(h->ref_inv.reserve(nr));
-  hipLaunchKernelGGL(k_ref_keys, dim3(nblk(nr)), dim3(256), 0, h->stream, src, nr, h->geom.p, h->keys.p, h->vals.p);
+  hipLaunchKernelGGL(k_ref_keys, dim3(nblk(nr)), dim3(256), 0, h->stream, src, nr, h->geom.p, h->sc->keys.p, h->sc->vals.p);
   rc = sort_pairs(h, nr, 48);
   if (rc) return rc;
   hipLaunchKernelGGL(k_ref_gather, dim3(nblk(nr + 8)), dim3(256), 0, h->stream, src, nsrc, nr,
-                     h->vals_alt.p, h->geom.p, h->pts.p, h->nrm.p, h->ref_inv.p);
+                     h->sc->vals_alt.p, h->geom.p, h->pts.p, h->nrm.p, h->ref_inv.p);
   // ---- chunks: flags -> inclusive scan -> bounds
   HIPC(h->flags.reserve(nr)); HIPC(h->cidx.reserve(nr));
-  hipLaunchKernelGGL(k_chunk_flags, dim3(nblk(nr)), dim3(256), 0, h->stream, h->keys_alt.p, nr, h->geom.p,
+  hipLaunchKernelGGL(k_chunk_flags, dim3(nblk(nr)), dim3(256), 0, h->stream, h->sc->keys_alt.p, nr, h->geom.p,
                      h->flags.p);
   {
     size_t bytes = 0;
     HIPC(rocprim::inclusive_scan(nullptr, bytes, h->flags.p, h->cidx.p, (size_t)nr,
                                  rocprim::plus<uint32_t>(), h->stream));
-    HIPC(h->sort_tmp.reserve(bytes));
-    bytes = h->sort_tmp.cap;
-    HIPC(rocprim::inclusive_scan((void*)h->sort_tmp.p, bytes, h->flags.p, h->cidx.p, (size_t)nr,
+    HIPC(h->sc->sort_tmp.reserve(bytes));
+    bytes = h->sc->sort_tmp.cap;
+    HIPC(rocprim::inclusive_scan((void*)h->sc->sort_tmp.p, bytes, h->flags.p, h->cidx.p, (size_t)nr,
                                  rocprim::plus<uint32_t>(), h->stream));
   }
   // ---- cell counts per level (+ chunk count, + the geometry) -> host, to size the tables
   HIPC(h->counters.reserve(64));
   HIPC(hipMemsetAsync(h->counters.p, 0, 64 * sizeof(uint32_t), h->stream));
-  hipLaunchKernelGGL(k_cells_count, dim3(std::min(512, nblk(nr))), dim3(256), 0, h->stream, h->keys_alt.p, nr, h->geom.p,
+  hipLaunchKernelGGL(k_cells_count, dim3(std::min(512, nblk(nr))), dim3(256), 0, h->stream, h->sc->keys_alt.p, nr, h->geom.p,
                      h->counters.p);
   uint32_t* hc = reinterpret_cast<uint32_t*>(h->h_pinned);
   GeomDev* hg = reinterpret_cast<GeomDev*>(h->h_pinned + 16);
@@ -719,9 +741,17 @@ int lsgpu_icp_set_reference(lsgpu_icp* h, const float* ref_xyz1, const float* re
   HIPC(hipMemcpyAsync(hc, h->counters.p, kMaxLevels * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
   HIPC(hipMemcpyAsync(hc + 20, h->cidx.p + (nr - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
   HIPC(hipMemcpyAsync(hg, h->geom.p, sizeof(GeomDev), hipMemcpyDeviceToHost, h->stream));
+  if (h->hook_before_ref_sync) {   // lsgpu_icp_compute: the reading's side of the work is enqueued on its own stream now
+    rc = h->hook_before_ref_sync();
+    if (rc) return rc;
+  }
   HIPC(hipStreamSynchronize(h->stream));
   if (hg->bad) { h->err = "set_reference: non-finite coordinates"; return LSGPU_BAD_ARG; }
   for (int d = 0; d < 3; ++d) h->mean[d] = hg->mean[d];
+  if (h->hook_after_ref_sync) {    // (the mean is known: the queries can be moved into the reference's frame)
+    rc = h->hook_after_ref_sync();
+    if (rc) return rc;
+  }
   const int bits = hg->bits, fine = hg->fine;
   const float h0 = hg->h0;
   GridDev g;
@@ -760,7 +790,7 @@ int lsgpu_icp_set_reference(lsgpu_icp* h, const float* ref_xyz1, const float* re
     ts.tab[l] = h->tables.p + off[l]; ts.mask[l] = cap[l] - 1;
     g.tab[l] = ts.tab[l]; g.mask[l] = ts.mask[l];
   }
-  hipLaunchKernelGGL(k_cells_fill, dim3((nchunks + 255) / 256, bits + 1), dim3(256), 0, h->stream, h->keys_alt.p,
+  hipLaunchKernelGGL(k_cells_fill, dim3((nchunks + 255) / 256, bits + 1), dim3(256), 0, h->stream, h->sc->keys_alt.p,
                      h->bounds.p, nchunks, fine, bits, ts);
   HIPC(hipGetLastError());  // (no sync: align / knn follow on the same stream)
   h->grid = g;
@@ -952,10 +982,10 @@ int lsgpu_rotate_descriptors(lsgpu_icp* h, const float T[16], const float* desc3
 // exclusive prefix sum of n uint32 on the handle's stream
 static int scan_u32(lsgpu_icp* h, const uint32_t* in, uint32_t* out, size_t n) {
   size_t bytes = 0;
-  HIPC(rocprim::exclusive_scan(nullptr, bytes, in, out, 0u, n, rocprim::plus<uint32_t>(), h->stream));
-  HIPC(h->sort_tmp.reserve(bytes));
-  bytes = h->sort_tmp.cap;
-  HIPC(rocprim::exclusive_scan((void*)h->sort_tmp.p, bytes, in, out, 0u, n, rocprim::plus<uint32_t>(), h->stream));
+  HIPC(rocprim::exclusive_scan(nullptr, bytes, in, out, 0u, n, rocprim::plus<uint32_t>(), h->cur));
+  HIPC(h->sc->sort_tmp.reserve(bytes));
+  bytes = h->sc->sort_tmp.cap;
+  HIPC(rocprim::exclusive_scan((void*)h->sc->sort_tmp.p, bytes, in, out, 0u, n, rocprim::plus<uint32_t>(), h->cur));
   return LSGPU_OK;
 }
 
@@ -1010,7 +1040,7 @@ struct DrawAhead {
   int ready() {
     if (worker.joinable()) worker.join();
     if (!uploaded && kmax) {
-      HIPC(hipMemcpyAsync(h->ssn_draws.p, h->draws_pinned, kmax * sizeof(float), hipMemcpyHostToDevice, h->stream));
+      HIPC(hipMemcpyAsync(h->ssn_draws.p, h->draws_pinned, kmax * sizeof(float), hipMemcpyHostToDevice, h->cur));
       uploaded = true;
     }
     return LSGPU_OK;
@@ -1026,16 +1056,16 @@ struct DrawAhead {
 // totals of two exclusive scans (last scanned value + last input) in one D2H, synchronises the stream
 static int scan_totals(lsgpu_icp* h, const uint32_t* in_a, const uint32_t* sc_a, size_t na,
                        const uint32_t* in_b, const uint32_t* sc_b, size_t nb, uint32_t* tot_a, uint32_t* tot_b) {
-  uint32_t* hp = reinterpret_cast<uint32_t*>(h->h_pinned + 100);
+  uint32_t* hp = reinterpret_cast<uint32_t*>(h->h_pinned + 100 + 4 * h->side_totals_slot);
   hp[0] = hp[1] = hp[2] = hp[3] = 0;
   hipError_t e = hipSuccess;
   if (in_a) {
-    e = hipMemcpyAsync(hp, in_a + (na - 1), 4, hipMemcpyDeviceToHost, h->stream);
-    if (e == hipSuccess) e = hipMemcpyAsync(hp + 1, sc_a + (na - 1), 4, hipMemcpyDeviceToHost, h->stream);
+    e = hipMemcpyAsync(hp, in_a + (na - 1), 4, hipMemcpyDeviceToHost, h->cur);
+    if (e == hipSuccess) e = hipMemcpyAsync(hp + 1, sc_a + (na - 1), 4, hipMemcpyDeviceToHost, h->cur);
   }
-  if (e == hipSuccess) e = hipMemcpyAsync(hp + 2, in_b + (nb - 1), 4, hipMemcpyDeviceToHost, h->stream);
-  if (e == hipSuccess) e = hipMemcpyAsync(hp + 3, sc_b + (nb - 1), 4, hipMemcpyDeviceToHost, h->stream);
-  if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(hp + 2, in_b + (nb - 1), 4, hipMemcpyDeviceToHost, h->cur);
+  if (e == hipSuccess) e = hipMemcpyAsync(hp + 3, sc_b + (nb - 1), 4, hipMemcpyDeviceToHost, h->cur);
+  if (e == hipSuccess) e = hipStreamSynchronize(h->cur);
   *tot_a = hp[0] + hp[1];
   *tot_b = hp[2] + hp[3];
   if (e != hipSuccess) HIPC(e);
@@ -1066,8 +1096,8 @@ static int ssn_device(lsgpu_icp* h, const float4* src, int64_t n, int knn, float
   HIPC(h->ssn_keep.reserve(n));
   HIPC(h->ssn_out_pos.reserve(n));
   HIPC(h->ssn_bb.reserve(8));
-  HIPC(h->keys.reserve(n));
-  HIPC(h->vals.reserve(n));
+  HIPC(h->sc->keys.reserve(n));
+  HIPC(h->sc->vals.reserve(n));
   HIPC(hipMemsetAsync(h->ssn_bb.p, 0xFF, 12, h->stream));
   HIPC(hipMemsetAsync(h->ssn_bb.p + 3, 0, 12, h->stream));
   hipLaunchKernelGGL(k_ssn_bounds, dim3(std::min(nblk(n), 256)), dim3(256), 0, h->stream, src, (int)n, h->ssn_bb.p);
@@ -1085,10 +1115,10 @@ static int ssn_device(lsgpu_icp* h, const float4* src, int64_t n, int knn, float
   }
   for (int L = 0; L < glevels; ++L) {
     hipLaunchKernelGGL(k_ssn_keys, dim3(nblk(n)), dim3(256), 0, h->stream, src, (int)n, idx,
-                       L ? h->ssn_seg_of.p : (const uint32_t*)nullptr, cur, knn, h->keys.p, h->vals.p);
+                       L ? h->ssn_seg_of.p : (const uint32_t*)nullptr, cur, knn, h->sc->keys.p, h->sc->vals.p);
     int rc = sort_pairs(h, n, 32 + L);
     if (rc) return rc;
-    idx = h->vals_alt.p;
+    idx = h->sc->vals_alt.p;
     const int ns = 1 << L;
     hipLaunchKernelGGL(k_ssn_split, dim3(nblk(ns)), dim3(256), 0, h->stream, src, idx, cur, ns, knn, nxt);
     hipLaunchKernelGGL(k_ssn_assign, dim3(nblk(n)), dim3(256), 0, h->stream, (int)n, cur, knn, h->ssn_seg_of.p, L == 0 ? 1 : 0);
@@ -1097,8 +1127,8 @@ static int ssn_device(lsgpu_icp* h, const float4* src, int64_t n, int knn, float
   if (glevels < levels) {
     if (glevels == 0) {  // the whole cloud fits one workgroup: identity order to start from
       hipLaunchKernelGGL(k_ssn_keys, dim3(nblk(n)), dim3(256), 0, h->stream, src, (int)n, (const uint32_t*)nullptr,
-                         (const uint32_t*)nullptr, cur, knn, h->keys.p, h->vals.p);
-      idx = h->vals.p;
+                         (const uint32_t*)nullptr, cur, knn, h->sc->keys.p, h->sc->vals.p);
+      idx = h->sc->vals.p;
     }
     hipLaunchKernelGGL(k_ssn_finish, dim3(1 << glevels), dim3(256), 0, h->stream, src, const_cast<uint32_t*>(idx), cur,
                        knn, levels - glevels, h->ssn_seg_of.p, nxt);
@@ -1106,9 +1136,9 @@ static int ssn_device(lsgpu_icp* h, const float4* src, int64_t n, int knn, float
   }
   if (levels == 0) {  // a single box: identity order
     hipLaunchKernelGGL(k_ssn_keys, dim3(nblk(n)), dim3(256), 0, h->stream, src, (int)n, (const uint32_t*)nullptr,
-                       (const uint32_t*)nullptr, cur, knn, h->keys.p, h->vals.p);
+                       (const uint32_t*)nullptr, cur, knn, h->sc->keys.p, h->sc->vals.p);
     HIPC(hipMemsetAsync(h->ssn_seg_of.p, 0, (size_t)n * 4, h->stream));
-    idx = h->vals.p;
+    idx = h->sc->vals.p;
   }
   hipLaunchKernelGGL(k_ssn_boxes, dim3((int)((nseg + 127) / 128)), dim3(128), 0, h->stream, src, idx, cur, (int)nseg,
                      h->ssn_box_normal.p, h->ssn_box_pts.p);
@@ -1152,10 +1182,10 @@ static int random_sampling_device(lsgpu_icp* h, const float4* src, int64_t n, fl
   ahead->used = first_draw + (size_t)n;  // one draw per point, whatever happens next
   rc = ahead->ready();
   if (rc) return rc;
-  hipLaunchKernelGGL(k_draw_select, dim3(nblk(n)), dim3(256), 0, h->stream, (int)n, h->ssn_draws.p + first_draw, prob, h->ssn_keep.p);
+  hipLaunchKernelGGL(k_draw_select, dim3(nblk(n)), dim3(256), 0, h->cur, (int)n, h->ssn_draws.p + first_draw, prob, h->ssn_keep.p);
   rc = scan_u32(h, h->ssn_keep.p, h->ssn_out_pos.p, (size_t)n);
   if (rc) return rc;
-  hipLaunchKernelGGL(k_compact_points, dim3(nblk(n)), dim3(256), 0, h->stream, src, (int)n, h->ssn_keep.p,
+  hipLaunchKernelGGL(k_compact_points, dim3(nblk(n)), dim3(256), 0, h->cur, src, (int)n, h->ssn_keep.p,
                      h->ssn_out_pos.p, out_xyz1);
   HIPC(hipGetLastError());
   uint32_t unused = 0, kept = 0;
@@ -1263,32 +1293,85 @@ int lsgpu_icp_compute(lsgpu_icp* h, const float* reading_xyz1, int64_t nq, const
   rc = ssn_device(h, src, nr, chain->ssn_knn, chain->ssn_ratio, -1, h->flt_ref.p, h->flt_nrm.p, &nrf, &draws);
   if (rc) return rc;
   if (nrf <= 0) { h->err = "compute: the reference filter left no point"; h->nr = 0; return LSGPU_NO_CONVERGENCE; }
-  // steps 2-3
-  rc = lsgpu_icp_set_reference(h, reinterpret_cast<const float*>(h->flt_ref.p), h->flt_nrm.p, nrf);
-  if (rc) return rc;
-  // step 4: reading filter (yaml:1-3)
-  if (overlap_upload) {
-    uploader.join();
-    if (upload_err != hipSuccess) { h->err = std::string("compute: reading upload: ") + hipGetErrorString(upload_err); (void)hipGetLastError(); return LSGPU_HIP_ERROR; }
-    HIPC(hipStreamWaitEvent(h->stream, h->copy_done, 0));
-    src = h->flt_in2.p;
-  } else {
-    src = reinterpret_cast<const float4*>(reading_xyz1);
-  }
-  const float4* rd_dev = src;
-  if (chain->reading_prob < 0.f) {
-    // no readingDataPointsFilters section: upstream runs no module at all -- every point, NO rand() call (a
-    // RandomSampling module with prob 1 would consume nq draws and drop the points whose draw rounds to 1.0f)
-    nqf = nq;
-  } else {
+  // steps 2-4.  The grid build (steps 2-3, h->stream) and the reading's side -- its filter (step 4) and the ordering of
+  // the queries (the first part of step 5) -- do not depend on each other: the latter is enqueued on a second stream,
+  // with its own sort scratch, from inside set_reference (right before its one host round trip), and the queries are
+  // moved into the reference's frame as soon as set_reference knows the mean.  Both are chains of short launches that
+  // leave most of the chip idle; side by side the shorter one disappears (LSGPU_NO_SIDE_STREAM: one after the other).
+  const bool side = tuning().side_stream && !h->comm;
+  const float4* rd_src = nullptr;
+  const float4* rd_dev = nullptr;
+  auto reading_ready = [&](hipStream_t on) -> int {   // the reading's upload, if it is ours, has to be there
+    if (overlap_upload) {
+      if (uploader.joinable()) uploader.join();
+      if (upload_err != hipSuccess) { h->err = std::string("compute: reading upload: ") + hipGetErrorString(upload_err); (void)hipGetLastError(); return LSGPU_HIP_ERROR; }
+      HIPC(hipStreamWaitEvent(on, h->copy_done, 0));
+      rd_src = h->flt_in2.p;
+    } else {
+      rd_src = reinterpret_cast<const float4*>(reading_xyz1);
+    }
+    return LSGPU_OK;
+  };
+  auto reading_filter = [&]() -> int {   // step 4: reading filter (yaml:1-3), on h->cur
+    rd_dev = rd_src;
+    if (chain->reading_prob < 0.f) {
+      // no readingDataPointsFilters section: upstream runs no module at all -- every point, NO rand() call (a
+      // RandomSampling module with prob 1 would consume nq draws and drop the points whose draw rounds to 1.0f)
+      nqf = nq;
+      return LSGPU_OK;
+    }
     HIPC(h->flt_rd.reserve(nq));
-    rc = random_sampling_device(h, src, nq, chain->reading_prob, -1, h->flt_rd.p, &nqf, &draws);
-    if (rc) return rc;
+    const int r = random_sampling_device(h, rd_src, nq, chain->reading_prob, -1, h->flt_rd.p, &nqf, &draws);
     rd_dev = h->flt_rd.p;
+    return r;
+  };
+  struct SideGuard {   // whatever happens, the helpers go back to the main stream and the side stream is drained
+    lsgpu_icp* h; bool used = false;
+    void enter() { used = true; h->cur = h->side_stream; h->sc = &h->scr_side; h->side_totals_slot = 1; }
+    void leave() { h->cur = h->stream; h->sc = &h->scr_main; h->side_totals_slot = 0; }
+    ~SideGuard() {
+      leave();
+      h->hook_before_ref_sync = nullptr; h->hook_after_ref_sync = nullptr;
+      if (used && h->side_stream) (void)hipStreamSynchronize(h->side_stream);
+    }
+  } side_guard{h};
+  bool side_prepared = false;
+  if (side) {
+    if (!h->side_stream) HIPC(hipStreamCreateWithFlags(&h->side_stream, hipStreamNonBlocking));
+    if (!h->side_done) HIPC(hipEventCreateWithFlags(&h->side_done, hipEventDisableTiming));
+    h->hook_before_ref_sync = [&]() -> int {
+      side_guard.enter();
+      int r = reading_ready(h->side_stream);
+      if (!r) r = reading_filter();              // (one short host wait on the side stream: the number of points kept)
+      if (!r && nqf > 0) r = prepare_queries(h, reinterpret_cast<const float*>(rd_dev), nqf, Mat34{}, /*gather*/ false);
+      side_guard.leave();
+      return r;
+    };
+    h->hook_after_ref_sync = [&]() -> int {
+      if (nqf <= 0) return LSGPU_OK;
+      float T_rm_in[16];
+      std::memcpy(T_rm_in, T_init, sizeof(T_rm_in));
+      for (int d = 0; d < 3; ++d) T_rm_in[12 + d] = T_init[12 + d] - h->mean[d];   // (as lsgpu_icp_align, step 5)
+      hipLaunchKernelGGL(k_query_gather, dim3(nblk(nqf)), dim3(256), 0, h->side_stream, rd_dev, nqf, h->scr_side.vals_alt.p,
+                         to_mat34(T_rm_in), h->rdq.p);
+      HIPC(hipGetLastError());
+      HIPC(hipEventRecord(h->side_done, h->side_stream));
+      side_prepared = true;
+      return LSGPU_OK;
+    };
+  }
+  rc = lsgpu_icp_set_reference(h, reinterpret_cast<const float*>(h->flt_ref.p), h->flt_nrm.p, nrf);
+  h->hook_before_ref_sync = nullptr; h->hook_after_ref_sync = nullptr;
+  if (rc) return rc;
+  if (!side) {
+    rc = reading_ready(h->stream);
+    if (!rc) rc = reading_filter();
+    if (rc) return rc;
   }
   draws.finish();
   const double t_filters = wall_ms() - t0;
   if (nqf <= 0) { h->err = "compute: the reading filter left no point"; return LSGPU_NO_CONVERGENCE; }
+  if (side_prepared) { h->prepared_rd = reinterpret_cast<const float*>(rd_dev); h->prepared_nq = nqf; }
   // steps 5-7
   rc = lsgpu_icp_align(h, reinterpret_cast<const float*>(rd_dev), nqf, T_init, T_out, stats);
   if (stats) stats->t_reserved[0] = t_filters;
@@ -1360,18 +1443,18 @@ int lsgpu_filter_voxel_grid(lsgpu_icp* h, const float* xyz1, int64_t n, const fl
     h->err = "voxel_grid: leaf size too small for the cloud, the voxel index would overflow";
     return LSGPU_BAD_ARG;
   }
-  HIPC(h->keys.reserve(n));
-  HIPC(h->vals.reserve(n));
+  HIPC(h->sc->keys.reserve(n));
+  HIPC(h->sc->vals.reserve(n));
   HIPC(h->ssn_keep.reserve(n));
   HIPC(h->ssn_out_pos.reserve(n));
   HIPC(h->ssn_seg_of.reserve(n));   // voxel head flags
   HIPC(h->flt_ref.reserve(n));      // centroids by sorted position
   hipLaunchKernelGGL(k_voxel_keys, dim3(nblk(n)), dim3(256), 0, h->stream, src, (int)n, inv[0], inv[1], inv[2],
-                     minb[0], minb[1], minb[2], divb[0], divb[0] * divb[1], h->keys.p, h->vals.p);
+                     minb[0], minb[1], minb[2], divb[0], divb[0] * divb[1], h->sc->keys.p, h->sc->vals.p);
   rc = sort_pairs(h, n, 31);  // stable: equal voxels keep input order
   if (rc) return rc;
-  hipLaunchKernelGGL(k_voxel_heads, dim3(nblk(n)), dim3(256), 0, h->stream, h->keys_alt.p, (int)n, h->ssn_seg_of.p);
-  hipLaunchKernelGGL(k_voxel_centroids, dim3(nblk(n)), dim3(256), 0, h->stream, src, h->keys_alt.p, h->vals_alt.p, (int)n,
+  hipLaunchKernelGGL(k_voxel_heads, dim3(nblk(n)), dim3(256), 0, h->stream, h->sc->keys_alt.p, (int)n, h->ssn_seg_of.p);
+  hipLaunchKernelGGL(k_voxel_centroids, dim3(nblk(n)), dim3(256), 0, h->stream, src, h->sc->keys_alt.p, h->sc->vals_alt.p, (int)n,
                      min_points, h->ssn_seg_of.p, h->flt_ref.p, h->ssn_keep.p);
   rc = scan_u32(h, h->ssn_keep.p, h->ssn_out_pos.p, (size_t)n);
   if (rc) return rc;
@@ -1479,9 +1562,9 @@ int lsgpu_cloud_from_pointcloud2(lsgpu_icp* h, const unsigned char* data, int64_
   HIPC(hipSetDevice(h->device));
   const unsigned char* src = data;
   if (!is_device_ptr(data)) {  // the message's byte block crosses PCIe once, as it is
-    HIPC(h->sort_tmp.reserve((size_t)n * (size_t)point_step));
-    HIPC(hipMemcpyAsync(h->sort_tmp.p, data, (size_t)n * (size_t)point_step, hipMemcpyHostToDevice, h->stream));
-    src = reinterpret_cast<const unsigned char*>(h->sort_tmp.p);
+    HIPC(h->sc->sort_tmp.reserve((size_t)n * (size_t)point_step));
+    HIPC(hipMemcpyAsync(h->sc->sort_tmp.p, data, (size_t)n * (size_t)point_step, hipMemcpyHostToDevice, h->stream));
+    src = reinterpret_cast<const unsigned char*>(h->sc->sort_tmp.p);
   }
   HIPC(h->flt_in.reserve(n));
   HIPC(h->ssn_keep.reserve(n));
@@ -1631,7 +1714,15 @@ int lsgpu_icp_align(lsgpu_icp* h, const float* reading_xyz1, int64_t nq, const f
   float T_rm_in[16];
   std::memcpy(T_rm_in, T_init, sizeof(T_rm_in));
   for (int d = 0; d < 3; ++d) T_rm_in[12 + d] = T_init[12 + d] - h->mean[d];
-  int rc = local_rc ? local_rc : prepare_queries(h, reading_xyz1, nq, to_mat34(T_rm_in));
+  // (lsgpu_icp_compute may have ordered and moved these very queries on its side stream already: the loop's stream
+  // only has to wait for that)
+  const bool prepared = !local_rc && !h->comm && h->prepared_rd == reading_xyz1 && h->prepared_nq == nq;
+  h->prepared_rd = nullptr; h->prepared_nq = 0;
+  int rc = local_rc;
+  if (!rc) {
+    if (prepared) HIPC(hipStreamWaitEvent(h->stream, h->side_done, 0));
+    else rc = prepare_queries(h, reading_xyz1, nq, to_mat34(T_rm_in));
+  }
   if (rc && !h->comm) return rc;
   int64_t nq_total = nq;
   if (h->comm) {

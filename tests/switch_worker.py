@@ -26,6 +26,9 @@ def main():
         T, st = h.align(rd, T_init)
         tr = h.trace()
         ids, d2 = h.knn(rd, synth.colmajor(T_init))
+        # the whole ICP::compute on the raw clouds (both filters with one draw stream, grid, loop)
+        Tc, stc = h.compute(rd, ref, T_init, 0.6, 10, 0.7, seed=5)
+        trc = h.trace()
     dg = hashlib.sha256()
     dg.update(np.ascontiguousarray(T).tobytes())
     for t in tr:
@@ -33,6 +36,10 @@ def main():
         dg.update(np.ascontiguousarray(t["A"]).tobytes()); dg.update(np.ascontiguousarray(t["T_iter"]).tobytes())
     dg.update(np.ascontiguousarray(d2).tobytes())
     dg.update(np.ascontiguousarray(rf).tobytes())
+    dg.update(np.ascontiguousarray(Tc).tobytes()); dg.update(np.int64(stc.iterations).tobytes())
+    for t in trc:
+        dg.update(np.float32(t["limit"]).tobytes()); dg.update(np.int64(t["n_used"]).tobytes())
+        dg.update(np.ascontiguousarray(t["A"]).tobytes())
     # what does not depend on the order in which the normal equations are summed: the search from T_init and the first
     # iteration's order statistic and inlier count
     di = hashlib.sha256()
