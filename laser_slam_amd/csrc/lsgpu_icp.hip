@@ -13,6 +13,7 @@
 #include <vector>
 #include <chrono>
 #include <functional>
+#include <system_error>
 #include <thread>
 
 #include <dlfcn.h>
@@ -1034,7 +1035,13 @@ struct DrawAhead {
     DrawStream::global().lock(seed);
     open = true;
     float* dst = h->draws_pinned;
-    if (kmax) worker = std::thread([dst, k] { DrawStream::global().generate(k, dst); });
+    if (kmax) {
+      try {
+        worker = std::thread([dst, k] { DrawStream::global().generate(k, dst); });
+      } catch (const std::system_error&) {   // no thread to be had: produce the draws here
+        DrawStream::global().generate(k, dst);
+      }
+    }
     return LSGPU_OK;
   }
   int ready() {
@@ -1268,12 +1275,17 @@ int lsgpu_icp_compute(lsgpu_icp* h, const float* reading_xyz1, int64_t nq, const
     if (!h->copy_stream) HIPC(hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking));
     if (!h->copy_done) HIPC(hipEventCreateWithFlags(&h->copy_done, hipEventDisableTiming));
     HIPC(h->flt_in2.reserve(nq));
-    uploader = std::thread([&] {
+    auto upload = [&] {
       hipError_t e = hipSetDevice(h->device);
       if (e == hipSuccess) e = hipMemcpyAsync(h->flt_in2.p, reading_xyz1, (size_t)nq * 16, hipMemcpyHostToDevice, h->copy_stream);
       if (e == hipSuccess) e = hipEventRecord(h->copy_done, h->copy_stream);
       upload_err = e;
-    });
+    };
+    try {
+      uploader = std::thread(upload);
+    } catch (const std::system_error&) {   // no thread to be had: copy here (no overlap)
+      upload();
+    }
   }
   struct Joiner { std::thread& t; ~Joiner() { if (t.joinable()) t.join(); } } joiner{uploader};   // every return path joins
   // the draws of both filters, produced on a helper thread from now on: at most one per reference point, then one per
