@@ -5,6 +5,7 @@
 
 #include <cstdio>
 #include <cstdlib>
+#include <thread>
 #include <vector>
 
 int main() {
@@ -23,6 +24,26 @@ int main() {
     for (size_t i = 0; i < k; ++i) mism += got[i] != (float)rand() / (float)RAND_MAX;
     for (size_t i = 0; i < tail.size(); ++i) mism += tail[i] != (float)rand() / (float)RAND_MAX;
     if (mism) { std::printf("kmax %zu k %zu: %zu mismatches\n", kmax, k, mism); ++bad; }
+    ++seed;
+  }
+  // the two-step form of lsgpu_icp_compute's DrawAhead: the owner locks, a helper thread generates, the owner commits --
+  // one request serving two consecutive filters (k1 draws of the first kmax1, then k2 more right behind them)
+  const size_t two[][4] = {{5000, 3210, 4000, 4000}, {1100000, 900001, 1000000, 1000000}, {70000, 0, 70000, 12345}};
+  for (const auto& c : two) {
+    const size_t kmax1 = c[0], k1 = c[1], kmax2 = c[2], k2 = c[3];
+    std::vector<float> got(kmax1 + kmax2), tail(100);
+    lsgpu::DrawStream::global().lock((int64_t)seed);
+    float* dst = got.data();
+    const size_t kmax = kmax1 + kmax2;
+    std::thread worker([dst, kmax] { lsgpu::DrawStream::global().generate(kmax, dst); });
+    worker.join();
+    lsgpu::DrawStream::global().commit(k1 + k2);   // the second filter's draws start at k1
+    lsgpu::DrawStream::global().take(-1, tail.size(), tail.data());
+    srand(seed);
+    size_t mism = 0;
+    for (size_t i = 0; i < k1 + k2; ++i) mism += got[i] != (float)rand() / (float)RAND_MAX;
+    for (size_t i = 0; i < tail.size(); ++i) mism += tail[i] != (float)rand() / (float)RAND_MAX;
+    if (mism) { std::printf("two-step kmax %zu k %zu: %zu mismatches\n", kmax, k1 + k2, mism); ++bad; }
     ++seed;
   }
   std::printf(bad ? "DRAWS_FAIL\n" : "DRAWS_OK\n");

@@ -167,9 +167,10 @@ def test_draw_stream_is_the_glibc_rand_sequence():
         libc.srand(C.c_uint(seed))
         assert np.array_equal(icp.random_sampling(4000, 0.37, seed), libc_keep(4000, 0.37)), seed
         assert np.array_equal(icp.random_sampling(1500, 0.5, -1), libc_keep(1500, 0.5)), seed   # continues
-    # large requests are produced in parallel segments whose start states come from the recurrence's jump-ahead matrix
+    # large requests (>= 1 M draws) are produced in parallel segments whose start states come from the recurrence's
+    # jump-ahead matrix
     libc.srand(C.c_uint(99))
-    assert np.array_equal(icp.random_sampling(300001, 0.37, 99), libc_keep(300001, 0.37))
+    assert np.array_equal(icp.random_sampling(1100001, 0.37, 99), libc_keep(1100001, 0.37))
     assert np.array_equal(icp.random_sampling(777, 0.5, -1), libc_keep(777, 0.5))             # continues after it
 
 
