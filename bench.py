@@ -231,14 +231,18 @@ def main():
     if not args.split and not args.no_compute_e2e:
         step_loop(); step_loop()
         torch.cuda.synchronize()
+        per_step = []
         tl = time.perf_counter()
         for _ in range(loop_steps):
-            Tl, stl = step_loop()
+            ts = time.perf_counter()
+            Tl, stl = step_loop()          # (align returns with its stream drained: per-step times are whole steps)
+            per_step.append(time.perf_counter() - ts)
             align_ms += stl.t_total_ms
             loop_iters += stl.iterations
         torch.cuda.synchronize()
         tl = time.perf_counter() - tl
         value_loop = {"value": loop_steps / tl, "unit": "scans/s", "ms_per_scan": tl / loop_steps * 1e3,
+                      "ms_per_scan_median": float(np.median(per_step)) * 1e3, "ms_per_scan_max": float(np.max(per_step)) * 1e3,
                       "ms_per_icp_iteration": align_ms / max(loop_iters, 1), "iterations": loop_iters / loop_steps,
                       "workload": "set_reference + align on the FILTERED clouds resident in HBM (steps 2-7 of ICP::compute: the north-star kernels)"}
     prof_steps = max(1, min(args.steps, 3))
