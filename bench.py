@@ -217,8 +217,11 @@ def main():
     iters = 0
     filt_ms = 0.0
     T = None
+    step_s = []
     for _ in range(args.steps):
+        ts = time.perf_counter()
         T, st = step()
+        step_s.append(time.perf_counter() - ts)
         iters += st.iterations
         filt_ms += st.t_reserved[0]
     barrier()
@@ -313,7 +316,8 @@ def main():
     et, er = synth.pose_error(T.astype(np.float64), T_true)
     units = 1 if args.split else world
     out = dict(base, metric="scans_per_sec", value=units * args.steps / elapsed, unit="scans/s",
-               ms_per_step=elapsed / args.steps * 1e3, icp_iterations_per_scan=iters / args.steps,
+               ms_per_step=elapsed / args.steps * 1e3, ms_per_step_median_rank0=float(np.median(step_s)) * 1e3,
+               ms_per_step_max_rank0=float(np.max(step_s)) * 1e3, icp_iterations_per_scan=iters / args.steps,
                scaling="strong" if args.split else "weak")
     if args.split:
         out["ms_per_icp_iteration"] = elapsed / max(iters, 1) * 1e3
