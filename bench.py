@@ -341,6 +341,10 @@ def main():
                        "launches": knn_launches, "timed_in": "%d extra profiled steps of the resident loop after the timed region (HIP events on the handle's stream)" % prof_steps,
                        "occupied_cells": ncell,
                        "stragglers_per_launch": strag / max(knn_launches, 1)}
+    if traffic and t_knn > 0:   # SURVEY.md 8d "roofline.measured": the literal rocprof HBM GB/s of the launch
+        out["roofline"]["measured"] = traffic / t_knn / 1e9
+        out["roofline"]["measured_frac"] = traffic / t_knn / 1e9 / HBM_PEAK_GBS
+        out["roofline"]["traffic_over_algorithmic"] = traffic / b_knn
     # second yardstick for a kernel that is vector-issue bound, not byte bound: the distance evaluations an ideal
     # per-query search would need (a libnabo kd-tree with bucket size 8 visits 20-30 points per query) x the
     # 7.75 vector operations one evaluation costs (6 for the defined arithmetic, 1.75 for minimum / runner-up / index),
