@@ -266,7 +266,7 @@ def main():
     # ---- the same compute handed HOST buffers (H2D + D2H inclusive), chains F and P, pageable and pinned
     value_e2e = None
     variants = None
-    if not args.split and not args.no_compute_e2e:
+    if not args.split and not args.no_compute_e2e and world == 1:   # (the PCIe-inclusive side figures: one rank only)
         variants = {}
         for name, prob, ratio in (("P_yaml_chain", 0.5, 0.5),):
             ts = []
