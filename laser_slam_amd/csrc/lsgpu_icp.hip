@@ -162,6 +162,8 @@ struct lsgpu_icp {
   SortScratch scr_main, scr_side;
   SortScratch* sc = &scr_main;
   hipStream_t cur = nullptr;           // == stream except while lsgpu_icp_compute enqueues its side work
+  hipStream_t draw_stream = nullptr;   // H2D of the filters' draws, issued by the helper thread that produces them
+  hipEvent_t draws_done = nullptr;
   hipStream_t side_stream = nullptr;   // lsgpu_icp_compute: reading filter + query order, beside the grid build
   hipEvent_t side_done = nullptr;
   int side_totals_slot = 0;            // scan_totals staging: the side path uses its own words of h_pinned
@@ -364,6 +366,8 @@ void lsgpu_icp_destroy(lsgpu_icp* h) {
   if (h->h_pinned) (void)hipHostFree(h->h_pinned);
   if (h->draws_pinned) (void)hipHostFree(h->draws_pinned);
   if (h->copy_done) (void)hipEventDestroy(h->copy_done);
+  if (h->draws_done) (void)hipEventDestroy(h->draws_done);
+  if (h->draw_stream) { (void)hipStreamSynchronize(h->draw_stream); (void)hipStreamDestroy(h->draw_stream); }
   if (h->side_done) (void)hipEventDestroy(h->side_done);
   if (h->side_stream) { (void)hipStreamSynchronize(h->side_stream); (void)hipStreamDestroy(h->side_stream); }
   if (h->copy_stream) (void)hipStreamDestroy(h->copy_stream);
@@ -1018,7 +1022,8 @@ static int upload_draws_begin(lsgpu_icp* h, int64_t seed, size_t kmax) {
 struct DrawAhead {
   lsgpu_icp* h = nullptr;
   size_t kmax = 0, used = 0;
-  bool open = false, uploaded = false;
+  bool open = false, waited = false;
+  hipError_t upload_err = hipSuccess;
   std::thread worker;
   DrawAhead() = default;
   DrawAhead(const DrawAhead&) = delete;
@@ -1032,29 +1037,42 @@ struct DrawAhead {
       h->draws_pinned_cap = kmax + 1;
     }
     HIPC(h->ssn_draws.reserve(kmax + 1));
+    if (!h->draw_stream) HIPC(hipStreamCreateWithFlags(&h->draw_stream, hipStreamNonBlocking));
+    if (!h->draws_done) HIPC(hipEventCreateWithFlags(&h->draws_done, hipEventDisableTiming));
     DrawStream::global().lock(seed);
     open = true;
-    float* dst = h->draws_pinned;
     if (kmax) {
+      // the helper produces the draws and sends them off on a stream of their own right away: the H2D (8 MB for two
+      // 1 M-point clouds) used to sit on the filter's stream in front of k_ssn_select, 0.18 ms of idle device
+      lsgpu_icp* hh2 = h;
+      auto produce = [hh2, k, this] {
+        DrawStream::global().generate(k, hh2->draws_pinned);
+        hipError_t e = hipSetDevice(hh2->device);
+        if (e == hipSuccess) e = hipMemcpyAsync(hh2->ssn_draws.p, hh2->draws_pinned, k * sizeof(float), hipMemcpyHostToDevice, hh2->draw_stream);
+        if (e == hipSuccess) e = hipEventRecord(hh2->draws_done, hh2->draw_stream);
+        upload_err = e;
+      };
       try {
-        worker = std::thread([dst, k] { DrawStream::global().generate(k, dst); });
+        worker = std::thread(produce);
       } catch (const std::system_error&) {   // no thread to be had: produce the draws here
-        DrawStream::global().generate(k, dst);
+        produce();
       }
     }
     return LSGPU_OK;
   }
-  int ready() {
+  int ready() {   // the stream the caller enqueues on (h->cur) waits for the draws
     if (worker.joinable()) worker.join();
-    if (!uploaded && kmax) {
-      HIPC(hipMemcpyAsync(h->ssn_draws.p, h->draws_pinned, kmax * sizeof(float), hipMemcpyHostToDevice, h->cur));
-      uploaded = true;
+    if (kmax) {
+      if (upload_err != hipSuccess) { (void)hipGetLastError(); HIPC(upload_err); }
+      HIPC(hipStreamWaitEvent(h->cur, h->draws_done, 0));
+      waited = true;
     }
     return LSGPU_OK;
   }
   void finish() {   // consume + unlock now (the stream must not stay locked while the ICP loop runs)
     if (worker.joinable()) worker.join();
     if (open) DrawStream::global().commit(std::min(used, kmax));
+    if (open && kmax && !waited && h->draw_stream) (void)hipStreamSynchronize(h->draw_stream);   // (nobody waited for the upload: the staging buffer must be free on return)
     open = false;
   }
   ~DrawAhead() { finish(); }

@@ -112,12 +112,16 @@ class DrawStream {
     }();
     return J;
   }
-  static void fill_segment(const uint32_t* state, size_t len, float* out, std::vector<uint32_t>* scratch) {
+  // (`snaps`: the state in front of every kSub-th draw of the segment, so that commit() replays at most kSub steps)
+  static constexpr size_t kSub = 2048;
+  static void fill_segment(const uint32_t* state, size_t len, float* out, std::vector<uint32_t>* scratch, uint32_t* snaps) {
     scratch->resize(31 + len);
     uint32_t* w = scratch->data();
     for (int i = 0; i < 31; ++i) w[i] = state[i];
     for (size_t i = 0; i < len; ++i) w[i + 31] = w[i] + w[i + 28];
     for (size_t i = 0; i < len; ++i) out[i] = (float)(w[i + 31] >> 1) / 2147483648.0f;
+    for (size_t j = 0; j * kSub <= len; ++j)
+      for (int i = 0; i < 31; ++i) snaps[j * 31 + i] = w[j * kSub + i];
   }
   // raw_[0..31) = the last 31 raw words (oldest first), raw_[31 + i] = the i-th not yet consumed word
   void generate_locked(size_t k, float* out) {
@@ -138,10 +142,13 @@ class DrawStream {
       }
       const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
       const size_t nthreads = std::min<size_t>(std::min<size_t>(nseg, 8), hw);
+      constexpr size_t kSnapsPerSeg = kSeg / kSub + 1;
+      sub_states_.resize(nseg * kSnapsPerSeg * 31);
       auto work = [&](size_t t) {
         std::vector<uint32_t> scratch;
         for (size_t sg = t; sg < nseg; sg += nthreads)
-          fill_segment(&seg_states_[sg * 31], std::min(kSeg, k - sg * kSeg), out + sg * kSeg, &scratch);
+          fill_segment(&seg_states_[sg * 31], std::min(kSeg, k - sg * kSeg), out + sg * kSeg, &scratch,
+                       &sub_states_[sg * kSnapsPerSeg * 31]);
       };
       std::vector<std::thread> pool;
       for (size_t t = 1; t < nthreads; ++t) pool.emplace_back(work, t);
@@ -158,10 +165,13 @@ class DrawStream {
       for (size_t i = 0; i < k; ++i) out[i] = (float)(w[i + 31] >> 1) / 2147483648.0f;  // (float)RAND_MAX == 2^31
   }
   void commit_locked(size_t k) {
-    if (!seg_states_.empty()) {   // (parallel request: replay from the start of the segment that holds draw k)
-      const size_t sg = k / kSeg, r = k % kSeg;
+    if (!seg_states_.empty()) {   // (parallel request: replay from the last snapshot in front of draw k, < kSub steps)
+      constexpr size_t kSnapsPerSeg = kSeg / kSub + 1;
+      size_t sg = k / kSeg, in_seg = k % kSeg;
+      if (sg * kSeg >= seg_k_ && sg > 0) { sg -= 1; in_seg = kSeg; }   // k == the end of the last (full) segment
+      const size_t j = in_seg / kSub, r = in_seg % kSub;
       std::vector<uint32_t> w(31 + r);
-      for (int i = 0; i < 31; ++i) w[i] = seg_states_[sg * 31 + i];
+      for (int i = 0; i < 31; ++i) w[i] = sub_states_[(sg * kSnapsPerSeg + j) * 31 + i];
       for (size_t i = 0; i < r; ++i) w[i + 31] = w[i] + w[i + 28];
       for (int i = 0; i < 31; ++i) hist_[i] = w[r + i];
       seg_states_.clear();
@@ -173,6 +183,7 @@ class DrawStream {
   uint32_t hist_[31];
   std::vector<uint32_t> raw_;
   std::vector<uint32_t> seg_states_;  // parallel request: state at the start of every segment (+ one past the end)
+  std::vector<uint32_t> sub_states_;  //   and in front of every kSub-th draw of every segment
   size_t seg_k_ = 0;
 };
 

@@ -11,7 +11,8 @@
 int main() {
   int bad = 0;
   const size_t cases[][2] = {{1000, 1000}, {1000, 0}, {1000, 517}, {300000, 299999}, {300000, 65536}, {300000, 65535},
-                             {1200000, 777777}, {1200000, 1200000}, {262144, 131072}};
+                             {1200000, 777777}, {1200000, 1200000}, {262144, 131072},
+                             {1310720, 1310720}, {1310720, 196608}, {1200000, 196607}, {1200000, 2048}, {1200000, 1198081}, {1200000, 0}};
   unsigned seed = 42;
   for (const auto& c : cases) {
     const size_t kmax = c[0], k = c[1];
