@@ -232,6 +232,7 @@ struct lsgpu_icp {
   DevBuf<float> limit_dev;
   double* h_pinned = nullptr; // 64 doubles of pinned host staging
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  hipEvent_t ev_state = nullptr;   // lsgpu_icp_align: completion of a loop-state copy (the stream goes on behind it)
   struct KnnEv { hipEvent_t a, b, c, d, e; };  // before kNN, after the main pass, after the wave-per-query pass, after the select, after the normal equations
   std::vector<KnnEv> knn_events;   // pool, reused across aligns
   size_t knn_events_used = 0;
@@ -363,6 +364,7 @@ void lsgpu_icp_destroy(lsgpu_icp* h) {
   for (auto& e : h->knn_events) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); (void)hipEventDestroy(e.c); (void)hipEventDestroy(e.d); (void)hipEventDestroy(e.e); }
   if (h->ev0) (void)hipEventDestroy(h->ev0);
   if (h->ev1) (void)hipEventDestroy(h->ev1);
+  if (h->ev_state) (void)hipEventDestroy(h->ev_state);
   if (h->h_pinned) (void)hipHostFree(h->h_pinned);
   if (h->draws_pinned) (void)hipHostFree(h->draws_pinned);
   if (h->copy_done) (void)hipEventDestroy(h->copy_done);
@@ -1874,25 +1876,41 @@ int lsgpu_icp_align(lsgpu_icp* h, const float* reading_xyz1, int64_t nq, const f
     if (ev) HIPC(hipEventRecord(ev->e, h->stream));
     return hipGetLastError() == hipSuccess ? LSGPU_OK : LSGPU_HIP_ERROR;
   };
-  auto fetch_state = [&]() -> int {
+  // A look at the loop state.  `ahead` (not in the split-scan mode): ONE more iteration is enqueued behind the copy before
+  // the host waits for it, so the device works through the round trip instead of idling (~25 us + a cold first launch per
+  // look); that iteration carries the decisions of the previous look, like the later iterations of any group, and exits
+  // at once if the state it finds says `done`.
+  const bool lookahead = tuning().lookahead && !h->comm;
+  if (lookahead && !h->ev_state) HIPC(hipEventCreateWithFlags(&h->ev_state, hipEventDisableTiming));
+  int enq = 0;
+  const int wide_iters = tuning().wide_iters;   // the first launches still have wide balls: their spread waves go to the wave-per-query pass
+  const int enq_limit = 8 * max_it + 64;        // (only guards against a device that never finishes, see below)
+  auto fetch_state = [&](int* enqueued_ahead) -> int {
+    *enqueued_ahead = 0;
     HIPC(hipMemcpyAsync(hst, h->state.p, sizeof(IcpState), hipMemcpyDeviceToHost, h->stream));
+    if (lookahead && enq < enq_limit) {
+      HIPC(hipEventRecord(h->ev_state, h->stream));
+      const int r = enqueue_iteration(false, true, enq < wide_iters);
+      if (r) return r;
+      ++enq; *enqueued_ahead = 1;
+      HIPC(hipEventSynchronize(h->ev_state));
+      return LSGPU_OK;
+    }
     return wait_stream(h);  // (bounded in the split-scan mode: a dead peer must not hang this rank)
   };
 
-  // the first launches still have wide balls: their spread waves go to the wave-per-query pass
-  const int wide_iters = tuning().wide_iters;
   // iteration 0: seeded; capped by the trim quantile of the seed distances (a guaranteed bound: no retry can follow)
   const bool seed_cap = tuning().seed_cap;
   rc = enqueue_iteration(true, seed_cap && h->cfg.reserved[0] == 0, true);
   if (rc) return rc;
-  int enq = 1, since_check = 1, sel_retries = 0;
+  enq = 1;
+  int since_check = 1, sel_retries = 0;
   std::vector<std::pair<int, size_t>> launch_of_iter;  // (enqueue ordinal -> event) bookkeeping below
   const int group = 6;
   // The device decides when the loop ends (CounterTransformationChecker raises `done` after max_iterations at the
   // latest); the host keeps feeding groups of launches until it sees `done`.  Launches enqueued behind an
   // iteration that had to be repeated exit at once, so the number of enqueues is NOT bounded by max_iterations;
   // the cap below only guards against a device that never finishes.
-  const int enq_limit = 8 * max_it + 64;
   for (;;) {
     if (enq < enq_limit && since_check < group) {
       rc = enqueue_iteration(false, true, enq < wide_iters);
@@ -1900,9 +1918,10 @@ int lsgpu_icp_align(lsgpu_icp* h, const float* reading_xyz1, int64_t nq, const f
       ++enq; ++since_check;
       continue;
     }
-    rc = fetch_state();
+    int ahead = 0;
+    rc = fetch_state(&ahead);
     if (rc) return rc;
-    since_check = 0;
+    since_check = ahead;
     commit_ok = hst->sel_streak >= 1 && hst->status == 0;  // (a miss below clears it until the streak is rebuilt)
     h->n_spread_host = hst->n_spread; h->n_spread_known = true;
     if (hst->done && hst->status == kStatusCapFailed) {

@@ -24,6 +24,7 @@
 //   LSGPU_FRONT_GUESS     2048  tiles the front of the grid is sized for before the host has seen the list
 //   LSGPU_NO_LAZY               wide launches (first iterations) use the plain tile kernel instead of the instantiation that re-tests chunks before fetching them
 //   LSGPU_NO_SIDE_STREAM        lsgpu_icp_compute: reading filter + query order AFTER the grid build, on the same stream (not beside it)
+//   LSGPU_NO_LOOKAHEAD          no iteration enqueued behind the copy of the loop state: the device idles while the host looks at it
 //   LSGPU_NO_ROUTE_ALL          (with NO_FRONT) settled spread waves search per lane inside the tile kernel
 //   LSGPU_NO_ROWQ               (with NO_FRONT) handed-over queries go to the wave-per-query kernel
 //   LSGPU_ROWQ_BLOCKS     2048  (with NO_FRONT) grid of the row pass
@@ -57,6 +58,7 @@ struct Tuning {
   bool predict_select = true, commit_select = true, comm_commit = true, seed_cap = true;
   bool front = true;
   bool lazy_need = true;
+  bool lookahead = true;     // LSGPU_NO_LOOKAHEAD: the host waits for the whole stream when it looks at the loop state
   bool side_stream = true;   // LSGPU_NO_SIDE_STREAM: lsgpu_icp_compute runs the reading's filter + query order after the grid build instead of beside it
   int front_guess = 2048;
   bool route_all = true, rowq = true;
@@ -109,6 +111,7 @@ inline Tuning read() {
   t.front = !flag("LSGPU_NO_FRONT");
   t.lazy_need = !flag("LSGPU_NO_LAZY");
   t.side_stream = !flag("LSGPU_NO_SIDE_STREAM");
+  t.lookahead = !flag("LSGPU_NO_LOOKAHEAD");
   t.front_guess = (int)number("LSGPU_FRONT_GUESS", 2048, 0, 8192);
   t.route_all = !flag("LSGPU_NO_ROUTE_ALL");
   t.rowq = !flag("LSGPU_NO_ROWQ");
@@ -125,7 +128,7 @@ inline Tuning read() {
   t.knn_dbg = (int)number("LSGPU_KNN_DBG", 0, 0, 1 << 20);
   static const char* known[] = {"LSGPU_QUERY_ORDER", "LSGPU_Q_ELEV", "LSGPU_Q_SECT", "LSGPU_GAP", "LSGPU_BUDGET", "LSGPU_BUDGET_WIDE", "LSGPU_WIDE_ITERS",
                                 "LSGPU_ROUTE_R", "LSGPU_ROUTE_CHUNKS", "LSGPU_SPLIT_UPDATE", "LSGPU_NO_PREDICT", "LSGPU_NO_COMMIT",
-                                "LSGPU_NO_COMM_COMMIT", "LSGPU_NO_SEED_CAP", "LSGPU_NO_FRONT", "LSGPU_NO_LAZY", "LSGPU_NO_SIDE_STREAM", "LSGPU_FRONT_GUESS", "LSGPU_NO_ROUTE_ALL",
+                                "LSGPU_NO_COMM_COMMIT", "LSGPU_NO_SEED_CAP", "LSGPU_NO_FRONT", "LSGPU_NO_LAZY", "LSGPU_NO_SIDE_STREAM", "LSGPU_NO_LOOKAHEAD", "LSGPU_FRONT_GUESS", "LSGPU_NO_ROUTE_ALL",
                                 "LSGPU_NO_ROWQ", "LSGPU_ROWQ_BLOCKS", "LSGPU_ROCPRIM_SORT", "LSGPU_SORT_ITEMS", "LSGPU_SSN_GLOBAL",
                                 "LSGPU_NE_BLOCKS", "LSGPU_COMM_TIMEOUT_MS", "LSGPU_KNN_DBG",
                                 // read by the Python / C++ hosts and the test drivers, not by this library:
