@@ -6,6 +6,9 @@ acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for r in rows:
     k = r["Kernel_Name"].split("(")[0]
     if pat in k:
+        # (launches enqueued behind the end of an alignment exit within microseconds: not part of the averages)
+        if float(r["End_Timestamp"]) - float(r["Start_Timestamp"]) < 20e3:
+            continue
         acc[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
 for k, d in acc.items():
     print(k)
