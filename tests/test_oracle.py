@@ -277,3 +277,68 @@ def test_independent_known_answers(oracle):
     for i in range(int(kat["trim_n"])):
         rc, lim = oracle.trim_limit(kat[f"trim{i}_d2"], float(kat[f"trim{i}_ratio"]))
         assert rc == 0 and np.float32(lim) == kat[f"trim{i}_limit"], i
+
+
+def _numpy_icp(reading, ref, nrm, T_init, ratio, max_it, min_rot, min_trans, smooth):
+    """ICP::compute written from SURVEY.md appendix A alone, in float64 numpy / scipy -- no code shared with oracle/ or the
+    product: centre on the reference mean, kd-tree 1-NN, TrimmedDist (index floor(n ratio), inclusive), point-to-plane
+    normal equations solved by numpy, AngleAxis update LEFT-multiplied, Counter + Differential checkers, composition."""
+    from scipy.spatial import cKDTree
+    from scipy.spatial.transform import Rotation
+    mean = ref[:, :3].astype(np.float64).mean(0)
+    ref_c = ref[:, :3].astype(np.float64) - mean
+    n_ref = nrm.astype(np.float64)
+    T_mean = np.eye(4); T_mean[:3, 3] = mean
+    T_rm_in = np.linalg.inv(T_mean) @ T_init
+    rd = reading[:, :3].astype(np.float64) @ T_rm_in[:3, :3].T + T_rm_in[:3, 3]
+    tree = cKDTree(ref_c)
+    T_iter = np.eye(4)
+    hist_q, hist_t = [Rotation.from_matrix(T_iter[:3, :3])], [T_iter[:3, 3].copy()]
+    rot_err, trans_err = [], []
+    trace = []
+    for it in range(max_it):
+        p = rd @ T_iter[:3, :3].T + T_iter[:3, 3]
+        d, ids = tree.query(p)
+        d2 = d * d
+        k = int(np.floor(d2.size * ratio))
+        limit = np.partition(d2, k)[k]
+        w = d2 <= limit
+        P, Q, N = p[w], ref_c[ids[w]], n_ref[ids[w]]
+        F = np.hstack([np.cross(P, N), N])
+        r = ((P - Q) * N).sum(1)
+        x = np.linalg.solve(F.T @ F, -(F.T @ r))
+        dT = np.eye(4)
+        ang = np.linalg.norm(x[:3])
+        if ang > 0:
+            dT[:3, :3] = Rotation.from_rotvec(x[:3]).as_matrix()
+        dT[:3, 3] = x[3:]
+        T_iter = dT @ T_iter
+        trace.append((limit, int(w.sum()), T_iter.copy()))
+        # checkers: counter (stop once `max_it` checks are made), differential (mean over the last `smooth` steps)
+        hist_q.append(Rotation.from_matrix(T_iter[:3, :3])); hist_t.append(T_iter[:3, 3].copy())
+        rot_err.append((hist_q[-1] * hist_q[-2].inv()).magnitude()); trans_err.append(np.linalg.norm(hist_t[-1] - hist_t[-2]))
+        if len(rot_err) >= smooth and np.mean(rot_err[-smooth:]) < min_rot and np.mean(trans_err[-smooth:]) < min_trans:
+            break
+    return T_mean @ T_iter @ T_rm_in, trace
+
+
+def test_oracle_loop_against_an_independent_numpy_icp(oracle):
+    """The COMPOSITION of the loop -- frames, left-multiplied update, inclusive trim at index floor(n ratio), the
+    differential checker's smoothing window -- against a float64 numpy / scipy ICP written from the survey's description
+    of libpointmatcher alone.  Same filtered clouds; per iteration the same trim limit (1e-4 relative), the same inlier
+    count (+- 3: float32 vs float64 at the limit), the same T_iter (1e-5); the same number of iterations and final T."""
+    from laser_slam_amd import synth
+    ref, rd, T_true, T_init = synth.scan_pair(192)
+    rf, rn = oracle.sampling_surface_normal(ref, 10, 1.0, 0)
+    for (mr, mt, sm, ratio) in ((1e-3, 1e-2, 4, 0.75), (1e-5, 1e-4, 4, 0.75), (1e-4, 1e-3, 3, 0.85)):
+        cfg = oracle.config_yaml(min_diff_rot=mr, min_diff_trans=mt, smooth_length=sm, trim_ratio=ratio, accum_double=1)
+        rc, To, st, tr = oracle.icp_compute(cfg, rd, rf, rn, synth.colmajor(T_init), 40)
+        assert rc == 0
+        Tn, trn = _numpy_icp(rd, rf, rn, T_init, ratio, 40, mr, mt, sm)
+        assert st.iterations == len(trn), (st.iterations, len(trn), mr, mt, sm)
+        for a, (lim, used, Ti) in zip(tr, trn):
+            assert abs(a["limit"] - lim) <= 1e-4 * lim
+            assert abs(a["n_used"] - used) <= 3
+            assert np.abs(synth.from_colmajor(a["T_iter"]) - Ti).max() < 1e-5
+        dt, dr = synth.pose_error(synth.from_colmajor(To), Tn)
+        assert dt < 1e-5 and dr < 1e-6, (dt, dr)
