@@ -342,3 +342,55 @@ def test_oracle_loop_against_an_independent_numpy_icp(oracle):
             assert np.abs(synth.from_colmajor(a["T_iter"]) - Ti).max() < 1e-5
         dt, dr = synth.pose_error(synth.from_colmajor(To), Tn)
         assert dt < 1e-5 and dr < 1e-6, (dt, dr)
+
+
+def test_surface_normal_filter_boxes_against_a_numpy_recursion(oracle):
+    """The box construction of SamplingSurfaceNormal as the restatement states it (widest axis, first on ties; STABLE order
+    along it; left = count - count / 2; cut value = first point of the right half) written as a plain numpy recursion:
+    with ratio 1 the filter must return exactly the cloud's points in the order of the recursion's leaves, and each box's
+    normal must be the smallest eigenvector of numpy's covariance of that box."""
+    rng = np.random.default_rng(5)
+    n, knn = 6000, 10
+    pts = np.ones((n, 4), np.float32)
+    pts[:, :3] = rng.normal(size=(n, 3)).astype(np.float32) * np.array([30.0, 12.0, 2.0], np.float32)
+    pts[::7, 2] = np.float32(0.25)          # ties along z, so that the stable order matters
+    pts[100:140, :3] = pts[100, :3]         # duplicates
+    boxes = []
+
+    def build(idx, lo, hi):
+        if idx.size <= knn:
+            boxes.append(idx)
+            return
+        cut = int(np.argmax(hi - lo))       # first of equal extents
+        order = idx[np.argsort(pts[idx, cut], kind="stable")]
+        left = idx.size - idx.size // 2
+        cutval = pts[order[left], cut]
+        hi_l, lo_r = hi.copy(), lo.copy()
+        hi_l[cut] = cutval; lo_r[cut] = cutval
+        build(order[:left], lo, hi_l)
+        build(order[left:], lo_r, hi)
+
+    build(np.arange(n), pts[:, :3].min(0), pts[:, :3].max(0))
+    from laser_slam_amd import icp
+    for impl in (oracle.sampling_surface_normal, icp.sampling_surface_normal):   # the oracle, the product's host filter
+        _check_boxes_against_recursion(pts, boxes, *impl(pts, knn, 1.0, 0))
+
+
+def _check_boxes_against_recursion(pts, boxes, out, nrm):
+    pos = 0
+    checked = 0
+    for b in boxes:                         # (a box is dropped only if its points are collinear / coincident)
+        d = pts[b, :3].astype(np.float64)
+        c = d - d.mean(0)
+        if np.linalg.matrix_rank(c.T @ c, tol=None) < 2:
+            continue                        # dropped by the rank test: nothing of it in the output
+        got = out[pos:pos + b.size]
+        assert np.array_equal(got[:, :3], pts[b, :3]), (pos, b[:4])
+        evals, evecs = np.linalg.eigh(c.T @ c)
+        nn = nrm[pos]
+        if evals[1] > 1e-3 * evals[2] and evals[0] < 0.5 * evals[1]:   # a well separated smallest eigenvalue
+            assert abs(abs(float(nn @ evecs[:, 0])) - 1.0) < 1e-3
+            checked += 1
+        assert np.array_equal(nrm[pos:pos + b.size], np.repeat(nn[None], b.size, 0))
+        pos += b.size
+    assert pos == out.shape[0] and checked > 300
