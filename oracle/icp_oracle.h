@@ -32,7 +32,8 @@
  *   2. split of a box: std::nth_element leaves ties and the order inside the halves unspecified; here "stable sort,
  *      split at the median".  Wrong => other box memberships where coordinates tie, other output ORDER of the kept
  *      points (which permutes the rand() draws of ratio < 1).  tests: test_filter_golden_vectors_reproduce,
- *      test_device_reference_filter_is_bit_identical (pin device == host == oracle, not upstream).
+ *      test_device_reference_filter_is_bit_identical (pin device == host == oracle, not upstream);
+ *      test_surface_normal_filter_boxes_against_a_numpy_recursion (the stated rule as a plain numpy recursion).
  *   3. kd-tree ties (libnabo): implementation defined => any nearest point is valid; the product returns the
  *      smallest index of its own order.  tests: _check_nn / test_golden_vectors accept equal-distance alternatives.
  *   4. TrimmedDistOutlierFilter: index floor(float(n) * ratio) over the matched pairs, weight 1 iff d2 <= limit
@@ -52,6 +53,9 @@
  *   9. MaxDist / MinDist input filters: radial branch compares the norm with |limit| (both), one-axis branch compares
  *      the SIGNED coordinate (MaxDist) / the absolute one (MinDist); an empty cloud into a non-empty chain throws.
  *      tests: test_input_filters_upstream_asymmetries.
+ * The COMPOSITION of ICP::compute (frames, left-multiplied update, checker window, steps 1-7 of SURVEY.md A.1) is pinned
+ * against a float64 numpy / scipy ICP that shares no code with this file:
+ * test_oracle_loop_against_an_independent_numpy_icp.
  *
  * Arithmetic definitions shared with the HIP path (so integer results are
  * bit-comparable):
