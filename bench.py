@@ -53,6 +53,18 @@ def csrc_digest() -> str:
     return d.hexdigest()[:16]
 
 
+def _cpu_model() -> str:
+    """Model name of the host CPU (SURVEY.md 8d asks for it next to the CPU baseline)."""
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.lower().startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -393,6 +405,7 @@ def main():
             "ms_filters": sto.t_filter_ms, "ms_per_icp_iteration": sto.t_loop_ms / max(sto.iterations, 1),
             "iterations": sto.iterations,
             "gpu_vs_cpu_transform": {"trans_m": dt, "rot_rad": dr},
+            "cpu_model": _cpu_model(),
         }
         # second row of SURVEY.md §8d: the same oracle with OpenMP over the queries on all host cores (what a
         # libnabo built with OpenMP does); reported next to the single-thread figure, never as the baseline value
