@@ -16,38 +16,48 @@ struct RefStats {
   double sum[3];
   float mn[3];
   float mx[3];
+  float zmn, zmx;   // range of zeta = z / |p| seen from the frame's own origin (rows of the direction index, lsgpu_cone.hip.h)
 };
 
 __global__ __launch_bounds__(256) void k_ref_stats(const float4* __restrict__ in, int64_t n,
                                                    RefStats* __restrict__ partials) {
   double sx = 0, sy = 0, sz = 0;
   float mnx = INFINITY, mny = INFINITY, mnz = INFINITY, mxx = -INFINITY, mxy = -INFINITY,
-        mxz = -INFINITY;
+        mxz = -INFINITY, zmn = INFINITY, zmx = -INFINITY;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
     const float4 p = in[i];
     sx += p.x; sy += p.y; sz += p.z;
     mnx = fminf(mnx, p.x); mny = fminf(mny, p.y); mnz = fminf(mnz, p.z);
     mxx = fmaxf(mxx, p.x); mxy = fmaxf(mxy, p.y); mxz = fmaxf(mxz, p.z);
+    const float r2 = p.x * p.x + p.y * p.y + p.z * p.z;
+    if (r2 > 0.f) {   // (fminf / fmaxf drop a NaN operand: non-finite points are reported through the box)
+      const float zeta = p.z * __builtin_amdgcn_rsqf(r2);
+      zmn = fminf(zmn, zeta); zmx = fmaxf(zmx, zeta);
+    }
   }
   sx = wave_sum(sx); sy = wave_sum(sy); sz = wave_sum(sz);
   mnx = wave_min(mnx); mny = wave_min(mny); mnz = wave_min(mnz);
   mxx = wave_max(mxx); mxy = wave_max(mxy); mxz = wave_max(mxz);
+  zmn = wave_min(zmn); zmx = wave_max(zmx);
   __shared__ RefStats sh[4];
   const int w = threadIdx.x >> 6;
   if ((threadIdx.x & 63) == 0) {
     sh[w].sum[0] = sx; sh[w].sum[1] = sy; sh[w].sum[2] = sz;
     sh[w].mn[0] = mnx; sh[w].mn[1] = mny; sh[w].mn[2] = mnz;
     sh[w].mx[0] = mxx; sh[w].mx[1] = mxy; sh[w].mx[2] = mxz;
+    sh[w].zmn = zmn; sh[w].zmx = zmx;
   }
   __syncthreads();
   if (threadIdx.x == 0) {
     RefStats r = sh[0];
-    for (int k = 1; k < 4; ++k)
+    for (int k = 1; k < 4; ++k) {
       for (int d = 0; d < 3; ++d) {
         r.sum[d] += sh[k].sum[d];
         r.mn[d] = fminf(r.mn[d], sh[k].mn[d]);
         r.mx[d] = fmaxf(r.mx[d], sh[k].mx[d]);
       }
+      r.zmn = fminf(r.zmn, sh[k].zmn); r.zmx = fmaxf(r.zmx, sh[k].zmx);
+    }
     partials[blockIdx.x] = r;
   }
 }
@@ -61,6 +71,10 @@ struct GeomDev {
   float h0, hf, inv_hf;
   int fine, bits;
   int bad;            // non-finite coordinates
+  // direction index (lsgpu_cone.hip.h): range of zeta = z / |p| about the frame's origin, and whether that origin lies
+  // inside the cloud's bounding box (a cloud seen from far outside itself has no use for an index by direction)
+  float zeta_lo, zeta_hi;
+  int origin_inside;
 };
 
 // One wave; fixed summation tree => deterministic mean.  nblocks <= 512.
@@ -70,18 +84,22 @@ __global__ __launch_bounds__(64) void k_ref_stats_final(const RefStats* __restri
   const int lane = threadIdx.x;
   double s[3] = {0, 0, 0};
   float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
-  for (int k = lane; k < nblocks; k += 64)
+  float zmn = INFINITY, zmx = -INFINITY;
+  for (int k = lane; k < nblocks; k += 64) {
     for (int d = 0; d < 3; ++d) {
       s[d] += partials[k].sum[d];
       mn[d] = fminf(mn[d], partials[k].mn[d]);
       mx[d] = fmaxf(mx[d], partials[k].mx[d]);
     }
+    zmn = fminf(zmn, partials[k].zmn); zmx = fmaxf(zmx, partials[k].zmx);
+  }
   RefStats r;
   for (int d = 0; d < 3; ++d) {
     r.sum[d] = wave_sum(s[d]);
     r.mn[d] = wave_min(mn[d]);
     r.mx[d] = wave_max(mx[d]);
   }
+  r.zmn = wave_min(zmn); r.zmx = wave_max(zmx);
   if (lane == 0) {
     *out = r;
     // same arithmetic the host used to do: float mean from the double sums, box in the mean frame, then 16 key bits per
@@ -102,6 +120,13 @@ __global__ __launch_bounds__(64) void k_ref_stats_final(const RefStats* __restri
     while (!gm.bad && h0 * (float)((1 << bits) - 1) < ext * 1.0001f) h0 *= 2.f;
     gm.ox = mn[0]; gm.oy = mn[1]; gm.oz = mn[2];
     gm.h0 = h0; gm.hf = h0 / (float)(1 << fine); gm.inv_hf = 1.0f / gm.hf; gm.fine = fine; gm.bits = bits;
+    gm.zeta_lo = r.zmn; gm.zeta_hi = r.zmx;
+    gm.origin_inside = 1;
+    for (int d = 0; d < 3; ++d) {   // the input frame's origin against the box, widened by a tenth of its extent
+      const float m = 0.1f * (r.mx[d] - r.mn[d]) + 1e-3f;
+      if (!(r.mn[d] - m <= 0.f && 0.f <= r.mx[d] + m)) gm.origin_inside = 0;
+    }
+    if (!(r.zmn <= r.zmx)) gm.origin_inside = 0;
     *geom = gm;
   }
 }

@@ -27,6 +27,7 @@
 #include "lsgpu_grid.hip.h"
 #include "lsgpu_tuning.h"
 #include "lsgpu_knn.hip.h"
+#include "lsgpu_cone.hip.h"
 #ifdef LSGPU_EXPERIMENTS
 #include "lsgpu_knn_rows.hip.h"   // measured-slower variants, kept as the record of what was tried
 #endif
@@ -178,6 +179,13 @@ struct lsgpu_icp {
   DevBuf<float> soa;            // chunk-blocked SoA copy of pts (k_soa_fill)
   DevBuf<uint32_t> soa_base, soa_cnt4, soa_first;
   uint32_t nchunks = 0;
+  // direction index of the reference (lsgpu_cone.hip.h): the settled launches of an align search it instead of the voxel grid
+  DevBuf<float> cone_x, cone_y, cone_z;
+  DevBuf<uint32_t> cone_map, cone_tab, cone_rowz_bits;
+  DevBuf<float2> cone_rowz;
+  ConeDev cone;
+  bool cone_ok = false;       // built for the current reference
+  bool cone_off = false;      // this align stopped using it (too many lanes it could not serve)
   DevBuf<uint4> knn_dbg_wave;
   DevBuf<unsigned long long> knn_dbg;  // LSGPU_KNN_STATS builds: 8 counters
   DevBuf<uint2> cell_cache;  // ntiles x 64
@@ -357,6 +365,7 @@ void lsgpu_icp_destroy(lsgpu_icp* h) {
   h->work.release();
 #endif
   h->pts.release();
+  h->cone_x.release(); h->cone_y.release(); h->cone_z.release(); h->cone_map.release(); h->cone_tab.release(); h->cone_rowz_bits.release(); h->cone_rowz.release();
   h->nrm.release(); h->ref_inv.release(); h->tables.release(); h->flags.release(); h->cidx.release(); h->bounds.release(); h->chunks.release(); h->soa.release(); h->soa_base.release(); h->soa_cnt4.release(); h->soa_first.release(); h->prev.release(); h->state.release(); h->lb.release(); h->cell_cache.release(); h->cell_tags.release(); h->ssn_seg_a.release(); h->ssn_seg_b.release(); h->ssn_seg_of.release(); h->ssn_box_pts.release(); h->ssn_box_base.release(); h->ssn_keep.release(); h->ssn_out_pos.release(); h->ssn_bb.release(); h->ssn_box_normal.release(); h->ssn_draws.release(); h->flt_in.release(); h->flt_in2.release(); h->flt_ref.release(); h->flt_rd.release(); h->flt_nrm.release(); h->chk_hist.release(); h->trace_dev.release(); h->knn_dbg.release(); h->knn_dbg_wave.release(); h->stat_partials.release(); h->geom.release();
   h->counters.release(); h->ang_cells.release(); h->sel_aux.release(); h->sel_win.release(); h->spread_flag.release(); h->spread_list.release(); h->spread_cnt.release(); h->q_in.release(); h->rdq.release(); h->ids.release(); h->d2.release();
   h->ids_io.release(); h->d2_io.release(); h->strag.release(); h->hist.release();
@@ -620,6 +629,14 @@ static int run_knn(lsgpu_icp* h, const Mat34& T, const IcpState* st, bool seed, 
     hipLaunchKernelGGL((k_knn_tile<4, false>), dim3((a.ntiles + 3) / 4), dim3(256), 0, h->stream, a);
   else
 #endif
+  if (capped && !wide && st && h->cone_ok && !h->cone_off) {
+    // settled launch: every lane searches its own windows of the direction-sorted reference (lsgpu_cone.hip.h)
+    a.front_blocks = 0;
+    hipLaunchKernelGGL(k_knn_cone, dim3(a.ntiles), dim3(64), 0, h->stream, a, h->cone);
+    if (timed) { HIPC(hipEventRecord(ev->b, h->stream)); HIPC(hipEventRecord(ev->c, h->stream)); }
+    HIPC(hipGetLastError());
+    return LSGPU_OK;
+  }
   if (wide && tn.lazy_need)   // balls still as wide as the last ICP step: the instantiation that re-tests chunks before fetching them
     hipLaunchKernelGGL((k_knn_tile<1, true>), dim3(a.ntiles + a.front_blocks), dim3(64), 0, h->stream, a);
   else
@@ -803,6 +820,35 @@ int lsgpu_icp_set_reference(lsgpu_icp* h, const float* ref_xyz1, const float* re
   h->grid = g;
   h->nr = nr;
   h->nchunks = nchunks;
+  // ---- direction index for the settled launches (after k_cells_fill: the sort below reuses the Morton keys' buffers)
+  h->cone_ok = false;
+  if (tuning().cone && hg->origin_inside && nr >= 1024) {
+    ConeDev c;
+    std::memset(&c, 0, sizeof(c));
+    c.ox = -hg->mean[0]; c.oy = -hg->mean[1]; c.oz = -hg->mean[2];
+    c.rows = tuning().cone_rows; c.cols = tuning().cone_cols;
+    const float zr = std::max(hg->zeta_hi - hg->zeta_lo, 1e-3f);
+    c.z0 = hg->zeta_lo - 1e-5f - 1e-4f * zr;
+    c.rs = (float)c.rows / (zr * 1.0002f + 2e-5f);
+    c.cs = (float)c.cols * 0.25f;
+    const size_t npad = (((size_t)nr + 3) & ~(size_t)3) + kConePad, nkeys = (size_t)c.rows * (size_t)c.cols;
+    HIPC(h->cone_x.reserve(npad)); HIPC(h->cone_y.reserve(npad)); HIPC(h->cone_z.reserve(npad)); HIPC(h->cone_map.reserve(npad));
+    HIPC(h->cone_tab.reserve(nkeys + 1)); HIPC(h->cone_rowz_bits.reserve(2 * (size_t)c.rows)); HIPC(h->cone_rowz.reserve((size_t)c.rows));
+    c.x = h->cone_x.p; c.y = h->cone_y.p; c.z = h->cone_z.p; c.map = h->cone_map.p; c.tab = h->cone_tab.p; c.rowz = h->cone_rowz.p;
+    hipLaunchKernelGGL(k_cone_keys, dim3(std::max(nblk(nr), nblk(2 * c.rows))), dim3(256), 0, h->stream, h->pts.p, nr, c,
+                       h->sc->keys.p, h->sc->vals.p, h->cone_rowz_bits.p);
+    int nbits = 1;
+    while (((size_t)1 << nbits) < nkeys) ++nbits;
+    rc = sort_pairs(h, nr, nbits);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_cone_gather, dim3(nblk((int64_t)npad)), dim3(256), 0, h->stream, h->pts.p, h->sc->vals_alt.p,
+                       h->sc->keys_alt.p, nr, c, h->cone_x.p, h->cone_y.p, h->cone_z.p, h->cone_map.p, h->cone_tab.p,
+                       h->cone_rowz_bits.p);
+    hipLaunchKernelGGL(k_cone_rowz, dim3(nblk(c.rows)), dim3(256), 0, h->stream, h->cone_rowz_bits.p, c.rows, h->cone_rowz.p);
+    HIPC(hipGetLastError());
+    h->cone = c;
+    h->cone_ok = true;
+  }
   std::memset(&h->info, 0, sizeof(h->info));
   h->info.n_reference = nr;
   h->info.bits_per_axis = bits;
@@ -1804,6 +1850,7 @@ int lsgpu_icp_align(lsgpu_icp* h, const float* reading_xyz1, int64_t nq, const f
   HIPC(h->spread_flag.reserve((size_t)((nq + 63) / 64))); HIPC(h->spread_list.reserve(kFrontMax)); HIPC(h->spread_cnt.reserve(2));
   HIPC(h->sel_win.reserve((size_t)kSelWinRows * 512));
   h->n_spread_host = 0; h->n_spread_known = false;
+  h->cone_off = false;
   ia.state = *hst;
   ia.sel0 = SelState{0u, k};   // sel[0] = {0, rank}: constant during an align
   ia.state_dev = h->state.p; ia.chk_hist = h->chk_hist.p; ia.sel = h->sel.p;
@@ -1905,6 +1952,7 @@ int lsgpu_icp_align(lsgpu_icp* h, const float* reading_xyz1, int64_t nq, const f
   if (rc) return rc;
   enq = 1;
   int since_check = 1, sel_retries = 0;
+  int look_iter = 0; unsigned long long look_strag = 0;   // loop state at the previous look (direction-index guard below)
   std::vector<std::pair<int, size_t>> launch_of_iter;  // (enqueue ordinal -> event) bookkeeping below
   const int group = 6;
   // The device decides when the loop ends (CounterTransformationChecker raises `done` after max_iterations at the
@@ -1924,6 +1972,13 @@ int lsgpu_icp_align(lsgpu_icp* h, const float* reading_xyz1, int64_t nq, const f
     since_check = ahead;
     commit_ok = hst->sel_streak >= 1 && hst->status == 0;  // (a miss below clears it until the streak is rebuilt)
     h->n_spread_host = hst->n_spread; h->n_spread_known = true;
+    // k_knn_cone counts the lanes its index could not serve (they search the voxel grid one by one) as stragglers: on
+    // the clouds it is made for they are a handful; where they are not (> 2 % of the queries per settled iteration)
+    // the rest of this align goes back to k_knn_tile
+    if (h->cone_ok && !h->cone_off && look_iter >= wide_iters && hst->iter > look_iter &&
+        (double)(hst->stragglers - look_strag) > 0.02 * (double)nq * (double)(hst->iter - look_iter))
+      h->cone_off = true;
+    look_iter = hst->iter; look_strag = hst->stragglers;
     if (hst->done && hst->status == kStatusCapFailed) {
       // the cap prediction failed for iteration hst->iter: repeat it uncapped, then carry on
       st.cap_retries++;

@@ -34,6 +34,9 @@
 //   LSGPU_NE_BLOCKS        256  blocks of k_normal_eq_loop (64 .. 2048)
 //   LSGPU_SPLIT_UPDATE          the per-iteration update as its own launch (profiling)
 //   LSGPU_COMM_TIMEOUT_MS 30000 bound on every stream wait of the split-scan mode
+//   LSGPU_NO_CONE               settled launches search the voxel grid (k_knn_tile) instead of the direction index (k_knn_cone)
+//   LSGPU_CONE_ROWS        128  rows (bins of the sine of the elevation) of the direction index
+//   LSGPU_CONE_COLS       8192  columns (bins of the pseudo-azimuth) of the direction index
 //   LSGPU_KNN_DBG            0  ablation flags of the -DLSGPU_KNN_STATS build (ignored by the product build)
 // Experiment switches, compiled in only with -DLSGPU_EXPERIMENTS (measured-slower variants kept as the record of what was
 // tried: DESIGN.md "Rejected after measurement"); the product build reports them as unknown:
@@ -70,6 +73,8 @@ struct Tuning {
   bool split_update = false;
   double comm_timeout_ms = 30000.0;
   int knn_dbg = 0;
+  bool cone = true;
+  int cone_rows = 128, cone_cols = 8192;
 #ifdef LSGPU_EXPERIMENTS
   int knn_rows = 0;
   bool knn_lane = false;
@@ -126,11 +131,14 @@ inline Tuning read() {
   t.ne_blocks = (int)number("LSGPU_NE_BLOCKS", 256, 64, 2048);
   t.comm_timeout_ms = number("LSGPU_COMM_TIMEOUT_MS", 30000, 1, 1e9);
   t.knn_dbg = (int)number("LSGPU_KNN_DBG", 0, 0, 1 << 20);
+  t.cone = !flag("LSGPU_NO_CONE");
+  t.cone_rows = (int)number("LSGPU_CONE_ROWS", 128, 8, 1024);
+  t.cone_cols = (int)number("LSGPU_CONE_COLS", 8192, 64, 65536) & ~3;
   static const char* known[] = {"LSGPU_QUERY_ORDER", "LSGPU_Q_ELEV", "LSGPU_Q_SECT", "LSGPU_GAP", "LSGPU_BUDGET", "LSGPU_BUDGET_WIDE", "LSGPU_WIDE_ITERS",
                                 "LSGPU_ROUTE_R", "LSGPU_ROUTE_CHUNKS", "LSGPU_SPLIT_UPDATE", "LSGPU_NO_PREDICT", "LSGPU_NO_COMMIT",
                                 "LSGPU_NO_COMM_COMMIT", "LSGPU_NO_SEED_CAP", "LSGPU_NO_FRONT", "LSGPU_NO_LAZY", "LSGPU_NO_SIDE_STREAM", "LSGPU_NO_LOOKAHEAD", "LSGPU_FRONT_GUESS", "LSGPU_NO_ROUTE_ALL",
                                 "LSGPU_NO_ROWQ", "LSGPU_ROWQ_BLOCKS", "LSGPU_ROCPRIM_SORT", "LSGPU_SORT_ITEMS", "LSGPU_SSN_GLOBAL",
-                                "LSGPU_NE_BLOCKS", "LSGPU_COMM_TIMEOUT_MS", "LSGPU_KNN_DBG",
+                                "LSGPU_NE_BLOCKS", "LSGPU_COMM_TIMEOUT_MS", "LSGPU_KNN_DBG", "LSGPU_NO_CONE", "LSGPU_CONE_ROWS", "LSGPU_CONE_COLS",
                                 // read by the Python / C++ hosts and the test drivers, not by this library:
                                 "LSGPU_SO", "LSGPU_STATS_SO", "LSGPU_GOLDEN_DIR", "LSGPU_SEQ_PERTURB", "LSGPU_SEQ_POSES", "LSGPU_TEST_INPUT_FILTERS",
 #ifdef LSGPU_EXPERIMENTS

@@ -338,9 +338,15 @@ def test_experiment_switches_do_not_change_results():
     import json
     import subprocess
     import sys
-    variants = [{}, {"LSGPU_NO_FRONT": "1"}, {"LSGPU_NO_FRONT": "1", "LSGPU_NO_ROWQ": "1"},
-                {"LSGPU_NO_FRONT": "1", "LSGPU_NO_ROUTE_ALL": "1"}, {"LSGPU_NO_COMMIT": "1"}, {"LSGPU_NO_PREDICT": "1"},
-                {"LSGPU_ROCPRIM_SORT": "1"}, {"LSGPU_SORT_ITEMS": "4"}, {"LSGPU_NO_SEED_CAP": "1"}, {"LSGPU_NO_LAZY": "1"}, {"LSGPU_NO_SIDE_STREAM": "1"}, {"LSGPU_NO_LOOKAHEAD": "1"}, {"LSGPU_FRONT_GUESS": "8"}, {"LSGPU_SSN_GLOBAL": "1"},
+    # settled launches search the direction index (k_knn_cone) by default; LSGPU_NO_CONE sends them back to the voxel
+    # grid (k_knn_tile), whose own switches only act there
+    tile = {"LSGPU_NO_CONE": "1"}
+    variants = [{}, tile, dict(tile, LSGPU_NO_FRONT="1"), dict(tile, LSGPU_NO_FRONT="1", LSGPU_NO_ROWQ="1"),
+                dict(tile, LSGPU_NO_FRONT="1", LSGPU_NO_ROUTE_ALL="1"), {"LSGPU_NO_COMMIT": "1"}, dict(tile, LSGPU_NO_COMMIT="1"),
+                {"LSGPU_NO_PREDICT": "1"}, dict(tile, LSGPU_NO_PREDICT="1"),
+                {"LSGPU_CONE_ROWS": "32", "LSGPU_CONE_COLS": "1024"}, {"LSGPU_CONE_ROWS": "512", "LSGPU_CONE_COLS": "32768"},
+                {"LSGPU_ROCPRIM_SORT": "1"}, {"LSGPU_SORT_ITEMS": "4"}, {"LSGPU_NO_SEED_CAP": "1"}, {"LSGPU_NO_LAZY": "1"}, {"LSGPU_NO_SIDE_STREAM": "1"}, {"LSGPU_NO_LOOKAHEAD": "1"},
+                dict(tile, LSGPU_FRONT_GUESS="8"), {"LSGPU_SSN_GLOBAL": "1"},
                 {"LSGPU_QUERY_ORDER": "0"}]
     # the measured-slower variants only exist in the -DLSGPU_EXPERIMENTS build (devtools/build.sh); when that build is
     # around it has to give the same bits as the product, switch by switch
@@ -349,8 +355,8 @@ def test_experiment_switches_do_not_change_results():
     variants.append({"LSGPU_SO": fenced_so})        # release / acquire fences instead of the fence-free hand-off: same bits
     exp_so = os.path.join(ROOT, "devtools", "liblsgpu_exp.so")
     if os.path.exists(exp_so) and os.path.getmtime(exp_so) >= os.path.getmtime(os.path.join(ROOT, "laser_slam_amd", "liblsgpu_icp.so")) - 600:   # (a stale build says nothing)
-        variants += [dict(v, LSGPU_SO=exp_so) for v in ({}, {"LSGPU_KNN_ROWS": "1"}, {"LSGPU_TILE_WAVES": "4"},
-                                                        {"LSGPU_NO_FRONT": "1", "LSGPU_SPARSE_LANES": "16"})]
+        variants += [dict(v, LSGPU_SO=exp_so) for v in ({}, dict(tile, LSGPU_KNN_ROWS="1"), dict(tile, LSGPU_TILE_WAVES="4"),
+                                                        dict(tile, LSGPU_NO_FRONT="1", LSGPU_SPARSE_LANES="16"))]
     results = []
     for env_add in variants:
         env = dict(os.environ)
@@ -720,6 +726,55 @@ def test_align_degenerate_and_badly_initialised_cases_match_oracle(icp_mod, orac
         else:
             with pytest.raises(ConvergenceError):
                 h.align(pair4k["rd"], T_bad)
+
+
+def test_direction_index_on_clouds_it_is_not_made_for(icp_mod, oracle):
+    """k_knn_cone (settled launches) must stay exact where its index is of little use: (1) a uniform cube around the
+    origin -- queries next to the origin, cones that reach the polar axis, no ring structure: lanes fall back to the voxel
+    grid one by one, and the host gives the index up for the align once they are not rare; (2) a cloud whose points
+    all share one elevation (a single row); (3) a reading that wraps around azimuth 0.  Per iteration the trim limit
+    (an order statistic of ALL distances) and the inlier count equal the oracle's bit for bit, the system to 1e-9."""
+    from laser_slam_amd._lib import IcpConfig, lib
+    import ctypes as C
+    rng = np.random.default_rng(21)
+    cases = []
+    cube = np.ones((30000, 4), np.float32)
+    cube[:, :3] = rng.uniform(-4, 4, (30000, 3))
+    cube[:, 2] = (0.3 * np.sin(cube[:, 0]) + 0.2 * cube[:, 1] + rng.normal(0, 0.6, 30000)).astype(np.float32)   # a thick wavy sheet through the origin
+    cases.append(("cube", cube, synth.se3(0.05, -0.04, 0.03, yaw=np.deg2rad(1.0), pitch=np.deg2rad(0.5))))
+    az = rng.uniform(0, 2 * np.pi, 20000); r = rng.uniform(3, 30, 20000)
+    disc = np.ones((20000, 4), np.float32)
+    disc[:, 0] = r * np.cos(az); disc[:, 1] = r * np.sin(az); disc[:, 2] = (-0.1 * r).astype(np.float32)                # a cone z = -0.1 rho: ONE elevation
+    disc[:, 2] += (0.05 * np.sin(3 * az) * r / 30).astype(np.float32)
+    cases.append(("one elevation", disc, synth.se3(0.1, 0.05, 0.02, yaw=np.deg2rad(2.0))))
+    ring = synth.scan_pair(512)[0]
+    cases.append(("lidar, large yaw", ring, synth.se3(0.2, 0.1, 0.0, yaw=np.deg2rad(3.0))))
+    cfg = IcpConfig()
+    lib().lsgpu_icp_config_yaml(C.byref(cfg))
+    cfg.min_diff_rot, cfg.min_diff_trans = 1e-5, 1e-4
+    for name, cloud, T_off in cases:
+        rf, rn = icp_mod.sampling_surface_normal(cloud, 10, 1.0, 3)
+        rd = cloud[::2].copy()
+        rd[:, :3] = (rd[:, :3].astype(np.float64) @ T_off[:3, :3].T + T_off[:3, 3] + rng.normal(0, 0.005, (rd.shape[0], 3))).astype(np.float32)
+        T_init = np.linalg.inv(T_off) @ synth.se3(0.03, 0.02, -0.01, yaw=np.deg2rad(0.4))
+        ocfg = oracle.config_yaml(accum_double=1, min_diff_rot=1e-5, min_diff_trans=1e-4)
+        rc, To, sto, tro = oracle.icp_compute(ocfg, rd, rf, rn, synth.colmajor(T_init), 40)
+        with icp_mod.IcpHandle(cfg) as h:
+            h.set_reference(rf, rn)
+            if rc != 0:
+                from laser_slam_amd._lib import ConvergenceError
+                with pytest.raises(ConvergenceError):
+                    h.align(rd, T_init)
+                continue
+            Tg, stg = h.align(rd, T_init)
+            trg = h.trace()
+        assert stg.iterations == sto.iterations and sto.iterations > 4, (name, stg.iterations, sto.iterations)
+        for k, (a, b) in enumerate(zip(trg, tro)):
+            assert np.float32(a["limit"]) == np.float32(b["limit"]), (name, k)
+            assert a["n_used"] == b["n_used"], (name, k)
+            assert np.linalg.norm(a["A"] - b["A"]) / np.linalg.norm(b["A"]) < 1e-9, (name, k)
+        dt, dr = synth.pose_error(synth.from_colmajor(To), Tg.astype(np.float64))
+        assert dt <= TOL_T and dr <= TOL_R, (name, dt, dr)
 
 
 def test_map_maintenance_filters_match_oracle(icp_mod, oracle):
