@@ -30,6 +30,6 @@ for s in $steps; do
     cfg3)    timeout 600 python devtools/config4_shape.py 16384 - gpurun_out/${tag}_config3_1gpu.json 2>&1 | tail -3 ;;
     sq)      rm -rf gpurun_out/sq_${tag}
              (cd /tmp && timeout 600 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS -d $OLDPWD/gpurun_out/sq_${tag} --output-format csv -- python $OLDPWD/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-compute-e2e > /dev/null 2> $OLDPWD/gpurun_out/${tag}_sq.err)
-             python devtools/pmc_summary.py $(find gpurun_out/sq_${tag} -name "*counter_collection.csv" | head -1) k_knn_tile > gpurun_out/${tag}_knn_sq_counters.txt 2>> gpurun_out/${tag}_sq.err; cat gpurun_out/${tag}_knn_sq_counters.txt ;;
+             python devtools/pmc_summary.py $(find gpurun_out/sq_${tag} -name "*counter_collection.csv" | head -1) k_knn_ > gpurun_out/${tag}_knn_sq_counters.txt 2>> gpurun_out/${tag}_sq.err; cat gpurun_out/${tag}_knn_sq_counters.txt ;;
   esac
 done

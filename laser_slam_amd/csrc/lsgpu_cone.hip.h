@@ -32,17 +32,17 @@ namespace lsgpu {
 
 constexpr int kConePad = 16;            // far points behind the direction-sorted arrays (group loads run to a multiple of 4)
 constexpr uint32_t kConeMaxWin = 512;   // longest run (points) a lane takes from one row
-constexpr int kConeRowBatch = 4;        // rows a lane looks up per round of table probes
 
 struct ConeDev {
   float ox, oy, oz;        // O in the reference-mean frame
   float z0, rs;            // row = floor((zeta - z0) * rs), clamped to [0, rows)
   float cs;                // column = floor(p * cs), cs = cols / 4
   int rows, cols;
-  const float* x; const float* y; const float* z;   // direction-sorted SoA copy of the reference (+ kConePad far points)
+  const float4* soa;       // direction-sorted copy of the reference in groups of four points: group g = {x0..x3}{y0..y3}{z0..z3}
+                           // (48 bytes, one cache line for all three loads of an evaluation step); + kConePad far points
   const uint32_t* map;     // direction-sorted position -> index in the Morton-sorted reference (pts)
   const uint32_t* tab;     // rows * cols + 1: first position whose key is >= row * cols + column
-  const float2* rowz;      // per row: {min, max} of zeta over its points; empty row: min > max
+  const float4* rowz;      // per row: {min zeta, max zeta, 1 / (4 min cos(elevation)), -} over its points; empty row: min > max
 };
 
 // direction of v = point - O: zeta = v.z / |v|, pseudo-azimuth pa in [0, 4), inv_rho = 1 / |v|, rxy = |v.xy|,
@@ -95,7 +95,7 @@ __device__ __forceinline__ float float_of_ord(uint32_t o) {
 // range of every row
 __global__ __launch_bounds__(256) void k_cone_gather(const float4* __restrict__ pts, const uint32_t* __restrict__ perm,
                                                      const uint64_t* __restrict__ keys, int64_t n, ConeDev c,
-                                                     float* __restrict__ x, float* __restrict__ y, float* __restrict__ z,
+                                                     float* __restrict__ soa,
                                                      uint32_t* __restrict__ map, uint32_t* __restrict__ tab,
                                                      uint32_t* __restrict__ rowz_bits) {
   const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -110,7 +110,8 @@ __global__ __launch_bounds__(256) void k_cone_gather(const float4* __restrict__ 
   if (valid) {
     const uint32_t i = perm[j];
     const float4 p = pts[i];
-    x[j] = p.x; y[j] = p.y; z[j] = p.z; map[j] = i;
+    float* g = soa + 12 * (j >> 2) + (j & 3);
+    g[0] = p.x; g[4] = p.y; g[8] = p.z; map[j] = i;
     const uint32_t key = (uint32_t)keys[j];
     gap_lo = j > 0 ? (uint32_t)keys[j - 1] + 1u : 0u;
     gap_hi = key + 1u;
@@ -120,7 +121,8 @@ __global__ __launch_bounds__(256) void k_cone_gather(const float4* __restrict__ 
     cone_dir(p.x - c.ox, p.y - c.oy, p.z - c.oz, inv_rho, zeta, pa, rxy, inv_h);
     if (!(fabsf(zeta) <= 1.5f)) zeta = 0.f;
   } else if (j < npad) {
-    x[j] = kPadCoord; y[j] = kPadCoord; z[j] = kPadCoord; map[j] = 0u;
+    float* g = soa + 12 * (j >> 2) + (j & 3);
+    g[0] = kPadCoord; g[4] = kPadCoord; g[8] = kPadCoord; map[j] = 0u;
     if (j == n) { gap_lo = (uint32_t)keys[n - 1] + 1u; gap_hi = nkeys + 1u; pos = (uint32_t)n; }   // everything behind the last key
   }
   // ---- table: short gaps per thread, long ones by the wave
@@ -145,61 +147,78 @@ __global__ __launch_bounds__(256) void k_cone_gather(const float4* __restrict__ 
   }
 }
 
-__global__ __launch_bounds__(256) void k_cone_rowz(const uint32_t* __restrict__ rowz_bits, int rows, float2* __restrict__ rowz) {
+__global__ __launch_bounds__(256) void k_cone_rowz(const uint32_t* __restrict__ rowz_bits, int rows, float4* __restrict__ rowz) {
   const int r = blockIdx.x * 256 + threadIdx.x;
   if (r >= rows) return;
   const uint32_t lo = rowz_bits[2 * r], hi = rowz_bits[2 * r + 1];
-  rowz[r] = lo == 0xFFFFFFFFu ? make_float2(INFINITY, -INFINITY) : make_float2(float_of_ord(lo), float_of_ord(hi));
+  float4 o = make_float4(INFINITY, -INFINITY, INFINITY, 0.f);
+  if (lo != 0xFFFFFFFFu) {
+    o.x = float_of_ord(lo); o.y = float_of_ord(hi);
+    const float zm = fmaxf(fabsf(o.x), fabsf(o.y));
+    const float cep = sqrtf(fmaxf(1.f - zm * zm, 0.f)) * (1.0f - 1e-5f);   // smallest cos(elevation) in the row, rounded down
+    o.z = 1.0f / (4.f * cep) * (1.0f + 1e-6f);                              // (a row that touches the polar axis: inf)
+  }
+  rowz[r] = o;
 }
 
 // ---------------------------------------------------------------- search
-// One window of one lane: groups [g0, g0 + len) of four consecutive direction-sorted points.  All lanes run the wave's
-// longest window; a lane past its own end sits the step out (no load is issued for it).
+// One window of one lane: groups [g0, g0 + len) of four consecutive direction-sorted points.  All lanes run until the
+// wave's longest window is through; a lane past its own end sits the step out (no load is issued for it).
 __device__ __forceinline__ void cone_eval_window(const ConeDev& c, uint32_t g0, uint32_t len, float qx, float qy, float qz,
                                                  float& best, float& sec, uint32_t& bgrp) {
-  const uint32_t trip = wave_max_u32(len);
-  const float4* __restrict__ x4 = reinterpret_cast<const float4*>(c.x);
-  const float4* __restrict__ y4 = reinterpret_cast<const float4*>(c.y);
-  const float4* __restrict__ z4 = reinterpret_cast<const float4*>(c.z);
   const f32x2 q2x = {qx, qx}, q2y = {qy, qy}, q2z = {qz, qz};
-#ifdef LSGPU_CONE_PIPE
-  // the next group's three loads are in flight while this one is evaluated
-  float4 X = make_float4(0.f, 0.f, 0.f, 0.f), Y = X, Z = X;
-  if (len) { X = x4[g0]; Y = y4[g0]; Z = z4[g0]; }
-  for (uint32_t t = 0; t < trip; ++t) {
-    float4 Xn = X, Yn = Y, Zn = Z;
-    if (t + 1u < len) { Xn = x4[g0 + t + 1u]; Yn = y4[g0 + t + 1u]; Zn = z4[g0 + t + 1u]; }
+  // two groups per step: six loads in flight, one memory round trip for eight candidates
+  for (uint32_t t = 0; __ballot(t < len); t += 2u) {
     if (t < len) {
+      const uint32_t g = g0 + t;
+      const bool two = t + 1u < len;
+      const float4* __restrict__ p = c.soa + 3u * (size_t)g;
+      const float4 X = p[0], Y = p[1], Z = p[2];
+      float4 X1 = X, Y1 = Y, Z1 = Z;
+      if (two) { X1 = p[3]; Y1 = p[4]; Z1 = p[5]; }
       const f32x2 d0 = dist2_pair(q2x, q2y, q2z, f32x2{X.x, X.y}, f32x2{Y.x, Y.y}, f32x2{Z.x, Z.y});
       const f32x2 d1 = dist2_pair(q2x, q2y, q2z, f32x2{X.z, X.w}, f32x2{Y.z, Y.w}, f32x2{Z.z, Z.w});
       const float m4 = fminf(fminf(fminf(d0.x, d0.y), d1.x), d1.y);
       sec = __builtin_amdgcn_fmed3f(best, m4, sec);
-      if (m4 < best) { best = m4; bgrp = g0 + t; }
-    }
-    X = Xn; Y = Yn; Z = Zn;
-  }
-#else
-  for (uint32_t t = 0; t < trip; ++t) {
-    if (t < len) {
-      const uint32_t g = g0 + t;
-      const float4 X = x4[g], Y = y4[g], Z = z4[g];
-      const f32x2 d0 = dist2_pair(q2x, q2y, q2z, f32x2{X.x, X.y}, f32x2{Y.x, Y.y}, f32x2{Z.x, Z.y});
-      const f32x2 d1 = dist2_pair(q2x, q2y, q2z, f32x2{X.z, X.w}, f32x2{Y.z, Y.w}, f32x2{Z.z, Z.w});
-      const float m4 = fminf(fminf(fminf(d0.x, d0.y), d1.x), d1.y);
-      sec = __builtin_amdgcn_fmed3f(best, m4, sec);   // second smallest group minimum (best <= sec always)
-      if (m4 < best) { best = m4; bgrp = g; }
+      bgrp = m4 < best ? g : bgrp;
+      best = fminf(best, m4);
+      if (two) {
+        const f32x2 e0 = dist2_pair(q2x, q2y, q2z, f32x2{X1.x, X1.y}, f32x2{Y1.x, Y1.y}, f32x2{Z1.x, Z1.y});
+        const f32x2 e1 = dist2_pair(q2x, q2y, q2z, f32x2{X1.z, X1.w}, f32x2{Y1.z, Y1.w}, f32x2{Z1.z, Z1.w});
+        const float n4 = fminf(fminf(fminf(e0.x, e0.y), e1.x), e1.y);
+        sec = __builtin_amdgcn_fmed3f(best, n4, sec);
+        bgrp = n4 < best ? g + 1u : bgrp;
+        best = fminf(best, n4);
+      }
     }
   }
-#endif
 }
 
-#ifndef LSGPU_CONE_OCC
-#define LSGPU_CONE_OCC 8
+// The kernel.  A workgroup takes WAVES consecutive tiles of 64 queries.  Phase 1, every wave for its own tile: the query,
+// its warm-start distance, the keep / far skips (as k_knn_tile); lanes that do not search are finished here.  The
+// searching lanes of all WAVES tiles are then packed through LDS (in query order) and phase 2 -- cone, rows, windows,
+// evaluation, results -- runs on full waves of searching lanes only: what a wave pays per row and per window it pays
+// for 64 lanes that need it, and the waves left without lanes exit.  (Per-tile waves spent 22-25 us of a 36 us launch
+// on that skeleton, whatever the number of lanes that searched: 80 % of them in iteration 3, 10 % in iteration 31, but
+// 83 % of the TILES still had one.)  Per-lane windows do not care who the neighbours in the wave are.
+#ifndef LSGPU_CONE_WAVES
+#define LSGPU_CONE_WAVES 4
 #endif
-__global__ __launch_bounds__(64, LSGPU_CONE_OCC) void k_knn_cone(KnnArgs a, ConeDev c) {
-  const int lane = threadIdx.x;
-  const uint32_t tile = blockIdx.x;
-  const int j = (int)(tile * 64u) + lane;
+struct ConeRec { float qx, qy, qz, ub, lbn; int id_in, j; uint32_t pad; };   // 32 B: one searching query on its way to phase 2
+
+#ifndef LSGPU_CONE_OCC
+#define LSGPU_CONE_OCC 7   // waves per SIMD the register budget is cut for
+#endif
+template <int WAVES>
+__global__ __launch_bounds__(WAVES * 64, LSGPU_CONE_OCC) void k_knn_cone(KnnArgs a, ConeDev c) {
+  __shared__ ConeRec rec[WAVES * 64];
+  __shared__ uint32_t wcount[WAVES];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  // (tiles go to the XCDs round robin, in dispatch order.  One contiguous eighth of the tiles per XCD -- whose L2 would then
+  // hold just the stretch of the index its tiles read -- was measured slower, 39-55 us per launch against 30-42: the tiles
+  // of near range cost several times those of the far field, and the launch ends with the slowest XCD.)
+  const uint32_t tile = blockIdx.x * (uint32_t)WAVES + (uint32_t)w;
+  int j = (int)(tile * 64u) + lane;
   const bool act = j < a.nq;
   float4 rraw = make_float4(0.f, 0.f, 0.f, 0.f), mp = rraw;
   float lb_in = 0.f;
@@ -208,12 +227,14 @@ __global__ __launch_bounds__(64, LSGPU_CONE_OCC) void k_knn_cone(KnnArgs a, Cone
     mp = a.prev[j];
     lb_in = a.lb[j];
   }
-  const int id_in = __float_as_int(mp.w);
+  int id_in = __float_as_int(mp.w);
   Mat34 T; float cap2;
-  if (!iter_params(a.st, a.T, a.cap2, 1, T, cap2)) return;
+  if (!iter_params(a.st, a.T, a.cap2, 1, T, cap2)) return;   // (the same answer in every wave of the block)
   const float cap2s = cap2 * kCapSearchMargin2;
   const float gap = a.gap;
-  // ---- the query, its warm-start distance, the keep / far skips: as k_knn_tile
+  const bool sel_on = a.sel_below && (a.st->sel_mode || a.sel_force);
+  const uint32_t sel_b1 = sel_on ? a.st->sel_bin1 : 0u;
+  // ---- phase 1
   float qx = 0.f, qy = 0.f, qz = 0.f, ub = 0.f, lbn = 0.f;
   bool skip = false;
   if (act) {
@@ -225,20 +246,50 @@ __global__ __launch_bounds__(64, LSGPU_CONE_OCC) void k_knn_cone(KnnArgs a, Cone
     for (int i = 0; i < 12; ++i) To.m[i] = a.st->T_rows_prev[i];
     const float3 qo = xform(To, rraw.x, rraw.y, rraw.z);
     const float ddx = qx - qo.x, ddy = qy - qo.y, ddz = qz - qo.z;
-    const float delta = sqrtf(ddx * ddx + ddy * ddy + ddz * ddz) * (1.0f + 1e-5f) + 1e-7f;
+    const float delta = __builtin_amdgcn_sqrtf(ddx * ddx + ddy * ddy + ddz * ddz) * (1.0f + 1e-5f) + 1e-7f;   // (hardware square root, 1 ulp: the factor covers it)
     lbn = fmaxf(lb_in * (1.0f - 1e-6f) - delta, 0.f);
     const float lb2 = lbn * lbn;
     const bool keep = ub * (1.0f + 1e-5f) < lb2;
     const bool far = fminf(ub, lb2) > cap2 * (1.0f + 1e-5f);
     skip = keep || far;
+    if (skip) {   // the match stands, only its distance moved
+      a.d2[j] = ub;
+      a.lb[j] = lbn;
+    }
   }
+  if (sel_on) {   // the skipped lanes' share of the trimmed-distance select (first two passes, as k_knn_tile)
+    const uint32_t bits = __float_as_uint(ub), top = bits >> 20;
+    const unsigned long long below = __ballot(act && skip && top < sel_b1);
+    if (act && skip && top == sel_b1) sel_count_inside(a, bits);
+    if (lane == 0 && below) atomicAdd(&a.sel_below[(tile & (kSelBelowSlots - 1)) * kSelBelowStride], (uint32_t)__popcll(below));
+  }
+  // ---- pack the searching lanes of the block
+  const unsigned long long sm = __ballot(act && !skip);
+  if (lane == 0) wcount[w] = (uint32_t)__popcll(sm);
+  __syncthreads();
+  uint32_t before = 0, total = 0;
+#pragma unroll
+  for (int k = 0; k < WAVES; ++k) { const uint32_t n = wcount[k]; before += k < w ? n : 0u; total += n; }
+  if (act && !skip) {
+    ConeRec r;
+    r.qx = qx; r.qy = qy; r.qz = qz; r.ub = ub; r.lbn = lbn; r.id_in = id_in; r.j = j; r.pad = 0u;
+    rec[before + (uint32_t)__popcll(sm & ((1ull << lane) - 1ull))] = r;
+  }
+  __syncthreads();
+  const uint32_t slot = (uint32_t)(w * 64 + lane);
+  if ((uint32_t)(w * 64) >= total) return;
+  const bool ing = slot < total;
+  if (ing) {
+    const ConeRec r = rec[slot];
+    qx = r.qx; qy = r.qy; qz = r.qz; ub = r.ub; lbn = r.lbn; id_in = r.id_in; j = r.j;
+  }
+  // ---- phase 2: the searching lanes
   const float lim0 = prune_lim(ub, gap, cap2s);                 // squared search radius: every point inside is evaluated
-  const float R = sqrtf(lim0) * (1.0f + 1e-5f) + 1e-7f;
-  const bool ing = act && !skip;
+  const float R = __builtin_amdgcn_sqrtf(lim0) * (1.0f + 1e-5f) + 1e-7f;
   bool fb = false;                 // this lane searches the voxel grid instead
   float best = INFINITY, sec = INFINITY;
   uint32_t bgrp = 0xFFFFFFFFu;     // group of four direction-sorted points that holds the evaluated minimum
-  if (__ballot(ing)) {
+  {
     // ---- the lane's cone.  sin(alpha) = R / rho.  A point within R of q is seen from O under an angle <= alpha from q.
     float inv_rho, zeta, pa, rxy, inv_h;
     cone_dir(qx - c.ox, qy - c.oy, qz - c.oz, inv_rho, zeta, pa, rxy, inv_h);
@@ -246,90 +297,62 @@ __global__ __launch_bounds__(64, LSGPU_CONE_OCC) void k_knn_cone(KnnArgs a, Cone
     const float ce = rxy * inv_rho;                             // cos(elevation of q)
     bool cone = ing && s <= 0.5f && ce > 0.f && ce <= 1.5f;     // (NaN-safe: |q - O| == 0 fails)
     const float alpha = s * (1.0f + 0.2f * s * s) + 2e-6f;      // >= asin(s) for s <= 0.5, + rounding of the zetas
+    const float alpha2 = alpha * alpha;
     // zeta of such a point: |sin(e_p) - sin(e_q)| <= |sin e_q| (1 - cos alpha) + cos e_q sin alpha <= |zeta| s^2 + ce s
     const float dz = __fmaf_rn(ce, s, fabsf(zeta) * s * s) + 2e-6f;
     const float gq = (rxy * inv_h) * (rxy * inv_h) * (1.0f + 1e-6f);   // d(pa) / d(azimuth) at q = rho_xy^2 / (|x| + |y|)^2, in [1/2, 1]
+    const float inv_ce = __builtin_amdgcn_rcpf(ce) * (1.0f + 1e-6f);
     const uint32_t r_lo = cone_clampu(floorf((zeta - dz - c.z0) * c.rs), c.rows - 1);
     const uint32_t r_hi = cone_clampu(floorf((zeta + dz - c.z0) * c.rs), c.rows - 1);
     fb = ing && !cone;
-    const uint32_t nrows = cone ? r_hi - r_lo + 1u : 0u;
-    const uint32_t maxrows = wave_max_u32(nrows);
-    for (uint32_t rb = 0; rb < maxrows; rb += (uint32_t)kConeRowBatch) {
-      // ---- per row of the batch: is the row inside the cone's zeta range, and which columns
-      int clo[kConeRowBatch], chi[kConeRowBatch];
-      uint32_t rowk[kConeRowBatch];
-      bool in[kConeRowBatch];
-      float2 rz[kConeRowBatch];
-#pragma unroll
-      for (int i = 0; i < kConeRowBatch; ++i) {
-        rowk[i] = r_lo + rb + (uint32_t)i;
-        in[i] = cone && rowk[i] <= r_hi;
-        rz[i] = make_float2(INFINITY, -INFINITY);
-        if (in[i]) rz[i] = c.rowz[rowk[i]];
-      }
-      bool wraps = false;
-#pragma unroll
-      for (int i = 0; i < kConeRowBatch; ++i) {
-        clo[i] = 0; chi[i] = -1;
-        // distance in zeta between q and the row's points: a LOWER bound of their difference in elevation
-        // (|sin a - sin b| <= |a - b|)
-        const float dzr = fmaxf(fmaxf(fmaxf(rz[i].x - zeta, zeta - rz[i].y), 0.f) - 1e-6f, 0.f);
-        in[i] = in[i] && rz[i].x <= rz[i].y && dzr <= alpha;
-        // azimuth: cos(theta) = cos(de) - cos(e_q) cos(e_p) (1 - cos(da)), theta <= alpha  =>
-        //   sin^2(da / 2) <= (cos(de) - cos(alpha)) / (2 ce ce_p) <= (alpha^2 - de^2) / (4 ce ce_p)
-        const float zm = fmaxf(fabsf(rz[i].x), fabsf(rz[i].y));
-        const float cep = sqrtf(fmaxf(1.f - zm * zm, 0.f)) * (1.0f - 1e-5f);   // smallest cos(elevation) in the row
-        const float u2 = __fmaf_rn(alpha, alpha, -dzr * dzr) / (4.f * ce * cep);
-        const bool polar = in[i] && !(u2 <= 0.25f);            // the cone reaches (or nears) the polar axis at this row
-        const float u = sqrtf(fmaxf(u2, 0.f));
-        const float da = 2.f * u * (1.0f + 0.2f * u * u);       // >= 2 asin(u)
-        // pseudo-azimuth: |pa' - gq| <= 2 sqrt 2 |da| (pa' is Lipschitz), so |d pa| <= gq da + 1.42 da^2
-        const float dp = __fmaf_rn(gq, da, 1.42f * da * da) + 4e-6f;
-        if (in[i] && !polar) {
-          clo[i] = (int)floorf((pa - dp) * c.cs);
-          chi[i] = (int)floorf((pa + dp) * c.cs);
+    // rows of the wave, one after the other (wave-uniform: the row's record is a scalar load, an empty row costs a compare)
+    const uint32_t row_first = (uint32_t)__builtin_amdgcn_readfirstlane((int)wave_max_u32(cone ? ~r_lo : 0u));   // ~min = max~
+    const uint32_t row_last = wave_max_u32(cone ? r_hi + 1u : 0u);
+    for (uint32_t row = ~row_first; row < row_last; ++row) {
+      const float4 rz = c.rowz[row];
+      if (!(rz.x <= rz.y)) continue;                             // empty row (between the rings of a spinning lidar)
+      // distance in zeta between q and the row's points: a LOWER bound of their difference in elevation
+      // (|sin a - sin b| <= |a - b|)
+      const float dzr = fmaxf(fmaxf(fmaxf(rz.x - zeta, zeta - rz.y), 0.f) - 1e-6f, 0.f);
+      bool in = cone && row >= r_lo && row <= r_hi && dzr <= alpha;
+      if (!__ballot(in)) continue;
+      // azimuth: cos(theta) = cos(de) - cos(e_q) cos(e_p) (1 - cos(da)), theta <= alpha  =>
+      //   sin^2(da / 2) <= (cos(de) - cos(alpha)) / (2 ce ce_p) <= (alpha^2 - de^2) / (4 ce ce_p)
+      const float u2 = __fmaf_rn(-dzr, dzr, alpha2) * inv_ce * rz.z;
+      const bool polar = in && !(u2 <= 0.25f);                  // the cone reaches (or nears) the polar axis at this row
+      const float u = __builtin_amdgcn_sqrtf(fmaxf(u2, 0.f)) * (1.0f + 1e-6f);
+      const float da = 2.f * u * (1.0f + 0.2f * u * u);         // >= 2 asin(u)
+      // pseudo-azimuth: its derivative is Lipschitz (2 sqrt 2), so |d pa| <= gq da + 1.42 da^2
+      const float dp = __fmaf_rn(gq, da, 1.42f * da * da) + 4e-6f;
+      const int clo = (int)floorf((pa - dp) * c.cs), chi = (int)floorf((pa + dp) * c.cs);
+      const bool wide = in && !polar && chi - clo >= (c.cols >> 2);
+      if (polar || wide) { fb = true; cone = false; }
+      in = in && cone;
+      const uint32_t base = row * (uint32_t)c.cols;
+      // pass 0: the part of the window inside [0, cols); pass 1: the wrapped part of the windows that have one
+      bool more = in;
+      for (int pass = 0; pass < 2 && __ballot(more); ++pass) {
+        int a0 = max(clo, 0), a1 = min(chi, c.cols - 1);
+        if (pass == 1) {
+          const bool wl = clo < 0;
+          a0 = wl ? clo + c.cols : 0; a1 = wl ? c.cols - 1 : chi - c.cols;
         }
-        const bool wide = in[i] && !polar && chi[i] - clo[i] >= (c.cols >> 2);
-        if (polar || wide) { fb = true; cone = false; }
-        in[i] = in[i] && !polar && !wide;
-        wraps = wraps || (in[i] && (clo[i] < 0 || chi[i] >= c.cols));
-      }
-      // ---- pass 0: the part of every window inside [0, cols); pass 1: the wrapped part of the windows that have one
-      for (int pass = 0; pass < 2; ++pass) {
-        if (pass == 1 && !__ballot(wraps && cone)) break;
-        uint32_t st[kConeRowBatch], en[kConeRowBatch];
-#pragma unroll
-        for (int i = 0; i < kConeRowBatch; ++i) {
-          st[i] = 0u; en[i] = 0u;
-          int a0, a1;
-          bool w;
-          if (pass == 0) {
-            a0 = max(clo[i], 0); a1 = min(chi[i], c.cols - 1); w = in[i] && cone;
-          } else {
-            const bool wl = clo[i] < 0, wh = chi[i] >= c.cols;
-            a0 = wl ? clo[i] + c.cols : 0; a1 = wl ? c.cols - 1 : chi[i] - c.cols; w = in[i] && cone && (wl || wh);
-          }
-          if (w) {
-            const uint32_t base = rowk[i] * (uint32_t)c.cols;
-            st[i] = c.tab[base + (uint32_t)a0];
-            en[i] = c.tab[base + (uint32_t)a1 + 1u];
-          }
+        uint32_t st = 0u, en = 0u;
+        if (more) {
+          st = c.tab[base + (uint32_t)a0];
+          en = c.tab[base + (uint32_t)a1 + 1u];
         }
-#pragma unroll
-        for (int i = 0; i < kConeRowBatch; ++i) {
-          if (en[i] - st[i] > kConeMaxWin) { fb = true; cone = false; }
-        }
-#pragma unroll
-        for (int i = 0; i < kConeRowBatch; ++i) {
-          const bool w = cone && en[i] > st[i];
-          const uint32_t g0 = st[i] >> 2, len = w ? ((en[i] + 3u) >> 2) - g0 : 0u;
-          if (__ballot(len != 0u)) cone_eval_window(c, g0, len, qx, qy, qz, best, sec, bgrp);
-        }
+        if (en - st > kConeMaxWin) { fb = true; cone = false; }
+        const bool w = more && cone && en > st;
+        const uint32_t g0 = st >> 2, len = w ? ((en + 3u) >> 2) - g0 : 0u;
+        cone_eval_window(c, g0, len, qx, qy, qz, best, sec, bgrp);
+        more = in && cone && pass == 0 && (clo < 0 || chi >= c.cols);
       }
     }
   }
   // ---- lanes the index could not serve: the voxel grid (same search as a spread wave's lanes in k_knn_tile)
   int bi = id_in;
+  mp = make_float4(0.f, 0.f, 0.f, __int_as_float(id_in));   // (only the index of the old match matters from here on)
   const unsigned long long fbm = __ballot(fb);
   if (fbm) {
     if (fb) {
@@ -339,18 +362,15 @@ __global__ __launch_bounds__(64, LSGPU_CONE_OCC) void k_knn_cone(KnnArgs a, Cone
     }
     if (lane == 0) atomicAdd(a.strag_count, (uint32_t)__popcll(fbm));   // (counted, not listed: they are done)
   }
-  if (act) {
+  if (ing) {
     float nb;  // new lower bound on the distance to every point other than the (new) match
     if (fb) {
       nb = best <= cap2s ? sqrtf(best) * (1.0f - 1e-6f) : fmaxf(lbn, sqrtf(cap2s) * (1.0f - 1e-5f));
-    } else if (!ing) {
-      best = ub;   // keep / far
-      nb = lbn;
     } else if (bgrp != 0xFFFFFFFFu && best <= ub) {
       // the evaluated minimum (the warm-start point itself unless something beat it): which point of its group, and
       // the runner-up inside the group (the group minima of all other groups are in `sec` already)
-      const float4 X = reinterpret_cast<const float4*>(c.x)[bgrp], Y = reinterpret_cast<const float4*>(c.y)[bgrp];
-      const float4 Z = reinterpret_cast<const float4*>(c.z)[bgrp];
+      const float4* __restrict__ p = c.soa + 3u * (size_t)bgrp;
+      const float4 X = p[0], Y = p[1], Z = p[2];
       const uint4 M = reinterpret_cast<const uint4*>(c.map)[bgrp];
       const float e0 = dist2(qx - X.x, qy - Y.x, qz - Z.x), e1 = dist2(qx - X.y, qy - Y.y, qz - Z.y);
       const float e2 = dist2(qx - X.z, qy - Y.z, qz - Z.z), e3 = dist2(qx - X.w, qy - Y.w, qz - Z.w);
@@ -367,10 +387,10 @@ __global__ __launch_bounds__(64, LSGPU_CONE_OCC) void k_knn_cone(KnnArgs a, Cone
         same = __float_as_int(mp.w) == id_in;
       }
       if (!same) others = fminf(others, ub);  // (covers a warm-start point outside the windows)
-      nb = sqrtf(others) * (1.0f - 1e-5f);
+      nb = __builtin_amdgcn_sqrtf(others) * (1.0f - 1e-5f);
       if (same) nb = fmaxf(nb, lbn);
     } else {  // the warm-start point lies beyond the cap and nothing closer exists: the match stands
-      nb = fmaxf(sqrtf(fminf(best, lim0)) * (1.0f - 1e-5f), lbn);
+      nb = fmaxf(__builtin_amdgcn_sqrtf(fminf(best, lim0)) * (1.0f - 1e-5f), lbn);
       best = ub;
     }
     if (a.write_all || __float_as_int(mp.w) != id_in) {
@@ -380,11 +400,11 @@ __global__ __launch_bounds__(64, LSGPU_CONE_OCC) void k_knn_cone(KnnArgs a, Cone
     a.d2[j] = best;
     a.lb[j] = nb;
   }
-  if (a.sel_below && (a.st->sel_mode || a.sel_force)) {   // first two passes of the trimmed-distance select (as k_knn_tile)
-    const uint32_t bits = __float_as_uint(best), top = bits >> 20, b1 = a.st->sel_bin1;
-    const unsigned long long below = __ballot(act && top < b1);
-    if (act && top == b1) sel_count_inside(a, bits);
-    if (lane == 0 && below) atomicAdd(&a.sel_below[(tile & (kSelBelowSlots - 1)) * kSelBelowStride], (uint32_t)__popcll(below));
+  if (sel_on) {   // the searching lanes' share of the select
+    const uint32_t bits = __float_as_uint(best), top = bits >> 20;
+    const unsigned long long below = __ballot(ing && top < sel_b1);
+    if (ing && top == sel_b1) sel_count_inside(a, bits);
+    if (lane == 0 && below) atomicAdd(&a.sel_below[((tile + 32u) & (kSelBelowSlots - 1)) * kSelBelowStride], (uint32_t)__popcll(below));
   }
 }
 

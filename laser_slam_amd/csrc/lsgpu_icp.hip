@@ -180,9 +180,9 @@ struct lsgpu_icp {
   DevBuf<uint32_t> soa_base, soa_cnt4, soa_first;
   uint32_t nchunks = 0;
   // direction index of the reference (lsgpu_cone.hip.h): the settled launches of an align search it instead of the voxel grid
-  DevBuf<float> cone_x, cone_y, cone_z;
+  DevBuf<float> cone_soa;
   DevBuf<uint32_t> cone_map, cone_tab, cone_rowz_bits;
-  DevBuf<float2> cone_rowz;
+  DevBuf<float4> cone_rowz;
   ConeDev cone;
   bool cone_ok = false;       // built for the current reference
   bool cone_off = false;      // this align stopped using it (too many lanes it could not serve)
@@ -241,7 +241,7 @@ struct lsgpu_icp {
   double* h_pinned = nullptr; // 64 doubles of pinned host staging
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   hipEvent_t ev_state = nullptr;   // lsgpu_icp_align: completion of a loop-state copy (the stream goes on behind it)
-  struct KnnEv { hipEvent_t a, b, c, d, e; };  // before kNN, after the main pass, after the wave-per-query pass, after the select, after the normal equations
+  struct KnnEv { hipEvent_t a, b, c, d, e; bool second; };  // before kNN, after the main pass, after the wave-per-query pass (recorded only if one was launched: `second`), after the select, after the normal equations
   std::vector<KnnEv> knn_events;   // pool, reused across aligns
   size_t knn_events_used = 0;
   std::vector<lsgpu_iter_trace> trace;
@@ -365,7 +365,7 @@ void lsgpu_icp_destroy(lsgpu_icp* h) {
   h->work.release();
 #endif
   h->pts.release();
-  h->cone_x.release(); h->cone_y.release(); h->cone_z.release(); h->cone_map.release(); h->cone_tab.release(); h->cone_rowz_bits.release(); h->cone_rowz.release();
+  h->cone_soa.release(); h->cone_map.release(); h->cone_tab.release(); h->cone_rowz_bits.release(); h->cone_rowz.release();
   h->nrm.release(); h->ref_inv.release(); h->tables.release(); h->flags.release(); h->cidx.release(); h->bounds.release(); h->chunks.release(); h->soa.release(); h->soa_base.release(); h->soa_cnt4.release(); h->soa_first.release(); h->prev.release(); h->state.release(); h->lb.release(); h->cell_cache.release(); h->cell_tags.release(); h->ssn_seg_a.release(); h->ssn_seg_b.release(); h->ssn_seg_of.release(); h->ssn_box_pts.release(); h->ssn_box_base.release(); h->ssn_keep.release(); h->ssn_out_pos.release(); h->ssn_bb.release(); h->ssn_box_normal.release(); h->ssn_draws.release(); h->flt_in.release(); h->flt_in2.release(); h->flt_ref.release(); h->flt_rd.release(); h->flt_nrm.release(); h->chk_hist.release(); h->trace_dev.release(); h->knn_dbg.release(); h->knn_dbg_wave.release(); h->stat_partials.release(); h->geom.release();
   h->counters.release(); h->ang_cells.release(); h->sel_aux.release(); h->sel_win.release(); h->spread_flag.release(); h->spread_list.release(); h->spread_cnt.release(); h->q_in.release(); h->rdq.release(); h->ids.release(); h->d2.release();
   h->ids_io.release(); h->d2_io.release(); h->strag.release(); h->hist.release();
@@ -542,7 +542,8 @@ static KnnArgs knn_args(lsgpu_icp* h, const Mat34& T) {
 //   capped   : search cap from the loop state (exact below cap, see lsgpu_knn.hip.h); otherwise uncapped,
 //              followed by the straggler fallback
 static int run_knn(lsgpu_icp* h, const Mat34& T, const IcpState* st, bool seed, bool capped, bool timed,
-                   bool wide = true, bool predicted = false, uint32_t seed_rank = 0xFFFFFFFFu, bool committed = false) {
+                   bool wide = true, bool predicted = false, uint32_t seed_rank = 0xFFFFFFFFu, bool committed = false,
+                   bool cone_iter = false) {
   const int nq = (int)h->nq;
   KnnArgs a = knn_args(h, T);
   h->dbg_launch_no++;
@@ -596,6 +597,7 @@ static int run_knn(lsgpu_icp* h, const Mat34& T, const IcpState* st, bool seed, 
       h->knn_events.push_back(n);
     }
     ev = &h->knn_events[h->knn_events_used++];
+    ev->second = false;
     HIPC(hipEventRecord(ev->a, h->stream));
   }
 #ifdef LSGPU_EXPERIMENTS
@@ -605,7 +607,7 @@ static int run_knn(lsgpu_icp* h, const Mat34& T, const IcpState* st, bool seed, 
   if (tn.knn_rows >= 1 && capped && !wide && st && !tn.knn_lane) {
     hipLaunchKernelGGL(k_knn_classify, dim3((nq + kClassifyPerBlock - 1) / kClassifyPerBlock), dim3(256), 0, h->stream, a);
     hipLaunchKernelGGL(k_knn_rows<true>, dim3(a.ntiles), dim3(64), 0, h->stream, a);
-    if (timed) { HIPC(hipEventRecord(ev->b, h->stream)); HIPC(hipEventRecord(ev->c, h->stream)); }
+    if (timed) { HIPC(hipEventRecord(ev->b, h->stream)); ev->second = true; HIPC(hipEventRecord(ev->c, h->stream)); }
     HIPC(hipGetLastError());
     return LSGPU_OK;
   }
@@ -614,13 +616,13 @@ static int run_knn(lsgpu_icp* h, const Mat34& T, const IcpState* st, bool seed, 
     hipLaunchKernelGGL(k_knn_rows<false>, dim3(a.ntiles), dim3(64), 0, h->stream, a);
     if (timed) HIPC(hipEventRecord(ev->b, h->stream));
     if (!capped) hipLaunchKernelGGL(k_knn_fallback, dim3(kFallbackBlocks), dim3(256), 0, h->stream, a);
-    if (timed) HIPC(hipEventRecord(ev->c, h->stream));
+    if (timed) { ev->second = true; HIPC(hipEventRecord(ev->c, h->stream)); }
     HIPC(hipGetLastError());
     return LSGPU_OK;
   }
   if (capped && tn.knn_lane) {
     hipLaunchKernelGGL(k_knn_lane, dim3(nblk(nq)), dim3(256), 0, h->stream, a);
-    if (timed) { HIPC(hipEventRecord(ev->b, h->stream)); HIPC(hipEventRecord(ev->c, h->stream)); }
+    if (timed) { HIPC(hipEventRecord(ev->b, h->stream)); ev->second = true; HIPC(hipEventRecord(ev->c, h->stream)); }
     HIPC(hipGetLastError());
     return LSGPU_OK;
   }
@@ -629,11 +631,11 @@ static int run_knn(lsgpu_icp* h, const Mat34& T, const IcpState* st, bool seed, 
     hipLaunchKernelGGL((k_knn_tile<4, false>), dim3((a.ntiles + 3) / 4), dim3(256), 0, h->stream, a);
   else
 #endif
-  if (capped && !wide && st && h->cone_ok && !h->cone_off) {
+  if (capped && cone_iter && st && h->cone_ok && !h->cone_off) {
     // settled launch: every lane searches its own windows of the direction-sorted reference (lsgpu_cone.hip.h)
     a.front_blocks = 0;
-    hipLaunchKernelGGL(k_knn_cone, dim3(a.ntiles), dim3(64), 0, h->stream, a, h->cone);
-    if (timed) { HIPC(hipEventRecord(ev->b, h->stream)); HIPC(hipEventRecord(ev->c, h->stream)); }
+    hipLaunchKernelGGL(k_knn_cone<LSGPU_CONE_WAVES>, dim3((a.ntiles + LSGPU_CONE_WAVES - 1) / LSGPU_CONE_WAVES), dim3(LSGPU_CONE_WAVES * 64), 0, h->stream, a, h->cone);
+    if (timed) HIPC(hipEventRecord(ev->b, h->stream));
     HIPC(hipGetLastError());
     return LSGPU_OK;
   }
@@ -644,14 +646,17 @@ static int run_knn(lsgpu_icp* h, const Mat34& T, const IcpState* st, bool seed, 
   if (timed) HIPC(hipEventRecord(ev->b, h->stream));
   // stragglers (balls > r_cap) only exist in uncapped launches; a settled launch without front rows hands a few
   // thousand queries at most to the row pass (one DPP row per query)
+  bool second = true;
   if (a.front_blocks > 0) {
-    // nothing was handed over
+    second = false;   // nothing was handed over
   } else if (settled && tn.rowq) {
     hipLaunchKernelGGL(k_knn_rowq, dim3(tn.rowq_blocks), dim3(256), 0, h->stream, a);
   } else if (!capped || a.spread_route_r > 0.f) {
     hipLaunchKernelGGL(k_knn_fallback, dim3(settled ? kFallbackBlocksSettled : kFallbackBlocks), dim3(256), 0, h->stream, a);
+  } else {
+    second = false;
   }
-  if (timed) HIPC(hipEventRecord(ev->c, h->stream));
+  if (timed && second) { ev->second = true; HIPC(hipEventRecord(ev->c, h->stream)); }   // (an event pair around nothing still reads ~5 us)
   HIPC(hipGetLastError());
   return LSGPU_OK;
 }
@@ -832,9 +837,9 @@ int lsgpu_icp_set_reference(lsgpu_icp* h, const float* ref_xyz1, const float* re
     c.rs = (float)c.rows / (zr * 1.0002f + 2e-5f);
     c.cs = (float)c.cols * 0.25f;
     const size_t npad = (((size_t)nr + 3) & ~(size_t)3) + kConePad, nkeys = (size_t)c.rows * (size_t)c.cols;
-    HIPC(h->cone_x.reserve(npad)); HIPC(h->cone_y.reserve(npad)); HIPC(h->cone_z.reserve(npad)); HIPC(h->cone_map.reserve(npad));
+    HIPC(h->cone_soa.reserve(3 * npad)); HIPC(h->cone_map.reserve(npad));
     HIPC(h->cone_tab.reserve(nkeys + 1)); HIPC(h->cone_rowz_bits.reserve(2 * (size_t)c.rows)); HIPC(h->cone_rowz.reserve((size_t)c.rows));
-    c.x = h->cone_x.p; c.y = h->cone_y.p; c.z = h->cone_z.p; c.map = h->cone_map.p; c.tab = h->cone_tab.p; c.rowz = h->cone_rowz.p;
+    c.soa = reinterpret_cast<const float4*>(h->cone_soa.p); c.map = h->cone_map.p; c.tab = h->cone_tab.p; c.rowz = h->cone_rowz.p;
     hipLaunchKernelGGL(k_cone_keys, dim3(std::max(nblk(nr), nblk(2 * c.rows))), dim3(256), 0, h->stream, h->pts.p, nr, c,
                        h->sc->keys.p, h->sc->vals.p, h->cone_rowz_bits.p);
     int nbits = 1;
@@ -842,7 +847,7 @@ int lsgpu_icp_set_reference(lsgpu_icp* h, const float* ref_xyz1, const float* re
     rc = sort_pairs(h, nr, nbits);
     if (rc) return rc;
     hipLaunchKernelGGL(k_cone_gather, dim3(nblk((int64_t)npad)), dim3(256), 0, h->stream, h->pts.p, h->sc->vals_alt.p,
-                       h->sc->keys_alt.p, nr, c, h->cone_x.p, h->cone_y.p, h->cone_z.p, h->cone_map.p, h->cone_tab.p,
+                       h->sc->keys_alt.p, nr, c, h->cone_soa.p, h->cone_map.p, h->cone_tab.p,
                        h->cone_rowz_bits.p);
     hipLaunchKernelGGL(k_cone_rowz, dim3(nblk(c.rows)), dim3(256), 0, h->stream, h->cone_rowz_bits.p, c.rows, h->cone_rowz.p);
     HIPC(hipGetLastError());
@@ -1872,6 +1877,8 @@ int lsgpu_icp_align(lsgpu_icp* h, const float* reading_xyz1, int64_t nq, const f
   const bool comm_commit = tuning().comm_commit;
   bool commit_ok = false;
   int committed_iterations = 0;
+  int enq = 0;   // iterations enqueued so far = the ordinal of the one being enqueued
+  const int cone_from = tuning().cone_from;   // the direction index serves the launches from this iteration on
   auto enqueue_iteration = [&](bool seed, bool capped, bool wide, bool knn = true) -> int {
     // capped launches without a wave-per-query pass may fold the first half of the select into the kNN kernel
     // (the device decides per iteration, IcpState::sel_mode); not in the RCCL mode (the counts are per shard).
@@ -1885,7 +1892,8 @@ int lsgpu_icp_align(lsgpu_icp* h, const float* reading_xyz1, int64_t nq, const f
     const bool committed = predicted && can_commit;
     int r = LSGPU_OK;
     if (knn) {
-      r = run_knn(h, Tdummy, h->state.p, seed, capped, timed, wide, predicted, seed && capped ? k : 0xFFFFFFFFu, committed);  // 6a+6b
+      r = run_knn(h, Tdummy, h->state.p, seed, capped, timed, wide, predicted, seed && capped ? k : 0xFFFFFFFFu, committed,
+                  !seed && capped && enq >= cone_from);  // 6a+6b
       if (r) return r;
       ev_of_launch.push_back(h->knn_events_used ? h->knn_events_used - 1 : 0);
     }
@@ -1929,7 +1937,6 @@ int lsgpu_icp_align(lsgpu_icp* h, const float* reading_xyz1, int64_t nq, const f
   // at once if the state it finds says `done`.
   const bool lookahead = tuning().lookahead && !h->comm;
   if (lookahead && !h->ev_state) HIPC(hipEventCreateWithFlags(&h->ev_state, hipEventDisableTiming));
-  int enq = 0;
   const int wide_iters = tuning().wide_iters;   // the first launches still have wide balls: their spread waves go to the wave-per-query pass
   const int enq_limit = 8 * max_it + 64;        // (only guards against a device that never finishes, see below)
   auto fetch_state = [&](int* enqueued_ahead) -> int {
@@ -1975,7 +1982,7 @@ int lsgpu_icp_align(lsgpu_icp* h, const float* reading_xyz1, int64_t nq, const f
     // k_knn_cone counts the lanes its index could not serve (they search the voxel grid one by one) as stragglers: on
     // the clouds it is made for they are a handful; where they are not (> 2 % of the queries per settled iteration)
     // the rest of this align goes back to k_knn_tile
-    if (h->cone_ok && !h->cone_off && look_iter >= wide_iters && hst->iter > look_iter &&
+    if (h->cone_ok && !h->cone_off && look_iter >= std::max(cone_from, wide_iters) && hst->iter > look_iter &&
         (double)(hst->stragglers - look_strag) > 0.02 * (double)nq * (double)(hst->iter - look_iter))
       h->cone_off = true;
     look_iter = hst->iter; look_strag = hst->stragglers;
@@ -2039,7 +2046,7 @@ int lsgpu_icp_align(lsgpu_icp* h, const float* reading_xyz1, int64_t nq, const f
     for (size_t i = 0; i < h->knn_events_used && i < ev_of_launch.size(); ++i) {
       const auto& e = h->knn_events[ev_of_launch[i]];
       float m1 = 0.f, m2 = 0.f;
-      if (hipEventElapsedTime(&m1, e.a, e.b) != hipSuccess || hipEventElapsedTime(&m2, e.b, e.c) != hipSuccess) {
+      if (hipEventElapsedTime(&m1, e.a, e.b) != hipSuccess || (e.second && hipEventElapsedTime(&m2, e.b, e.c) != hipSuccess)) {
         (void)hipGetLastError();
         continue;
       }
@@ -2047,7 +2054,7 @@ int lsgpu_icp_align(lsgpu_icp* h, const float* reading_xyz1, int64_t nq, const f
       if (m1 < 0.02f) continue;  // exited immediately (enqueued behind an iteration that had to be repeated)
       st.t_knn_main_ms += m1; st.t_knn_fallback_ms += m2; st.t_knn_ms += m1 + m2; st.knn_launches++;
       float m3 = 0.f, m4 = 0.f;
-      if (hipEventElapsedTime(&m3, e.c, e.d) == hipSuccess && hipEventElapsedTime(&m4, e.d, e.e) == hipSuccess) { st.t_select_ms += m3; st.t_ne_ms += m4; }
+      if (hipEventElapsedTime(&m3, e.second ? e.c : e.b, e.d) == hipSuccess && hipEventElapsedTime(&m4, e.d, e.e) == hipSuccess) { st.t_select_ms += m3; st.t_ne_ms += m4; }
       else (void)hipGetLastError();
       if (t < h->trace.size()) { h->trace[t].knn_main_us = m1 * 1e3f; h->trace[t].knn_fallback_us = m2 * 1e3f; ++t; }
     }
