@@ -600,6 +600,14 @@ static int run_knn(lsgpu_icp* h, const Mat34& T, const IcpState* st, bool seed, 
     ev->second = false;
     HIPC(hipEventRecord(ev->a, h->stream));
   }
+  if (capped && cone_iter && st && h->cone_ok && !h->cone_off) {
+    // settled launch: every lane searches its own windows of the direction-sorted reference (lsgpu_cone.hip.h)
+    a.front_blocks = 0;
+    hipLaunchKernelGGL(k_knn_cone<LSGPU_CONE_WAVES>, dim3((a.ntiles + LSGPU_CONE_WAVES - 1) / LSGPU_CONE_WAVES), dim3(LSGPU_CONE_WAVES * 64), 0, h->stream, a, h->cone);
+    if (timed) HIPC(hipEventRecord(ev->b, h->stream));
+    HIPC(hipGetLastError());
+    return LSGPU_OK;
+  }
 #ifdef LSGPU_EXPERIMENTS
   // measured-slower variants (DESIGN.md "Rejected after measurement"), compiled only into the experiments build:
   //   knn_rows 1: settled launches classify first and search row-wise on the compacted list; 2: k_knn_rows also stands
@@ -631,14 +639,6 @@ static int run_knn(lsgpu_icp* h, const Mat34& T, const IcpState* st, bool seed, 
     hipLaunchKernelGGL((k_knn_tile<4, false>), dim3((a.ntiles + 3) / 4), dim3(256), 0, h->stream, a);
   else
 #endif
-  if (capped && cone_iter && st && h->cone_ok && !h->cone_off) {
-    // settled launch: every lane searches its own windows of the direction-sorted reference (lsgpu_cone.hip.h)
-    a.front_blocks = 0;
-    hipLaunchKernelGGL(k_knn_cone<LSGPU_CONE_WAVES>, dim3((a.ntiles + LSGPU_CONE_WAVES - 1) / LSGPU_CONE_WAVES), dim3(LSGPU_CONE_WAVES * 64), 0, h->stream, a, h->cone);
-    if (timed) HIPC(hipEventRecord(ev->b, h->stream));
-    HIPC(hipGetLastError());
-    return LSGPU_OK;
-  }
   if (wide && tn.lazy_need)   // balls still as wide as the last ICP step: the instantiation that re-tests chunks before fetching them
     hipLaunchKernelGGL((k_knn_tile<1, true>), dim3(a.ntiles + a.front_blocks), dim3(64), 0, h->stream, a);
   else
