@@ -250,7 +250,7 @@ def main():
         tl = time.perf_counter()
         for _ in range(loop_steps):
             ts = time.perf_counter()
-            Tl, stl = step_loop()          # (align returns with its stream drained: per-step times are whole steps)
+            Tl, stl = step_loop()          # (align returns once the loop state says done: at most one queued launch that exits at once is behind it)
             per_step.append(time.perf_counter() - ts)
             align_ms += stl.t_total_ms
             loop_iters += stl.iterations

@@ -107,7 +107,10 @@ void lsgpu_icp_destroy(lsgpu_icp* h);
  * grid.  `normals` = the descriptor SamplingSurfaceNormalDataPointsFilter attached (yaml:5-7). */
 int lsgpu_icp_set_reference(lsgpu_icp* h, const float* ref_xyz1, const float* ref_normals, int64_t nr);
 
-/* Steps 5-7 of ICP::compute on the (already filtered) reading.  T_out = T_init on failure. */
+/* Steps 5-7 of ICP::compute on the (already filtered) reading.  T_out = T_init on failure.  A T_init that is not rigid
+ * (lsgpu_check_rigid: |1 - det R| > 1e-3) is LSGPU_BAD_ARG -- step 5 is a RigidTransformation::compute, which throws
+ * PointMatcher's TransformationError for it; neither call site of the reference corrects its guess
+ * (laser_track.cpp:489-496, incremental_estimator.cpp:92-108). */
 int lsgpu_icp_align(lsgpu_icp* h, const float* reading_xyz1, int64_t nq, const float T_init[16],
                     float T_out[16], lsgpu_icp_stats* stats);
 

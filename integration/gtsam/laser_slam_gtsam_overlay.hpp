@@ -370,8 +370,7 @@ class IncrementalEstimator {
       laser_slam_amd::DataPoints sub_map_a, sub_map_b;
       track_a.mirrorTrack().buildSubMapAroundTime(loop_closure.time_a_ns, params_.loop_closures_sub_maps_radius, &sub_map_a);
       track_b.mirrorTrack().buildSubMapAroundTime(loop_closure.time_b_ns, params_.loop_closures_sub_maps_radius, &sub_map_b);
-      laser_slam_amd::correctTransformationMatrix(&initial_guess);
-      // a ConvergenceError propagates, as in the reference (no try block around :108)
+      // (the guess goes in uncorrected and exceptions of icp_.compute propagate, as at incremental_estimator.cpp:89-108)
       const laser_slam_amd::TransformationParameters icp_solution = icp_.compute(sub_map_b, sub_map_a, initial_guess);
       updated_loop_closure.T_a_b = overlay_detail::fromMirror(laser_slam_amd::SE3::fromTransformationMatrix(icp_solution.data()));
     }

@@ -54,6 +54,11 @@ inline TransformationParameters identityTransformation() {
 struct ConvergenceError : std::runtime_error {
   explicit ConvergenceError(const std::string& w) : std::runtime_error(w) {}
 };
+// PointMatcher::TransformationError: RigidTransformation::compute on a matrix that fails checkParameters -- also what
+// ICP::compute throws for a non-rigid initial guess (its step 5 moves the reading with RigidTransformation)
+struct TransformationError : std::runtime_error {
+  explicit TransformationError(const std::string& w) : std::runtime_error(w) {}
+};
 struct ConfigError : std::runtime_error {
   explicit ConfigError(const std::string& w) : std::runtime_error(w) {}
 };
@@ -73,7 +78,7 @@ class RigidTransformation {
   // features' = T * features; the "normals" descriptor is rotated.  Host arithmetic identical to the
   // device kernel (fma chain), so clouds built on either side agree bit for bit.
   static DataPoints compute(const DataPoints& in, const TransformationParameters& T) {
-    if (!checkParameters(T)) throw std::runtime_error("RigidTransformation: matrix is not rigid");
+    if (!checkParameters(T)) throw TransformationError("RigidTransformation: matrix is not rigid");
     DataPoints out;
     const int64_t n = in.getNbPoints();
     out.features.resize((size_t)n * 4);
@@ -303,9 +308,17 @@ class ICP {
     release();
   }
 
+  static void requireRigid(const TransformationParameters& T_init) {
+    if (!RigidTransformation::checkParameters(T_init)) throw TransformationError("ICP::compute: the initial guess is not a rigid transformation");
+  }
+
   // T with p_reference = T * p_reading.  Throws ConvergenceError exactly where PointMatcher would.
   TransformationParameters compute(const DataPoints& reading, const DataPoints& reference,
                                    const TransformationParameters& T_init) {
+    // step 5 of ICP::compute moves the reading by T_refMean_dataIn with RigidTransformation::compute, which refuses a
+    // matrix that is not rigid; neither call site corrects its guess (laser_track.cpp:489-496, incremental_estimator.cpp:
+    // 92-108: only the sub-map transforms go through correctTransformationMatrix) and neither catches this exception
+    requireRigid(T_init);
 #ifdef LSGPU_TEST_SEAMS
     if (override_) return override_(*this, reading, reference, T_init);
 #endif
@@ -345,6 +358,7 @@ class ICP {
   TransformationParameters computeClouds(int reading, const std::vector<int>& refs,
                                          const std::vector<TransformationParameters>& ref_T,
                                          const TransformationParameters& T_init) {
+    requireRigid(T_init);
     ensureHandle();
     if (refs.size() != ref_T.size()) throw std::logic_error("one transform per reference cloud");
     lsgpu_chain_config chain;

@@ -113,8 +113,9 @@ class IncrementalEstimator {
       DataPoints sub_map_a, sub_map_b;
       track_a.buildSubMapAroundTime(loop_closure.time_a_ns, params_.loop_closures_sub_maps_radius, &sub_map_a);
       track_b.buildSubMapAroundTime(loop_closure.time_b_ns, params_.loop_closures_sub_maps_radius, &sub_map_b);
-      correctTransformationMatrix(&initial_guess);
-      // ConvergenceError propagates, as in the reference (no try block around :108)
+      // (the guess goes in as it is: unlike laser_track.cpp:489-491 this call site does not correct it, and an exception of
+      // icp_.compute -- ConvergenceError, or TransformationError for a guess that is not rigid -- propagates: no try block
+      // around incremental_estimator.cpp:108)
       const TransformationParameters icp_solution = icp_.compute(sub_map_b, sub_map_a, initial_guess);
       updated.T_a_b = SE3::fromTransformationMatrix(icp_solution.data());
       last_loop_closure_icp_stats_ = icp_.lastStats();

@@ -20,8 +20,7 @@
 
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>  // types only: the library is opened lazily (dlopen) by lsgpu_icp_comm_init
-#include <rocprim/device/device_radix_sort.hpp>
-#include <rocprim/device/device_scan.hpp>
+#include <rocprim/device/device_radix_sort.hpp>   // only behind LSGPU_ROCPRIM_SORT: the library sort as a cross-check of lsgpu_sort.hip.h
 
 #include "../../include/lsgpu_icp.h"
 #include "lsgpu_grid.hip.h"
@@ -35,6 +34,7 @@
 #include "lsgpu_host_math.h"
 #include "lsgpu_ssn.hip.h"
 #include "lsgpu_sort.hip.h"
+#include "lsgpu_scan.hip.h"
 #include "lsgpu_rand.h"
 
 using namespace lsgpu;
@@ -241,6 +241,11 @@ struct lsgpu_icp {
   double* h_pinned = nullptr; // 64 doubles of pinned host staging
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   hipEvent_t ev_state = nullptr;   // lsgpu_icp_align: completion of a loop-state copy (the stream goes on behind it)
+  // lsgpu_icp_align may return with ONE more iteration queued on `stream` behind its last look at the loop state (it
+  // exits at once: the state says `done`).  Work the next call starts on the handle's OTHER streams is ordered behind
+  // it through this event, so that nothing ever depends on what that launch does not touch.
+  hipEvent_t ev_tail = nullptr;
+  bool tail_pending = false;
   struct KnnEv { hipEvent_t a, b, c, d, e; bool second; };  // before kNN, after the main pass, after the wave-per-query pass (recorded only if one was launched: `second`), after the select, after the normal equations
   std::vector<KnnEv> knn_events;   // pool, reused across aligns
   size_t knn_events_used = 0;
@@ -268,6 +273,10 @@ static int wait_stream(lsgpu_icp* h) {
     }
     if (spin > 200) std::this_thread::sleep_for(std::chrono::microseconds(20));
   }
+}
+
+static void order_after_tail(lsgpu_icp* h, hipStream_t s) {
+  if (h->tail_pending && s && h->ev_tail && hipStreamWaitEvent(s, h->ev_tail, 0) != hipSuccess) (void)hipGetLastError();
 }
 
 static constexpr int kNeBlocksMax = 2048;
@@ -374,6 +383,7 @@ void lsgpu_icp_destroy(lsgpu_icp* h) {
   if (h->ev0) (void)hipEventDestroy(h->ev0);
   if (h->ev1) (void)hipEventDestroy(h->ev1);
   if (h->ev_state) (void)hipEventDestroy(h->ev_state);
+  if (h->ev_tail) (void)hipEventDestroy(h->ev_tail);
   if (h->h_pinned) (void)hipHostFree(h->h_pinned);
   if (h->draws_pinned) (void)hipHostFree(h->draws_pinned);
   if (h->copy_done) (void)hipEventDestroy(h->copy_done);
@@ -390,7 +400,7 @@ void lsgpu_icp_destroy(lsgpu_icp* h) {
 
 // ---------------------------------------------------------------- internals
 
-static int scan_u32(lsgpu_icp* h, const uint32_t* in, uint32_t* out, size_t n);
+static int scan_u32(lsgpu_icp* h, const uint32_t* in, uint32_t* out, size_t n, bool inclusive = false);
 
 template <int ITEMS>
 static void radix_pass(lsgpu_icp* h, const uint64_t* kin, const uint32_t* vin, uint64_t* kout, uint32_t* vout, int64_t n,
@@ -410,16 +420,16 @@ static int sort_pairs(lsgpu_icp* h, int64_t n, int nbits) {
   HIPC(h->sc->keys_alt.reserve(n));
   HIPC(h->sc->vals_alt.reserve(n));
   const bool lib_sort = tuning().rocprim_sort;
-  if (!lib_sort && n >= 8192 && nbits > 0) {   // own radix sort (lsgpu_sort.hip.h); tiny inputs stay with the library
+  if (!lib_sort) {   // own radix sort (lsgpu_sort.hip.h)
     const int items_env = tuning().sort_items;
     const int items = items_env ? items_env : n >= (1 << 21) ? 16 : n >= (1 << 19) ? 8 : 4;
     const int nblocks = (int)((n + 256 * items - 1) / (256 * items));
     HIPC(h->sc->sort_hist.reserve((size_t)256 * nblocks + 256));
-    const int passes = (nbits + 7) / 8;
+    const int passes = std::max(1, (nbits + 7) / 8);   // (no key bits: one pass over an all-zero digit = a stable copy)
     uint64_t *kin = h->sc->keys.p, *kout = h->sc->keys_alt.p;
     uint32_t *vin = h->sc->vals.p, *vout = h->sc->vals_alt.p;
     for (int p = 0; p < passes; ++p) {
-      const int shift = 8 * p, width = std::min(8, nbits - shift);
+      const int shift = 8 * p, width = std::max(0, std::min(8, nbits - shift));
       const uint32_t mask = (1u << width) - 1u;
       if (items == 16) radix_pass<16>(h, kin, vin, kout, vout, n, shift, mask, nblocks);
       else if (items == 8) radix_pass<8>(h, kin, vin, kout, vout, n, shift, mask, nblocks);
@@ -750,15 +760,8 @@ int lsgpu_icp_set_reference(lsgpu_icp* h, const float* ref_xyz1, const float* re
   HIPC(h->flags.reserve(nr)); HIPC(h->cidx.reserve(nr));
   hipLaunchKernelGGL(k_chunk_flags, dim3(nblk(nr)), dim3(256), 0, h->stream, h->sc->keys_alt.p, nr, h->geom.p,
                      h->flags.p);
-  {
-    size_t bytes = 0;
-    HIPC(rocprim::inclusive_scan(nullptr, bytes, h->flags.p, h->cidx.p, (size_t)nr,
-                                 rocprim::plus<uint32_t>(), h->stream));
-    HIPC(h->sc->sort_tmp.reserve(bytes));
-    bytes = h->sc->sort_tmp.cap;
-    HIPC(rocprim::inclusive_scan((void*)h->sc->sort_tmp.p, bytes, h->flags.p, h->cidx.p, (size_t)nr,
-                                 rocprim::plus<uint32_t>(), h->stream));
-  }
+  rc = scan_u32(h, h->flags.p, h->cidx.p, (size_t)nr, /*inclusive*/ true);
+  if (rc) return rc;
   // ---- cell counts per level (+ chunk count, + the geometry) -> host, to size the tables
   HIPC(h->counters.reserve(64));
   HIPC(hipMemsetAsync(h->counters.p, 0, 64 * sizeof(uint32_t), h->stream));
@@ -1037,13 +1040,20 @@ int lsgpu_rotate_descriptors(lsgpu_icp* h, const float T[16], const float* desc3
 
 }  // extern "C"
 
-// exclusive prefix sum of n uint32 on the handle's stream
-static int scan_u32(lsgpu_icp* h, const uint32_t* in, uint32_t* out, size_t n) {
-  size_t bytes = 0;
-  HIPC(rocprim::exclusive_scan(nullptr, bytes, in, out, 0u, n, rocprim::plus<uint32_t>(), h->cur));
-  HIPC(h->sc->sort_tmp.reserve(bytes));
-  bytes = h->sc->sort_tmp.cap;
-  HIPC(rocprim::exclusive_scan((void*)h->sc->sort_tmp.p, bytes, in, out, 0u, n, rocprim::plus<uint32_t>(), h->cur));
+// prefix sum of n uint32 on the handle's current stream (lsgpu_scan.hip.h; in == out is fine)
+static int scan_u32(lsgpu_icp* h, const uint32_t* in, uint32_t* out, size_t n, bool inclusive) {
+  if (n == 0) return LSGPU_OK;
+  const int nb = (int)((n + kScanTile - 1) / kScanTile);
+  uint32_t* sums = nullptr;
+  if (nb > 1) {
+    HIPC(h->sc->sort_tmp.reserve((size_t)nb * sizeof(uint32_t)));
+    sums = reinterpret_cast<uint32_t*>(h->sc->sort_tmp.p);
+    hipLaunchKernelGGL(k_scan_sums, dim3(nb), dim3(256), 0, h->cur, in, n, sums);
+    hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(1024), 0, h->cur, sums, nb);
+  }
+  if (inclusive) hipLaunchKernelGGL(k_scan_write<true>, dim3(nb), dim3(256), 0, h->cur, in, out, n, (const uint32_t*)sums);
+  else hipLaunchKernelGGL(k_scan_write<false>, dim3(nb), dim3(256), 0, h->cur, in, out, n, (const uint32_t*)sums);
+  HIPC(hipGetLastError());
   return LSGPU_OK;
 }
 
@@ -1075,7 +1085,7 @@ static int upload_draws_begin(lsgpu_icp* h, int64_t seed, size_t kmax) {
 struct DrawAhead {
   lsgpu_icp* h = nullptr;
   size_t kmax = 0, used = 0;
-  bool open = false, waited = false;
+  bool open = false, waited = false, unlocked_early = false;
   hipError_t upload_err = hipSuccess;
   std::thread worker;
   DrawAhead() = default;
@@ -1092,6 +1102,7 @@ struct DrawAhead {
     HIPC(h->ssn_draws.reserve(kmax + 1));
     if (!h->draw_stream) HIPC(hipStreamCreateWithFlags(&h->draw_stream, hipStreamNonBlocking));
     if (!h->draws_done) HIPC(hipEventCreateWithFlags(&h->draws_done, hipEventDisableTiming));
+    order_after_tail(h, h->draw_stream);
     DrawStream::global().lock(seed);
     open = true;
     if (kmax) {
@@ -1122,11 +1133,21 @@ struct DrawAhead {
     }
     return LSGPU_OK;
   }
+  // The number of draws the filters will have consumed is known: consume them and unlock NOW -- the values are
+  // already on their way to the device, the filters that still have to run only read them there.  (The process-wide
+  // stream used to stay locked from the first filter to the end of the last, i.e. across the whole grid build and its
+  // host round trip: compute calls on other handles -- other robots' tracks, a loop-closure ICP -- took turns there.)
+  void commit_now(size_t total) {
+    if (worker.joinable()) worker.join();
+    if (open) DrawStream::global().commit(std::min(total, kmax));
+    if (open) unlocked_early = true;
+    open = false;
+  }
   void finish() {   // consume + unlock now (the stream must not stay locked while the ICP loop runs)
     if (worker.joinable()) worker.join();
     if (open) DrawStream::global().commit(std::min(used, kmax));
-    if (open && kmax && !waited && h->draw_stream) (void)hipStreamSynchronize(h->draw_stream);   // (nobody waited for the upload: the staging buffer must be free on return)
-    open = false;
+    if ((open || unlocked_early) && kmax && !waited && h->draw_stream) (void)hipStreamSynchronize(h->draw_stream);   // (nobody waited for the upload: the staging buffer must be free on return)
+    open = false; unlocked_early = false;
   }
   ~DrawAhead() { finish(); }
 };
@@ -1346,6 +1367,7 @@ int lsgpu_icp_compute(lsgpu_icp* h, const float* reading_xyz1, int64_t nq, const
     if (!h->copy_stream) HIPC(hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking));
     if (!h->copy_done) HIPC(hipEventCreateWithFlags(&h->copy_done, hipEventDisableTiming));
     HIPC(h->flt_in2.reserve(nq));
+    order_after_tail(h, h->copy_stream);
     auto upload = [&] {
       hipError_t e = hipSetDevice(h->device);
       if (e == hipSuccess) e = hipMemcpyAsync(h->flt_in2.p, reading_xyz1, (size_t)nq * 16, hipMemcpyHostToDevice, h->copy_stream);
@@ -1358,7 +1380,16 @@ int lsgpu_icp_compute(lsgpu_icp* h, const float* reading_xyz1, int64_t nq, const
       upload();
     }
   }
-  struct Joiner { std::thread& t; ~Joiner() { if (t.joinable()) t.join(); } } joiner{uploader};   // every return path joins
+  // every return path joins the uploader and drains its stream: a pinned host reading is read by DMA, and the caller
+  // may free or reuse it as soon as this call has returned, error or not (after a completed alignment the copy is long
+  // over and the wait returns at once)
+  struct Joiner {
+    std::thread& t; lsgpu_icp* h; bool started;
+    ~Joiner() {
+      if (t.joinable()) t.join();
+      if (started && h->copy_stream) (void)hipStreamSynchronize(h->copy_stream);
+    }
+  } joiner{uploader, h, overlap_upload};
   // the draws of both filters, produced on a helper thread from now on: at most one per reference point, then one per
   // reading point
   DrawAhead draws;
@@ -1376,6 +1407,8 @@ int lsgpu_icp_compute(lsgpu_icp* h, const float* reading_xyz1, int64_t nq, const
   rc = ssn_device(h, src, nr, chain->ssn_knn, chain->ssn_ratio, -1, h->flt_ref.p, h->flt_nrm.p, &nrf, &draws);
   if (rc) return rc;
   if (nrf <= 0) { h->err = "compute: the reference filter left no point"; h->nr = 0; return LSGPU_NO_CONVERGENCE; }
+  // the reading filter draws once per reading point, whatever it keeps: the total is known, the stream can go
+  draws.commit_now(draws.used + (chain->reading_prob < 0.f ? (size_t)0 : (size_t)nq));
   // steps 2-4.  The grid build (steps 2-3, h->stream) and the reading's side -- its filter (step 4) and the ordering of
   // the queries (the first part of step 5) -- do not depend on each other: the latter is enqueued on a second stream,
   // with its own sort scratch, from inside set_reference (right before its one host round trip), and the queries are
@@ -1422,6 +1455,7 @@ int lsgpu_icp_compute(lsgpu_icp* h, const float* reading_xyz1, int64_t nq, const
   if (side) {
     if (!h->side_stream) HIPC(hipStreamCreateWithFlags(&h->side_stream, hipStreamNonBlocking));
     if (!h->side_done) HIPC(hipEventCreateWithFlags(&h->side_done, hipEventDisableTiming));
+    order_after_tail(h, h->side_stream);
     h->hook_before_ref_sync = [&]() -> int {
       side_guard.enter();
       int r = reading_ready(h->side_stream);
@@ -1787,11 +1821,17 @@ int lsgpu_icp_align(lsgpu_icp* h, const float* reading_xyz1, int64_t nq, const f
     local_rc = LSGPU_NO_CONVERGENCE;
   } else if (nq > 0x7FFFFFF0ll) {
     local_rc = LSGPU_BAD_ARG;
+  } else if (!lsgpu_check_rigid(T_init)) {
+    // step 5 moves the reading with RigidTransformation::compute, which throws TransformationError for such a matrix
+    // (after both filters have run, as here when the call came through lsgpu_icp_compute)
+    h->err = "align: the initial guess is not a rigid transformation (|1 - det R| > 1e-3)";
+    local_rc = LSGPU_BAD_ARG;
   }
   if (local_rc && !h->comm) return local_rc;
   HIPC(hipSetDevice(h->device));
   const double t0 = wall_ms();
   h->knn_events_used = 0;
+  h->tail_pending = false;   // (from here on everything is behind it on h->stream itself)
 
   // step 5: T_refMean_dataIn = T_refIn_refMean^-1 * T_init (pure translation inverse)
   float T_rm_in[16];
@@ -2011,7 +2051,14 @@ int lsgpu_icp_align(lsgpu_icp* h, const float* reading_xyz1, int64_t nq, const f
       since_check = 1;
       continue;
     }
-    if (hst->done) break;
+    if (hst->done) {
+      if (ahead) {   // one launch is still queued behind the look that saw `done`
+        if (!h->ev_tail) HIPC(hipEventCreateWithFlags(&h->ev_tail, hipEventDisableTiming));
+        HIPC(hipEventRecord(h->ev_tail, h->stream));
+        h->tail_pending = true;
+      }
+      break;
+    }
     if (enq >= enq_limit) {
       h->err = "align: the device loop did not finish";
       return LSGPU_HIP_ERROR;

@@ -7,8 +7,8 @@
 // r >> 1, seeded by the Lehmer recurrence 16807 and 310 discarded outputs), so that
 //   * a seeded filter call selects exactly the points the sequential CPU chain selects,
 //   * no global libc state is touched (handles on different threads do not race on rand()),
-//   * the draws of a whole cloud can be produced while the device works: ~1.3 ns each on one core, and for clouds of
-//     several hundred thousand points on up to 8 threads -- the recurrence is linear over Z/2^32, so the state
+//   * the draws of a whole cloud can be produced while the device works: ~1.3 ns each on one core, and for requests of
+//     16 segments (about a million draws) or more on up to 8 threads -- the recurrence is linear over Z/2^32, so the state
 //     65536 draws ahead is one 31 x 31 matrix product away (jump-ahead), and the segments are filled independently
 //     (3.1 M draws of a three-scan sub-map: 4.2 ms -> 0.7 ms; it used to be the longest item of a LaserTrack scan).
 // seed >= 0 reseeds the stream; seed < 0 continues it (like calling rand() again).  An unseeded

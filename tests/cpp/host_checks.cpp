@@ -419,6 +419,24 @@ int main(int argc, char** argv) {
     if (b.getIcpTransformations().size() == 2)
       CHECK(b.getIcpTransformations()[1].time_a_ns == 200 && b.getIcpTransformations()[1].time_b_ns == 300);
   }
+  // --- a guess that is not rigid: TransformationError out of ICP::compute (its step 5 is a RigidTransformation::compute),
+  // before anything touches the device; the loop-closure call site hands its guess over uncorrected and lets the
+  // exception through (incremental_estimator.cpp:92-108)
+  {
+    ICP icp;
+    DataPoints a; a.features = {0, 0, 0, 1, 1, 0, 0, 1, 0, 1, 0, 1, 0, 0, 1, 1};
+    TransformationParameters T = identityTransformation();
+    T[0] = 1.1f;   // det 1.1
+    bool threw = false;
+    try { icp.compute(a, a, T); } catch (const TransformationError&) { threw = true; }
+    CHECK(threw);
+    threw = false;
+    try { icp.computeClouds(0, {1}, {identityTransformation()}, T); } catch (const TransformationError&) { threw = true; }
+    CHECK(threw);
+    T[0] = 1.0005f;   // inside checkParameters' tolerance (|1 - det| <= 1e-3): accepted; the fake stands in for the device
+    icp.setComputeOverride([](const ICP&, const DataPoints&, const DataPoints&, const TransformationParameters& Ti) { return Ti; });
+    CHECK(icp.compute(a, a, T)[0] == 1.0005f);
+  }
   // --- no GPU => loud error (only checked when asked, i.e. on the CPU-only container)
   if (argc > 1 && std::string(argv[1]) == "--expect-no-gpu") {
     ICP icp;

@@ -241,6 +241,10 @@ def test_errors_are_loud(icp_mod):
         h.set_reference(ref, np.tile(np.float32([0, 0, 1]), (100, 1)))
         with pytest.raises(ConvergenceError):  # empty reading
             h.align(np.zeros((0, 4), np.float32), np.eye(4))
+        bad = np.eye(4)
+        bad[0, 0] = 1.1                        # not rigid: PointMatcher's TransformationError out of ICP::compute, step 5
+        with pytest.raises(LsgpuError):
+            h.align(ref[:50].copy(), bad)
 
 
 def test_icp_class_compute_recovers_pose(icp_mod, pair64k):
