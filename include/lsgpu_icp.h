@@ -254,6 +254,10 @@ int lsgpu_filter_voxel_grid(lsgpu_icp* h, const float* xyz1, int64_t n, const fl
  *   FixStepSamplingDataPointsFilter  keeps points phase, phase + step, ...; phase = rand() % step; afterwards
  *                                step *= stepMult, clamped at endStep (the step persists from scan to scan: `state`)
  *   RandomSamplingDataPointsFilter   keeps point i iff draw_i < prob
+ *   RemoveNaNDataPointsFilter        drops the points with a NaN among their four feature rows x, y, z, pad (Inf stays)
+ * (MaxPointCountDataPointsFilter is NOT offered: which points it keeps depends on the libpointmatcher version --
+ *  std::random_shuffle in the 1.2 line, sequential selection sampling later -- and on the C++ library's shuffle; it
+ *  cannot be restated from the reference, which configures none.  Unknown module names are configuration errors.)
  * |p| = sqrt(fma(z,z,fma(y,y,x*x))) in float.  Draws: the library's glibc-sequence stream (see lsgpu_icp_compute);
  * seed >= 0 reseeds it before the first filter.  LSGPU_NO_CONVERGENCE if a filter is handed an empty cloud
  * (PointMatcher::ConvergenceError "no points to filter" upstream); an empty chain copies the cloud. */
@@ -262,7 +266,8 @@ enum {
   LSGPU_FILTER_MIN_DIST = 2,
   LSGPU_FILTER_BOUNDING_BOX = 3,
   LSGPU_FILTER_FIX_STEP_SAMPLING = 4,
-  LSGPU_FILTER_RANDOM_SAMPLING = 5
+  LSGPU_FILTER_RANDOM_SAMPLING = 5,
+  LSGPU_FILTER_REMOVE_NAN = 6
 };
 typedef struct lsgpu_point_filter {
   int    type;     /* LSGPU_FILTER_*                                                                          */

@@ -109,7 +109,7 @@ class PointFilter(C.Structure):
                 ("state", C.c_double)]
 
 
-FILTER_MAX_DIST, FILTER_MIN_DIST, FILTER_BOUNDING_BOX, FILTER_FIX_STEP_SAMPLING, FILTER_RANDOM_SAMPLING = 1, 2, 3, 4, 5
+FILTER_MAX_DIST, FILTER_MIN_DIST, FILTER_BOUNDING_BOX, FILTER_FIX_STEP_SAMPLING, FILTER_RANDOM_SAMPLING, FILTER_REMOVE_NAN = 1, 2, 3, 4, 5, 6
 
 
 class LsgpuError(RuntimeError):

@@ -200,6 +200,9 @@ class DataPointsFilters {
       } else if (m.name == "RandomSamplingDataPointsFilter") {
         only({"prob"});
         f.type = LSGPU_FILTER_RANDOM_SAMPLING; f.v[0] = (float)num("prob", 0.75);
+      } else if (m.name == "RemoveNaNDataPointsFilter") {
+        only({});
+        f.type = LSGPU_FILTER_REMOVE_NAN;
       } else {
         throw ConfigError("input filters: module " + m.name + " is not implemented on the HIP path");
       }

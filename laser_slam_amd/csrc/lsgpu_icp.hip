@@ -1601,7 +1601,8 @@ int lsgpu_apply_point_filters(lsgpu_icp* h, lsgpu_point_filter* filters, int n_f
     const bool ok = (f.type == LSGPU_FILTER_MAX_DIST || f.type == LSGPU_FILTER_MIN_DIST) ? (f.dim >= -1 && f.dim <= 2)
                     : f.type == LSGPU_FILTER_BOUNDING_BOX ? true
                     : f.type == LSGPU_FILTER_FIX_STEP_SAMPLING ? (f.v[0] >= 1.f && f.v[1] >= 1.f && f.v[2] > 0.f)
-                    : f.type == LSGPU_FILTER_RANDOM_SAMPLING ? (f.v[0] >= 0.f && f.v[0] <= 1.f) : false;
+                    : f.type == LSGPU_FILTER_RANDOM_SAMPLING ? (f.v[0] >= 0.f && f.v[0] <= 1.f)
+                    : f.type == LSGPU_FILTER_REMOVE_NAN ? true : false;
     if (!ok) { h->err = "apply_point_filters: unknown filter type or parameter out of range"; return LSGPU_BAD_CONFIG; }
   }
   if (seed >= 0) DrawStream::global().take(seed, 0, nullptr);

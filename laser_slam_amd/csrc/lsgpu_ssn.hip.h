@@ -490,6 +490,8 @@ __global__ __launch_bounds__(256) void k_point_filter_select(const float4* __res
     k = (uint32_t)i >= f.phase && ((uint32_t)i - f.phase) % f.step == 0u;
   } else if (f.type == 5) {          // RandomSampling
     k = draws[i] < f.v[0];
+  } else if (f.type == 6) {          // RemoveNaN: a column with a NaN in any feature row goes (colArray == colArray).all()
+    k = p.x == p.x && p.y == p.y && p.z == p.z && p.w == p.w;
   }
   keep[i] = k ? 1u : 0u;
 }

@@ -1024,6 +1024,9 @@ int64_t lso_apply_point_filters(lso_point_filter* filters, int n_filters, const 
       } else if (f->type == 5) {
         const float r = (float)rand() / (float)RAND_MAX;
         keep = r < f->v[0];
+      } else if (f->type == 6) { /* RemoveNaNDataPointsFilter: !(col == col).all() over the feature rows (x, y, z, pad) */
+        const float w = cur[4 * i + 3];
+        keep = x == x && y == y && z == z && w == w;
       }
       if (keep) { if (o != i) memcpy(cur + 4 * o, cur + 4 * i, 16); ++o; }
     }

@@ -361,6 +361,13 @@ int main(int argc, char** argv) {
     bool threw = false;
     try { DataPointsFilters bad(unknown); } catch (const ConfigError&) { threw = true; }
     CHECK(threw);
+    std::istringstream nan_chain("- RemoveNaNDataPointsFilter\n- MinDistDataPointsFilter: {minDist: 1}\n");
+    DataPointsFilters with_nan(nan_chain);
+    CHECK(with_nan.size() == 2 && with_nan.modules()[0].type == LSGPU_FILTER_REMOVE_NAN);
+    std::istringstream max_count("- MaxPointCountDataPointsFilter: {maxCount: 1000}\n");   // version-dependent selection: refused
+    threw = false;
+    try { DataPointsFilters bad(max_count); } catch (const ConfigError&) { threw = true; }
+    CHECK(threw);
     std::istringstream typo("- MaxDistDataPointsFilter: {maxDistance: 5}\n");
     threw = false;
     try { DataPointsFilters bad(typo); } catch (const ConfigError&) { threw = true; }

@@ -1061,6 +1061,13 @@ def test_input_filter_chain_matches_oracle(icp_mod, oracle):
         assert (h.apply_point_filters(_chain(_lib, [(_lib.FILTER_MAX_DIST, 0, 0, [3.0])]), scans[0])[:, 0] < -3.0).any()
         with pytest.raises(_lib.LsgpuError):
             h.apply_point_filters(_chain(_lib, [(77, 0, 0, [1.0])]), scans[0])
+        # RemoveNaN: a NaN in any of the four feature rows removes the point, an infinity does not; order preserved
+        dirty = scans[0][:5000].copy()
+        dirty[7, 0] = np.nan; dirty[8, 1] = np.nan; dirty[9, 2] = np.nan; dirty[10, 3] = np.nan; dirty[11, 0] = np.inf; dirty[4999, 2] = np.nan
+        got = h.apply_point_filters(_chain(_lib, [(_lib.FILTER_REMOVE_NAN, 0, 0, [0.0])]), dirty)
+        want = oracle.apply_point_filters(_chain(oracle, [(_lib.FILTER_REMOVE_NAN, 0, 0, [0.0])]), dirty)
+        keep = ~np.isnan(dirty).any(1)
+        assert got.shape[0] == 4995 and np.array_equal(got.view(np.uint32), want.view(np.uint32)) and np.array_equal(got.view(np.uint32), dirty[keep].view(np.uint32))
 
 
 def test_pointcloud2_conversion_round_trip(icp_mod):

@@ -234,6 +234,9 @@ def test_input_filters_upstream_asymmetries(oracle):
     assert keep(oracle.apply_point_filters(chain(1, -1, -2.5), pts)) == [-1.0, 0.5, 2.0]          # radial: |p| < |-2.5|
     assert keep(oracle.apply_point_filters(chain(2, -1, -2.5), pts)) == [-5.0, 30.0]              # radial: |p| > |-2.5|
     assert oracle.apply_point_filters(chain(1, 0, 1.0), pts[:0]) is None                          # empty cloud, non-empty chain
+    dirty = pts.copy()                                                                            # RemoveNaN: NaN in any feature row, Inf stays
+    dirty[0, 1] = np.nan; dirty[1, 3] = np.nan; dirty[2, 2] = np.inf
+    assert np.array_equal(oracle.apply_point_filters(chain(6, 0, 0.0), dirty).view(np.uint32), dirty[2:].view(np.uint32))
     empty_chain = (oracle.PointFilter * 0)()
     assert oracle.apply_point_filters(empty_chain, pts).shape[0] == 5 and oracle.apply_point_filters(empty_chain, pts[:0]).shape[0] == 0
 
