@@ -1,0 +1,144 @@
+#!/usr/bin/env python3
+"""Everything somebody WITH libpointmatcher needs to diff the restatement this library was written against
+(oracle/icp_oracle.c; "parity unpinned": SURVEY.md 8c) against upstream -- CPU only, no GPU, deterministic.
+
+For a synthetic HDL-64E pair (default: the 4 k-point pair of the parity tests, `--n-az 1024` = the 64 k pair) it writes
+
+  reading.vtk / .csv, reference.vtk / .csv   the RAW clouds `icp_.compute(reading, reference, T_init)` is handed
+                                             (laser_slam/src/laser_track.cpp:496), as DataPoints::load reads them
+  icp.yaml                                   the module chain (tests/golden/icp_chain*.yaml, loadable by
+                                             PointMatcher::ICP::loadFromYaml; checked here with this repo's own loader)
+  T_init.txt                                 4 x 4, row major, "%.9g"
+  reference_filtered.csv                     what SamplingSurfaceNormalDataPointsFilter leaves (x,y,z,nx,ny,nz): choices 1, 2, 8
+  reading_filtered.csv                       what RandomSamplingDataPointsFilter leaves: choice 8 (the draws continue the
+                                             reference filter's; the process starts at srand(1) like an unseeded one)
+  input_filtered.csv                         reading.csv through tests/golden/input_filters.yaml (srand(1) again): choice 9
+  oracle_trace.csv                           per iteration: iter, limit (squared metres), n_used, T_iter (16, column major)
+  oracle_result.txt                          rc, iterations, converged, final T (4 x 4 row major)
+  README.txt                                 what is what, and which file / column each restatement choice would change
+
+The files regenerate byte for byte (tests/test_oracle.py::test_upstream_dump_regenerates).  INTEGRATION.md has the
+C++ program that replays them on a real PointMatcher<float>::ICP and prints a trace in the same format.
+usage: dump_for_upstream.py OUT_DIR [--n-az 64] [--chain tests/golden/icp_chain_tight.yaml]
+"""
+import argparse
+import os
+import shutil
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from laser_slam_amd import cloud_io, synth  # noqa: E402
+from oracle import oracle_py as O  # noqa: E402
+
+CHOICES = """Restatement choices of oracle/icp_oracle.h and where a different upstream behaviour shows:
+ 1 box rank test (FullPivHouseholderQR, eps * 3)      reference_filtered.csv: number of rows (thin boxes kept / dropped)
+ 2 box split (stable sort, split at the median)      reference_filtered.csv: row ORDER and the normals of boxes with tied coordinates
+ 3 kd-tree ties (any nearest point)                  nothing: oracle_trace.csv is the same for every valid tie order
+ 4 TrimmedDist: index floor(n * ratio), d2 <= limit  oracle_trace.csv: columns limit and n_used
+ 5 reference mean in double, rounded to float        oracle_trace.csv: last digits of T_iter (1e-6 level)
+ 6 minimiser: float J, LLT solve in float            oracle_trace.csv: T_iter from the first iteration on
+ 7 differential checker: 2 atan2(|vec|, |w|)         oracle_trace.csv: number of rows (the iteration it stops at)
+ 8 rand(): glibc sequence, draw < prob keeps         reading_filtered.csv (and reference_filtered.csv for ratio < 1): WHICH rows
+ 9 MaxDist signed on one axis, MinDist absolute      input_filtered.csv: rows
+"""
+
+
+def g(v) -> str:
+    return "%.9g" % float(v)
+
+
+def parse_chain(path):
+    """The chain file through this repo's own loader (laser_slam_amd.icp.ICP.load_from_yaml): the values the oracle runs."""
+    from laser_slam_amd import icp
+    m = icp.ICP()
+    m.load_from_yaml(path)
+    return m.chain
+
+
+def input_filter_chain(path):
+    """tests/golden/input_filters.yaml -> oracle PointFilter array (the five module types of the golden chain)."""
+    import yaml
+    doc = yaml.safe_load(open(path).read()) or []
+    arr = (O.PointFilter * len(doc))()
+    for a, item in zip(arr, doc):
+        (name, p), = item.items() if isinstance(item, dict) else ((item, {}),)
+        p = p or {}
+        a.state = 0.0
+        if name == "BoundingBoxDataPointsFilter":
+            a.type, a.flag = 3, int(p.get("removeInside", 1))
+            for i, k in enumerate(("xMin", "xMax", "yMin", "yMax", "zMin", "zMax")):
+                a.v[i] = float(p.get(k, -1.0 if i % 2 == 0 else 1.0))
+        elif name == "MaxDistDataPointsFilter":
+            a.type, a.dim = 1, int(p.get("dim", -1)); a.v[0] = float(p.get("maxDist", 1.0))
+        elif name == "MinDistDataPointsFilter":
+            a.type, a.dim = 2, int(p.get("dim", -1)); a.v[0] = float(p.get("minDist", 1.0))
+        elif name == "FixStepSamplingDataPointsFilter":
+            a.type = 4; a.v[0] = float(p.get("startStep", 10)); a.v[1] = float(p.get("endStep", 10)); a.v[2] = float(p.get("stepMult", 1))
+        elif name == "RandomSamplingDataPointsFilter":
+            a.type = 5; a.v[0] = float(p.get("prob", 0.75))
+        elif name == "RemoveNaNDataPointsFilter":
+            a.type = 6
+        else:
+            raise SystemExit("input filter %s is not in the restatement" % name)
+    return arr
+
+
+def dump(out_dir, n_az, chain_path):
+    os.makedirs(out_dir, exist_ok=True)
+    ref, rd, T_true, T_init = synth.scan_pair(n_az)
+    ch = parse_chain(chain_path)
+    shutil.copyfile(chain_path, os.path.join(out_dir, "icp.yaml"))
+    cloud_io.save_vtk(os.path.join(out_dir, "reading.vtk"), rd)
+    cloud_io.save_csv(os.path.join(out_dir, "reading.csv"), rd)
+    cloud_io.save_vtk(os.path.join(out_dir, "reference.vtk"), ref)
+    cloud_io.save_csv(os.path.join(out_dir, "reference.csv"), ref)
+    T16 = synth.colmajor(T_init)
+    Tm = T16.reshape(4, 4).T
+    with open(os.path.join(out_dir, "T_init.txt"), "w") as f:
+        for r in range(4):
+            f.write(" ".join(g(Tm[r, c]) for c in range(4)) + "\n")
+    # ICP::compute, steps 1 and 4 with ONE draw stream that starts where an unseeded process starts (srand(1))
+    rf, rn = O.sampling_surface_normal(ref, ch.surface_normal_knn, ch.surface_normal_ratio, 1)
+    if ch.reading_sampling_prob >= 0:
+        rdf = rd[O.random_sampling(rd.shape[0], ch.reading_sampling_prob, -1)]
+    else:
+        rdf = rd
+    cloud_io.save_csv(os.path.join(out_dir, "reference_filtered.csv"), rf, rn)
+    cloud_io.save_csv(os.path.join(out_dir, "reading_filtered.csv"), rdf)
+    flt = input_filter_chain(os.path.join(ROOT, "tests", "golden", "input_filters.yaml"))
+    kept = O.apply_point_filters(flt, rd, seed=1)
+    cloud_io.save_csv(os.path.join(out_dir, "input_filtered.csv"), kept if kept is not None else rd[:0])
+    cfg = O.config_yaml(accum_double=0, trim_ratio=ch.trim_ratio, max_iterations=ch.max_iterations,
+                        min_diff_rot=ch.min_diff_rot, min_diff_trans=ch.min_diff_trans, smooth_length=ch.smooth_length)
+    rc, T, st, tr = O.icp_compute(cfg, rdf, rf, rn, T16, trace_cap=ch.max_iterations)
+    with open(os.path.join(out_dir, "oracle_trace.csv"), "w") as f:
+        f.write("iter,limit,n_used," + ",".join("T%d%d" % (r, c) for c in range(4) for r in range(4)) + "\n")
+        for k, t in enumerate(tr):
+            f.write("%d,%s,%d,%s\n" % (k, g(t["limit"]), t["n_used"], ",".join(g(v) for v in t["T_iter"])))
+    Tf = np.asarray(T, np.float32).reshape(4, 4).T
+    with open(os.path.join(out_dir, "oracle_result.txt"), "w") as f:
+        f.write("rc %d iterations %d converged %d\n" % (rc, st.iterations, st.converged))
+        for r in range(4):
+            f.write(" ".join(g(Tf[r, c]) for c in range(4)) + "\n")
+    with open(os.path.join(out_dir, "README.txt"), "w") as f:
+        f.write("Synthetic HDL-64E pair, %d azimuth steps: reading %d points, reference %d points; chain %s\n"
+                "(reading_sampling_prob %s, surface normal knn %d ratio %s, trim %s, checkers %d / %s / %s / %d).\n"
+                "Written by devtools/dump_for_upstream.py; the float accumulation of libpointmatcher (accum_double 0).\n"
+                "Replay on libpointmatcher: INTEGRATION.md, \"Diffing against a real libpointmatcher\".\n\n%s"
+                % (n_az, rd.shape[0], ref.shape[0], os.path.relpath(chain_path, ROOT), g(ch.reading_sampling_prob),
+                   ch.surface_normal_knn, g(ch.surface_normal_ratio), g(ch.trim_ratio), ch.max_iterations,
+                   g(ch.min_diff_rot), g(ch.min_diff_trans), ch.smooth_length, CHOICES))
+    return rc, st.iterations
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("out_dir")
+    ap.add_argument("--n-az", type=int, default=64)
+    ap.add_argument("--chain", default=os.path.join(ROOT, "tests", "golden", "icp_chain.yaml"))
+    a = ap.parse_args()
+    rc, it = dump(a.out_dir, a.n_az, a.chain)
+    print("wrote %s: oracle rc %d, %d iterations" % (a.out_dir, rc, it))

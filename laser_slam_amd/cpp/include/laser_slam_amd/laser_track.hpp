@@ -26,6 +26,7 @@
 #include <vector>
 
 #include "laser_slam_amd/icp.hpp"
+#include "laser_slam_amd/cloud_io.hpp"
 #include "laser_slam_amd/se3.hpp"
 #include "laser_slam_amd/pose_graph.hpp"
 
@@ -62,7 +63,9 @@ struct LaserTrackParams {  // laser_slam/include/laser_slam/parameters.hpp:8-23
   bool use_icp_factors = true;
   bool use_odom_factors = true;
   int nscan_in_sub_map = 3;
-  bool save_icp_results = false;
+  bool save_icp_results = false;        // laser_track.cpp:504-513: dump the reading, the sub-map and the reading moved by the
+                                        // guess / by the solution as .vtk after every ICP (cloud_io.hpp)
+  std::string save_icp_results_dir = "/tmp";   // (the reference's paths are /tmp/last_scan.vtk ...; not a reference parameter)
   bool force_priors = false;
   int device = 0;                       // HIP device of this track's ICP handle
   int scans_on_device = 16;             // most recent scans kept in HBM for sub-map assembly (0: host assembly)
@@ -376,6 +379,19 @@ class LaserTrack {
       }
     } catch (const ConvergenceError&) {
       // keep the initial guess (laser_track.cpp:499-502)
+    }
+    if (params_.save_icp_results) {   // laser_track.cpp:504-513 (incl. the corrected solution going on into the factor)
+      DataPoints sub_map = laser_scans_[members[0]].scan;
+      for (size_t i = 1; i < members.size(); ++i)
+        sub_map.concatenate(RigidTransformation::compute(laser_scans_[members[i]].scan, member_T[i]));
+      const std::string dir = params_.save_icp_results_dir;
+      saveVTK(last_scan.scan, dir + "/last_scan.vtk");
+      saveVTK(sub_map, dir + "/sub_map.vtk");
+      TransformationParameters guess_corrected = T_init;
+      correctTransformationMatrix(&guess_corrected);
+      saveVTK(RigidTransformation::compute(last_scan.scan, guess_corrected), dir + "/last_scan_alligned_by_initial_guess.vtk");
+      correctTransformationMatrix(&solution);
+      saveVTK(RigidTransformation::compute(last_scan.scan, solution), dir + "/last_scan_alligned_by_solution.vtk");
     }
     icp.T_a_b = SE3::fromTransformationMatrix(solution.data());  // convertTransformationMatrixToSE3
     icp.key_a = getPoseKey(icp.time_a_ns);

@@ -22,37 +22,43 @@
  *   T maps reading -> reference:  p_ref = T * p_reading.
  *
  * RESTATEMENT CHOICES -- where upstream's behaviour is not derivable from /root/reference and this file (and the
- * product, which shares the choice) had to pick one.  Each line names what would change if the choice were wrong and
+ * product, which shares the choice) had to pick one.  devtools/dump_for_upstream.py writes the inputs, the filters'
+ * outputs and this file's per-iteration trace in a form a real libpointmatcher build can replay (INTEGRATION.md,
+ * "Diffing against a real libpointmatcher"); [in brackets] the dumped file / column in which a wrong choice shows.  Each line names what would change if the choice were wrong and
  * the test that pins the choice to the mathematics (not to upstream).  A session with libpointmatcher available
  * should diff exactly these:
  *   1. rank test of a box (SamplingSurfaceNormal::fuseRange): FullPivHouseholderQR::rank() + 1 >= 3, default
  *      threshold eps * 3 (rounds 1-2 restated it with FullPivLU pivots).  Wrong => borderline-thin boxes kept /
  *      dropped differently (a few points of 1 M).  tests: test_independent_known_answers (collinear boxes dropped,
- *      planar ones kept, normals == numpy.linalg.eigh).
+ *      planar ones kept, normals == numpy.linalg.eigh).  [reference_filtered.csv: number of rows]
  *   2. split of a box: std::nth_element leaves ties and the order inside the halves unspecified; here "stable sort,
  *      split at the median".  Wrong => other box memberships where coordinates tie, other output ORDER of the kept
  *      points (which permutes the rand() draws of ratio < 1).  tests: test_filter_golden_vectors_reproduce,
  *      test_device_reference_filter_is_bit_identical (pin device == host == oracle, not upstream);
- *      test_surface_normal_filter_boxes_against_a_numpy_recursion (the stated rule as a plain numpy recursion).
+ *      test_surface_normal_filter_boxes_against_a_numpy_recursion (the stated rule as a plain numpy recursion).  [reference_filtered.csv: row order, normals]
  *   3. kd-tree ties (libnabo): implementation defined => any nearest point is valid; the product returns the
- *      smallest index of its own order.  tests: _check_nn / test_golden_vectors accept equal-distance alternatives.
+ *      smallest index of its own order.  tests: _check_nn / test_golden_vectors accept equal-distance alternatives.  [none: the trace is the same for every
+ *      valid tie order]
  *   4. TrimmedDistOutlierFilter: index floor(float(n) * ratio) over the matched pairs, weight 1 iff d2 <= limit
  *      (inclusive).  Wrong ('<') => pairs at exactly the limit lose their weight (>= 1 pair, more with ties).
  *      tests: test_independent_known_answers (numpy.partition index), test_trim_limit_is_order_statistic.
+ *      [oracle_trace.csv: limit, n_used]
  *   5. reference mean: accumulated in double, rounded to float (Eigen's rowwise().sum() in float would differ in the
- *      last bits of the centring).  Affects T at the 1e-6 level.
+ *      last bits of the centring).  Affects T at the 1e-6 level.  [oracle_trace.csv: last digits of T00..T33]
  *   6. minimiser: A and b from float J, accumulated in double (accum_double 1) or float (0, as upstream);
  *      x = A.llt().solve(b) in float; LLT failure => ConvergenceError (newer upstream falls back to a QR / SVD
  *      min-norm solve).  tests: test_independent_known_answers (numpy Cholesky), test_point_to_plane_matches_numpy_lstsq.
+ *      [oracle_trace.csv: T00..T33 from row 0 on]
  *   7. DifferentialTransformationChecker: Eigen >= 3.3 angularDistance = 2 atan2(|vec|, |w|) of q_a conj(q_b) (older
- *      Eigen: 2 acos(|dot|), equal to ~1e-7 rad).  tests: test_independent_known_answers (scipy Rotation.magnitude).
+ *      Eigen: 2 acos(|dot|), equal to ~1e-7 rad).  tests: test_independent_known_answers (scipy Rotation.magnitude).  [oracle_trace.csv: number of rows]
  *   8. rand(): glibc's srand/rand sequence; draw = (float)rand() / (float)RAND_MAX, kept iff draw < prob; one stream
  *      consumed in the order reference filter -> reading filter -> (input filters, per scan).  A caller that wants
  *      reproducible runs reseeds per call (seed >= 0); upstream never seeds.  tests: test_draw_stream_is_the_glibc_
  *      rand_sequence; the sequence tests run both "reseed per call" and "one continuing stream".
+ *      [reading_filtered.csv, and reference_filtered.csv for ratio < 1: which rows]
  *   9. MaxDist / MinDist input filters: radial branch compares the norm with |limit| (both), one-axis branch compares
  *      the SIGNED coordinate (MaxDist) / the absolute one (MinDist); an empty cloud into a non-empty chain throws.
- *      tests: test_input_filters_upstream_asymmetries.
+ *      tests: test_input_filters_upstream_asymmetries.  [input_filtered.csv: rows]
  * The COMPOSITION of ICP::compute (frames, left-multiplied update, checker window, steps 1-7 of SURVEY.md A.1) is pinned
  * against a float64 numpy / scipy ICP that shares no code with this file:
  * test_oracle_loop_against_an_independent_numpy_icp.

@@ -407,12 +407,17 @@ int main(int argc, char** argv) {
     auto fake = [](const ICP&, const DataPoints&, const DataPoints&, const TransformationParameters& T) { return T; };
     LaserTrackParams p;
     p.icp_input_filters_file = no_filters;
-    LaserTrack a(p, 0u), b(p, 0u);
+    LaserTrackParams pb = p;
+    if (const char* dump = std::getenv("LSGPU_TEST_DUMP_DIR")) {   // save_icp_results (laser_track.cpp:504-513): the test reads the files back
+      pb.save_icp_results = true;
+      pb.save_icp_results_dir = dump;
+    }
+    LaserTrack a(p, 0u), b(pb, 0u);
     a.icp().setComputeOverride(fake);
     b.icp().setComputeOverride(fake);
     for (int i = 0; i < 3; ++i) {
       Pose pose; pose.time_ns = 100 * (i + 1); pose.T_w = SE3({1, 0, 0, 0}, {0.8 * i, 0, 0});
-      LaserScan sc; sc.time_ns = pose.time_ns; sc.scan.features = {float(i), 0, 0, 1};
+      LaserScan sc; sc.time_ns = pose.time_ns; sc.scan.features = {float(i), 0, 0, 1, 0.1f * float(i), 1.f / 3.f, -2.5e-7f, 1};
       a.processPose(pose);
       a.processLaserScan(sc);
       b.processPoseAndLaserScan(pose, sc);

@@ -26,8 +26,22 @@ def test_cpp_host_checks(tmp_path):
     exe = _build(tmp_path, "host_checks.cpp", "host_checks")
     args = [exe] + ([] if torch.cuda.is_available() else ["--expect-no-gpu"])
     r = subprocess.run(args, capture_output=True, text=True, timeout=120,
-                       env=dict(os.environ, LSGPU_GOLDEN_DIR=os.path.join(ROOT, "tests", "golden")))
+                       env=dict(os.environ, LSGPU_GOLDEN_DIR=os.path.join(ROOT, "tests", "golden"), LSGPU_TEST_DUMP_DIR=str(tmp_path)))
     assert r.returncode == 0 and "host_checks: ok" in r.stdout, r.stdout + r.stderr
+    # save_icp_results (laser_track.cpp:504-513): the four .vtk files of the last ICP (scan 2 against scans 1 + 0 in the frame
+    # of scan 1, the fake ICP returns its guess), byte for byte what the Python writer emits, and loadable again
+    from laser_slam_amd import cloud_io
+    scan = lambda i: np.array([[i, 0, 0, 1], [0.1 * i, 1.0 / 3.0, -2.5e-7, 1]], np.float32)
+    assert open(tmp_path / "last_scan.vtk").read() == cloud_io.vtk_text(scan(2))
+    back, nrm = cloud_io.load_vtk(str(tmp_path / "last_scan.vtk"))
+    assert nrm is None and np.array_equal(back.view(np.uint32), scan(2).view(np.uint32))
+    sub, _ = cloud_io.load_vtk(str(tmp_path / "sub_map.vtk"))
+    moved0 = scan(0).copy()
+    moved0[:, 0] -= np.float32(0.8)                       # scan 0 in the frame of scan 1 (poses 0.8 m apart along x)
+    assert np.allclose(sub, np.concatenate([scan(1), moved0]), atol=1e-6)
+    by_guess, _ = cloud_io.load_vtk(str(tmp_path / "last_scan_alligned_by_initial_guess.vtk"))
+    by_solution, _ = cloud_io.load_vtk(str(tmp_path / "last_scan_alligned_by_solution.vtk"))
+    assert np.array_equal(by_guess, by_solution) and np.allclose(by_guess[:, 0], scan(2)[:, 0] + 0.8, atol=1e-6)
 
 
 def test_gtsam_overlay_parses_and_resolves_the_ros_worker_calls():

@@ -9,6 +9,8 @@ import pytest
 
 from laser_slam_amd import synth
 
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
 GOLD = os.path.join(os.path.dirname(__file__), "golden", "icp_pair4k.npz")
 
 
@@ -397,3 +399,30 @@ def _check_boxes_against_recursion(pts, boxes, out, nrm):
         assert np.array_equal(nrm[pos:pos + b.size], np.repeat(nn[None], b.size, 0))
         pos += b.size
     assert pos == out.shape[0] and checked > 300
+
+
+def test_upstream_dump_regenerates(tmp_path):
+    """devtools/dump_for_upstream.py (round-3 verdict, "make the oracle diffable by someone who has libpointmatcher"): the
+    clouds, chain, guess, filter outputs and per-iteration oracle trace of the 4 k pair regenerate byte for byte
+    (MANIFEST.sha256 covers the clouds, which are not committed; the small files are), the .vtk loads back bit for bit,
+    and the trace has one row per iteration."""
+    import hashlib
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("dump_for_upstream", os.path.join(ROOT, "devtools", "dump_for_upstream.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    rc, iters = mod.dump(str(tmp_path), 64, os.path.join(ROOT, "tests", "golden", "icp_chain.yaml"))
+    assert rc == 0 and iters > 5
+    gold = os.path.join(ROOT, "tests", "golden", "upstream_pair4k")
+    want = dict(line.split()[::-1] for line in open(os.path.join(gold, "MANIFEST.sha256")).read().splitlines())
+    assert sorted(want) == sorted(os.listdir(tmp_path))
+    for name, digest in want.items():
+        assert hashlib.sha256(open(tmp_path / name, "rb").read()).hexdigest() == digest, name
+        if os.path.exists(os.path.join(gold, name)):
+            assert open(os.path.join(gold, name), "rb").read() == open(tmp_path / name, "rb").read(), name
+    from laser_slam_amd import cloud_io
+    ref, rd, _, _ = synth.scan_pair(64)
+    back, nrm = cloud_io.load_vtk(str(tmp_path / "reference.vtk"))
+    assert nrm is None and np.array_equal(back.view(np.uint32), ref.view(np.uint32))
+    rows = open(tmp_path / "oracle_trace.csv").read().splitlines()
+    assert rows[0].startswith("iter,limit,n_used,T00,T10") and len(rows) == iters + 1
