@@ -65,6 +65,69 @@ def _cpu_model() -> str:
     return "unknown"
 
 
+def track_section(n_az: int, n_scans: int, cpu_threads: int):
+    """SURVEY.md 8d, the reference's OWN timed region: `scan_matching_times_` of LaserTrack::processPoseAndLaserScan
+    (laser_slam/src/laser_track.cpp:128, 208-209 -- the clock runs from the top of the call to the end of
+    computeICPTransformations) for a drive of `n_scans` synthetic 64 x n_az-ray scans through the C++ mirror
+    (tests/cpp/track_driver.cpp): nscan_in_sub_map 3, the yaml chain (tests/golden/icp_chain.yaml = icp_default.yaml's
+    modules), scans resident in HBM (scans_on_device 16).  A second run of the same drive hands ONE scan's ICP inputs --
+    the reading, the assembled 3-scan sub-map, the guess -- to the CPU oracle as well: its wall time for that
+    `icp_.compute` is the CPU leg (everything else processPoseAndLaserScan does is O(1) beside it), the difference of
+    the two transforms the per-call parity figure."""
+    import multiprocessing as mp
+    import shutil
+    import subprocess
+    import tempfile
+    from laser_slam_amd import synth
+    from oracle import oracle_py
+    oracle_py.build()
+    d = tempfile.mkdtemp(prefix="lsgpu_track_")
+    try:
+        exe = os.path.join(d, "track_driver")
+        subprocess.check_call(["g++", "-std=c++17", "-O2", "-DLSGPU_TRACK_SHADOW", "-DLSGPU_TEST_SEAMS", "-I", os.path.join(ROOT, "include"),
+                               "-I", os.path.join(ROOT, "laser_slam_amd", "cpp", "include"), os.path.join(ROOT, "tests", "cpp", "track_driver.cpp"),
+                               "-o", exe, "-L", os.path.join(ROOT, "laser_slam_amd"), "-llsgpu_icp", "-L", os.path.join(ROOT, "oracle"), "-llsoracle",
+                               "-Wl,-rpath," + os.path.join(ROOT, "laser_slam_amd"), "-Wl,-rpath," + os.path.join(ROOT, "oracle")])
+        poses = [synth.se3(0.8 * i, 0.05 * i, synth.SENSOR_HEIGHT, yaw=np.deg2rad(2.0 * i)) for i in range(n_scans)]
+        jobs = [(1234, poses[i], n_az, 10 + i) for i in range(n_scans)]
+        with mp.get_context("spawn").Pool(min(n_scans, os.cpu_count() or 1)) as pool:
+            scans = pool.map(synth.scan_job, jobs)
+        with open(os.path.join(d, "poses.txt"), "w") as f:
+            for i, (T, sc) in enumerate(zip(poses, scans)):
+                sc.tofile(os.path.join(d, "scan%d.bin" % i))
+                q = synth.quat_wxyz(T @ synth.se3(0.1, -0.05, 0.0, yaw=np.deg2rad(0.5)))   # odometry: truth off by 10 cm / 0.5 deg
+                f.write("%d %s\n" % (100000000 * i, " ".join(repr(float(v)) for v in [*q, *(T @ synth.se3(0.1, -0.05, 0.0, yaw=np.deg2rad(0.5)))[:3, 3]])))
+        yaml = os.path.join(ROOT, "tests", "golden", "icp_chain.yaml")
+        shadow_scan = min(5, n_scans - 1)
+
+        def run(extra):
+            r = subprocess.run([exe, d, str(n_scans), yaml, "3", "16", *extra], capture_output=True, text=True, timeout=900)
+            if r.returncode != 0:
+                raise RuntimeError("track_driver failed: " + r.stdout[-500:] + r.stderr[-500:])
+            return r.stdout.splitlines()
+        lines = run([])
+        ms = [float(l.split()[-1]) for l in lines if l.startswith("icp_iterations")]          # scans 1 .. n-1
+        its = [int(l.split()[1]) for l in lines if l.startswith("icp_iterations")]
+        steady = ms[3:]                                                                         # the sub-map holds 3 scans from scan 4 on
+        sh = [l.split() for l in run([str(shadow_scan), str(cpu_threads)]) if l.startswith("shadow ")]
+        out = {"value": 1e3 / float(np.median(steady)), "unit": "scans/s", "ms_per_scan_median": float(np.median(steady)),
+               "ms_per_scan": [round(m, 3) for m in ms], "icp_iterations": its, "n_scans": n_scans, "points_per_scan": int(scans[0].shape[0]),
+               "workload": "LaserTrack::processPoseAndLaserScan through the C++ mirror, %d scans of 64 x %d rays 0.8 m / 2 deg apart, nscan_in_sub_map 3 "
+                           "(sub-map of ~%.1f M points), yaml chain (prob 0.5 / ratio 0.5), scans_on_device 16; timed region = scan_matching_times_ "
+                           "(laser_track.cpp:128, 208-209); steady state = scans 4 .. %d" % (n_scans, n_az, 3 * scans[0].shape[0] / 1e6, n_scans - 1)}
+        if sh:
+            t = sh[0]
+            kv = {t[i]: t[i + 1] for i in range(1, len(t) - 1, 2)}
+            out["cpu_baseline_track"] = {"value": 1e3 / float(kv["oracle_ms"]), "unit": "scans/s", "ms_per_scan": float(kv["oracle_ms"]), "cores": int(kv["threads"]),
+                                         "kind": "port", "sample": "the icp_.compute of scan %s of the same drive (reading %s points, sub-map %s points, same guess, same draws) on the CPU oracle"
+                                                                   % (kv["scan"], kv["reading"], kv["reference"]),
+                                         "oracle_iterations": int(kv["oracle_iterations"]), "device_iterations": int(kv["device_iterations"])}
+            out["gpu_vs_cpu_transform"] = {"trans_m": float(kv["dt"]), "rot_rad": float(kv["dr"]), "calls_compared": 1}
+        return out, scans, poses
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -76,6 +139,8 @@ def main():
     ap.add_argument("--no-compute-e2e", action="store_true",
                     help="skip the value_loop / value_e2e sections (used for the rocprofv3 runs, so that the kernel\n"
                          "averages of the profile cover the timed workload only)")
+    ap.add_argument("--no-track", action="store_true", help="skip value_track (LaserTrack::processPoseAndLaserScan through the C++ mirror, with the oracle-driven facade beside it)")
+    ap.add_argument("--track-scans", type=int, default=10)
     ap.add_argument("--batch", action="store_true", help="BASELINE configs[2]: 256 x 200 k-point pairs sharded over the ranks")
     ap.add_argument("--batch-pairs", type=int, default=256)
     ap.add_argument("--batch-handles", type=int, default=16)
@@ -345,7 +410,7 @@ def main():
                                   "per iteration" if args.split else "one scan pair per rank, no collective")}
     out["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                        "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_note,
-                       "kernel": "k_knn_tile (+ k_knn_fallback / k_knn_rowq where a launch hands queries over: the first three iterations) -- exact 1-NN correspondence search",
+                       "kernel": "k_knn_cone (direction-indexed search, iterations >= 2) / k_knn_tile + k_knn_fallback (voxel-grid search, iterations 0-1) -- exact 1-NN correspondence search",
                        "algorithmic_bytes_per_launch": b_knn,
                        "avg_launch_us": t_knn * 1e6,
                        "avg_main_us": knn_main_ms / max(knn_launches, 1) * 1e3,
@@ -416,6 +481,38 @@ def main():
             rc_mt, _To, sto_mt = O.icp_compute_full(ocfg, raw_rd, raw_ref, synth.colmajor(T_init), seed=0)
             out["cpu_baseline"]["all_threads"] = {"value": 1.0 / (time.perf_counter() - tc), "unit": "scans/s", "cores": nthr,
                                                   "iterations": sto_mt.iterations}
+    # ---- the reference's own timed region (value_track) and the real call shape of localScanToSubMap: a reference of
+    # three scans (compute_variants.F_submap3 / P_submap3)
+    if rank == 0 and world == 1 and not args.no_track and not args.no_compute_e2e and not args.split:
+        try:
+            trk, scans, poses = track_section(args.n_az, args.track_scans, args.cpu_threads)
+            out["value_track"] = trk
+            # reading = scan 3, reference = scans 2, 1, 0 in the frame of scan 2 (what localScanToSubMap assembles), raw clouds in HBM
+            Ta = poses[2]
+            parts = []
+            for k in (2, 1, 0):
+                Trel = np.linalg.inv(Ta) @ poses[k]
+                p = scans[k].copy()
+                p[:, :3] = (scans[k][:, :3].astype(np.float64) @ Trel[:3, :3].T + Trel[:3, 3]).astype(np.float32)
+                parts.append(p)
+            d_sub = torch.from_numpy(np.concatenate(parts)).cuda()
+            d_rd3 = torch.from_numpy(scans[3]).cuda()
+            T_g = (np.linalg.inv(Ta) @ poses[3]) @ synth.se3(0.1, -0.05, 0.0, yaw=np.deg2rad(0.5))
+            torch.cuda.synchronize()
+            for name, prob, ratio in (("F_submap3", 1.0, 1.0), ("P_submap3", 0.5, 0.5)):
+                ts, fg = [], []
+                for rep in range(5):
+                    tc0 = time.perf_counter()
+                    Te, ste = h.compute(d_rd3, d_sub, T_g, prob, 10, ratio, seed=0)
+                    ts.append((time.perf_counter() - tc0) * 1e3)
+                    fg.append(ste.t_reserved[0])
+                out.setdefault("compute_variants", {})[name] = {
+                    "ms_per_compute": float(np.median(ts[1:])), "scans_per_s": 1e3 / float(np.median(ts[1:])),
+                    "filters_and_grid_ms": float(np.median(fg[1:])), "iterations": ste.iterations, "n_reference_raw": int(d_sub.shape[0]),
+                    "n_reference_after_filter": int(h.info().n_reference),
+                    "trans_err_m": synth.pose_error(Te.astype(np.float64), np.linalg.inv(Ta) @ poses[3])[0]}
+        except Exception as e:   # (a side figure must not take the headline down with it)
+            out["value_track"] = {"error": repr(e)[:400]}
     if rank == 0:
         print(json.dumps(out))
     h.close()

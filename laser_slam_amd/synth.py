@@ -130,6 +130,12 @@ def hdl64_scan(scene: Scene, T_w_s: np.ndarray, n_az: int, noise_seed: int,
     return out
 
 
+def scan_job(job):
+    """(scene_seed, pose 4x4, n_az, noise_seed) -> scan; a top-level function so that a process pool can run it."""
+    scene_seed, T, n_az, noise_seed = job
+    return hdl64_scan(Scene(scene_seed), np.asarray(T, np.float64), n_az, noise_seed)
+
+
 def scan_pair(n_az: int, scene_seed: int = 1234, noise_seeds=(1, 2), guess_seed: int = 7,
               step=(0.8, 0.05, 0.0), yaw_deg: float = 2.0, pitch_deg: float = 0.2,
               guess_err=(0.3, 1.5)):

@@ -1,6 +1,9 @@
 // track_driver.cpp -- drives laser_slam_amd::LaserTrack like LaserSlamWorker::scanCallback does
 // (laser_slam_ros/src/laser_slam_worker.cpp:133): one processPoseAndLaserScan per scan.
-//   usage: track_driver <dir> <n_scans> <icp_yaml> <nscan_in_sub_map> [<scans_on_device>]
+//   usage: track_driver <dir> <n_scans> <icp_yaml> <nscan_in_sub_map> [<scans_on_device> [<shadow_scan> <oracle_threads>]]
+// (built with -DLSGPU_TRACK_SHADOW -DLSGPU_TEST_SEAMS and linked with oracle/liblsoracle.so -- bench.py's value_track
+// section: at scan <shadow_scan> the CPU oracle aligns the very clouds the device just aligned, from the same guess, and a
+// "shadow" line reports its wall time and the difference of the two transforms)
 // <dir>/scan<i>.bin = float32 N x 4 (x,y,z,1), <dir>/poses.txt = one "t_ns qw qx qy qz px py pz" per scan
 // (odometry pose measurements).  Prints one line per produced factor / ICP result.
 #include <cstdio>
@@ -10,6 +13,11 @@
 #include <string>
 
 #include "laser_slam_amd/laser_track.hpp"
+#ifdef LSGPU_TRACK_SHADOW
+#include <chrono>
+#include <cmath>
+#include "../../oracle/icp_oracle.h"
+#endif
 
 using namespace laser_slam_amd;
 
@@ -44,6 +52,38 @@ int main(int argc, char** argv) {
   std::srand(4);
   try {
     LaserTrack track(p, 0u);
+#ifdef LSGPU_TRACK_SHADOW
+    const int shadow_scan = argc > 6 ? std::atoi(argv[6]) : -1;
+    const int oracle_threads = argc > 7 ? std::atoi(argv[7]) : 1;
+    int current_scan = -1;
+    track.icp().setSeed(7);   // every compute() reseeds the filters' draw stream: device and oracle consume the same draws
+    if (shadow_scan >= 0) track.icp().setComputeObserver([&](const ICP& self, const DataPoints& reading, const DataPoints& reference,
+                                       const TransformationParameters& T_init, const TransformationParameters& T_dev) {
+      if (current_scan != shadow_scan) return;
+      lso_config c;
+      lso_config_default(&c);
+      c.reading_sampling_prob = self.readingSamplingProb(); c.surface_normal_knn = self.surfaceNormalKnn();
+      c.surface_normal_ratio = self.surfaceNormalRatio(); c.trim_ratio = self.config().trim_ratio;
+      c.max_iterations = self.config().max_iterations; c.min_diff_rot = self.config().min_diff_rot;
+      c.min_diff_trans = self.config().min_diff_trans; c.smooth_length = self.config().smooth_length;
+      c.accum_double = 1; c.num_threads = oracle_threads;
+      TransformationParameters T = T_init;
+      lso_stats st;
+      const auto t0 = std::chrono::steady_clock::now();
+      const int rc = lso_icp_compute_full(&c, reading.features.data(), reading.getNbPoints(), reference.features.data(),
+                                          reference.getNbPoints(), T_init.data(), self.seed(), T.data(), &st);
+      const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+      double dt = 0, tr = 0;   // |translation difference|, rotation angle of R_oracle^T R_device
+      for (int r = 0; r < 3; ++r) {
+        dt += (double)(T[12 + r] - T_dev[12 + r]) * (double)(T[12 + r] - T_dev[12 + r]);
+        for (int k = 0; k < 3; ++k) tr += (double)T[4 * r + k] * (double)T_dev[4 * r + k];   // trace(Ro^T Rd) = sum of column dot products
+      }
+      const double dr = std::acos(std::fmin(1.0, std::fmax(-1.0, (tr - 1.0) / 2.0)));
+      std::printf("shadow scan %d rc %d oracle_ms %.3f oracle_iterations %d device_iterations %d dt %.3e dr %.3e reading %lld reference %lld threads %d\n",
+                  current_scan, rc, ms, st.iterations, self.lastStats().iterations, std::sqrt(dt), dr,
+                  (long long)reading.getNbPoints(), (long long)reference.getNbPoints(), oracle_threads);
+    });
+#endif
     std::ifstream poses(dir + "/poses.txt");
     for (int i = 0; i < n; ++i) {
       Pose pose;
@@ -58,6 +98,9 @@ int main(int argc, char** argv) {
       FactorList factors;
       Values values;
       bool is_prior = false;
+#ifdef LSGPU_TRACK_SHADOW
+      current_scan = i;
+#endif
       track.processPoseAndLaserScan(pose, scan, &factors, &values, &is_prior);
       std::printf("scan %d prior %d factors %zu values %zu numscans %zu\n", i, (int)is_prior, factors.size(),
                   values.size(), track.getNumScans());
