@@ -125,10 +125,11 @@ __global__ __launch_bounds__(256) void k_cone_gather(const float4* __restrict__ 
     g[0] = kPadCoord; g[4] = kPadCoord; g[8] = kPadCoord; map[j] = 0u;
     if (j == n) { gap_lo = (uint32_t)keys[n - 1] + 1u; gap_hi = nkeys + 1u; pos = (uint32_t)n; }   // everything behind the last key
   }
-  // ---- table: short gaps per thread, long ones by the wave
+  // ---- table: a thread whose key is the next one after its predecessor's writes one entry (the common case: one or two
+  // points per bin); longer gaps -- empty bins, empty rows -- by the whole wave
   const uint32_t glen = gap_hi - gap_lo;
-  if (glen <= 16u) for (uint32_t k = gap_lo; k < gap_hi; ++k) tab[k] = pos;
-  unsigned long long big = __ballot(glen > 16u);
+  if (glen == 1u) tab[gap_lo] = pos;
+  unsigned long long big = __ballot(glen > 1u);
   while (big) {
     const int src = __ffsll((long long)big) - 1;
     big &= big - 1;

@@ -142,6 +142,7 @@ struct lsgpu_icp {
   hipStream_t stream = nullptr;
   hipStream_t copy_stream = nullptr;   // lsgpu_icp_compute: the reading's H2D, overlapped with the reference filter
   hipEvent_t copy_done = nullptr;
+  hipEvent_t ref_up_done = nullptr;    // the reference's H2D on `stream`: the reading's copy queues behind it
   std::string err;
 
   // reference (steps 2-3)
@@ -184,7 +185,12 @@ struct lsgpu_icp {
   DevBuf<uint32_t> cone_map, cone_tab, cone_rowz_bits;
   DevBuf<float4> cone_rowz;
   ConeDev cone;
-  bool cone_ok = false;       // built for the current reference
+  bool cone_ok = false;       // built (or being built on the side stream: cone_pending) for the current reference
+  bool defer_cone = false;    // lsgpu_icp_compute: set_reference leaves the build to the side stream
+  bool cone_pending = false;  // the loop's stream has not yet waited for cone_done
+  hipEvent_t cone_done = nullptr;
+  float cone_zeta_lo = 0.f, cone_zeta_hi = 0.f;
+  bool cone_origin_inside = false;
   bool cone_off = false;      // this align stopped using it (too many lanes it could not serve)
   DevBuf<uint4> knn_dbg_wave;
   DevBuf<unsigned long long> knn_dbg;  // LSGPU_KNN_STATS builds: 8 counters
@@ -384,9 +390,11 @@ void lsgpu_icp_destroy(lsgpu_icp* h) {
   if (h->ev1) (void)hipEventDestroy(h->ev1);
   if (h->ev_state) (void)hipEventDestroy(h->ev_state);
   if (h->ev_tail) (void)hipEventDestroy(h->ev_tail);
+  if (h->cone_done) (void)hipEventDestroy(h->cone_done);
   if (h->h_pinned) (void)hipHostFree(h->h_pinned);
   if (h->draws_pinned) (void)hipHostFree(h->draws_pinned);
   if (h->copy_done) (void)hipEventDestroy(h->copy_done);
+  if (h->ref_up_done) (void)hipEventDestroy(h->ref_up_done);
   if (h->draws_done) (void)hipEventDestroy(h->draws_done);
   if (h->draw_stream) { (void)hipStreamSynchronize(h->draw_stream); (void)hipStreamDestroy(h->draw_stream); }
   if (h->side_done) (void)hipEventDestroy(h->side_done);
@@ -612,6 +620,10 @@ static int run_knn(lsgpu_icp* h, const Mat34& T, const IcpState* st, bool seed, 
   }
   if (capped && cone_iter && st && h->cone_ok && !h->cone_off) {
     // settled launch: every lane searches its own windows of the direction-sorted reference (lsgpu_cone.hip.h)
+    if (h->cone_pending) {   // (built on the side stream beside the first iterations: lsgpu_icp_compute)
+      HIPC(hipStreamWaitEvent(h->stream, h->cone_done, 0));
+      h->cone_pending = false;
+    }
     a.front_blocks = 0;
     hipLaunchKernelGGL(k_knn_cone<LSGPU_CONE_WAVES>, dim3((a.ntiles + LSGPU_CONE_WAVES - 1) / LSGPU_CONE_WAVES), dim3(LSGPU_CONE_WAVES * 64), 0, h->stream, a, h->cone);
     if (timed) HIPC(hipEventRecord(ev->b, h->stream));
@@ -701,6 +713,40 @@ static int run_select(lsgpu_icp* h, const float* d2, int n, uint32_t k, bool zer
                      h->sel_aux.p);
   if (use_comm && h->comm) RCCLC(rccl_api()->AllReduce(h->hist.p + 2 * kHistBins, h->hist.p + 2 * kHistBins, kHistBins, ncclUint32, ncclSum, h->comm, h->stream));
   HIPC(hipGetLastError());
+  return LSGPU_OK;
+}
+
+// Direction index of the current reference (lsgpu_cone.hip.h) on the handle's current stream / sort scratch: keys of
+// the Morton-sorted points, three radix passes, SoA copy + position map + (row, column) table + zeta range per row.
+static int build_cone_index(lsgpu_icp* h) {
+  const int64_t nr = h->nr;
+  h->cone_ok = false;
+  if (!(tuning().cone && h->cone_origin_inside && nr >= 1024)) return LSGPU_OK;
+  ConeDev c;
+  std::memset(&c, 0, sizeof(c));
+  c.ox = -h->mean[0]; c.oy = -h->mean[1]; c.oz = -h->mean[2];
+  c.rows = tuning().cone_rows; c.cols = tuning().cone_cols;
+  const float zr = std::max(h->cone_zeta_hi - h->cone_zeta_lo, 1e-3f);
+  c.z0 = h->cone_zeta_lo - 1e-5f - 1e-4f * zr;
+  c.rs = (float)c.rows / (zr * 1.0002f + 2e-5f);
+  c.cs = (float)c.cols * 0.25f;
+  const size_t npad = (((size_t)nr + 3) & ~(size_t)3) + kConePad, nkeys = (size_t)c.rows * (size_t)c.cols;
+  HIPC(h->cone_soa.reserve(3 * npad)); HIPC(h->cone_map.reserve(npad));
+  HIPC(h->cone_tab.reserve(nkeys + 1)); HIPC(h->cone_rowz_bits.reserve(2 * (size_t)c.rows)); HIPC(h->cone_rowz.reserve((size_t)c.rows));
+  HIPC(h->sc->keys.reserve(nr)); HIPC(h->sc->vals.reserve(nr));
+  c.soa = reinterpret_cast<const float4*>(h->cone_soa.p); c.map = h->cone_map.p; c.tab = h->cone_tab.p; c.rowz = h->cone_rowz.p;
+  hipLaunchKernelGGL(k_cone_keys, dim3(std::max(nblk(nr), nblk(2 * c.rows))), dim3(256), 0, h->cur, h->pts.p, nr, c,
+                     h->sc->keys.p, h->sc->vals.p, h->cone_rowz_bits.p);
+  int nbits = 1;
+  while (((size_t)1 << nbits) < nkeys) ++nbits;
+  const int rc = sort_pairs(h, nr, nbits);
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_cone_gather, dim3(nblk((int64_t)npad)), dim3(256), 0, h->cur, h->pts.p, h->sc->vals_alt.p,
+                     h->sc->keys_alt.p, nr, c, h->cone_soa.p, h->cone_map.p, h->cone_tab.p, h->cone_rowz_bits.p);
+  hipLaunchKernelGGL(k_cone_rowz, dim3(nblk(c.rows)), dim3(256), 0, h->cur, h->cone_rowz_bits.p, c.rows, h->cone_rowz.p);
+  HIPC(hipGetLastError());
+  h->cone = c;
+  h->cone_ok = true;
   return LSGPU_OK;
 }
 
@@ -828,34 +874,13 @@ int lsgpu_icp_set_reference(lsgpu_icp* h, const float* ref_xyz1, const float* re
   h->grid = g;
   h->nr = nr;
   h->nchunks = nchunks;
-  // ---- direction index for the settled launches (after k_cells_fill: the sort below reuses the Morton keys' buffers)
-  h->cone_ok = false;
-  if (tuning().cone && hg->origin_inside && nr >= 1024) {
-    ConeDev c;
-    std::memset(&c, 0, sizeof(c));
-    c.ox = -hg->mean[0]; c.oy = -hg->mean[1]; c.oz = -hg->mean[2];
-    c.rows = tuning().cone_rows; c.cols = tuning().cone_cols;
-    const float zr = std::max(hg->zeta_hi - hg->zeta_lo, 1e-3f);
-    c.z0 = hg->zeta_lo - 1e-5f - 1e-4f * zr;
-    c.rs = (float)c.rows / (zr * 1.0002f + 2e-5f);
-    c.cs = (float)c.cols * 0.25f;
-    const size_t npad = (((size_t)nr + 3) & ~(size_t)3) + kConePad, nkeys = (size_t)c.rows * (size_t)c.cols;
-    HIPC(h->cone_soa.reserve(3 * npad)); HIPC(h->cone_map.reserve(npad));
-    HIPC(h->cone_tab.reserve(nkeys + 1)); HIPC(h->cone_rowz_bits.reserve(2 * (size_t)c.rows)); HIPC(h->cone_rowz.reserve((size_t)c.rows));
-    c.soa = reinterpret_cast<const float4*>(h->cone_soa.p); c.map = h->cone_map.p; c.tab = h->cone_tab.p; c.rowz = h->cone_rowz.p;
-    hipLaunchKernelGGL(k_cone_keys, dim3(std::max(nblk(nr), nblk(2 * c.rows))), dim3(256), 0, h->stream, h->pts.p, nr, c,
-                       h->sc->keys.p, h->sc->vals.p, h->cone_rowz_bits.p);
-    int nbits = 1;
-    while (((size_t)1 << nbits) < nkeys) ++nbits;
-    rc = sort_pairs(h, nr, nbits);
+  // ---- direction index for the settled launches (after k_cells_fill: its sort reuses the Morton keys' buffers).
+  // lsgpu_icp_compute builds it on its side stream instead, beside the first iterations of the loop (defer_cone).
+  h->cone_ok = false; h->cone_pending = false;
+  h->cone_zeta_lo = hg->zeta_lo; h->cone_zeta_hi = hg->zeta_hi; h->cone_origin_inside = hg->origin_inside != 0;
+  if (!h->defer_cone) {
+    rc = build_cone_index(h);
     if (rc) return rc;
-    hipLaunchKernelGGL(k_cone_gather, dim3(nblk((int64_t)npad)), dim3(256), 0, h->stream, h->pts.p, h->sc->vals_alt.p,
-                       h->sc->keys_alt.p, nr, c, h->cone_soa.p, h->cone_map.p, h->cone_tab.p,
-                       h->cone_rowz_bits.p);
-    hipLaunchKernelGGL(k_cone_rowz, dim3(nblk(c.rows)), dim3(256), 0, h->stream, h->cone_rowz_bits.p, c.rows, h->cone_rowz.p);
-    HIPC(hipGetLastError());
-    h->cone = c;
-    h->cone_ok = true;
   }
   std::memset(&h->info, 0, sizeof(h->info));
   h->info.n_reference = nr;
@@ -1357,6 +1382,17 @@ int lsgpu_icp_compute(lsgpu_icp* h, const float* reading_xyz1, int64_t nq, const
   if (nq > 0x7FFFFFF0ll || nr > 0x7FFFFFF0ll) return LSGPU_BAD_ARG;
   HIPC(hipSetDevice(h->device));
   const double t0 = wall_ms();
+  // the draws of both filters, produced on a helper thread from now on: at most one per reference point, then one per
+  // reading point
+  DrawAhead draws;
+  {
+    const int rc0 = draws.begin(h, -1, (size_t)nr + (chain->reading_prob < 0.f ? (size_t)0 : (size_t)nq));
+    if (rc0) return rc0;
+  }
+  // step 1: reference filter (yaml:5-7)
+  const float4* src = nullptr;
+  int rc = stage_points(h, reference_xyz1, nr, h->flt_in, &src);
+  if (rc) return rc;
   // A reading handed over in HOST memory crosses PCIe while the reference is being filtered: its own stream, and its own
   // host thread, because a copy from pageable memory keeps the calling thread until the last chunk is staged
   // (SURVEY.md §8d counts H2D in scans/s).  The loop's stream waits for it right before the reading filter.
@@ -1368,6 +1404,13 @@ int lsgpu_icp_compute(lsgpu_icp* h, const float* reading_xyz1, int64_t nq, const
     if (!h->copy_done) HIPC(hipEventCreateWithFlags(&h->copy_done, hipEventDisableTiming));
     HIPC(h->flt_in2.reserve(nq));
     order_after_tail(h, h->copy_stream);
+    // the reference's own upload goes first: it is in front of everything, the reading is not needed before the reading
+    // filter, and two copies at once share the link (from pinned buffers they did: the pinned path was the slower one)
+    if (src != reinterpret_cast<const float4*>(reference_xyz1)) {
+      if (!h->ref_up_done) HIPC(hipEventCreateWithFlags(&h->ref_up_done, hipEventDisableTiming));
+      HIPC(hipEventRecord(h->ref_up_done, h->stream));
+      HIPC(hipStreamWaitEvent(h->copy_stream, h->ref_up_done, 0));
+    }
     auto upload = [&] {
       hipError_t e = hipSetDevice(h->device);
       if (e == hipSuccess) e = hipMemcpyAsync(h->flt_in2.p, reading_xyz1, (size_t)nq * 16, hipMemcpyHostToDevice, h->copy_stream);
@@ -1390,17 +1433,6 @@ int lsgpu_icp_compute(lsgpu_icp* h, const float* reading_xyz1, int64_t nq, const
       if (started && h->copy_stream) (void)hipStreamSynchronize(h->copy_stream);
     }
   } joiner{uploader, h, overlap_upload};
-  // the draws of both filters, produced on a helper thread from now on: at most one per reference point, then one per
-  // reading point
-  DrawAhead draws;
-  {
-    const int rc0 = draws.begin(h, -1, (size_t)nr + (chain->reading_prob < 0.f ? (size_t)0 : (size_t)nq));
-    if (rc0) return rc0;
-  }
-  // step 1: reference filter (yaml:5-7)
-  const float4* src = nullptr;
-  int rc = stage_points(h, reference_xyz1, nr, h->flt_in, &src);
-  if (rc) return rc;
   HIPC(h->flt_ref.reserve(nr));
   HIPC(h->flt_nrm.reserve(3 * nr));
   int64_t nrf = 0, nqf = 0;
@@ -1477,9 +1509,26 @@ int lsgpu_icp_compute(lsgpu_icp* h, const float* reading_xyz1, int64_t nq, const
       return LSGPU_OK;
     };
   }
+  h->defer_cone = side;
   rc = lsgpu_icp_set_reference(h, reinterpret_cast<const float*>(h->flt_ref.p), h->flt_nrm.p, nrf);
   h->hook_before_ref_sync = nullptr; h->hook_after_ref_sync = nullptr;
+  h->defer_cone = false;
   if (rc) return rc;
+  if (side) {
+    // the direction index of the reference is not needed before the loop's third search: built on the side stream (behind
+    // the reading's filter and query order, with that stream's sort scratch) it runs beside the first two iterations
+    // instead of in front of the loop (0.16 ms per 1 M-point compute)
+    if (!h->cone_done) HIPC(hipEventCreateWithFlags(&h->cone_done, hipEventDisableTiming));
+    side_guard.enter();
+    rc = build_cone_index(h);
+    if (!rc && h->cone_ok) {
+      const hipError_t e = hipEventRecord(h->cone_done, h->side_stream);
+      if (e != hipSuccess) { (void)hipGetLastError(); rc = LSGPU_HIP_ERROR; h->err = "compute: event record"; }
+      h->cone_pending = true;
+    }
+    side_guard.leave();
+    if (rc) return rc;
+  }
   if (!side) {
     rc = reading_ready(h->stream);
     if (!rc) rc = reading_filter();
