@@ -113,6 +113,10 @@ bool is_device_ptr(const void* p) {
   return a.type == hipMemoryTypeDevice || a.type == hipMemoryTypeManaged;
 }
 
+// (Uploading a PINNED cloud with a copy kernel over its device mapping instead of hipMemcpyAsync was measured slower:
+// 5.93 vs 5.48 ms per 1 M-point compute from host buffers; what had made the pinned path the slower one was two copies
+// sharing the link -- lsgpu_icp_compute now queues the reading's copy behind the reference's.)
+
 Mat34 to_mat34(const float* Tcm) {  // column-major 4x4 -> rows
   Mat34 m;
   for (int r = 0; r < 3; ++r)

@@ -73,12 +73,17 @@ int main(int argc, char** argv) {
       const int rc = lso_icp_compute_full(&c, reading.features.data(), reading.getNbPoints(), reference.features.data(),
                                           reference.getNbPoints(), T_init.data(), self.seed(), T.data(), &st);
       const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-      double dt = 0, tr = 0;   // |translation difference|, rotation angle of R_oracle^T R_device
-      for (int r = 0; r < 3; ++r) {
-        dt += (double)(T[12 + r] - T_dev[12 + r]) * (double)(T[12 + r] - T_dev[12 + r]);
-        for (int k = 0; k < 3; ++k) tr += (double)T[4 * r + k] * (double)T_dev[4 * r + k];   // trace(Ro^T Rd) = sum of column dot products
-      }
-      const double dr = std::acos(std::fmin(1.0, std::fmax(-1.0, (tr - 1.0) / 2.0)));
+      // |translation difference| and the rotation angle of D = R_oracle^T R_device, from D's skew part (acos of the trace
+      // loses half the digits near zero)
+      double dt = 0, D[3][3];
+      for (int r = 0; r < 3; ++r) dt += (double)(T[12 + r] - T_dev[12 + r]) * (double)(T[12 + r] - T_dev[12 + r]);
+      for (int a = 0; a < 3; ++a)
+        for (int b = 0; b < 3; ++b) {
+          D[a][b] = 0;
+          for (int k = 0; k < 3; ++k) D[a][b] += (double)T[4 * a + k] * (double)T_dev[4 * b + k];   // column a of Ro . column b of Rd
+        }
+      const double sx = 0.5 * (D[2][1] - D[1][2]), sy = 0.5 * (D[0][2] - D[2][0]), sz = 0.5 * (D[1][0] - D[0][1]);
+      const double dr = std::atan2(std::sqrt(sx * sx + sy * sy + sz * sz), 0.5 * (D[0][0] + D[1][1] + D[2][2] - 1.0));
       std::printf("shadow scan %d rc %d oracle_ms %.3f oracle_iterations %d device_iterations %d dt %.3e dr %.3e reading %lld reference %lld threads %d\n",
                   current_scan, rc, ms, st.iterations, self.lastStats().iterations, std::sqrt(dt), dr,
                   (long long)reading.getNbPoints(), (long long)reference.getNbPoints(), oracle_threads);
