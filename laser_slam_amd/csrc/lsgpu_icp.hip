@@ -225,6 +225,9 @@ struct lsgpu_icp {
 
   // device filters (lsgpu_ssn.hip.h)
   DevBuf<SsnSeg> ssn_seg_a, ssn_seg_b;
+  DevBuf<int> ssn_axis_a, ssn_axis_b;       // per segment: the axis its current order follows (segmented level sorts)
+  DevBuf<uint32_t> ssn_seg_fb;
+  DevBuf<SegBlock> ssn_blocktab;
   DevBuf<uint32_t> ssn_seg_of, ssn_box_pts, ssn_box_base, ssn_keep, ssn_out_pos, ssn_bb;
   DevBuf<float> ssn_box_normal, ssn_draws;
   DevBuf<float4> flt_in, flt_in2, flt_ref, flt_rd;
@@ -385,7 +388,7 @@ void lsgpu_icp_destroy(lsgpu_icp* h) {
 #endif
   h->pts.release();
   h->cone_soa.release(); h->cone_map.release(); h->cone_tab.release(); h->cone_rowz_bits.release(); h->cone_rowz.release();
-  h->nrm.release(); h->ref_inv.release(); h->tables.release(); h->flags.release(); h->cidx.release(); h->bounds.release(); h->chunks.release(); h->soa.release(); h->soa_base.release(); h->soa_cnt4.release(); h->soa_first.release(); h->prev.release(); h->state.release(); h->lb.release(); h->cell_cache.release(); h->cell_tags.release(); h->ssn_seg_a.release(); h->ssn_seg_b.release(); h->ssn_seg_of.release(); h->ssn_box_pts.release(); h->ssn_box_base.release(); h->ssn_keep.release(); h->ssn_out_pos.release(); h->ssn_bb.release(); h->ssn_box_normal.release(); h->ssn_draws.release(); h->flt_in.release(); h->flt_in2.release(); h->flt_ref.release(); h->flt_rd.release(); h->flt_nrm.release(); h->chk_hist.release(); h->trace_dev.release(); h->knn_dbg.release(); h->knn_dbg_wave.release(); h->stat_partials.release(); h->geom.release();
+  h->nrm.release(); h->ref_inv.release(); h->tables.release(); h->flags.release(); h->cidx.release(); h->bounds.release(); h->chunks.release(); h->soa.release(); h->soa_base.release(); h->soa_cnt4.release(); h->soa_first.release(); h->prev.release(); h->state.release(); h->lb.release(); h->cell_cache.release(); h->cell_tags.release(); h->ssn_seg_a.release(); h->ssn_seg_b.release(); h->ssn_axis_a.release(); h->ssn_axis_b.release(); h->ssn_seg_fb.release(); h->ssn_blocktab.release(); h->ssn_seg_of.release(); h->ssn_box_pts.release(); h->ssn_box_base.release(); h->ssn_keep.release(); h->ssn_out_pos.release(); h->ssn_bb.release(); h->ssn_box_normal.release(); h->ssn_draws.release(); h->flt_in.release(); h->flt_in2.release(); h->flt_ref.release(); h->flt_rd.release(); h->flt_nrm.release(); h->chk_hist.release(); h->trace_dev.release(); h->knn_dbg.release(); h->knn_dbg_wave.release(); h->stat_partials.release(); h->geom.release();
   h->counters.release(); h->ang_cells.release(); h->sel_aux.release(); h->sel_win.release(); h->spread_flag.release(); h->spread_list.release(); h->spread_cnt.release(); h->q_in.release(); h->rdq.release(); h->ids.release(); h->d2.release();
   h->ids_io.release(); h->d2_io.release(); h->strag.release(); h->hist.release();
   h->sel.release(); h->ne_partials.release(); h->ne_gpartials.release(); h->ne_tickets.release(); h->ne_out.release(); h->limit_dev.release();
@@ -1241,16 +1244,59 @@ static int ssn_device(lsgpu_icp* h, const float4* src, int64_t n, int knn, float
     int64_t c = n;
     while (glevels < levels && !(lds_finish && c <= kSsnLdsMax && levels - glevels <= kSsnLdsLevels)) { c -= c / 2; ++glevels; }
   }
-  for (int L = 0; L < glevels; ++L) {
-    hipLaunchKernelGGL(k_ssn_keys, dim3(nblk(n)), dim3(256), 0, h->stream, src, (int)n, idx,
-                       L ? h->ssn_seg_of.p : (const uint32_t*)nullptr, cur, knn, h->sc->keys.p, h->sc->vals.p);
-    int rc = sort_pairs(h, n, 32 + L);
-    if (rc) return rc;
-    idx = h->sc->vals_alt.p;
-    const int ns = 1 << L;
-    hipLaunchKernelGGL(k_ssn_split, dim3(nblk(ns)), dim3(256), 0, h->stream, src, idx, cur, ns, knn, nxt);
-    hipLaunchKernelGGL(k_ssn_assign, dim3(nblk(n)), dim3(256), 0, h->stream, (int)n, cur, knn, h->ssn_seg_of.p, L == 0 ? 1 : 0);
-    std::swap(cur, nxt);
+  if (tuning().ssn_full_sort) {   // rounds 1-3: the whole cloud sorted by (segment, coordinate) at every level
+    for (int L = 0; L < glevels; ++L) {
+      hipLaunchKernelGGL(k_ssn_keys, dim3(nblk(n)), dim3(256), 0, h->stream, src, (int)n, idx,
+                         L ? h->ssn_seg_of.p : (const uint32_t*)nullptr, cur, knn, h->sc->keys.p, h->sc->vals.p);
+      int rc = sort_pairs(h, n, 32 + L);
+      if (rc) return rc;
+      idx = h->sc->vals_alt.p;
+      const int ns = 1 << L;
+      hipLaunchKernelGGL(k_ssn_split, dim3(nblk(ns)), dim3(256), 0, h->stream, src, idx, cur, ns, knn, nxt,
+                         (const int*)nullptr, (int*)nullptr);
+      hipLaunchKernelGGL(k_ssn_assign, dim3(nblk(n)), dim3(256), 0, h->stream, (int)n, cur, knn, h->ssn_seg_of.p, L == 0 ? 1 : 0);
+      std::swap(cur, nxt);
+    }
+  } else if (glevels > 0) {
+    // segmented sorts (lsgpu_segsort.hip.h): per level only the segments that cut along a new axis, four passes of
+    // (uint32 key, uint32 index) pairs, every segment inside its own range of the arrays
+    const size_t nseg_g = (size_t)1 << glevels;
+    const int cap = (int)(n / kSegTile + (int64_t)(nseg_g / 2) + 2);
+    HIPC(h->sc->vals_alt.reserve(n));
+    HIPC(h->ssn_axis_a.reserve(nseg_g)); HIPC(h->ssn_axis_b.reserve(nseg_g)); HIPC(h->ssn_seg_fb.reserve(nseg_g));
+    HIPC(h->ssn_blocktab.reserve((size_t)cap)); HIPC(h->sc->sort_hist.reserve((size_t)256 * cap + 256 + 4));
+    uint32_t* keyA = reinterpret_cast<uint32_t*>(h->sc->keys.p);
+    uint32_t* keyB = keyA + n;
+    uint32_t* valA = h->sc->vals.p;
+    uint32_t* valB = h->sc->vals_alt.p;
+    uint32_t* bh = h->sc->sort_hist.p;
+    uint32_t* dtot = bh + (size_t)256 * cap;
+    uint32_t* nblocks_dev = dtot + 256;
+    int* ax_cur = h->ssn_axis_a.p;
+    int* ax_nxt = h->ssn_axis_b.p;
+    HIPC(hipMemsetAsync(ax_cur, 0xFF, sizeof(int), h->stream));   // the root's order follows no axis (-1)
+    for (int L = 0; L < glevels; ++L) {
+      const int ns = 1 << L;
+      const int grid = (int)std::min<int64_t>(cap, n / kSegTile + ns + 1);
+      hipLaunchKernelGGL(k_ssn_plan, dim3(1), dim3(256), 0, h->stream, cur, ns, knn, ax_cur, h->ssn_seg_fb.p,
+                         h->ssn_blocktab.p, nblocks_dev);
+      hipLaunchKernelGGL(k_ssn_keys32, dim3(nblk(n)), dim3(256), 0, h->stream, src, (int)n, valA, h->ssn_seg_of.p, cur,
+                         h->ssn_seg_fb.p, L == 0 ? 1 : 0, keyA);
+      for (int pass = 0; pass < 4; ++pass) {
+        const uint32_t* kin = (pass & 1) ? keyB : keyA; const uint32_t* vin = (pass & 1) ? valB : valA;
+        uint32_t* kout = (pass & 1) ? keyA : keyB; uint32_t* vout = (pass & 1) ? valA : valB;
+        hipLaunchKernelGGL(k_seg_hist<kSegItems>, dim3(grid), dim3(256), 0, h->stream, kin, h->ssn_blocktab.p, nblocks_dev, 8 * pass, bh, cap);
+        hipLaunchKernelGGL(k_seg_scan, dim3(256), dim3(256), 0, h->stream, bh, cap, nblocks_dev, dtot);
+        hipLaunchKernelGGL((k_seg_scatter<kSegItems>), dim3(grid), dim3(256), 0, h->stream, kin, vin, kout, vout,
+                           h->ssn_blocktab.p, nblocks_dev, 8 * pass, bh, dtot, cap);
+      }
+      idx = valA;
+      hipLaunchKernelGGL(k_ssn_split, dim3(nblk(ns)), dim3(256), 0, h->stream, src, idx, cur, ns, knn, nxt, (const int*)ax_cur, ax_nxt);
+      hipLaunchKernelGGL(k_ssn_assign, dim3(nblk(n)), dim3(256), 0, h->stream, (int)n, cur, knn, h->ssn_seg_of.p, L == 0 ? 1 : 0);
+      std::swap(cur, nxt);
+      std::swap(ax_cur, ax_nxt);
+    }
+    HIPC(hipGetLastError());
   }
   if (glevels < levels) {
     if (glevels == 0) {  // the whole cloud fits one workgroup: identity order to start from

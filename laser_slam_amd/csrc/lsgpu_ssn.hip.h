@@ -13,6 +13,7 @@
 #pragma once
 #include "lsgpu_common.hip.h"
 #include "lsgpu_box_normal.h"
+#include "lsgpu_segsort.hip.h"
 
 namespace lsgpu {
 
@@ -95,25 +96,110 @@ __global__ __launch_bounds__(256) void k_ssn_keys(const float4* __restrict__ p, 
   vals[pos] = i;
 }
 
-// children of every segment of this level (2s, 2s+1); a finished segment carries over as child 2s
+// children of every segment of this level (2s, 2s+1); a finished segment carries over as child 2s.
+// axis_in / axis_out (nullable): the axis whose stable order a segment's points are in -- a child is a contiguous half of
+// its parent's sorted order, so it inherits the parent's cut axis (lsgpu_segsort.hip.h: a child that cuts along the same
+// axis again needs no sort).
 __global__ __launch_bounds__(256) void k_ssn_split(const float4* __restrict__ p, const uint32_t* __restrict__ idx,
                                                    const SsnSeg* __restrict__ segs, int nseg, int knn,
-                                                   SsnSeg* __restrict__ out) {
+                                                   SsnSeg* __restrict__ out, const int* __restrict__ axis_in = nullptr,
+                                                   int* __restrict__ axis_out = nullptr) {
   const int s = blockIdx.x * 256 + threadIdx.x;
   if (s >= nseg) return;
   const SsnSeg sg = segs[s];
   SsnSeg a = sg, b = sg;
+  int ax = axis_in ? axis_in[s] : -1;
   if (sg.count > (uint32_t)knn) {
     const int cut = ssn_cut_axis(sg);
     const uint32_t right = sg.count / 2, left = sg.count - right;
     const float cutval = coord_of(p[idx[sg.start + left]], cut);
     a.count = left; a.hi[cut] = cutval;
     b.start = sg.start + left; b.count = right; b.lo[cut] = cutval;
+    ax = cut;
   } else {
     b.start = sg.start + sg.count; b.count = 0;
   }
   out[2 * s] = a;
   out[2 * s + 1] = b;
+  if (axis_out) { axis_out[2 * s] = ax; axis_out[2 * s + 1] = ax; }
+}
+
+// ---- segmented sorts of a level (lsgpu_segsort.hip.h)
+constexpr int kSegItems = 8;
+constexpr uint32_t kSegTile = 256u * kSegItems;   // elements per block
+constexpr uint32_t kSegNone = 0xFFFFFFFFu;
+
+// ONE block: which segments of the level have to be sorted (they still split, and along another axis than the one their
+// order already follows), their blocks, the block table.  seg_fb[s] = first block of segment s or kSegNone.
+__global__ __launch_bounds__(256) void k_ssn_plan(const SsnSeg* __restrict__ segs, int ns, int knn,
+                                                  const int* __restrict__ axis, uint32_t* __restrict__ seg_fb,
+                                                  SegBlock* __restrict__ tab, uint32_t* __restrict__ nblocks_dev) {
+  __shared__ uint32_t wsum[4];
+  __shared__ uint32_t big_list[256];
+  __shared__ uint32_t big_n;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  uint32_t carry = 0u;
+  for (int s0 = 0; s0 < ns; s0 += 256) {
+    const int s = s0 + (int)threadIdx.x;
+    SsnSeg sg;
+    sg.start = 0; sg.count = 0;
+    uint32_t nb = 0u;
+    if (s < ns) {
+      sg = segs[s];
+      const bool need = sg.count > (uint32_t)knn && ssn_cut_axis(sg) != axis[s];
+      nb = need ? (sg.count + kSegTile - 1u) / kSegTile : 0u;
+    }
+    const uint32_t incl = wave_scan_incl_u32(nb, lane);
+    if (lane == 63) wsum[w] = incl;
+    if (threadIdx.x == 0) big_n = 0u;
+    __syncthreads();
+    uint32_t before = carry;
+    for (int ww = 0; ww < w; ++ww) before += wsum[ww];
+    const uint32_t fb = before + incl - nb;
+    if (s < ns) seg_fb[s] = nb ? fb : kSegNone;
+    // the blocks of this segment: a few -> this thread; many (the top levels) -> the whole block, below
+    if (nb > 8u) {
+      big_list[atomicAdd(&big_n, 1u)] = (uint32_t)threadIdx.x;
+    } else {
+      for (uint32_t k = 0; k < nb; ++k) {
+        SegBlock e;
+        e.first = sg.start + k * kSegTile; e.count = min(kSegTile, sg.count - k * kSegTile);
+        e.seg_start = sg.start; e.fb = fb; e.nb = nb; e.pad[0] = e.pad[1] = e.pad[2] = 0u;
+        tab[fb + k] = e;
+      }
+    }
+    carry += wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    __syncthreads();
+    const uint32_t nbig = big_n;
+    for (uint32_t q = 0; q < nbig; ++q) {
+      const int sb = s0 + (int)big_list[q];
+      const SsnSeg g = segs[sb];
+      const uint32_t gnb = (g.count + kSegTile - 1u) / kSegTile, gfb = seg_fb[sb];
+      for (uint32_t k = threadIdx.x; k < gnb; k += 256u) {
+        SegBlock e;
+        e.first = g.start + k * kSegTile; e.count = min(kSegTile, g.count - k * kSegTile);
+        e.seg_start = g.start; e.fb = gfb; e.nb = gnb; e.pad[0] = e.pad[1] = e.pad[2] = 0u;
+        tab[gfb + k] = e;
+      }
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) *nblocks_dev = carry;
+}
+
+// 32-bit level keys: the ordered cut coordinate of every point whose segment is sorted at this level; the other points
+// are not touched (their segments keep their order).  idx == nullptr: level 0, identity order (written to vals).
+__global__ __launch_bounds__(256) void k_ssn_keys32(const float4* __restrict__ p, int n, uint32_t* __restrict__ idx,
+                                                    const uint32_t* __restrict__ seg_of, const SsnSeg* __restrict__ segs,
+                                                    const uint32_t* __restrict__ seg_fb, int first_level,
+                                                    uint32_t* __restrict__ keys) {
+  const int pos = blockIdx.x * 256 + threadIdx.x;
+  if (pos >= n) return;
+  const uint32_t s = first_level ? 0u : seg_of[pos];
+  uint32_t i = (uint32_t)pos;
+  if (first_level) idx[pos] = i; else i = idx[pos];
+  if (seg_fb[s] == kSegNone) return;
+  keys[pos] = float_order_key(coord_of(p[i], ssn_cut_axis(segs[s])));
 }
 
 __global__ __launch_bounds__(256) void k_ssn_assign(int n, const SsnSeg* __restrict__ parents, int knn,

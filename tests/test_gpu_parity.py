@@ -350,7 +350,7 @@ def test_experiment_switches_do_not_change_results():
                 {"LSGPU_NO_PREDICT": "1"}, dict(tile, LSGPU_NO_PREDICT="1"),
                 {"LSGPU_CONE_ROWS": "32", "LSGPU_CONE_COLS": "1024"}, {"LSGPU_CONE_ROWS": "512", "LSGPU_CONE_COLS": "32768"},
                 {"LSGPU_ROCPRIM_SORT": "1"}, {"LSGPU_SORT_ITEMS": "4"}, {"LSGPU_NO_SEED_CAP": "1"}, {"LSGPU_NO_LAZY": "1"}, {"LSGPU_NO_SIDE_STREAM": "1"}, {"LSGPU_NO_LOOKAHEAD": "1"},
-                dict(tile, LSGPU_FRONT_GUESS="8"), {"LSGPU_SSN_GLOBAL": "1"},
+                dict(tile, LSGPU_FRONT_GUESS="8"), {"LSGPU_SSN_GLOBAL": "1"}, {"LSGPU_SSN_FULL_SORT": "1"}, {"LSGPU_SSN_FULL_SORT": "1", "LSGPU_SSN_GLOBAL": "1"},
                 {"LSGPU_QUERY_ORDER": "0"}]
     # the measured-slower variants only exist in the -DLSGPU_EXPERIMENTS build (devtools/build.sh); when that build is
     # around it has to give the same bits as the product, switch by switch
