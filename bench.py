@@ -263,6 +263,7 @@ def main():
     with icp.IcpHandle(None, local_rank) as hf:               # chain (F): ratio 1.0, knn 10; the device filter
         d_ref, d_nrm = hf.filter_reference(torch.from_numpy(ref).cuda(), 10, 1.0, 0)  # == host filter == oracle
     d_ref, d_nrm = d_ref.contiguous().clone(), d_nrm.contiguous().clone()
+    rd_whole = rd
     if args.split:
         rd = rd[sharding.split_shard(rd.shape[0], rank, world)]
     d_rd = torch.from_numpy(rd).cuda()
@@ -328,8 +329,8 @@ def main():
                       "ms_per_icp_iteration": align_ms / max(loop_iters, 1), "iterations": loop_iters / loop_steps,
                       "workload": "set_reference + align on the FILTERED clouds resident in HBM (steps 2-7 of ICP::compute: the north-star kernels)"}
     prof_steps = max(1, min(args.steps, 3))
-    sel_ms = ne_ms = knn_ms = knn_main_ms = knn_fb_ms = 0.0
-    knn_launches = strag = 0
+    sel_ms = ne_ms = knn_ms = knn_main_ms = knn_fb_ms = comm_ms = 0.0
+    knn_launches = strag = comm_calls = 0
     step_loop(hp)
     for _ in range(prof_steps):
         Tp, stp = step_loop(hp)
@@ -340,6 +341,8 @@ def main():
         strag += stp.stragglers
         sel_ms += stp.t_select_ms
         ne_ms += stp.t_ne_ms
+        comm_ms += stp.t_comm_ms
+        comm_calls += stp.comm_calls
     loop_equals_compute = bool(np.array_equal(Tp, T))   # (chain F keeps every point: the loop on filtered clouds is the same alignment)
 
     # ---- the same compute handed HOST buffers (H2D + D2H inclusive), chains F and P, pageable and pinned
@@ -407,6 +410,35 @@ def main():
         out["value_is"] = ("the whole ICP::compute (lsgpu_icp_compute: reference filter + grid + reading filter + loop) on RAW clouds "
                            "resident in HBM; value_loop = the loop alone on filtered clouds; value_e2e = the same compute from host "
                            "buffers (PCIe inclusive)")
+    if args.split:
+        # what the exchange costs ("all-reduce us / iteration"): HIP events around every RCCL call of
+        # the profiled steps; and, on rank 0, the SAME map, reading and guess through a plain handle (no communicator,
+        # the whole reading on this GPU) -- split mode against the plain path on identical inputs, side by side
+        out["split_exchange"] = {"allreduce_us_per_iteration": comm_ms / max(knn_launches, 1) * 1e3,
+                                 "rccl_calls_per_iteration": comm_calls / max(knn_launches, 1),
+                                 "timed_in": "%d profiled steps (HIP events around every collective of the loop)" % prof_steps,
+                                 "knn_us_per_launch": knn_ms / max(knn_launches, 1) * 1e3,
+                                 "select_us_per_iteration": sel_ms / max(knn_launches, 1) * 1e3,
+                                 "ne_update_us_per_iteration": ne_ms / max(knn_launches, 1) * 1e3}
+        if rank == 0:
+            cfg_q = IcpConfig()
+            C.memmove(C.byref(cfg_q), C.byref(cfg_p), C.sizeof(cfg_p))
+            d_whole = torch.from_numpy(rd_whole).cuda()
+            with icp.IcpHandle(cfg_q, local_rank) as hq:
+                ts, kn, se, ne, its, kl = [], 0.0, 0.0, 0.0, 0, 0
+                for rep in range(prof_steps + 1):
+                    torch.cuda.synchronize()
+                    tq = time.perf_counter()
+                    hq.set_reference(d_ref, d_nrm)
+                    Tq, stq = hq.align(d_whole, T_init)
+                    ts.append((time.perf_counter() - tq) * 1e3)
+                    if rep:
+                        kn += stq.t_knn_ms; se += stq.t_select_ms; ne += stq.t_ne_ms; its += stq.iterations; kl += stq.knn_launches
+            out["split_exchange"]["plain_same_inputs"] = {
+                "ms_per_step": float(np.median(ts[1:])), "iterations": its / prof_steps, "knn_us_per_launch": kn / max(kl, 1) * 1e3,
+                "select_us_per_iteration": se / max(kl, 1) * 1e3, "ne_update_us_per_iteration": ne / max(kl, 1) * 1e3,
+                "transform_equals_split": bool(np.allclose(Tq, T, atol=1e-6)),
+                "what": "set_reference + align of the whole reading on one GPU without a communicator (profiled handle: events cost a few per cent)"}
     out["config"] = {"workload": workload, "n_reading": nq, "n_reference": nr, "pairs_per_gpu_per_step": 1,
                      "sharding": ("one scan pair per step, reading sharded over ranks, RCCL all-reduce of the select tables + 29 f64 "
                                   "per iteration" if args.split else "one scan pair per rank, no collective")}

@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define LSGPU_ABI_VERSION 3
+#define LSGPU_ABI_VERSION 4
 
 /* Return codes.  NO_CONVERGENCE is PointMatcher::ConvergenceError: laser_track.cpp:499-502 catches it
  * and keeps the odometry guess; incremental_estimator.cpp:108 lets it propagate. */
@@ -82,7 +82,8 @@ typedef struct lsgpu_icp_stats {
   int     committed_select_iterations;  /* iterations whose trim limit came from the search kernels' own tables (no select launch) */
   int     spread_tiles;                 /* 64-query tiles whose queries share no candidates (searched row-wise by the front of the tile kernel) */
   int     reference_reused;             /* lsgpu_icp_align_batch: 1 if this pair kept the previous pair's reference structures (no set_reference) */
-  int     pad2_;
+  int     comm_calls;                   /* split-scan mode, profile_kernels=1: RCCL calls of the loop ... */
+  double  t_comm_ms;                    /* ... and the time between their first and last kernel on the stream, summed */
 } lsgpu_icp_stats;
 
 /* One record per iteration (optional parity/debug trace; replaces the VTKFileInspector dump of

@@ -72,7 +72,8 @@ class IcpStats(C.Structure):
         ("committed_select_iterations", C.c_int),
         ("spread_tiles", C.c_int),
         ("reference_reused", C.c_int),
-        ("pad2_", C.c_int),
+        ("comm_calls", C.c_int),
+        ("t_comm_ms", C.c_double),
     ]
 
 

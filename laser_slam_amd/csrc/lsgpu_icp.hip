@@ -261,6 +261,10 @@ struct lsgpu_icp {
   bool tail_pending = false;
   struct KnnEv { hipEvent_t a, b, c, d, e; bool second; };  // before kNN, after the main pass, after the wave-per-query pass (recorded only if one was launched: `second`), after the select, after the normal equations
   std::vector<KnnEv> knn_events;   // pool, reused across aligns
+  // split-scan mode with profile_kernels: an event pair around every RCCL call of the loop (stats.t_comm_ms)
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> comm_events;
+  size_t comm_events_used = 0;
+  bool time_comm = false;
   size_t knn_events_used = 0;
   std::vector<lsgpu_iter_trace> trace;
 };
@@ -285,6 +289,21 @@ static int wait_stream(lsgpu_icp* h) {
       return LSGPU_HIP_ERROR;
     }
     if (spin > 200) std::this_thread::sleep_for(std::chrono::microseconds(20));
+  }
+}
+
+// event pair around a collective (only when the align is profiled)
+static void comm_mark(lsgpu_icp* h, bool begin) {
+  if (!h->time_comm) return;
+  if (begin) {
+    if (h->comm_events_used == h->comm_events.size()) {
+      hipEvent_t a = nullptr, b = nullptr;
+      if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) { (void)hipGetLastError(); h->time_comm = false; return; }
+      h->comm_events.emplace_back(a, b);
+    }
+    (void)hipEventRecord(h->comm_events[h->comm_events_used].first, h->stream);
+  } else {
+    (void)hipEventRecord(h->comm_events[h->comm_events_used++].second, h->stream);
   }
 }
 
@@ -392,6 +411,7 @@ void lsgpu_icp_destroy(lsgpu_icp* h) {
   h->counters.release(); h->ang_cells.release(); h->sel_aux.release(); h->sel_win.release(); h->spread_flag.release(); h->spread_list.release(); h->spread_cnt.release(); h->q_in.release(); h->rdq.release(); h->ids.release(); h->d2.release();
   h->ids_io.release(); h->d2_io.release(); h->strag.release(); h->hist.release();
   h->sel.release(); h->ne_partials.release(); h->ne_gpartials.release(); h->ne_tickets.release(); h->ne_out.release(); h->limit_dev.release();
+  for (auto& e : h->comm_events) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
   for (auto& e : h->knn_events) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); (void)hipEventDestroy(e.c); (void)hipEventDestroy(e.d); (void)hipEventDestroy(e.e); }
   if (h->ev0) (void)hipEventDestroy(h->ev0);
   if (h->ev1) (void)hipEventDestroy(h->ev1);
@@ -711,14 +731,14 @@ static int run_select(lsgpu_icp* h, const float* d2, int n, uint32_t k, bool zer
   const int nb = std::min(kHistBlocks, nblk(n));
   const int pr = predicted && st ? 1 : 0;
   hipLaunchKernelGGL(k_hist1, dim3(nb), dim3(256), 0, h->stream, d2, n, h->hist.p, st, pr);
-  if (use_comm && h->comm) RCCLC(rccl_api()->AllReduce(h->hist.p, h->hist.p, kHistBins, ncclUint32, ncclSum, h->comm, h->stream));
+  if (use_comm && h->comm) { comm_mark(h, true); RCCLC(rccl_api()->AllReduce(h->hist.p, h->hist.p, kHistBins, ncclUint32, ncclSum, h->comm, h->stream)); comm_mark(h, false); }
   hipLaunchKernelGGL(k_hist_refine<2>, dim3(nb), dim3(256), 0, h->stream, d2, n, h->hist.p,
                      h->sel.p, h->sel.p + 1, h->hist.p + kHistBins, st, pr, h->sel_aux.p);
-  if (use_comm && h->comm) RCCLC(rccl_api()->AllReduce(h->hist.p + kHistBins, h->hist.p + kHistBins, kHistBins, ncclUint32, ncclSum, h->comm, h->stream));
+  if (use_comm && h->comm) { comm_mark(h, true); RCCLC(rccl_api()->AllReduce(h->hist.p + kHistBins, h->hist.p + kHistBins, kHistBins, ncclUint32, ncclSum, h->comm, h->stream)); comm_mark(h, false); }
   hipLaunchKernelGGL(k_hist_refine<3>, dim3(nb), dim3(256), 0, h->stream, d2, n,
                      h->hist.p + kHistBins, h->sel.p + 1, h->sel.p + 2, h->hist.p + 2 * kHistBins, st, pr,
                      h->sel_aux.p);
-  if (use_comm && h->comm) RCCLC(rccl_api()->AllReduce(h->hist.p + 2 * kHistBins, h->hist.p + 2 * kHistBins, kHistBins, ncclUint32, ncclSum, h->comm, h->stream));
+  if (use_comm && h->comm) { comm_mark(h, true); RCCLC(rccl_api()->AllReduce(h->hist.p + 2 * kHistBins, h->hist.p + 2 * kHistBins, kHistBins, ncclUint32, ncclSum, h->comm, h->stream)); comm_mark(h, false); }
   HIPC(hipGetLastError());
   return LSGPU_OK;
 }
@@ -1931,6 +1951,8 @@ int lsgpu_icp_align(lsgpu_icp* h, const float* reading_xyz1, int64_t nq, const f
   HIPC(hipSetDevice(h->device));
   const double t0 = wall_ms();
   h->knn_events_used = 0;
+  h->comm_events_used = 0;
+  h->time_comm = h->comm != nullptr && h->cfg.profile_kernels != 0;
   h->tail_pending = false;   // (from here on everything is behind it on h->stream itself)
 
   // step 5: T_refMean_dataIn = T_refIn_refMean^-1 * T_init (pure translation inverse)
@@ -2039,11 +2061,13 @@ int lsgpu_icp_align(lsgpu_icp* h, const float* reading_xyz1, int64_t nq, const f
     }
     if (committed && h->comm) {  // one exchange for the whole select: {counts below, 11-bit histogram, window table}
       RcclApi* api = rccl_api();
+      comm_mark(h, true);
       if (api->GroupStart) RCCLC(api->GroupStart());
       RCCLC(api->AllReduce(h->sel_aux.p, h->sel_aux.p, kSelFailFlag, ncclUint32, ncclSum, h->comm, h->stream));
       RCCLC(api->AllReduce(h->hist.p + kHistBins, h->hist.p + kHistBins, kHistBins, ncclUint32, ncclSum, h->comm, h->stream));
       RCCLC(api->AllReduce(h->sel_win.p, h->sel_win.p, (size_t)kSelWinRows * 512, ncclUint32, ncclSum, h->comm, h->stream));
       if (api->GroupEnd) RCCLC(api->GroupEnd());
+      comm_mark(h, false);
     }
     if (!committed) {
       r = run_select(h, h->d2.p, (int)nq, k, false /* armed by k_align_init / k_seed_cap / the previous k_normal_eq_loop */,
@@ -2061,10 +2085,12 @@ int lsgpu_icp_align(lsgpu_icp* h, const float* reading_xyz1, int64_t nq, const f
                        h->chk_hist.p, h->trace_dev.p, max_it, capped ? 1 : 0, (h->comm || split_update) ? 0 : 1,
                        h->sel_aux.p, h->sel_win.p, committed ? 1 : 0, h->spread_cnt.p);   // 6d (+6e)
     if (h->comm || split_update) {   // split scan: every rank gets the sums over all shards (the limit, slot 29, is already global)
+      if (h->comm) comm_mark(h, true);
       if (h->comm && rccl_api()->AllReduce(h->ne_out.p, h->ne_out.p, kNe, ncclDouble, ncclSum, h->comm, h->stream) != ncclSuccess) {
         h->err = "RCCL all-reduce of the normal equations failed";
         return LSGPU_HIP_ERROR;
       }
+      if (h->comm) comm_mark(h, false);
       hipLaunchKernelGGL(k_icp_update, dim3(1), dim3(64), 0, h->stream, h->state.p, h->ne_out.p,
                          h->chk_hist.p, h->trace_dev.p, max_it, capped ? 1 : 0, h->sel_aux.p);           // 6d+6e
     }
@@ -2204,6 +2230,13 @@ int lsgpu_icp_align(lsgpu_icp* h, const float* reading_xyz1, int64_t nq, const f
       if (hipEventElapsedTime(&m3, e.second ? e.c : e.b, e.d) == hipSuccess && hipEventElapsedTime(&m4, e.d, e.e) == hipSuccess) { st.t_select_ms += m3; st.t_ne_ms += m4; }
       else (void)hipGetLastError();
       if (t < h->trace.size()) { h->trace[t].knn_main_us = m1 * 1e3f; h->trace[t].knn_fallback_us = m2 * 1e3f; ++t; }
+    }
+  }
+  if (h->time_comm) {   // time inside the collectives (launches enqueued behind the end exit at once and add next to nothing)
+    for (size_t i = 0; i < h->comm_events_used; ++i) {
+      float m = 0.f;
+      if (hipEventElapsedTime(&m, h->comm_events[i].first, h->comm_events[i].second) == hipSuccess) { st.t_comm_ms += m; st.comm_calls++; }
+      else (void)hipGetLastError();
     }
   }
   st.pad_ = sel_retries;  // (select predictions that missed; informational)

@@ -27,7 +27,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(L, name), f"{name} declared in include/lsgpu_icp.h but not exported"
     assert sorted(_lib.ABI_SYMBOLS) == declared
-    assert L.lsgpu_abi_version() == 3
+    assert L.lsgpu_abi_version() == 4
 
 
 def test_config_presets_match_yaml_and_setdefault():
