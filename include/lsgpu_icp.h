@@ -84,6 +84,9 @@ typedef struct lsgpu_icp_stats {
   int     reference_reused;             /* lsgpu_icp_align_batch: 1 if this pair kept the previous pair's reference structures (no set_reference) */
   int     comm_calls;                   /* split-scan mode, profile_kernels=1: RCCL calls of the loop ... */
   double  t_comm_ms;                    /* ... and the time between their first and last kernel on the stream, summed */
+  int     direction_index_launches;     /* searches served by the direction index (k_knn_cone) instead of the voxel grid */
+  float   direction_index_occupancy;    /* reference points per occupied bin of that index (0: not built / not looked at);
+                                           above LSGPU_CONE_MAX_OCC (7) the settled searches stay on the voxel grid */
 } lsgpu_icp_stats;
 
 /* One record per iteration (optional parity/debug trace; replaces the VTKFileInspector dump of

@@ -74,6 +74,8 @@ class IcpStats(C.Structure):
         ("reference_reused", C.c_int),
         ("comm_calls", C.c_int),
         ("t_comm_ms", C.c_double),
+        ("direction_index_launches", C.c_int),
+        ("direction_index_occupancy", C.c_float),
     ]
 
 

@@ -97,7 +97,8 @@ __global__ __launch_bounds__(256) void k_cone_gather(const float4* __restrict__ 
                                                      const uint64_t* __restrict__ keys, int64_t n, ConeDev c,
                                                      float* __restrict__ soa,
                                                      uint32_t* __restrict__ map, uint32_t* __restrict__ tab,
-                                                     uint32_t* __restrict__ rowz_bits) {
+                                                     uint32_t* __restrict__ rowz_bits,
+                                                     uint32_t* __restrict__ occupied /* += bins that hold a point */) {
   const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
   const int lane = threadIdx.x & 63;
   const int64_t npad = ((n + 3) & ~(int64_t)3) + kConePad;
@@ -124,6 +125,12 @@ __global__ __launch_bounds__(256) void k_cone_gather(const float4* __restrict__ 
     float* g = soa + 12 * (j >> 2) + (j & 3);
     g[0] = kPadCoord; g[4] = kPadCoord; g[8] = kPadCoord; map[j] = 0u;
     if (j == n) { gap_lo = (uint32_t)keys[n - 1] + 1u; gap_hi = nkeys + 1u; pos = (uint32_t)n; }   // everything behind the last key
+  }
+  // ---- occupied bins (the host decides from points per occupied bin whether this index or the voxel grid serves the
+  // settled searches: a local map of many scans is several times denser in direction than one scan)
+  {
+    const unsigned long long firsts = __ballot(valid && gap_hi > gap_lo);
+    if (lane == 0 && firsts) atomicAdd(occupied, (uint32_t)__popcll(firsts));
   }
   // ---- table: a thread whose key is the next one after its predecessor's writes one entry (the common case: one or two
   // points per bin); longer gaps -- empty bins, empty rows -- by the whole wave

@@ -193,6 +193,12 @@ struct lsgpu_icp {
   bool defer_cone = false;    // lsgpu_icp_compute: set_reference leaves the build to the side stream
   bool cone_pending = false;  // the loop's stream has not yet waited for cone_done
   hipEvent_t cone_done = nullptr;
+  DevBuf<uint32_t> cone_occ;          // occupied (row, column) bins of the index
+  hipEvent_t cone_occ_ready = nullptr;
+  bool cone_decided = false;          // ... looked at: cone_dense says whether the reference is too dense in direction
+  bool cone_dense = false;
+  int cone_launches = 0;              // of the running align
+  float cone_occupancy = 0.f;         // points per occupied bin
   float cone_zeta_lo = 0.f, cone_zeta_hi = 0.f;
   bool cone_origin_inside = false;
   bool cone_off = false;      // this align stopped using it (too many lanes it could not serve)
@@ -406,7 +412,7 @@ void lsgpu_icp_destroy(lsgpu_icp* h) {
   h->work.release();
 #endif
   h->pts.release();
-  h->cone_soa.release(); h->cone_map.release(); h->cone_tab.release(); h->cone_rowz_bits.release(); h->cone_rowz.release();
+  h->cone_soa.release(); h->cone_occ.release(); h->cone_map.release(); h->cone_tab.release(); h->cone_rowz_bits.release(); h->cone_rowz.release();
   h->nrm.release(); h->ref_inv.release(); h->tables.release(); h->flags.release(); h->cidx.release(); h->bounds.release(); h->chunks.release(); h->soa.release(); h->soa_base.release(); h->soa_cnt4.release(); h->soa_first.release(); h->prev.release(); h->state.release(); h->lb.release(); h->cell_cache.release(); h->cell_tags.release(); h->ssn_seg_a.release(); h->ssn_seg_b.release(); h->ssn_axis_a.release(); h->ssn_axis_b.release(); h->ssn_seg_fb.release(); h->ssn_blocktab.release(); h->ssn_seg_of.release(); h->ssn_box_pts.release(); h->ssn_box_base.release(); h->ssn_keep.release(); h->ssn_out_pos.release(); h->ssn_bb.release(); h->ssn_box_normal.release(); h->ssn_draws.release(); h->flt_in.release(); h->flt_in2.release(); h->flt_ref.release(); h->flt_rd.release(); h->flt_nrm.release(); h->chk_hist.release(); h->trace_dev.release(); h->knn_dbg.release(); h->knn_dbg_wave.release(); h->stat_partials.release(); h->geom.release();
   h->counters.release(); h->ang_cells.release(); h->sel_aux.release(); h->sel_win.release(); h->spread_flag.release(); h->spread_list.release(); h->spread_cnt.release(); h->q_in.release(); h->rdq.release(); h->ids.release(); h->d2.release();
   h->ids_io.release(); h->d2_io.release(); h->strag.release(); h->hist.release();
@@ -418,6 +424,7 @@ void lsgpu_icp_destroy(lsgpu_icp* h) {
   if (h->ev_state) (void)hipEventDestroy(h->ev_state);
   if (h->ev_tail) (void)hipEventDestroy(h->ev_tail);
   if (h->cone_done) (void)hipEventDestroy(h->cone_done);
+  if (h->cone_occ_ready) (void)hipEventDestroy(h->cone_occ_ready);
   if (h->h_pinned) (void)hipHostFree(h->h_pinned);
   if (h->draws_pinned) (void)hipHostFree(h->draws_pinned);
   if (h->copy_done) (void)hipEventDestroy(h->copy_done);
@@ -588,7 +595,7 @@ static KnnArgs knn_args(lsgpu_icp* h, const Mat34& T) {
 //              followed by the straggler fallback
 static int run_knn(lsgpu_icp* h, const Mat34& T, const IcpState* st, bool seed, bool capped, bool timed,
                    bool wide = true, bool predicted = false, uint32_t seed_rank = 0xFFFFFFFFu, bool committed = false,
-                   bool cone_iter = false) {
+                   bool cone_iter = false, bool dense_wait = false) {
   const int nq = (int)h->nq;
   KnnArgs a = knn_args(h, T);
   h->dbg_launch_no++;
@@ -645,8 +652,23 @@ static int run_knn(lsgpu_icp* h, const Mat34& T, const IcpState* st, bool seed, 
     ev->second = false;
     HIPC(hipEventRecord(ev->a, h->stream));
   }
-  if (capped && cone_iter && st && h->cone_ok && !h->cone_off) {
+  if (capped && cone_iter && st && h->cone_ok && !h->cone_off && !h->cone_decided) {
+    // first search through the index for this reference: is it worth it?  The windows of a lane grow with the number of
+    // reference points per direction -- measured on local maps of K scans of 1 M points (devtools/cone_density.py), kNN
+    // per settled launch: K = 1: 48 us against 82 with the voxel grid, K = 3: 69 / 107, K = 8: 423 / 186.  Points per
+    // occupied bin: 2, 3, 8.  (The wait is for a copy queued behind the build; the device is in the first iterations.)
+    HIPC(hipEventSynchronize(h->cone_occ_ready));
+    const uint32_t occ = *reinterpret_cast<uint32_t*>(h->h_pinned + 110);
+    h->cone_occupancy = occ ? (float)((double)h->nr / (double)occ) : 1e9f;
+    h->cone_dense = h->cone_occupancy > tn.cone_max_occupancy;
+    h->cone_decided = true;
+  }
+  // (a denser reference also keeps the index out of one more iteration: its third search still has balls of centimetres,
+  // measured 364 us through the index against 179 on the voxel grid on a three-scan map, 143 / 143 on one scan)
+  if (cone_iter && h->cone_decided && h->cone_occupancy > 3.f && dense_wait) cone_iter = false;
+  if (capped && cone_iter && st && h->cone_ok && !h->cone_off && !h->cone_dense) {
     // settled launch: every lane searches its own windows of the direction-sorted reference (lsgpu_cone.hip.h)
+    h->cone_launches++;
     if (h->cone_pending) {   // (built on the side stream beside the first iterations: lsgpu_icp_compute)
       HIPC(hipStreamWaitEvent(h->stream, h->cone_done, 0));
       h->cone_pending = false;
@@ -768,12 +790,22 @@ static int build_cone_index(lsgpu_icp* h) {
   while (((size_t)1 << nbits) < nkeys) ++nbits;
   const int rc = sort_pairs(h, nr, nbits);
   if (rc) return rc;
+  HIPC(h->cone_occ.reserve(1));
+  HIPC(hipMemsetAsync(h->cone_occ.p, 0, sizeof(uint32_t), h->cur));
   hipLaunchKernelGGL(k_cone_gather, dim3(nblk((int64_t)npad)), dim3(256), 0, h->cur, h->pts.p, h->sc->vals_alt.p,
-                     h->sc->keys_alt.p, nr, c, h->cone_soa.p, h->cone_map.p, h->cone_tab.p, h->cone_rowz_bits.p);
+                     h->sc->keys_alt.p, nr, c, h->cone_soa.p, h->cone_map.p, h->cone_tab.p, h->cone_rowz_bits.p, h->cone_occ.p);
   hipLaunchKernelGGL(k_cone_rowz, dim3(nblk(c.rows)), dim3(256), 0, h->cur, h->cone_rowz_bits.p, c.rows, h->cone_rowz.p);
   HIPC(hipGetLastError());
+  // the number of occupied bins travels to the host behind the build; lsgpu_icp_align looks at it before its first
+  // search through the index (the device is busy with the first two iterations by then)
+  if (!h->cone_occ_ready) HIPC(hipEventCreateWithFlags(&h->cone_occ_ready, hipEventDisableTiming));
+  uint32_t* ho = reinterpret_cast<uint32_t*>(h->h_pinned + 110);
+  *ho = 0u;
+  HIPC(hipMemcpyAsync(ho, h->cone_occ.p, sizeof(uint32_t), hipMemcpyDeviceToHost, h->cur));
+  HIPC(hipEventRecord(h->cone_occ_ready, h->cur));
   h->cone = c;
   h->cone_ok = true;
+  h->cone_decided = false;
   return LSGPU_OK;
 }
 
@@ -1952,6 +1984,7 @@ int lsgpu_icp_align(lsgpu_icp* h, const float* reading_xyz1, int64_t nq, const f
   const double t0 = wall_ms();
   h->knn_events_used = 0;
   h->comm_events_used = 0;
+  h->cone_launches = 0;
   h->time_comm = h->comm != nullptr && h->cfg.profile_kernels != 0;
   h->tail_pending = false;   // (from here on everything is behind it on h->stream itself)
 
@@ -2055,7 +2088,7 @@ int lsgpu_icp_align(lsgpu_icp* h, const float* reading_xyz1, int64_t nq, const f
     int r = LSGPU_OK;
     if (knn) {
       r = run_knn(h, Tdummy, h->state.p, seed, capped, timed, wide, predicted, seed && capped ? k : 0xFFFFFFFFu, committed,
-                  !seed && capped && enq >= cone_from);  // 6a+6b
+                  !seed && capped && enq >= cone_from, enq == cone_from);  // 6a+6b
       if (r) return r;
       ev_of_launch.push_back(h->knn_events_used ? h->knn_events_used - 1 : 0);
     }
@@ -2239,6 +2272,8 @@ int lsgpu_icp_align(lsgpu_icp* h, const float* reading_xyz1, int64_t nq, const f
       else (void)hipGetLastError();
     }
   }
+  st.direction_index_launches = h->cone_launches;   // (enqueued; those behind the end of the loop exited at once)
+  st.direction_index_occupancy = h->cone_decided ? h->cone_occupancy : 0.f;
   st.pad_ = sel_retries;  // (select predictions that missed; informational)
   st.committed_select_iterations = committed_iterations;
   st.spread_tiles = (int)hst->n_spread;

@@ -38,6 +38,8 @@
 //   LSGPU_NO_CONE               settled launches search the voxel grid (k_knn_tile) instead of the direction index (k_knn_cone)
 //   LSGPU_CONE_FROM          2  first iteration of an align that searches the direction index (0 and 1 have balls as wide as the
 //                               initial guess is off: measured 464 us for iteration 1 on the benchmark pair against 230 with the voxel grid)
+//   LSGPU_CONE_MAX_OCC       7  reference points per occupied bin of the direction index above which the settled launches use the voxel grid
+//                               (local maps of K 1 M-point scans: K = 3 -> 4.3: 67 us per launch against 107; K = 5 -> 8.5: 147 / 140; K = 6 -> 9.8: 249 / 161)
 //   LSGPU_CONE_ROWS        128  rows (bins of the sine of the elevation) of the direction index
 //   LSGPU_CONE_COLS       8192  columns (bins of the pseudo-azimuth) of the direction index
 //   LSGPU_KNN_DBG            0  ablation flags of the -DLSGPU_KNN_STATS build (ignored by the product build)
@@ -79,6 +81,7 @@ struct Tuning {
   int knn_dbg = 0;
   bool cone = true;
   int cone_rows = 128, cone_cols = 8192, cone_from = 2;
+  float cone_max_occupancy = 7.0f;
 #ifdef LSGPU_EXPERIMENTS
   int knn_rows = 0;
   bool knn_lane = false;
@@ -138,13 +141,14 @@ inline Tuning read() {
   t.knn_dbg = (int)number("LSGPU_KNN_DBG", 0, 0, 1 << 20);
   t.cone = !flag("LSGPU_NO_CONE");
   t.cone_from = (int)number("LSGPU_CONE_FROM", 2, 1, 1 << 20);
+  t.cone_max_occupancy = (float)number("LSGPU_CONE_MAX_OCC", 7.0, 0.0, 1e9);
   t.cone_rows = (int)number("LSGPU_CONE_ROWS", 128, 8, 1024);
   t.cone_cols = (int)number("LSGPU_CONE_COLS", 8192, 64, 65536) & ~3;
   static const char* known[] = {"LSGPU_QUERY_ORDER", "LSGPU_Q_ELEV", "LSGPU_Q_SECT", "LSGPU_GAP", "LSGPU_BUDGET", "LSGPU_BUDGET_WIDE", "LSGPU_WIDE_ITERS",
                                 "LSGPU_ROUTE_R", "LSGPU_ROUTE_CHUNKS", "LSGPU_SPLIT_UPDATE", "LSGPU_NO_PREDICT", "LSGPU_NO_COMMIT",
                                 "LSGPU_NO_COMM_COMMIT", "LSGPU_NO_SEED_CAP", "LSGPU_NO_FRONT", "LSGPU_NO_LAZY", "LSGPU_NO_SIDE_STREAM", "LSGPU_NO_LOOKAHEAD", "LSGPU_FRONT_GUESS", "LSGPU_NO_ROUTE_ALL",
                                 "LSGPU_NO_ROWQ", "LSGPU_ROWQ_BLOCKS", "LSGPU_ROCPRIM_SORT", "LSGPU_SORT_ITEMS", "LSGPU_SSN_GLOBAL", "LSGPU_SSN_FULL_SORT",
-                                "LSGPU_NE_BLOCKS", "LSGPU_COMM_TIMEOUT_MS", "LSGPU_KNN_DBG", "LSGPU_NO_CONE", "LSGPU_CONE_ROWS", "LSGPU_CONE_COLS", "LSGPU_CONE_FROM",
+                                "LSGPU_NE_BLOCKS", "LSGPU_COMM_TIMEOUT_MS", "LSGPU_KNN_DBG", "LSGPU_NO_CONE", "LSGPU_CONE_ROWS", "LSGPU_CONE_COLS", "LSGPU_CONE_FROM", "LSGPU_CONE_MAX_OCC",
                                 // read by the Python / C++ hosts and the test drivers, not by this library:
                                 "LSGPU_SO", "LSGPU_STATS_SO", "LSGPU_GOLDEN_DIR", "LSGPU_SEQ_PERTURB", "LSGPU_SEQ_POSES", "LSGPU_TEST_INPUT_FILTERS",
 #ifdef LSGPU_EXPERIMENTS
