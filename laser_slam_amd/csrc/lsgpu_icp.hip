@@ -771,6 +771,9 @@ static int build_cone_index(lsgpu_icp* h) {
   const int64_t nr = h->nr;
   h->cone_ok = false;
   if (!(tuning().cone && h->cone_origin_inside && nr >= 1024)) return LSGPU_OK;
+  // a reference with more points than 0.6 x the occupancy limit x the number of bins cannot come out below the limit
+  // (measured: 4.3 / 6.3 / 8.5 points per occupied bin at 3.0 / 4.0 / 5.0 per bin): spare it the build (1.8 ms at 8 M points)
+  if ((double)nr > 0.6 * (double)tuning().cone_max_occupancy * (double)tuning().cone_rows * (double)tuning().cone_cols) return LSGPU_OK;
   ConeDev c;
   std::memset(&c, 0, sizeof(c));
   c.ox = -h->mean[0]; c.oy = -h->mean[1]; c.oz = -h->mean[2];
