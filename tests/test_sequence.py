@@ -182,11 +182,21 @@ def test_config4_sequence_gpu_icp_vs_oracle_icp(tmp_path):
               "rmse_gpu_vs_cpu_reference_m": between, "rmse_gpu_vs_truth_m": e_dev, "rmse_cpu_reference_vs_truth_m": e_sha,
               "rmse_dead_reckoning_m": e_dead, "ms_gpu_run_incl_oracle_calls": out["dev"]["time"], "loop_closures": len(out["dev"]["lc"]),
               "mean_icp_iterations": float(np.mean([d[1] for d in calls_d]))}
+    # BASELINE.md config 5 row "wall time": the same sequence once more with the device ICP ALONE (no oracle call in the
+    # loop), scans resident in HBM -- what a robot would run; it must retrace the shadow run's device trajectory
+    alone = run_driver(exe, stream, 3, 2, "dev", 1, 900, YAML_TIGHT, extra=(16,))
+    dev_alone = [p[3] for p in alone["dev"]["pose"]]
+    report["ms_gpu_only_run"] = alone["dev"]["time"]
+    report["gpu_only_scans_per_s"] = n / (alone["dev"]["time"] * 1e-3)
+    report["gpu_only_is"] = ("wall time of the whole sequence through LaserTrack::processPoseAndLaserScan + IncrementalEstimator::estimate / "
+                             "processLoopClosure with the device ICP only (scans_on_device 16), %d poses of 64 x 256 rays" % n)
+    report["rmse_gpu_only_vs_shadow_run_m"] = _rmse(dev_alone, dev)
     print("config4:", report)
     import json
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
     with open(os.path.join(ROOT, "gpurun_out", "config4_sequence.json"), "w") as f:
         json.dump(report, f, indent=1)
+    assert report["rmse_gpu_only_vs_shadow_run_m"] <= 1e-6, report
     assert len(beyond) <= 0.005 * len(ce) and report["max_call_dt_m"] <= 1e-3, report
     assert between <= 1e-3, report
     assert e_dev < e_dead / 5 and e_sha < e_dead / 5, report
