@@ -217,7 +217,7 @@ struct ConeRec { float qx, qy, qz, ub, lbn; int id_in, j; uint32_t pad; };   // 
 #ifndef LSGPU_CONE_OCC
 #define LSGPU_CONE_OCC 7   // waves per SIMD the register budget is cut for
 #endif
-template <int WAVES>
+template <int WAVES, bool PROBE = false>
 __global__ __launch_bounds__(WAVES * 64, LSGPU_CONE_OCC) void k_knn_cone(KnnArgs a, ConeDev c) {
   __shared__ ConeRec rec[WAVES * 64];
   __shared__ uint32_t wcount[WAVES];
@@ -292,15 +292,45 @@ __global__ __launch_bounds__(WAVES * 64, LSGPU_CONE_OCC) void k_knn_cone(KnnArgs
     qx = r.qx; qy = r.qy; qz = r.qz; ub = r.ub; lbn = r.lbn; id_in = r.id_in; j = r.j;
   }
   // ---- phase 2: the searching lanes
-  const float lim0 = prune_lim(ub, gap, cap2s);                 // squared search radius: every point inside is evaluated
+  float inv_rho, zeta, pa, rxy, inv_h;
+  cone_dir(qx - c.ox, qy - c.oy, qz - c.oz, inv_rho, zeta, pa, rxy, inv_h);
+  float ubs = ub;                  // upper bound of the nearest-neighbour distance the search starts from
+  if (PROBE) {
+    // Launches whose balls are still as wide as the last ICP step (the warm-start point is the match of a transform that
+    // has since moved by centimetres): the reference points in the query's OWN direction -- its column and the two next
+    // to it, in the occupied rows within two of its own -- are real points, so the nearest of them is an upper bound of
+    // the nearest-neighbour distance, usually a far tighter one.  A dozen candidates per lane; the search proper then
+    // runs with that radius (and meets these points again: the probe keeps nothing but the bound).
+    const bool pr = ing && fabsf(zeta) <= 1.5f && pa >= 0.f && pa <= 4.f;
+    const int rq = (int)cone_clampu(floorf((zeta - c.z0) * c.rs), c.rows - 1);
+    const int cq = (int)cone_clampu(floorf(pa * c.cs), c.cols - 1);
+    const uint32_t p_first = (uint32_t)__builtin_amdgcn_readfirstlane((int)wave_max_u32(pr ? ~(uint32_t)max(rq - 2, 0) : 0u));
+    const uint32_t p_last = wave_max_u32(pr ? (uint32_t)min(rq + 2, c.rows - 1) + 1u : 0u);
+    float pb = INFINITY, ps = INFINITY;
+    uint32_t pg = 0u;
+    for (uint32_t row = ~p_first; row < p_last; ++row) {
+      const float4 rz = c.rowz[row];
+      if (!(rz.x <= rz.y)) continue;
+      const bool in = pr && (int)row >= rq - 2 && (int)row <= rq + 2;
+      const uint32_t base = row * (uint32_t)c.cols;
+      uint32_t st = 0u, en = 0u;
+      if (in) {
+        st = c.tab[base + (uint32_t)max(cq - 1, 0)];
+        en = c.tab[base + (uint32_t)min(cq + 1, c.cols - 1) + 1u];
+      }
+      const uint32_t g0 = st >> 2;
+      const uint32_t len = en > st ? min(((en + 3u) >> 2) - g0, 4u) : 0u;   // (a bound needs no more than a few groups)
+      cone_eval_window(c, g0, len, qx, qy, qz, pb, ps, pg);
+    }
+    ubs = fminf(ub, pb);
+  }
+  const float lim0 = prune_lim(ubs, gap, cap2s);                // squared search radius: every point inside is evaluated
   const float R = __builtin_amdgcn_sqrtf(lim0) * (1.0f + 1e-5f) + 1e-7f;
   bool fb = false;                 // this lane searches the voxel grid instead
   float best = INFINITY, sec = INFINITY;
   uint32_t bgrp = 0xFFFFFFFFu;     // group of four direction-sorted points that holds the evaluated minimum
   {
     // ---- the lane's cone.  sin(alpha) = R / rho.  A point within R of q is seen from O under an angle <= alpha from q.
-    float inv_rho, zeta, pa, rxy, inv_h;
-    cone_dir(qx - c.ox, qy - c.oy, qz - c.oz, inv_rho, zeta, pa, rxy, inv_h);
     const float s = R * inv_rho * (1.0f + 1e-5f) + 4e-6f;      // (margin: rounding of q - O and of the points' own directions)
     const float ce = rxy * inv_rho;                             // cos(elevation of q)
     bool cone = ing && s <= 0.5f && ce > 0.f && ce <= 1.5f;     // (NaN-safe: |q - O| == 0 fails)

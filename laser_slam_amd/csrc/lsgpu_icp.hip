@@ -674,7 +674,10 @@ static int run_knn(lsgpu_icp* h, const Mat34& T, const IcpState* st, bool seed, 
       h->cone_pending = false;
     }
     a.front_blocks = 0;
-    hipLaunchKernelGGL(k_knn_cone<LSGPU_CONE_WAVES>, dim3((a.ntiles + LSGPU_CONE_WAVES - 1) / LSGPU_CONE_WAVES), dim3(LSGPU_CONE_WAVES * 64), 0, h->stream, a, h->cone);
+    if (wide && tn.cone_probe)   // balls as wide as the last ICP step: a probe of the query's own direction first
+      hipLaunchKernelGGL((k_knn_cone<LSGPU_CONE_WAVES, true>), dim3((a.ntiles + LSGPU_CONE_WAVES - 1) / LSGPU_CONE_WAVES), dim3(LSGPU_CONE_WAVES * 64), 0, h->stream, a, h->cone);
+    else
+      hipLaunchKernelGGL((k_knn_cone<LSGPU_CONE_WAVES, false>), dim3((a.ntiles + LSGPU_CONE_WAVES - 1) / LSGPU_CONE_WAVES), dim3(LSGPU_CONE_WAVES * 64), 0, h->stream, a, h->cone);
     if (timed) HIPC(hipEventRecord(ev->b, h->stream));
     HIPC(hipGetLastError());
     return LSGPU_OK;
