@@ -101,7 +101,8 @@ def track_section(n_az: int, n_scans: int, cpu_threads: int):
         shadow_scan = n_scans - 1
 
         def run(extra):
-            r = subprocess.run([exe, d, str(n_scans), yaml, "3", "16", *extra], capture_output=True, text=True, timeout=900)
+            r = subprocess.run([exe, d, str(n_scans), yaml, "3", "16", *extra], capture_output=True, text=True, timeout=900,
+                               env=dict(os.environ, LSGPU_TRACK_STAGES="1"))
             if r.returncode != 0:
                 raise RuntimeError("track_driver failed: " + r.stdout[-500:] + r.stderr[-500:])
             return r.stdout.splitlines()
@@ -111,12 +112,20 @@ def track_section(n_az: int, n_scans: int, cpu_threads: int):
         # steady state: the sub-map holds 3 scans from scan 4 on, but the track keeps allocating HBM slots for new scans until
         # `scans_on_device` (16) of them are resident -- a robot drives thousands of scans, the first sixteen are start-up
         steady = ms[16:] if len(ms) > 18 else ms[3:]
+        stages = [dict(zip(l.split()[1::2], map(float, l.split()[2::2]))) for l in lines if l.startswith("stages ")]
+        all_stages = stages
+        stages = stages[16:] if len(stages) > 18 else stages[3:]
         sh = [l.split() for l in run([str(shadow_scan), str(cpu_threads)]) if l.startswith("shadow ")]
         out = {"value": 1e3 / float(np.median(steady)), "unit": "scans/s", "ms_per_scan_median": float(np.median(steady)),
                "ms_per_scan": [round(m, 3) for m in ms], "icp_iterations": its, "n_scans": n_scans, "points_per_scan": int(scans[0].shape[0]),
                "workload": "LaserTrack::processPoseAndLaserScan through the C++ mirror, %d scans of 64 x %d rays 0.8 m / 2 deg apart, nscan_in_sub_map 3 "
                            "(sub-map of ~%.1f M points), yaml chain (prob 0.5 / ratio 0.5), scans_on_device 16; timed region = scan_matching_times_ "
                            "(laser_track.cpp:128, 208-209); steady state = scans %d .. %d (every HBM slot allocated)" % (n_scans, n_az, 3 * scans[0].shape[0] / 1e6, n_scans - len(steady), n_scans - 1)}
+        if stages:
+            out["stages_ms_median"] = {k[:-3]: round(float(np.median([st[k] for st in stages])), 3) for k in stages[0] if k.endswith("_ms")}
+            out["stages_ms"] = {k[:-3] if k.endswith("_ms") else k: [round(st[k], 2) for st in all_stages] for k in all_stages[0]}
+            out["stages_are"] = ("copy = the call's working copy of the scan + input filters (host); upload = the new scan's H2D into its HBM slot; "
+                                 "icp = icp_.compute on the resident clouds (device_filters / device_total: the C ABI's own clocks inside it)")
         if sh:
             t = sh[0]
             kv = {t[i]: t[i + 1] for i in range(1, len(t) - 1, 2)}

@@ -14,7 +14,7 @@ h = icp.IcpHandle(cfg)
 dref, dn, drd = torch.from_numpy(rf).cuda(), torch.from_numpy(rn).cuda(), torch.from_numpy(rd).cuda()
 for rep in range(2):
     t=time.perf_counter(); h.set_reference(dref, dn); t1=time.perf_counter(); T, st = h.align(drd, Ti); t2=time.perf_counter()
-print("set_reference ms", (t1-t)*1e3, "align ms", (t2-t1)*1e3, "iters", st.iterations, "retries", st.cap_retries, "sel_retries", st.pad_)
+print("set_reference ms", (t1-t)*1e3, "align ms", (t2-t1)*1e3, "iters", st.iterations, "retries", st.cap_retries, "sel_retries", st.pad_, "heavy %.4f" % st.direction_index_heavy_share)
 info = h.info(); print("chunks", info.n_chunks, "cells", list(info.cells)[:12], "h0", info.cell_size)
 for i, tr in enumerate(h.trace()):
     print(i, "limit %.5f used %d knn_main %.1f us fb %.1f us strag %d" % (tr["limit"], tr["n_used"], tr["knn_main_us"], tr["knn_fallback_us"], tr["stragglers"]))

@@ -87,6 +87,9 @@ typedef struct lsgpu_icp_stats {
   int     direction_index_launches;     /* searches served by the direction index (k_knn_cone) instead of the voxel grid */
   float   direction_index_occupancy;    /* reference points per occupied bin of that index (0: not built / not looked at);
                                            above LSGPU_CONE_MAX_OCC (7) the settled searches stay on the voxel grid */
+  float   direction_index_heavy_share;  /* share of the searching queries whose windows in that index would be long (priced by the
+                                           search before its first use; -1: not priced); above LSGPU_CONE_HEAVY_SHARE (0.02)
+                                           this alignment stays on the voxel grid */
 } lsgpu_icp_stats;
 
 /* One record per iteration (optional parity/debug trace; replaces the VTKFileInspector dump of

@@ -76,6 +76,7 @@ class IcpStats(C.Structure):
         ("t_comm_ms", C.c_double),
         ("direction_index_launches", C.c_int),
         ("direction_index_occupancy", C.c_float),
+        ("direction_index_heavy_share", C.c_float),
     ]
 
 

@@ -147,6 +147,8 @@ class LaserTrack {
     if (newValues) newValues->clear();
     LaserScan scan = in_scan;
     input_filters_.apply(scan.scan);  // laser_track.cpp:146
+    stage_times_ = StageTimes{};
+    stage_times_.copy_ms = msSince(t0);
     pose_measurements_.push_back(pose);
     const bool first = trajectory_.isEmpty();
     RelativePose odom;
@@ -254,6 +256,10 @@ class LaserTrack {
   const std::vector<RelativePose>& getIcpTransformations() const { return icp_transformations_; }
   const std::vector<RelativePose>& getOdometryMeasurements() const { return odometry_measurements_; }
   const lsgpu_icp_stats& lastIcpStats() const { return icp_.lastStats(); }
+  // where the wall time of the last processPoseAndLaserScan went (milliseconds; not a reference accessor): the working copy
+  // of the scan + the input filters, the scans that had to cross PCIe, icp_.compute on the resident clouds
+  struct StageTimes { double copy_ms = 0, upload_ms = 0, icp_ms = 0; };
+  const StageTimes& lastStageTimes() const { return stage_times_; }
   ICP& icp() { return icp_; }  // configuration access (seed, test seam); the reference keeps icp_ private
   DataPointsFilters& inputFilters() { return input_filters_; }
 
@@ -281,6 +287,9 @@ class LaserTrack {
 
  private:
   static constexpr double kDistanceBetweenPriorPoses_m = 100.0;  // laser_track.hpp:235
+  static double msSince(std::chrono::steady_clock::time_point t) {
+    return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t).count();
+  }
   static constexpr double kPriorSigma = 1e-7;                    // laser_track.cpp:56-64
 
   SE3 getPoseMeasurement(Time t) const {  // findPose (:521-555): exact time stamp required
@@ -360,9 +369,14 @@ class LaserTrack {
       if (params_.scans_on_device > 0 && (int)members.size() + 1 <= params_.scans_on_device &&
           !icp_.hasComputeOverride()) {
         // the scans stay in HBM; the sub-map is assembled there (same arithmetic as RigidTransformation::compute)
+        const auto t_up = std::chrono::steady_clock::now();
         std::vector<int> slots;
         for (size_t m : members) slots.push_back(deviceSlot(m));
-        solution = icp_.computeClouds(deviceSlot(n - 1), slots, member_T, T_init);
+        const int reading_slot = deviceSlot(n - 1);
+        stage_times_.upload_ms = msSince(t_up);
+        const auto t_icp = std::chrono::steady_clock::now();
+        solution = icp_.computeClouds(reading_slot, slots, member_T, T_init);
+        stage_times_.icp_ms = msSince(t_icp);
 #ifdef LSGPU_TEST_SEAMS
         if (icp_.hasComputeObserver()) {   // parity drivers: hand the observer the clouds the device just matched
           DataPoints sub_map = laser_scans_[members[0]].scan;
@@ -425,6 +439,7 @@ class LaserTrack {
   std::vector<LaserScan> laser_scans_;
   std::map<Time, double> scan_matching_times_;
   std::vector<size_t> slot_owner_;   // which scan each device slot holds
+  StageTimes stage_times_;
   unsigned slot_generation_ = 0;
   mutable std::recursive_mutex mutex_;
 };

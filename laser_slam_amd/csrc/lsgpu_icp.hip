@@ -201,7 +201,13 @@ struct lsgpu_icp {
   float cone_occupancy = 0.f;         // points per occupied bin
   float cone_zeta_lo = 0.f, cone_zeta_hi = 0.f;
   bool cone_origin_inside = false;
-  bool cone_off = false;      // this align stopped using it (too many lanes it could not serve)
+  bool cone_off = false;      // this align stopped using it (too many lanes it could not serve, or its price check said no)
+  hipEvent_t price_ready = nullptr;   // the price check's two counters are on the host
+  bool price_pending = false;
+  DevBuf<uint32_t> price_cnt;         // kPriceSlots x kPriceStride words (lsgpu_knn.hip.h: ConePrice::count)
+  uint32_t* h_price = nullptr;        // ... and their pinned copy
+  float cone_heavy = -1.f;    // share of heavy lanes among the searching ones (-1: not priced)
+  bool cone_off_price = false;   // cone_off because of that price: priced again before every later look
   DevBuf<uint4> knn_dbg_wave;
   DevBuf<unsigned long long> knn_dbg;  // LSGPU_KNN_STATS builds: 8 counters
   DevBuf<uint2> cell_cache;  // ntiles x 64
@@ -414,7 +420,7 @@ void lsgpu_icp_destroy(lsgpu_icp* h) {
   h->pts.release();
   h->cone_soa.release(); h->cone_occ.release(); h->cone_map.release(); h->cone_tab.release(); h->cone_rowz_bits.release(); h->cone_rowz.release();
   h->nrm.release(); h->ref_inv.release(); h->tables.release(); h->flags.release(); h->cidx.release(); h->bounds.release(); h->chunks.release(); h->soa.release(); h->soa_base.release(); h->soa_cnt4.release(); h->soa_first.release(); h->prev.release(); h->state.release(); h->lb.release(); h->cell_cache.release(); h->cell_tags.release(); h->ssn_seg_a.release(); h->ssn_seg_b.release(); h->ssn_axis_a.release(); h->ssn_axis_b.release(); h->ssn_seg_fb.release(); h->ssn_blocktab.release(); h->ssn_seg_of.release(); h->ssn_box_pts.release(); h->ssn_box_base.release(); h->ssn_keep.release(); h->ssn_out_pos.release(); h->ssn_bb.release(); h->ssn_box_normal.release(); h->ssn_draws.release(); h->flt_in.release(); h->flt_in2.release(); h->flt_ref.release(); h->flt_rd.release(); h->flt_nrm.release(); h->chk_hist.release(); h->trace_dev.release(); h->knn_dbg.release(); h->knn_dbg_wave.release(); h->stat_partials.release(); h->geom.release();
-  h->counters.release(); h->ang_cells.release(); h->sel_aux.release(); h->sel_win.release(); h->spread_flag.release(); h->spread_list.release(); h->spread_cnt.release(); h->q_in.release(); h->rdq.release(); h->ids.release(); h->d2.release();
+  h->counters.release(); h->price_cnt.release(); h->ang_cells.release(); h->sel_aux.release(); h->sel_win.release(); h->spread_flag.release(); h->spread_list.release(); h->spread_cnt.release(); h->q_in.release(); h->rdq.release(); h->ids.release(); h->d2.release();
   h->ids_io.release(); h->d2_io.release(); h->strag.release(); h->hist.release();
   h->sel.release(); h->ne_partials.release(); h->ne_gpartials.release(); h->ne_tickets.release(); h->ne_out.release(); h->limit_dev.release();
   for (auto& e : h->comm_events) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
@@ -426,6 +432,7 @@ void lsgpu_icp_destroy(lsgpu_icp* h) {
   if (h->cone_done) (void)hipEventDestroy(h->cone_done);
   if (h->cone_occ_ready) (void)hipEventDestroy(h->cone_occ_ready);
   if (h->h_pinned) (void)hipHostFree(h->h_pinned);
+  if (h->h_price) (void)hipHostFree(h->h_price);
   if (h->draws_pinned) (void)hipHostFree(h->draws_pinned);
   if (h->copy_done) (void)hipEventDestroy(h->copy_done);
   if (h->ref_up_done) (void)hipEventDestroy(h->ref_up_done);
@@ -564,6 +571,12 @@ static int prepare_queries(lsgpu_icp* h, const float* q_xyz1, int64_t nq, const 
 static int run_select(lsgpu_icp* h, const float* d2, int n, uint32_t k, bool zero_hist, const IcpState* st,
                       bool use_comm, bool predicted);
 
+static float price_share(const lsgpu_icp* h) {   // heavy lanes / searching lanes of the priced launch (its counters are on the host)
+  uint64_t heavy = 0, searching = 0;
+  for (int i = 0; i < kPriceSlots; ++i) { heavy += h->h_price[i * kPriceStride]; searching += h->h_price[i * kPriceStride + 1]; }
+  return searching ? (float)((double)heavy / (double)searching) : 0.f;
+}
+
 static KnnArgs knn_args(lsgpu_icp* h, const Mat34& T) {
   KnnArgs a;
   a.rdq = h->rdq.p; a.nq = (int)h->nq; a.T = T; a.g = h->grid; a.pts = h->pts.p;
@@ -572,6 +585,7 @@ static KnnArgs knn_args(lsgpu_icp* h, const Mat34& T) {
   a.r_cap = 1.0f; a.group_r = 0.75f; a.cap2 = INFINITY; a.st = nullptr; a.use_state_cap = 0; a.lb = nullptr;
   a.spread_route_r = 0.f; a.route_chunks = 1 << 30; a.sel_hist2 = nullptr; a.sel_below = nullptr;
   a.sel_hist3w = nullptr; a.sel_force = 0; a.write_all = 1; a.spread_flag = nullptr; a.spread_list = nullptr; a.spread_cnt = nullptr; a.front_blocks = 0;
+  a.price.count = nullptr;
   a.gap = tuning().gap;
   a.ntiles = (int)((h->nq + 63) / 64); a.pad_index = (int)h->nr;
   a.chunk_budget = tuning().chunk_budget;
@@ -595,7 +609,7 @@ static KnnArgs knn_args(lsgpu_icp* h, const Mat34& T) {
 //              followed by the straggler fallback
 static int run_knn(lsgpu_icp* h, const Mat34& T, const IcpState* st, bool seed, bool capped, bool timed,
                    bool wide = true, bool predicted = false, uint32_t seed_rank = 0xFFFFFFFFu, bool committed = false,
-                   bool cone_iter = false, bool dense_wait = false) {
+                   bool cone_iter = false, bool dense_wait = false, bool price_iter = false) {
   const int nq = (int)h->nq;
   KnnArgs a = knn_args(h, T);
   h->dbg_launch_no++;
@@ -632,6 +646,18 @@ static int run_knn(lsgpu_icp* h, const Mat34& T, const IcpState* st, bool seed, 
   if (predicted && !wide && capped && st) { a.sel_hist2 = h->hist.p + kHistBins; a.sel_below = h->sel_aux.p; }
   if (committed && a.sel_below) { a.sel_hist3w = h->sel_win.p; a.sel_force = 1; }
   a.route_chunks = tn.route_chunks;
+  // the search before the first one through the direction index prices the index (lsgpu_knn.hip.h: cone_price)
+  const bool pricing = price_iter && capped && st && !seed && h->cone_ok && (!h->cone_off || h->cone_off_price) && !h->cone_dense &&
+                       tn.cone_heavy_share < 2.f;
+  if (pricing) {
+    constexpr size_t kPriceBytes = (size_t)kPriceSlots * kPriceStride * sizeof(uint32_t);
+    HIPC(h->price_cnt.reserve((size_t)kPriceSlots * kPriceStride));
+    if (!h->h_price) HIPC(hipHostMalloc((void**)&h->h_price, kPriceBytes, hipHostMallocDefault));
+    HIPC(hipMemsetAsync(h->price_cnt.p, 0, kPriceBytes, h->stream));
+    a.price.ox = h->cone.ox; a.price.oy = h->cone.oy; a.price.oz = h->cone.oz; a.price.rs = h->cone.rs; a.price.cs = h->cone.cs;
+    a.price.dens4 = (float)(0.25 * (double)h->nr / ((double)h->cone.rows * (double)h->cone.cols));
+    a.price.heavy = tn.cone_heavy_steps; a.price.count = h->price_cnt.p;
+  }
   if (seed && !st) HIPC(hipMemsetAsync(a.strag_count, 0, sizeof(uint32_t), h->stream));  // (align: k_align_init, then re-armed by k_normal_eq_loop)
   if (seed) hipLaunchKernelGGL(k_knn_seed, dim3(nblk(nq)), dim3(256), 0, h->stream, a);
   if (seed && capped && st && seed_rank != 0xFFFFFFFFu) {
@@ -662,6 +688,16 @@ static int run_knn(lsgpu_icp* h, const Mat34& T, const IcpState* st, bool seed, 
     h->cone_occupancy = occ ? (float)((double)h->nr / (double)occ) : 1e9f;
     h->cone_dense = h->cone_occupancy > tn.cone_max_occupancy;
     h->cone_decided = true;
+  }
+  if (cone_iter && h->price_pending) {
+    // ... and what would this align pay for it?  The search before this one counted the lanes whose windows would be long
+    // (wide balls next to O: a wall a metre from the sensor; a sparse reading on a dense map that converges in steps of
+    // millimetres): the index evaluates each lane's windows alone, the voxel kernel shares one candidate stream among 64
+    // lanes whose balls overlap -- measured on such clouds 1.6-2.0 ms per search against 0.6
+    HIPC(hipEventSynchronize(h->price_ready));
+    h->price_pending = false;
+    h->cone_heavy = price_share(h);
+    if (h->cone_heavy > tn.cone_heavy_share) { h->cone_off = true; h->cone_off_price = true; }
   }
   // (a denser reference also keeps the index out of one more iteration: its third search still has balls of centimetres,
   // measured 364 us through the index against 179 on the voxel grid on a three-scan map, 143 / 143 on one scan)
@@ -731,6 +767,12 @@ static int run_knn(lsgpu_icp* h, const Mat34& T, const IcpState* st, bool seed, 
     second = false;
   }
   if (timed && second) { ev->second = true; HIPC(hipEventRecord(ev->c, h->stream)); }   // (an event pair around nothing still reads ~5 us)
+  if (pricing) {
+    if (!h->price_ready) HIPC(hipEventCreateWithFlags(&h->price_ready, hipEventDisableTiming));
+    HIPC(hipMemcpyAsync(h->h_price, h->price_cnt.p, (size_t)kPriceSlots * kPriceStride * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
+    HIPC(hipEventRecord(h->price_ready, h->stream));
+    h->price_pending = true;
+  }
   HIPC(hipGetLastError());
   return LSGPU_OK;
 }
@@ -2056,7 +2098,7 @@ int lsgpu_icp_align(lsgpu_icp* h, const float* reading_xyz1, int64_t nq, const f
   HIPC(h->spread_flag.reserve((size_t)((nq + 63) / 64))); HIPC(h->spread_list.reserve(kFrontMax)); HIPC(h->spread_cnt.reserve(2));
   HIPC(h->sel_win.reserve((size_t)kSelWinRows * 512));
   h->n_spread_host = 0; h->n_spread_known = false;
-  h->cone_off = false;
+  h->cone_off = false; h->price_pending = false; h->cone_heavy = -1.f; h->cone_off_price = false;
   ia.state = *hst;
   ia.sel0 = SelState{0u, k};   // sel[0] = {0, rank}: constant during an align
   ia.state_dev = h->state.p; ia.chk_hist = h->chk_hist.p; ia.sel = h->sel.p;
@@ -2080,6 +2122,7 @@ int lsgpu_icp_align(lsgpu_icp* h, const float* reading_xyz1, int64_t nq, const f
   int committed_iterations = 0;
   int enq = 0;   // iterations enqueued so far = the ordinal of the one being enqueued
   const int cone_from = tuning().cone_from;   // the direction index serves the launches from this iteration on
+  bool price_next = false;                     // the next launch prices the index again (an align that found it too dear)
   auto enqueue_iteration = [&](bool seed, bool capped, bool wide, bool knn = true) -> int {
     // capped launches without a wave-per-query pass may fold the first half of the select into the kNN kernel
     // (the device decides per iteration, IcpState::sel_mode); not in the RCCL mode (the counts are per shard).
@@ -2094,7 +2137,7 @@ int lsgpu_icp_align(lsgpu_icp* h, const float* reading_xyz1, int64_t nq, const f
     int r = LSGPU_OK;
     if (knn) {
       r = run_knn(h, Tdummy, h->state.p, seed, capped, timed, wide, predicted, seed && capped ? k : 0xFFFFFFFFu, committed,
-                  !seed && capped && enq >= cone_from, enq == cone_from);  // 6a+6b
+                  !seed && capped && enq >= cone_from, enq == cone_from, enq == cone_from - 1 || price_next);  // 6a+6b
       if (r) return r;
       ev_of_launch.push_back(h->knn_events_used ? h->knn_events_used - 1 : 0);
     }
@@ -2173,7 +2216,9 @@ int lsgpu_icp_align(lsgpu_icp* h, const float* reading_xyz1, int64_t nq, const f
   // the cap below only guards against a device that never finishes.
   for (;;) {
     if (enq < enq_limit && since_check < group) {
+      price_next = h->cone_off_price && since_check == group - 1;   // (the counters travel in front of the look's state copy)
       rc = enqueue_iteration(false, true, enq < wide_iters);
+      price_next = false;
       if (rc) return rc;
       ++enq; ++since_check;
       continue;
@@ -2191,6 +2236,11 @@ int lsgpu_icp_align(lsgpu_icp* h, const float* reading_xyz1, int64_t nq, const f
         (double)(hst->stragglers - look_strag) > 0.02 * (double)nq * (double)(hst->iter - look_iter))
       h->cone_off = true;
     look_iter = hst->iter; look_strag = hst->stragglers;
+    if (h->price_pending && h->cone_off_price) {   // priced again by the last launch in front of this look: cheap enough by now?
+      h->cone_heavy = price_share(h);
+      if (h->cone_heavy <= tuning().cone_heavy_share) { h->cone_off = false; h->cone_off_price = false; }
+      h->price_pending = false;
+    }
     if (hst->done && hst->status == kStatusCapFailed) {
       // the cap prediction failed for iteration hst->iter: repeat it uncapped, then carry on
       st.cap_retries++;
@@ -2280,6 +2330,7 @@ int lsgpu_icp_align(lsgpu_icp* h, const float* reading_xyz1, int64_t nq, const f
   }
   st.direction_index_launches = h->cone_launches;   // (enqueued; those behind the end of the loop exited at once)
   st.direction_index_occupancy = h->cone_decided ? h->cone_occupancy : 0.f;
+  st.direction_index_heavy_share = h->cone_heavy;
   st.pad_ = sel_retries;  // (select predictions that missed; informational)
   st.committed_select_iterations = committed_iterations;
   st.spread_tiles = (int)hst->n_spread;

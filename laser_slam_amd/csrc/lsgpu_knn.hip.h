@@ -37,6 +37,29 @@ constexpr float kPruneShrink = 1.0f - 2e-6f;  // a box is skipped only if mind2 
 constexpr float kCapSearchMargin2 = 1.05f * 1.05f;  // (search radius / cap radius)^2 in capped launches
 constexpr float kPadCoord = 3e18f;            // LDS pad point: squared distance ~2.7e37, never best
 
+// What k_knn_cone would pay for a lane: rows of its cone x columns at the query's own elevation x reference points per bin,
+// in evaluation steps of four candidates (the quantities of lsgpu_cone.hip.h's phase 2 without their margins).  A spinning
+// lidar's cloud is uniform in DIRECTION whatever the range, so the density is one number per reference.
+constexpr int kPriceSlots = 64, kPriceStride = 32;
+struct ConePrice {
+  float ox, oy, oz, rs, cs, dens4;
+  float heavy;              // a lane above this many steps is "heavy" (so is one the index cannot serve)
+  uint32_t* count;          // kPriceSlots x {heavy lanes, searching lanes}, one pair per 128-byte line (hashed by tile: atomics
+                            // on one line serialise in the L2 -- two counters for 16 k waves cost 100 us)
+};
+__device__ __forceinline__ float cone_price(const ConePrice& c, float qx, float qy, float qz, float R) {
+  const float vx = qx - c.ox, vy = qy - c.oy, vz = qz - c.oz;
+  const float r2 = __fmaf_rn(vy, vy, vx * vx);
+  const float inv_rho = __builtin_amdgcn_rsqf(__fmaf_rn(vz, vz, r2));
+  const float rxy = __builtin_amdgcn_sqrtf(r2);
+  const float sn = R * inv_rho, ce = rxy * inv_rho, zeta = fabsf(vz * inv_rho);
+  const float g = rxy * __builtin_amdgcn_rcpf(fabsf(vx) + fabsf(vy));
+  const float rows = 2.f * (ce * sn + zeta * sn * sn) * c.rs + 1.f;
+  const float cols = 2.f * (g * g) * sn * __builtin_amdgcn_rcpf(ce) * c.cs + 1.f;
+  const bool served = sn <= 0.5f && ce > 0.05f && ce <= 1.5f;
+  return served ? rows * __fmaf_rn(cols, c.dens4, 0.5f) : INFINITY;
+}
+
 struct KnnArgs {
   const float4* rdq;        // sorted reading (already moved by T_refMean_dataIn), w = caller index
   int nq;
@@ -70,6 +93,8 @@ struct KnnArgs {
   uint32_t* spread_list;    // tiles found spread so far
   uint32_t* spread_cnt;     // [0] entries the front rows may use (committed by k_normal_eq_loop), [1] entries appended
   int front_blocks;
+  // the search before the first one through the direction index (lsgpu_cone.hip.h) prices that index for this align
+  ConePrice price;          // price.count == nullptr: not this launch
   uint32_t* sel_hist2;      // predicted select (IcpState::sel_mode): 2048-bin histogram of bits [19:9] inside the bin
   uint32_t* sel_below;      //   kSelBelowSlots counters of distances below the bin (nullable: launch without prediction)
   uint32_t* sel_hist3w;     // committed select: kSelWinRows x 512 histogram of bits [8:0] around the last limit (nullable)
@@ -776,6 +801,14 @@ __global__ __launch_bounds__(WAVES * 64, LSGPU_TILE_OCC) void k_knn_tile(KnnArgs
   const bool ing = act && !straggler && !skip;
   bool routed = false;
   const unsigned long long ing_mask = __ballot(ing);
+  if (a.price.count) {   // (one launch per align)
+    const unsigned long long hv = __ballot(ing && !(cone_price(a.price, qx, qy, qz, R) <= a.price.heavy));
+    if (lane == 0 && ing_mask) {
+      uint32_t* slot = a.price.count + (tile & (uint32_t)(kPriceSlots - 1)) * (uint32_t)kPriceStride;
+      if (hv) atomicAdd(slot, (uint32_t)__popcll(hv));
+      atomicAdd(slot + 1, (uint32_t)__popcll(ing_mask));
+    }
+  }
 #ifdef LSGPU_EXPERIMENTS
   // Experiment (LSGPU_SPARSE_LANES): a wave with few searching lanes evaluates every candidate of its region for all 64
   // lanes (about 1400 vector instructions whatever the number of lanes that need them), so hand those lanes to the

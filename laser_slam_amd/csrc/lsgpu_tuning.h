@@ -35,6 +35,8 @@
 //   LSGPU_NE_BLOCKS        256  blocks of k_normal_eq_loop (64 .. 2048)
 //   LSGPU_SPLIT_UPDATE          the per-iteration update as its own launch (profiling)
 //   LSGPU_COMM_TIMEOUT_MS 30000 bound on every stream wait of the split-scan mode
+//   LSGPU_CONE_HEAVY_STEPS / _SHARE  price check before the first search through the index: lanes whose windows would hold more
+//                               than STEPS (1024) evaluation steps are heavy; more than SHARE (0.07; 2 = never) of them: voxel grid
 //   LSGPU_NO_CONE_PROBE         no probe of the query's own direction in the index's wide launches (iterations < LSGPU_WIDE_ITERS)
 //   LSGPU_NO_CONE               settled launches search the voxel grid (k_knn_tile) instead of the direction index (k_knn_cone)
 //   LSGPU_CONE_FROM          2  first iteration of an align that searches the direction index (0 and 1 have balls as wide as the
@@ -84,6 +86,8 @@ struct Tuning {
   bool cone_probe = true;
   int cone_rows = 128, cone_cols = 8192, cone_from = 2;
   float cone_max_occupancy = 7.0f;
+  float cone_heavy_steps = 1024.f;   // the index's price check: a lane whose windows would hold more steps of four than this is heavy
+  float cone_heavy_share = 0.07f;   // ... and an align with more than this share of heavy lanes among the searching ones keeps the voxel grid
 #ifdef LSGPU_EXPERIMENTS
   int knn_rows = 0;
   bool knn_lane = false;
@@ -145,13 +149,15 @@ inline Tuning read() {
   t.cone_probe = !flag("LSGPU_NO_CONE_PROBE");
   t.cone_from = (int)number("LSGPU_CONE_FROM", 2, 1, 1 << 20);
   t.cone_max_occupancy = (float)number("LSGPU_CONE_MAX_OCC", 7.0, 0.0, 1e9);
+  t.cone_heavy_steps = (float)number("LSGPU_CONE_HEAVY_STEPS", 1024.0, 0.0, 1e9);
+  t.cone_heavy_share = (float)number("LSGPU_CONE_HEAVY_SHARE", 0.07, 0.0, 2.0);
   t.cone_rows = (int)number("LSGPU_CONE_ROWS", 128, 8, 1024);
   t.cone_cols = (int)number("LSGPU_CONE_COLS", 8192, 64, 65536) & ~3;
   static const char* known[] = {"LSGPU_QUERY_ORDER", "LSGPU_Q_ELEV", "LSGPU_Q_SECT", "LSGPU_GAP", "LSGPU_BUDGET", "LSGPU_BUDGET_WIDE", "LSGPU_WIDE_ITERS",
                                 "LSGPU_ROUTE_R", "LSGPU_ROUTE_CHUNKS", "LSGPU_SPLIT_UPDATE", "LSGPU_NO_PREDICT", "LSGPU_NO_COMMIT",
                                 "LSGPU_NO_COMM_COMMIT", "LSGPU_NO_SEED_CAP", "LSGPU_NO_FRONT", "LSGPU_NO_LAZY", "LSGPU_NO_SIDE_STREAM", "LSGPU_NO_LOOKAHEAD", "LSGPU_FRONT_GUESS", "LSGPU_NO_ROUTE_ALL",
                                 "LSGPU_NO_ROWQ", "LSGPU_ROWQ_BLOCKS", "LSGPU_ROCPRIM_SORT", "LSGPU_SORT_ITEMS", "LSGPU_SSN_GLOBAL", "LSGPU_SSN_FULL_SORT",
-                                "LSGPU_NE_BLOCKS", "LSGPU_COMM_TIMEOUT_MS", "LSGPU_KNN_DBG", "LSGPU_NO_CONE", "LSGPU_NO_CONE_PROBE", "LSGPU_CONE_ROWS", "LSGPU_CONE_COLS", "LSGPU_CONE_FROM", "LSGPU_CONE_MAX_OCC",
+                                "LSGPU_NE_BLOCKS", "LSGPU_COMM_TIMEOUT_MS", "LSGPU_KNN_DBG", "LSGPU_NO_CONE", "LSGPU_NO_CONE_PROBE", "LSGPU_CONE_ROWS", "LSGPU_CONE_COLS", "LSGPU_CONE_FROM", "LSGPU_CONE_MAX_OCC", "LSGPU_CONE_HEAVY_STEPS", "LSGPU_CONE_HEAVY_SHARE",
                                 // read by the Python / C++ hosts and the test drivers, not by this library:
                                 "LSGPU_SO", "LSGPU_STATS_SO", "LSGPU_GOLDEN_DIR", "LSGPU_SEQ_PERTURB", "LSGPU_SEQ_POSES", "LSGPU_TEST_INPUT_FILTERS",
 #ifdef LSGPU_EXPERIMENTS

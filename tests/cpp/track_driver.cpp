@@ -115,6 +115,10 @@ int main(int argc, char** argv) {
         std::printf("factor %d keys %zu %zu q %.9f %.9f %.9f %.9f p %.9f %.9f %.9f\n", (int)f.type, f.key_a,
                     f.key_b, qq[0], qq[1], qq[2], qq[3], pp[0], pp[1], pp[2]);
       }
+      if (i > 0 && std::getenv("LSGPU_TRACK_STAGES"))
+        std::printf("stages copy_ms %.3f upload_ms %.3f icp_ms %.3f device_filters_ms %.3f device_total_ms %.3f cone_launches %d cone_occupancy %.2f\n", track.lastStageTimes().copy_ms,
+                    track.lastStageTimes().upload_ms, track.lastStageTimes().icp_ms, track.lastIcpStats().t_reserved[0], track.lastIcpStats().t_total_ms,
+                    (int)track.lastIcpStats().direction_index_launches, (double)track.lastIcpStats().direction_index_occupancy);
       if (i > 0) std::printf("icp_iterations %d converged %d scan_ms %.3f\n", track.lastIcpStats().iterations,
                              track.lastIcpStats().converged, track.getScanMatchingTimes().at(scan.time_ns));
     }
