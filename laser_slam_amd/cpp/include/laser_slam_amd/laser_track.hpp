@@ -23,6 +23,7 @@
 #include <stdexcept>
 #include <string>
 #include <utility>
+#include <thread>
 #include <vector>
 
 #include "laser_slam_amd/icp.hpp"
@@ -69,6 +70,8 @@ struct LaserTrackParams {  // laser_slam/include/laser_slam/parameters.hpp:8-23
   bool force_priors = false;
   int device = 0;                       // HIP device of this track's ICP handle
   int scans_on_device = 16;             // most recent scans kept in HBM for sub-map assembly (0: host assembly)
+  bool overlap_scan_copy = true;        // processPoseAndLaserScan with an empty input chain: the host copy of the scan is made
+                                        // beside the device's registration instead of in front of it (not a reference parameter)
 };
 
 // Factor / FactorList / Values: pose_graph.hpp
@@ -145,14 +148,52 @@ class LaserTrack {
     const auto t0 = std::chrono::steady_clock::now();
     if (newFactors && !newFactors->empty()) throw std::logic_error("newFactors must be empty");
     if (newValues) newValues->clear();
-    LaserScan scan = in_scan;
-    input_filters_.apply(scan.scan);  // laser_track.cpp:146
+    // The working copy of the scan (laser_track.cpp:145-146: `LaserScan scan = in_scan` + the input filters; it ends up in
+    // laser_scans_).  16 MB for 1 M points, 2.5 ms of page faults and memcpy on the host -- a third of what the device needs
+    // for the whole registration.  With an empty input chain the copy IS in_scan's points, so it is made on a helper thread
+    // while the device registers in_scan's own buffer (valid for the whole call), and joins laser_scans_.back() before
+    // anything else looks at it.  Same results, same state afterwards; any other configuration copies first, as upstream.
+    LaserScan scan;
+    scan.time_ns = in_scan.time_ns; scan.key = in_scan.key;
+    bool overlap = params_.overlap_scan_copy && input_filters_.empty() && params_.scans_on_device > 0 && params_.use_icp_factors &&
+                   !params_.save_icp_results && !icp_.hasComputeOverride() && !trajectory_.isEmpty();
+#ifdef LSGPU_TEST_SEAMS
+    overlap = overlap && !icp_.hasComputeObserver();
+#endif
+    struct CopyJoin {   // joins on every path out of this call and puts the points where they belong
+      LaserTrack* self; size_t n_before; std::thread t; DataPoints points; bool armed = false;
+      ~CopyJoin() {   // (an exception on the way: the scan, if it was stored, still gets its points)
+        if (t.joinable()) t.join();
+        self->pending_reading_ = nullptr;
+        if (armed && self->laser_scans_.size() == n_before + 1) self->laser_scans_.back().scan = std::move(points);
+      }
+    } copy{this, laser_scans_.size(), {}, {}};
+    if (overlap) {
+      try {
+        copy.t = std::thread([&copy, &in_scan] { copy.points = in_scan.scan; });
+      } catch (const std::system_error&) { overlap = false; }   // no thread to be had: copy here
+    }
+    if (overlap) {
+      pending_reading_ = &in_scan.scan;
+      copy.armed = true;   // (registerScan below stores the scan, points to follow, before it runs the ICP)
+    } else {
+      scan.scan = in_scan.scan;
+      input_filters_.apply(scan.scan);  // laser_track.cpp:146
+    }
     stage_times_ = StageTimes{};
     stage_times_.copy_ms = msSince(t0);
     pose_measurements_.push_back(pose);
     const bool first = trajectory_.isEmpty();
     RelativePose odom;
     registerScan(&scan, &odom, /*icp_before_store=*/false);
+    if (overlap) {   // the points join the stored scan here (not at the end of the call: the factors below do not need them, a reader of laser_scans_ does)
+      const auto tj = std::chrono::steady_clock::now();
+      copy.t.join();
+      pending_reading_ = nullptr;
+      laser_scans_.back().scan = std::move(copy.points);
+      copy.armed = false;
+      stage_times_.copy_ms += msSince(tj);
+    }
     if (first) {
       if (newFactors) {
         Pose prior = pose;
@@ -346,6 +387,7 @@ class LaserTrack {
   void localScanToSubMap() {
     const size_t n = laser_scans_.size();
     const LaserScan& last_scan = laser_scans_.back();
+    const DataPoints& reading = pending_reading_ ? *pending_reading_ : last_scan.scan;   // (processPoseAndLaserScan: the copy may still be under way)
     RelativePose icp;
     icp.time_b_ns = last_scan.time_ns;
     icp.time_a_ns = laser_scans_[n - 2].time_ns;
@@ -382,14 +424,14 @@ class LaserTrack {
           DataPoints sub_map = laser_scans_[members[0]].scan;
           for (size_t i = 1; i < members.size(); ++i)
             sub_map.concatenate(RigidTransformation::compute(laser_scans_[members[i]].scan, member_T[i]));
-          icp_.notifyObserver(last_scan.scan, sub_map, T_init, solution);
+          icp_.notifyObserver(reading, sub_map, T_init, solution);
         }
 #endif
       } else {
         DataPoints sub_map = laser_scans_[members[0]].scan;
         for (size_t i = 1; i < members.size(); ++i)
           sub_map.concatenate(RigidTransformation::compute(laser_scans_[members[i]].scan, member_T[i]));
-        solution = icp_.compute(last_scan.scan, sub_map, T_init);
+        solution = icp_.compute(reading, sub_map, T_init);
       }
     } catch (const ConvergenceError&) {
       // keep the initial guess (laser_track.cpp:499-502)
@@ -399,13 +441,13 @@ class LaserTrack {
       for (size_t i = 1; i < members.size(); ++i)
         sub_map.concatenate(RigidTransformation::compute(laser_scans_[members[i]].scan, member_T[i]));
       const std::string dir = params_.save_icp_results_dir;
-      saveVTK(last_scan.scan, dir + "/last_scan.vtk");
+      saveVTK(reading, dir + "/last_scan.vtk");
       saveVTK(sub_map, dir + "/sub_map.vtk");
       TransformationParameters guess_corrected = T_init;
       correctTransformationMatrix(&guess_corrected);
-      saveVTK(RigidTransformation::compute(last_scan.scan, guess_corrected), dir + "/last_scan_alligned_by_initial_guess.vtk");
+      saveVTK(RigidTransformation::compute(reading, guess_corrected), dir + "/last_scan_alligned_by_initial_guess.vtk");
       correctTransformationMatrix(&solution);
-      saveVTK(RigidTransformation::compute(last_scan.scan, solution), dir + "/last_scan_alligned_by_solution.vtk");
+      saveVTK(RigidTransformation::compute(reading, solution), dir + "/last_scan_alligned_by_solution.vtk");
     }
     icp.T_a_b = SE3::fromTransformationMatrix(solution.data());  // convertTransformationMatrixToSE3
     icp.key_a = getPoseKey(icp.time_a_ns);
@@ -421,7 +463,7 @@ class LaserTrack {
     if (slot_generation_ != icp_.generation()) { slot_owner_.clear(); slot_generation_ = icp_.generation(); }
     if ((int)slot_owner_.size() < params_.scans_on_device) slot_owner_.resize((size_t)params_.scans_on_device, (size_t)-1);
     if (slot_owner_[(size_t)slot] != index || !icp_.hasCloud(slot)) {
-      icp_.uploadCloud(slot, laser_scans_[index].scan);
+      icp_.uploadCloud(slot, (pending_reading_ && index + 1 == laser_scans_.size()) ? *pending_reading_ : laser_scans_[index].scan);
       slot_owner_[(size_t)slot] = index;
       slot_generation_ = icp_.generation();  // (uploadCloud may have created the handle)
     }
@@ -440,6 +482,7 @@ class LaserTrack {
   std::map<Time, double> scan_matching_times_;
   std::vector<size_t> slot_owner_;   // which scan each device slot holds
   StageTimes stage_times_;
+  const DataPoints* pending_reading_ = nullptr;   // the newest scan's points while their copy into laser_scans_ is under way
   unsigned slot_generation_ = 0;
   mutable std::recursive_mutex mutex_;
 };
