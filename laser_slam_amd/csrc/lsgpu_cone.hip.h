@@ -132,11 +132,14 @@ __global__ __launch_bounds__(256) void k_cone_gather(const float4* __restrict__ 
     const unsigned long long firsts = __ballot(valid && gap_hi > gap_lo);
     if (lane == 0 && firsts) atomicAdd(occupied, (uint32_t)__popcll(firsts));
   }
-  // ---- table: a thread whose key is the next one after its predecessor's writes one entry (the common case: one or two
-  // points per bin); longer gaps -- empty bins, empty rows -- by the whole wave
+  // ---- table: a thread whose key follows its predecessor's closely writes the few entries in between itself; longer
+  // gaps -- sparse directions, empty rows -- by the whole wave
   const uint32_t glen = gap_hi - gap_lo;
-  if (glen == 1u) tab[gap_lo] = pos;
-  unsigned long long big = __ballot(glen > 1u);
+  if (glen >= 1u && glen <= 6u) {   // (half of the bins of a 1 M-point scan are empty: most gaps are two or three entries --
+    tab[gap_lo] = pos;              // handing each of them to the whole wave made this kernel 190 us long)
+    for (uint32_t k = 1u; k < glen; ++k) tab[gap_lo + k] = pos;
+  }
+  unsigned long long big = __ballot(glen > 6u);
   while (big) {
     const int src = __ffsll((long long)big) - 1;
     big &= big - 1;

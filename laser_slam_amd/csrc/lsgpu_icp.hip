@@ -1635,6 +1635,9 @@ int lsgpu_icp_compute(lsgpu_icp* h, const float* reading_xyz1, int64_t nq, const
   } side_guard{h};
   bool side_prepared = false;
   if (side) {
+    // (Tried: this stream at the lowest stream priority, so that the loop's short kernels never wait for a compute unit behind
+    // the direction index's build.  Measured slower, 5.27 -> 5.41..5.60 ms per compute from host buffers, level from resident
+    // ones: the reading's filter and query order run here too and ARE on the critical path.)
     if (!h->side_stream) HIPC(hipStreamCreateWithFlags(&h->side_stream, hipStreamNonBlocking));
     if (!h->side_done) HIPC(hipEventCreateWithFlags(&h->side_done, hipEventDisableTiming));
     order_after_tail(h, h->side_stream);
