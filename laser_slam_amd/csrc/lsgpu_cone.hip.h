@@ -66,10 +66,8 @@ __device__ __forceinline__ uint32_t cone_clampu(float t, int hi) {   // floor al
 // ---------------------------------------------------------------- build
 // keys of the Morton-sorted, centred reference: (row, column) of every point's direction
 __global__ __launch_bounds__(256) void k_cone_keys(const float4* __restrict__ pts, int64_t n, ConeDev c,
-                                                   uint64_t* __restrict__ keys, uint32_t* __restrict__ vals,
-                                                   uint32_t* __restrict__ rowz_bits) {
+                                                   uint64_t* __restrict__ keys, uint32_t* __restrict__ vals) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (i < 2 * (int64_t)c.rows) rowz_bits[i] = (i & 1) ? 0u : 0xFFFFFFFFu;   // {min, max} in ordered-integer form
   if (i >= n) return;
   const float4 p = pts[i];
   float inv_rho, zeta, pa, rxy, inv_h;
@@ -82,32 +80,22 @@ __global__ __launch_bounds__(256) void k_cone_keys(const float4* __restrict__ pt
   vals[i] = (uint32_t)i;
 }
 
-__device__ __forceinline__ uint32_t ord_of_float(float f) {   // order-preserving float -> uint32
-  const uint32_t b = __float_as_uint(f);
-  return b ^ ((b >> 31) ? 0xFFFFFFFFu : 0x80000000u);
-}
-__device__ __forceinline__ float float_of_ord(uint32_t o) {
-  return __uint_as_float(o ^ ((o >> 31) ? 0x80000000u : 0xFFFFFFFFu));
-}
-
 // after the stable sort by key: SoA copy + position map, the (row, column) -> first position table (every thread fills
-// the table entries between its predecessor's key and its own; long gaps -- empty rows -- by the whole wave), the zeta
-// range of every row
+// the table entries between its predecessor's key and its own; long gaps -- empty rows -- by the whole wave).  No atomics:
+// the zeta range of every row and the number of occupied bins are k_cone_rows' (a row is ~8 k consecutive points, i.e. 128
+// consecutive waves: their two atomics per wave on the row's two words serialised in the L2 and made this kernel 190 us
+// long -- 16 k waves waiting 15 us each for 50 MB of traffic)
 __global__ __launch_bounds__(256) void k_cone_gather(const float4* __restrict__ pts, const uint32_t* __restrict__ perm,
                                                      const uint64_t* __restrict__ keys, int64_t n, ConeDev c,
                                                      float* __restrict__ soa,
-                                                     uint32_t* __restrict__ map, uint32_t* __restrict__ tab,
-                                                     uint32_t* __restrict__ rowz_bits,
-                                                     uint32_t* __restrict__ occupied /* += bins that hold a point */) {
+                                                     uint32_t* __restrict__ map, uint32_t* __restrict__ tab) {
   const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
   const int lane = threadIdx.x & 63;
   const int64_t npad = ((n + 3) & ~(int64_t)3) + kConePad;
   const uint32_t nkeys = (uint32_t)c.rows * (uint32_t)c.cols;
   uint32_t gap_lo = 0, gap_hi = 0;   // this thread writes tab[gap_lo .. gap_hi) = its own position
   uint32_t pos = 0;
-  bool valid = j < n;
-  uint32_t row = 0xFFFFFFFFu;
-  float zeta = 0.f;
+  const bool valid = j < n;
   if (valid) {
     const uint32_t i = perm[j];
     const float4 p = pts[i];
@@ -117,26 +105,16 @@ __global__ __launch_bounds__(256) void k_cone_gather(const float4* __restrict__ 
     gap_lo = j > 0 ? (uint32_t)keys[j - 1] + 1u : 0u;
     gap_hi = key + 1u;
     pos = (uint32_t)j;
-    row = key / (uint32_t)c.cols;
-    float inv_rho, pa, rxy, inv_h;
-    cone_dir(p.x - c.ox, p.y - c.oy, p.z - c.oz, inv_rho, zeta, pa, rxy, inv_h);
-    if (!(fabsf(zeta) <= 1.5f)) zeta = 0.f;
   } else if (j < npad) {
     float* g = soa + 12 * (j >> 2) + (j & 3);
     g[0] = kPadCoord; g[4] = kPadCoord; g[8] = kPadCoord; map[j] = 0u;
     if (j == n) { gap_lo = (uint32_t)keys[n - 1] + 1u; gap_hi = nkeys + 1u; pos = (uint32_t)n; }   // everything behind the last key
   }
-  // ---- occupied bins (the host decides from points per occupied bin whether this index or the voxel grid serves the
-  // settled searches: a local map of many scans is several times denser in direction than one scan)
-  {
-    const unsigned long long firsts = __ballot(valid && gap_hi > gap_lo);
-    if (lane == 0 && firsts) atomicAdd(occupied, (uint32_t)__popcll(firsts));
-  }
   // ---- table: a thread whose key follows its predecessor's closely writes the few entries in between itself; longer
   // gaps -- sparse directions, empty rows -- by the whole wave
   const uint32_t glen = gap_hi - gap_lo;
-  if (glen >= 1u && glen <= 6u) {   // (half of the bins of a 1 M-point scan are empty: most gaps are two or three entries --
-    tab[gap_lo] = pos;              // handing each of them to the whole wave made this kernel 190 us long)
+  if (glen >= 1u && glen <= 6u) {   // (half of the bins of a 1 M-point scan are empty: most gaps are two or three entries)
+    tab[gap_lo] = pos;
     for (uint32_t k = 1u; k < glen; ++k) tab[gap_lo + k] = pos;
   }
   unsigned long long big = __ballot(glen > 6u);
@@ -146,30 +124,46 @@ __global__ __launch_bounds__(256) void k_cone_gather(const float4* __restrict__ 
     const uint32_t lo = rl_u(gap_lo, src), hi = rl_u(gap_hi, src), ps = rl_u(pos, src);
     for (uint32_t k = lo + (uint32_t)lane; k < hi; k += 64u) tab[k] = ps;
   }
-  // ---- zeta range per row: one pair of atomics per wave where the wave is inside one row (almost always)
-  const uint32_t r0 = rl_u(row, 0);
-  const bool same = __ballot(valid && row == r0) == __ballot(valid) && __ballot(valid);
-  if (same) {
-    const float mn = wave_min(valid ? zeta : INFINITY), mx = wave_max(valid ? zeta : -INFINITY);
-    if (lane == 0) { atomicMin(&rowz_bits[2u * r0], ord_of_float(mn)); atomicMax(&rowz_bits[2u * r0 + 1u], ord_of_float(mx)); }
-  } else if (valid) {
-    atomicMin(&rowz_bits[2u * row], ord_of_float(zeta));
-    atomicMax(&rowz_bits[2u * row + 1u], ord_of_float(zeta));
-  }
 }
 
-__global__ __launch_bounds__(256) void k_cone_rowz(const uint32_t* __restrict__ rowz_bits, int rows, float4* __restrict__ rowz) {
-  const int r = blockIdx.x * 256 + threadIdx.x;
-  if (r >= rows) return;
-  const uint32_t lo = rowz_bits[2 * r], hi = rowz_bits[2 * r + 1];
-  float4 o = make_float4(INFINITY, -INFINITY, INFINITY, 0.f);
-  if (lo != 0xFFFFFFFFu) {
-    o.x = float_of_ord(lo); o.y = float_of_ord(hi);
-    const float zm = fmaxf(fabsf(o.x), fabsf(o.y));
-    const float cep = sqrtf(fmaxf(1.f - zm * zm, 0.f)) * (1.0f - 1e-5f);   // smallest cos(elevation) in the row, rounded down
-    o.z = 1.0f / (4.f * cep) * (1.0f + 1e-6f);                              // (a row that touches the polar axis: inf)
+// One workgroup per row, behind k_cone_gather: the zeta range of the row's points (a contiguous run of the sorted copy),
+// 1 / (4 min cos(elevation)), and the row's occupied bins (the host decides from points per occupied bin whether this
+// index or the voxel grid serves the settled searches: a local map of many scans is several times denser in direction
+// than one scan) -- one add per row.
+__global__ __launch_bounds__(256) void k_cone_rows(ConeDev c, float4* __restrict__ rowz, uint32_t* __restrict__ occupied) {
+  __shared__ float mn_sh[4], mx_sh[4];
+  __shared__ uint32_t cnt_sh[4];
+  const uint32_t row = blockIdx.x, base = row * (uint32_t)c.cols;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const uint32_t st = c.tab[base], en = c.tab[base + (uint32_t)c.cols];
+  const float* __restrict__ soa = reinterpret_cast<const float*>(c.soa);
+  float mn = INFINITY, mx = -INFINITY;
+  for (uint32_t p = st + threadIdx.x; p < en; p += 256u) {
+    const float* g = soa + 12u * (size_t)(p >> 2) + (p & 3u);
+    float inv_rho, zeta, pa, rxy, inv_h;
+    cone_dir(g[0] - c.ox, g[4] - c.oy, g[8] - c.oz, inv_rho, zeta, pa, rxy, inv_h);
+    if (!(fabsf(zeta) <= 1.5f)) zeta = 0.f;   // (as k_cone_keys)
+    mn = fminf(mn, zeta); mx = fmaxf(mx, zeta);
   }
-  rowz[r] = o;
+  uint32_t cnt = 0;
+  for (uint32_t b = threadIdx.x; b < (uint32_t)c.cols; b += 256u) cnt += c.tab[base + b + 1u] > c.tab[base + b] ? 1u : 0u;
+  mn = wave_min(mn); mx = wave_max(mx); cnt = wave_sum_u32(cnt);
+  if (lane == 0) { mn_sh[w] = mn; mx_sh[w] = mx; cnt_sh[w] = cnt; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    mn = fminf(fminf(mn_sh[0], mn_sh[1]), fminf(mn_sh[2], mn_sh[3]));
+    mx = fmaxf(fmaxf(mx_sh[0], mx_sh[1]), fmaxf(mx_sh[2], mx_sh[3]));
+    float4 o = make_float4(INFINITY, -INFINITY, INFINITY, 0.f);
+    if (en > st) {
+      o.x = mn; o.y = mx;
+      const float zm = fmaxf(fabsf(mn), fabsf(mx));
+      const float cep = sqrtf(fmaxf(1.f - zm * zm, 0.f)) * (1.0f - 1e-5f);   // smallest cos(elevation) in the row, rounded down
+      o.z = 1.0f / (4.f * cep) * (1.0f + 1e-6f);                              // (a row that touches the polar axis: inf)
+    }
+    rowz[row] = o;
+    const uint32_t total = cnt_sh[0] + cnt_sh[1] + cnt_sh[2] + cnt_sh[3];
+    if (total) atomicAdd(occupied, total);
+  }
 }
 
 // ---------------------------------------------------------------- search

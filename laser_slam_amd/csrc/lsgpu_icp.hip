@@ -186,7 +186,7 @@ struct lsgpu_icp {
   uint32_t nchunks = 0;
   // direction index of the reference (lsgpu_cone.hip.h): the settled launches of an align search it instead of the voxel grid
   DevBuf<float> cone_soa;
-  DevBuf<uint32_t> cone_map, cone_tab, cone_rowz_bits;
+  DevBuf<uint32_t> cone_map, cone_tab;
   DevBuf<float4> cone_rowz;
   ConeDev cone;
   bool cone_ok = false;       // built (or being built on the side stream: cone_pending) for the current reference
@@ -418,7 +418,7 @@ void lsgpu_icp_destroy(lsgpu_icp* h) {
   h->work.release();
 #endif
   h->pts.release();
-  h->cone_soa.release(); h->cone_occ.release(); h->cone_map.release(); h->cone_tab.release(); h->cone_rowz_bits.release(); h->cone_rowz.release();
+  h->cone_soa.release(); h->cone_occ.release(); h->cone_map.release(); h->cone_tab.release(); h->cone_rowz.release();
   h->nrm.release(); h->ref_inv.release(); h->tables.release(); h->flags.release(); h->cidx.release(); h->bounds.release(); h->chunks.release(); h->soa.release(); h->soa_base.release(); h->soa_cnt4.release(); h->soa_first.release(); h->prev.release(); h->state.release(); h->lb.release(); h->cell_cache.release(); h->cell_tags.release(); h->ssn_seg_a.release(); h->ssn_seg_b.release(); h->ssn_axis_a.release(); h->ssn_axis_b.release(); h->ssn_seg_fb.release(); h->ssn_blocktab.release(); h->ssn_seg_of.release(); h->ssn_box_pts.release(); h->ssn_box_base.release(); h->ssn_keep.release(); h->ssn_out_pos.release(); h->ssn_bb.release(); h->ssn_box_normal.release(); h->ssn_draws.release(); h->flt_in.release(); h->flt_in2.release(); h->flt_ref.release(); h->flt_rd.release(); h->flt_nrm.release(); h->chk_hist.release(); h->trace_dev.release(); h->knn_dbg.release(); h->knn_dbg_wave.release(); h->stat_partials.release(); h->geom.release();
   h->counters.release(); h->price_cnt.release(); h->ang_cells.release(); h->sel_aux.release(); h->sel_win.release(); h->spread_flag.release(); h->spread_list.release(); h->spread_cnt.release(); h->q_in.release(); h->rdq.release(); h->ids.release(); h->d2.release();
   h->ids_io.release(); h->d2_io.release(); h->strag.release(); h->hist.release();
@@ -829,11 +829,11 @@ static int build_cone_index(lsgpu_icp* h) {
   c.cs = (float)c.cols * 0.25f;
   const size_t npad = (((size_t)nr + 3) & ~(size_t)3) + kConePad, nkeys = (size_t)c.rows * (size_t)c.cols;
   HIPC(h->cone_soa.reserve(3 * npad)); HIPC(h->cone_map.reserve(npad));
-  HIPC(h->cone_tab.reserve(nkeys + 1)); HIPC(h->cone_rowz_bits.reserve(2 * (size_t)c.rows)); HIPC(h->cone_rowz.reserve((size_t)c.rows));
+  HIPC(h->cone_tab.reserve(nkeys + 1)); HIPC(h->cone_rowz.reserve((size_t)c.rows));
   HIPC(h->sc->keys.reserve(nr)); HIPC(h->sc->vals.reserve(nr));
   c.soa = reinterpret_cast<const float4*>(h->cone_soa.p); c.map = h->cone_map.p; c.tab = h->cone_tab.p; c.rowz = h->cone_rowz.p;
-  hipLaunchKernelGGL(k_cone_keys, dim3(std::max(nblk(nr), nblk(2 * c.rows))), dim3(256), 0, h->cur, h->pts.p, nr, c,
-                     h->sc->keys.p, h->sc->vals.p, h->cone_rowz_bits.p);
+  hipLaunchKernelGGL(k_cone_keys, dim3(nblk(nr)), dim3(256), 0, h->cur, h->pts.p, nr, c,
+                     h->sc->keys.p, h->sc->vals.p);
   int nbits = 1;
   while (((size_t)1 << nbits) < nkeys) ++nbits;
   const int rc = sort_pairs(h, nr, nbits);
@@ -841,8 +841,8 @@ static int build_cone_index(lsgpu_icp* h) {
   HIPC(h->cone_occ.reserve(1));
   HIPC(hipMemsetAsync(h->cone_occ.p, 0, sizeof(uint32_t), h->cur));
   hipLaunchKernelGGL(k_cone_gather, dim3(nblk((int64_t)npad)), dim3(256), 0, h->cur, h->pts.p, h->sc->vals_alt.p,
-                     h->sc->keys_alt.p, nr, c, h->cone_soa.p, h->cone_map.p, h->cone_tab.p, h->cone_rowz_bits.p, h->cone_occ.p);
-  hipLaunchKernelGGL(k_cone_rowz, dim3(nblk(c.rows)), dim3(256), 0, h->cur, h->cone_rowz_bits.p, c.rows, h->cone_rowz.p);
+                     h->sc->keys_alt.p, nr, c, h->cone_soa.p, h->cone_map.p, h->cone_tab.p);
+  hipLaunchKernelGGL(k_cone_rows, dim3(c.rows), dim3(256), 0, h->cur, c, h->cone_rowz.p, h->cone_occ.p);
   HIPC(hipGetLastError());
   // the number of occupied bins travels to the host behind the build; lsgpu_icp_align looks at it before its first
   // search through the index (the device is busy with the first two iterations by then)
