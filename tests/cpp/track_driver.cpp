@@ -47,6 +47,7 @@ int main(int argc, char** argv) {
   }
   p.nscan_in_sub_map = std::atoi(argv[4]);
   if (argc > 5) p.scans_on_device = std::atoi(argv[5]);
+  if (std::getenv("LSGPU_TRACK_NO_OVERLAP")) p.overlap_scan_copy = false;   // the scan's host copy in front of the registration, as upstream
   p.odometry_noise_model = {0.05, 0.05, 0.05, 0.01, 0.01, 0.01};
   p.icp_noise_model = {0.005, 0.005, 0.005, 0.0015, 0.0015, 0.0015};
   std::srand(4);

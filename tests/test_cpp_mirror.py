@@ -196,7 +196,9 @@ def test_cpp_incremental_estimator_closes_a_loop(tmp_path):
 @pytest.mark.gpu
 def test_cpp_submap_on_device_equals_host_assembly(tmp_path):
     """LaserTrack with scans resident in HBM (sub-map assembled by lsgpu_icp_compute_clouds) must produce the
-    same ICP factors, bit for bit, as the host assembly of laser_track.cpp:474-486."""
+    same ICP factors, bit for bit, as the host assembly of laser_track.cpp:474-486 -- with the scan's host copy made
+    beside the registration (the default with an empty input chain) and in front of it, and the stored scans must be
+    complete either way (the clouds built from laser_scans_ at the end of the run have the same sizes)."""
     exe = _build(tmp_path, "track_driver.cpp", "track_driver")
     scene = synth.Scene(1234)
     n = 5
@@ -207,12 +209,14 @@ def test_cpp_submap_on_device_equals_host_assembly(tmp_path):
             f.write(_pose_line(100000000 * i, T @ synth.se3(0.1 * i, -0.05 * i, 0, yaw=np.deg2rad(0.5 * i))))
     yaml = os.path.join(ROOT, "tests", "golden", "icp_chain.yaml")
     outs = []
-    for on_device in ("16", "0"):
-        r = subprocess.run([exe, str(tmp_path), str(n), yaml, "3", on_device], capture_output=True, text=True, timeout=300)
+    for on_device, env in (("16", {}), ("0", {}), ("16", {"LSGPU_TRACK_NO_OVERLAP": "1"})):
+        r = subprocess.run([exe, str(tmp_path), str(n), yaml, "3", on_device], capture_output=True, text=True, timeout=300,
+                           env=dict(os.environ, **env))
         assert r.returncode == 0, r.stdout + r.stderr
-        outs.append([l for l in r.stdout.splitlines() if l.startswith("factor ") or l.startswith("icp_iterations")])
+        outs.append([l for l in r.stdout.splitlines() if l.startswith(("factor ", "icp_iterations", "world_cloud "))])
     strip = lambda ls: [" ".join(l.split()[:5]) if l.startswith("icp_iterations") else l for l in ls]
-    assert strip(outs[0]) == strip(outs[1]) and len(outs[0]) > 2 * (n - 1)
+    assert strip(outs[0]) == strip(outs[1]) == strip(outs[2]) and len(outs[0]) > 2 * (n - 1)
+    assert any(l.startswith("world_cloud ") for l in outs[0])
 
 
 @pytest.mark.gpu
