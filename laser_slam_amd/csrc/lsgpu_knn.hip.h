@@ -81,6 +81,7 @@ struct KnnArgs {
   float gap;                // capped launches search `gap` metres beyond the current best (keep-match bound)
   float spread_route_r;     // > 0: a spread wave whose largest ball exceeds this hands its lanes to k_knn_fallback
   int route_chunks;         // (with spread_route_r > 0) so does any wave whose cell block holds more chunks than this
+  int route_dense;          // (with spread_route_r > 0) and a SPREAD wave whose cell block holds more chunks than this, whatever its balls
 #ifdef LSGPU_EXPERIMENTS
   int sparse_lanes;         // > 0: a wave with at most this many searching lanes hands them to k_knn_rowq
   int xcd_swizzle;          // 1: block b -> XCD (b % 8) gets a contiguous eighth of the tiles
@@ -893,7 +894,8 @@ __global__ __launch_bounds__(WAVES * 64, LSGPU_TILE_OCC) void k_knn_tile(KnnArgs
 #ifdef LSGPU_KNN_STATS
     if (spread && (a.dbg_flags & 32)) { /* ablation: drop spread waves */ } else
 #endif
-    if (a.spread_route_r > 0.f && Rmax > a.spread_route_r && (spread || block_chunks > (uint32_t)a.route_chunks)) {
+    if (a.spread_route_r > 0.f && ((Rmax > a.spread_route_r && (spread || block_chunks > (uint32_t)a.route_chunks)) ||
+                                   (spread && block_chunks > (uint32_t)a.route_dense))) {
       // wide balls and no shared candidates: 64 divergent per-lane searches would hold this wave for up
       // to a millisecond (the tail of the first launches); one wave per query (k_knn_fallback) instead
       routed = ing;

@@ -349,7 +349,7 @@ def test_experiment_switches_do_not_change_results():
                 dict(tile, LSGPU_NO_FRONT="1", LSGPU_NO_ROUTE_ALL="1"), {"LSGPU_NO_COMMIT": "1"}, dict(tile, LSGPU_NO_COMMIT="1"),
                 {"LSGPU_NO_PREDICT": "1"}, dict(tile, LSGPU_NO_PREDICT="1"),
                 {"LSGPU_CONE_ROWS": "32", "LSGPU_CONE_COLS": "1024"}, {"LSGPU_CONE_ROWS": "512", "LSGPU_CONE_COLS": "32768"},
-                {"LSGPU_NO_CONE_PROBE": "1"}, {"LSGPU_CONE_FROM": "1"}, {"LSGPU_CONE_HEAVY_SHARE": "2"},
+                {"LSGPU_NO_CONE_PROBE": "1"}, {"LSGPU_CONE_FROM": "1"}, {"LSGPU_CONE_HEAVY_SHARE": "2"}, dict(tile, LSGPU_ROUTE_DENSE="16"), dict(tile, LSGPU_ROUTE_DENSE="1073741824"),
                 {"LSGPU_CONE_HEAVY_STEPS": "8", "LSGPU_CONE_HEAVY_SHARE": "0.5"},   # (too dear at first, priced again before every look)
                 {"LSGPU_ROCPRIM_SORT": "1"}, {"LSGPU_SORT_ITEMS": "4"}, {"LSGPU_NO_SEED_CAP": "1"}, {"LSGPU_NO_LAZY": "1"}, {"LSGPU_NO_SIDE_STREAM": "1"}, {"LSGPU_NO_LOOKAHEAD": "1"},
                 dict(tile, LSGPU_FRONT_GUESS="8"), {"LSGPU_SSN_GLOBAL": "1"}, {"LSGPU_SSN_FULL_SORT": "1"}, {"LSGPU_SSN_FULL_SORT": "1", "LSGPU_SSN_GLOBAL": "1"},
