@@ -65,6 +65,31 @@ def _cpu_model() -> str:
     return "unknown"
 
 
+def relaunch_argv(argv, n_gpus: int, port: int):
+    """`python bench.py --gpus N ...` started WITHOUT a launcher (no WORLD_SIZE in the environment): the command line that
+    runs the same arguments as N ranks of one node, one rank per GPU over RCCL -- exactly the shape the driver uses
+    (`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py ...`).
+    Pure function of its arguments (tests/test_sharding.py checks it on the CPU)."""
+    if n_gpus < 2:
+        raise ValueError("a single rank needs no launcher")
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(int(n_gpus)),
+            "--master-addr", "127.0.0.1", "--master-port", str(int(port)), os.path.abspath(__file__), *argv]
+
+
+def needs_relaunch(n_gpus: int, environ) -> bool:
+    """True when --gpus asks for more ranks than this process is part of (no launcher environment)."""
+    return n_gpus > 1 and "WORLD_SIZE" not in environ and "RANK" not in environ
+
+
+def _free_port() -> int:
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
 def track_section(n_az: int, n_scans: int, cpu_threads: int):
     """SURVEY.md 8d, the reference's OWN timed region: `scan_matching_times_` of LaserTrack::processPoseAndLaserScan
     (laser_slam/src/laser_track.cpp:128, 208-209 -- the clock runs from the top of the call to the end of
@@ -159,12 +184,21 @@ def main():
     ap.add_argument("--split-pair", action="store_true", help="(with --split) the configs[1] pair instead of the 8-scan local map")
     args = ap.parse_args()
 
+    if needs_relaunch(args.gpus, os.environ):
+        # `python bench.py --gpus 8` (no launcher): become N ranks of this node, default / --batch / --split alike
+        import subprocess
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        raise SystemExit(subprocess.call(relaunch_argv(sys.argv[1:], args.gpus, _free_port()), env=env))
+
     import torch
     import torch.distributed as dist
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus != world and rank == 0:
+        print("bench.py: --gpus %d but the launcher started %d rank(s); n_gpus reports the ranks that ran" % (args.gpus, world), file=sys.stderr)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a ROCm GPU: the ICP hot path has no CPU fallback")
     torch.cuda.set_device(local_rank)
@@ -307,12 +341,14 @@ def main():
     filt_ms = 0.0
     T = None
     step_s = []
+    n_converged = 0
     for _ in range(args.steps):
         ts = time.perf_counter()
         T, st = step()
         step_s.append(time.perf_counter() - ts)
         iters += st.iterations
         filt_ms += st.t_reserved[0]
+        n_converged += int(st.converged)
     barrier()
     elapsed = max_over_ranks(time.perf_counter() - t0)
 
@@ -410,6 +446,10 @@ def main():
                ms_per_step=elapsed / args.steps * 1e3, ms_per_step_median_rank0=float(np.median(step_s)) * 1e3,
                ms_per_step_max_rank0=float(np.max(step_s)) * 1e3, icp_iterations_per_scan=iters / args.steps,
                scaling="strong" if args.split else "weak")
+    # stopped by the differential checker (1) or by the counter at max_iterations (0): configs[3]'s street does NOT settle
+    # within 40 iterations (the CPU oracle agrees at reduced size) -- a step there is 40 capped iterations
+    out["registration_converged"] = {"steps_stopped_by_the_differential_checker": n_converged, "of": args.steps,
+                                     "max_iterations": int(cfg.max_iterations)}
     if args.split:
         out["ms_per_icp_iteration"] = elapsed / max(iters, 1) * 1e3
         out["value_is"] = "set_reference + align of one pair whose reading is sharded over the ranks (filtered clouds resident in HBM)"

@@ -183,3 +183,30 @@ def test_split_scan_allreduce_scheme_matches_unsharded():
     assert [(s.start, s.stop) for s in parts] == [(0, 2), (2, 3), (3, 4), (4, 5)]
     with pytest.raises(ValueError):
         sharding.split_shard(3, 0, 4)
+
+
+def test_bench_relaunches_itself_for_more_than_one_gpu():
+    """`python bench.py --gpus N` without a launcher must become N ranks under torch.distributed.run (the driver's own
+    command shape); with a launcher environment, or N = 1, it must not."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    assert not bench.needs_relaunch(1, {})
+    assert bench.needs_relaunch(8, {})
+    assert not bench.needs_relaunch(8, {"WORLD_SIZE": "8", "RANK": "3"})
+    argv = bench.relaunch_argv(["--gpus", "8", "--steps", "5", "--warmup", "1", "--split"], 8, 29511)
+    assert argv[0] == sys.executable and argv[1:3] == ["-m", "torch.distributed.run"]
+    assert "--nnodes=1" in argv
+    assert argv[argv.index("--nproc-per-node") + 1] == "8"
+    assert argv[argv.index("--master-addr") + 1] == "127.0.0.1"
+    assert argv[argv.index("--master-port") + 1] == "29511"
+    script = argv.index(os.path.join(ROOT, "bench.py"))
+    assert argv[script + 1:] == ["--gpus", "8", "--steps", "5", "--warmup", "1", "--split"]   # the user's arguments, verbatim, after the script
+    with pytest.raises(ValueError):
+        bench.relaunch_argv([], 1, 1)
+    # the launcher's own module parses that command line (no process is started)
+    from torch.distributed.run import get_args_parser
+    ns = get_args_parser().parse_args(argv[3:])
+    assert ns.nproc_per_node == "8" and ns.training_script == os.path.join(ROOT, "bench.py")
+    assert ns.training_script_args == ["--gpus", "8", "--steps", "5", "--warmup", "1", "--split"]
