@@ -6,7 +6,15 @@ import numpy as np, torch
 from laser_slam_amd import synth, icp
 scene = synth.Scene(1234)
 poses = [synth.se3(0.8 * i, 0.05 * i, synth.SENSOR_HEIGHT, yaw=np.deg2rad(2.0 * i)) for i in range(4)]
-scans = [synth.hdl64_scan(scene, poses[i], 16384, 10 + i) for i in range(4)]
+cache = "/tmp/lsgpu_filter_time_scans.npy"   # (the ray casting takes longer than everything timed here)
+if os.path.exists(cache):
+    scans = list(np.load(cache, allow_pickle=True))
+else:
+    scans = [synth.hdl64_scan(scene, poses[i], 16384, 10 + i) for i in range(4)]
+    arr = np.empty(4, object)
+    for i in range(4):
+        arr[i] = scans[i]
+    np.save(cache, arr, allow_pickle=True)
 parts = []
 for k in (2, 1, 0):
     Trel = np.linalg.inv(poses[2]) @ poses[k]

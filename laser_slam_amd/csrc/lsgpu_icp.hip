@@ -33,6 +33,7 @@
 #include "lsgpu_solve.hip.h"
 #include "lsgpu_host_math.h"
 #include "lsgpu_ssn.hip.h"
+#include "lsgpu_ssn_tree.hip.h"
 #include "lsgpu_sort.hip.h"
 #include "lsgpu_scan.hip.h"
 #include "lsgpu_rand.h"
@@ -1339,10 +1340,15 @@ static int ssn_device(lsgpu_icp* h, const float4* src, int64_t n, int knn, float
   // levels [0, glevels) with global sorts; the rest inside one workgroup per segment once a segment fits
   // its LDS (<= kSsnLdsMax points, <= kSsnLdsLevels levels to go)
   int glevels = 0;
+  // (k_ssn_tree: up to ssn_root points and log2(ssn_root / 8) levels per workgroup; k_ssn_finish, LSGPU_SSN_OLD_FINISH: 2048 / 8)
+  const bool tree_finish = !tuning().ssn_old_finish;
+  const int root_max = tree_finish ? tuning().ssn_root : kSsnLdsMax;
+  int root_levels = kSsnLdsLevels;
+  if (tree_finish) { root_levels = 0; while ((8 << root_levels) < root_max) ++root_levels; }
   {
     const bool lds_finish = !tuning().ssn_global;
     int64_t c = n;
-    while (glevels < levels && !(lds_finish && c <= kSsnLdsMax && levels - glevels <= kSsnLdsLevels)) { c -= c / 2; ++glevels; }
+    while (glevels < levels && !(lds_finish && c <= root_max && levels - glevels <= root_levels)) { c -= c / 2; ++glevels; }
   }
   if (tuning().ssn_full_sort) {   // rounds 1-3: the whole cloud sorted by (segment, coordinate) at every level
     for (int L = 0; L < glevels; ++L) {
@@ -1404,8 +1410,15 @@ static int ssn_device(lsgpu_icp* h, const float4* src, int64_t n, int knn, float
                          (const uint32_t*)nullptr, cur, knn, h->sc->keys.p, h->sc->vals.p);
       idx = h->sc->vals.p;
     }
-    hipLaunchKernelGGL(k_ssn_finish, dim3(1 << glevels), dim3(256), 0, h->stream, src, const_cast<uint32_t*>(idx), cur,
-                       knn, levels - glevels, h->ssn_seg_of.p, nxt);
+    uint32_t* idx_rw = const_cast<uint32_t*>(idx);
+    if (!tree_finish)
+      hipLaunchKernelGGL(k_ssn_finish, dim3(1 << glevels), dim3(256), 0, h->stream, src, idx_rw, cur, knn, levels - glevels, h->ssn_seg_of.p, nxt);
+    else if (root_max == 8192)
+      hipLaunchKernelGGL(k_ssn_tree<8192>, dim3(1 << glevels), dim3(1024), 0, h->stream, src, idx_rw, cur, knn, levels - glevels, h->ssn_seg_of.p, nxt);
+    else if (root_max == 4096)
+      hipLaunchKernelGGL(k_ssn_tree<4096>, dim3(1 << glevels), dim3(512), 0, h->stream, src, idx_rw, cur, knn, levels - glevels, h->ssn_seg_of.p, nxt);
+    else
+      hipLaunchKernelGGL(k_ssn_tree<2048>, dim3(1 << glevels), dim3(256), 0, h->stream, src, idx_rw, cur, knn, levels - glevels, h->ssn_seg_of.p, nxt);
     std::swap(cur, nxt);
   }
   if (levels == 0) {  // a single box: identity order

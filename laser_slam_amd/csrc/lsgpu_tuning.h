@@ -34,6 +34,9 @@
 //   LSGPU_SORT_ITEMS         0  keys per thread of the radix passes (0: by size; 4, 8, 16)
 //   LSGPU_SSN_FULL_SORT         the reference filter's levels as whole-cloud sorts by (segment, coordinate) (rounds 1-3) instead of segmented sorts
 //   LSGPU_SSN_GLOBAL            every level of the reference filter as a global sort (no in-LDS finish)
+//   LSGPU_SSN_OLD_FINISH        the last levels with k_ssn_finish (rounds 2-4: 2048 points per workgroup, a radix sort per level) instead of
+//                               k_ssn_tree (presorted axes, a stable partition per level)
+//   LSGPU_SSN_ROOT        8192  points per workgroup of k_ssn_tree (2048, 4096, 8192)
 //   LSGPU_NE_BLOCKS        256  blocks of k_normal_eq_loop (64 .. 2048)
 //   LSGPU_SPLIT_UPDATE          the per-iteration update as its own launch (profiling)
 //   LSGPU_COMM_TIMEOUT_MS 30000 bound on every stream wait of the split-scan mode
@@ -81,6 +84,8 @@ struct Tuning {
   int sort_items = 0;
   bool ssn_global = false;
   bool ssn_full_sort = false;
+  bool ssn_old_finish = false;
+  int ssn_root = 8192;
   int ne_blocks = 256;
   bool split_update = false;
   double comm_timeout_ms = 30000.0;
@@ -146,6 +151,12 @@ inline Tuning read() {
   }
   t.ssn_global = flag("LSGPU_SSN_GLOBAL");
   t.ssn_full_sort = flag("LSGPU_SSN_FULL_SORT");
+  t.ssn_old_finish = flag("LSGPU_SSN_OLD_FINISH");
+  t.ssn_root = (int)number("LSGPU_SSN_ROOT", 8192, 2048, 8192);
+  if (t.ssn_root != 2048 && t.ssn_root != 4096 && t.ssn_root != 8192) {
+    fprintf(stderr, "liblsgpu_icp: LSGPU_SSN_ROOT must be 2048, 4096 or 8192; using 8192\n");
+    t.ssn_root = 8192;
+  }
   t.ne_blocks = (int)number("LSGPU_NE_BLOCKS", 256, 64, 2048);
   t.comm_timeout_ms = number("LSGPU_COMM_TIMEOUT_MS", 30000, 1, 1e9);
   t.knn_dbg = (int)number("LSGPU_KNN_DBG", 0, 0, 1 << 20);
@@ -160,7 +171,7 @@ inline Tuning read() {
   static const char* known[] = {"LSGPU_QUERY_ORDER", "LSGPU_Q_ELEV", "LSGPU_Q_SECT", "LSGPU_GAP", "LSGPU_BUDGET", "LSGPU_BUDGET_WIDE", "LSGPU_WIDE_ITERS",
                                 "LSGPU_ROUTE_R", "LSGPU_ROUTE_CHUNKS", "LSGPU_ROUTE_DENSE", "LSGPU_SPLIT_UPDATE", "LSGPU_NO_PREDICT", "LSGPU_NO_COMMIT",
                                 "LSGPU_NO_COMM_COMMIT", "LSGPU_NO_SEED_CAP", "LSGPU_NO_FRONT", "LSGPU_NO_LAZY", "LSGPU_NO_SIDE_STREAM", "LSGPU_NO_LOOKAHEAD", "LSGPU_FRONT_GUESS", "LSGPU_NO_ROUTE_ALL",
-                                "LSGPU_NO_ROWQ", "LSGPU_ROWQ_BLOCKS", "LSGPU_ROCPRIM_SORT", "LSGPU_SORT_ITEMS", "LSGPU_SSN_GLOBAL", "LSGPU_SSN_FULL_SORT",
+                                "LSGPU_NO_ROWQ", "LSGPU_ROWQ_BLOCKS", "LSGPU_ROCPRIM_SORT", "LSGPU_SORT_ITEMS", "LSGPU_SSN_GLOBAL", "LSGPU_SSN_FULL_SORT", "LSGPU_SSN_OLD_FINISH", "LSGPU_SSN_ROOT",
                                 "LSGPU_NE_BLOCKS", "LSGPU_COMM_TIMEOUT_MS", "LSGPU_KNN_DBG", "LSGPU_NO_CONE", "LSGPU_NO_CONE_PROBE", "LSGPU_CONE_ROWS", "LSGPU_CONE_COLS", "LSGPU_CONE_FROM", "LSGPU_CONE_MAX_OCC", "LSGPU_CONE_HEAVY_STEPS", "LSGPU_CONE_HEAVY_SHARE",
                                 // read by the Python / C++ hosts and the test drivers, not by this library:
                                 "LSGPU_SO", "LSGPU_STATS_SO", "LSGPU_GOLDEN_DIR", "LSGPU_SEQ_PERTURB", "LSGPU_SEQ_POSES", "LSGPU_TEST_INPUT_FILTERS",

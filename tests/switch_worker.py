@@ -35,7 +35,7 @@ def main():
         dg.update(np.float32(t["limit"]).tobytes()); dg.update(np.int64(t["n_used"]).tobytes())
         dg.update(np.ascontiguousarray(t["A"]).tobytes()); dg.update(np.ascontiguousarray(t["T_iter"]).tobytes())
     dg.update(np.ascontiguousarray(d2).tobytes())
-    dg.update(np.ascontiguousarray(rf).tobytes())
+    dg.update(np.ascontiguousarray(rf).tobytes()); dg.update(np.ascontiguousarray(rn).tobytes())
     dg.update(np.ascontiguousarray(Tc).tobytes()); dg.update(np.int64(stc.iterations).tobytes())
     for t in trc:
         dg.update(np.float32(t["limit"]).tobytes()); dg.update(np.int64(t["n_used"]).tobytes())

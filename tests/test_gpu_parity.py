@@ -353,6 +353,7 @@ def test_experiment_switches_do_not_change_results():
                 {"LSGPU_CONE_HEAVY_STEPS": "8", "LSGPU_CONE_HEAVY_SHARE": "0.5"},   # (too dear at first, priced again before every look)
                 {"LSGPU_ROCPRIM_SORT": "1"}, {"LSGPU_SORT_ITEMS": "4"}, {"LSGPU_NO_SEED_CAP": "1"}, {"LSGPU_NO_LAZY": "1"}, {"LSGPU_NO_SIDE_STREAM": "1"}, {"LSGPU_NO_LOOKAHEAD": "1"},
                 dict(tile, LSGPU_FRONT_GUESS="8"), {"LSGPU_SSN_GLOBAL": "1"}, {"LSGPU_SSN_FULL_SORT": "1"}, {"LSGPU_SSN_FULL_SORT": "1", "LSGPU_SSN_GLOBAL": "1"},
+                {"LSGPU_SSN_OLD_FINISH": "1"}, {"LSGPU_SSN_ROOT": "2048"}, {"LSGPU_SSN_ROOT": "4096"},   # k_ssn_finish / smaller roots of k_ssn_tree
                 {"LSGPU_QUERY_ORDER": "0"}]
     # the measured-slower variants only exist in the -DLSGPU_EXPERIMENTS build (devtools/build.sh); when that build is
     # around it has to give the same bits as the product, switch by switch
@@ -627,7 +628,13 @@ def test_device_reference_filter_edge_cases(icp_mod, oracle):
         tiny = np.concatenate([rng.normal(size=(7, 3)), np.ones((7, 1))], 1).astype(np.float32)
         dup = np.repeat(np.concatenate([rng.integers(0, 6, size=(400, 3)), np.ones((400, 1))], 1), 3, 0).astype(np.float32)
         line = np.zeros((500, 4), np.float32); line[:, 0] = np.arange(500); line[:, 3] = 1
-        for cloud in (tiny, dup, line):
+        # coordinates on a coarse grid, more points than one workgroup of k_ssn_tree holds: runs of equal coordinates at the
+        # global levels AND inside the workgroups (the stable order of ties is what the presorted lists have to reproduce)
+        grid = np.ones((40000, 4), np.float32)
+        grid[:, :3] = (np.round(rng.normal(size=(40000, 3)) * np.array([40.0, 25.0, 6.0])) / 4).astype(np.float32)
+        # ... and one constant axis on top (a sheet): every cut alternates between the two others
+        sheet = grid[:20000].copy(); sheet[:, 2] = np.float32(1.5)
+        for cloud in (tiny, dup, line, grid, sheet):
             of, on = oracle.sampling_surface_normal(cloud, 10, 1.0, 2)
             gf, gn = h.filter_reference(cloud, 10, 1.0, 2)
             assert np.array_equal(gf, of) and np.array_equal(gn, on), len(cloud)

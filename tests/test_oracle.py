@@ -381,6 +381,33 @@ def test_surface_normal_filter_boxes_against_a_numpy_recursion(oracle):
         _check_boxes_against_recursion(pts, boxes, *impl(pts, knn, 1.0, 0))
 
 
+def test_presorted_lists_equal_the_chain_of_stable_sorts():
+    """k_ssn_tree (csrc/lsgpu_ssn_tree.hip.h) builds the filter's lower levels from three presorted axes and stable
+    partitions instead of a sort per level.  Its scheme, modelled step for step in tests/ssn_tree_model.py, must give the
+    leaves of the restatement's chain of stable sorts -- also where equal coordinates make the stable order matter (grids
+    of few values, a constant axis, duplicates)."""
+    import ssn_tree_model as M
+    rng = np.random.default_rng(1)
+    for trial in range(240):
+        n = int(rng.integers(1, 400))
+        mode = trial % 4
+        if mode == 0:
+            pts = rng.normal(size=(n, 3)).astype(np.float32)
+        elif mode == 1:
+            pts = rng.integers(0, 4, size=(n, 3)).astype(np.float32)
+        elif mode == 2:
+            pts = (np.round(rng.normal(size=(n, 3)) * 3) / 2).astype(np.float32)
+        else:
+            pts = rng.integers(0, 3, size=(n, 3)).astype(np.float32)
+            pts[:, 2] = 0.0
+        pts = pts * np.array([3.0, 2.0, 1.0], np.float32)
+        knn = int(rng.integers(3, 12))
+        lo, hi = pts.min(0), pts.max(0)
+        a, b = M.chain_of_stable_sorts(pts, knn, lo, hi), M.presorted_lists(pts, knn, lo, hi)
+        assert len(a) == len(b), trial
+        assert all(np.array_equal(x, y) for x, y in zip(a, b)), trial
+
+
 def _check_boxes_against_recursion(pts, boxes, out, nrm):
     pos = 0
     checked = 0
