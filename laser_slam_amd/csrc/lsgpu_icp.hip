@@ -25,6 +25,7 @@
 #include "../../include/lsgpu_icp.h"
 #include "lsgpu_grid.hip.h"
 #include "lsgpu_tuning.h"
+#include "lsgpu_policy.h"
 #include "lsgpu_knn.hip.h"
 #include "lsgpu_cone.hip.h"
 #ifdef LSGPU_EXPERIMENTS
@@ -196,19 +197,18 @@ struct lsgpu_icp {
   hipEvent_t cone_done = nullptr;
   DevBuf<uint32_t> cone_occ;          // occupied (row, column) bins of the index
   hipEvent_t cone_occ_ready = nullptr;
-  bool cone_decided = false;          // ... looked at: cone_dense says whether the reference is too dense in direction
+  bool cone_decided = false;          // ... looked at (per reference): cone_dense says whether the reference is too dense in direction
   bool cone_dense = false;
-  int cone_launches = 0;              // of the running align
   float cone_occupancy = 0.f;         // points per occupied bin
   float cone_zeta_lo = 0.f, cone_zeta_hi = 0.f;
   bool cone_origin_inside = false;
-  bool cone_off = false;      // this align stopped using it (too many lanes it could not serve, or its price check said no)
+  uint32_t* h_cone_occ = nullptr;     // pinned word the build's occupancy count travels to
   hipEvent_t price_ready = nullptr;   // the price check's two counters are on the host
-  bool price_pending = false;
   DevBuf<uint32_t> price_cnt;         // kPriceSlots x kPriceStride words (lsgpu_knn.hip.h: ConePrice::count)
   uint32_t* h_price = nullptr;        // ... and their pinned copy
-  float cone_heavy = -1.f;    // share of heavy lanes among the searching ones (-1: not priced)
-  bool cone_off_price = false;   // cone_off because of that price: priced again before every later look
+  // launch policy of the running align (lsgpu_policy.h): every decision about what is enqueued next lives there
+  policy::Config pol_cfg;
+  policy::State pol;
   DevBuf<uint4> knn_dbg_wave;
   DevBuf<unsigned long long> knn_dbg;  // LSGPU_KNN_STATS builds: 8 counters
   DevBuf<uint2> cell_cache;  // ntiles x 64
@@ -434,6 +434,7 @@ void lsgpu_icp_destroy(lsgpu_icp* h) {
   if (h->cone_occ_ready) (void)hipEventDestroy(h->cone_occ_ready);
   if (h->h_pinned) (void)hipHostFree(h->h_pinned);
   if (h->h_price) (void)hipHostFree(h->h_price);
+  if (h->h_cone_occ) (void)hipHostFree(h->h_cone_occ);
   if (h->draws_pinned) (void)hipHostFree(h->draws_pinned);
   if (h->copy_done) (void)hipEventDestroy(h->copy_done);
   if (h->ref_up_done) (void)hipEventDestroy(h->ref_up_done);
@@ -608,9 +609,13 @@ static KnnArgs knn_args(lsgpu_icp* h, const Mat34& T) {
 //   seed     : the queries have no warm start yet (first iteration, kernel-level API)
 //   capped   : search cap from the loop state (exact below cap, see lsgpu_knn.hip.h); otherwise uncapped,
 //              followed by the straggler fallback
-static int run_knn(lsgpu_icp* h, const Mat34& T, const IcpState* st, bool seed, bool capped, bool timed,
-                   bool wide = true, bool predicted = false, uint32_t seed_rank = 0xFFFFFFFFu, bool committed = false,
-                   bool cone_iter = false, bool dense_wait = false, bool price_iter = false) {
+//   it       : what the launch policy decided for this iteration (lsgpu_policy.h); the kernel-level API passes a seeded,
+//              uncapped, wide search outside any loop
+static int run_knn(lsgpu_icp* h, const Mat34& T, const IcpState* st, const policy::Iteration& it, bool timed,
+                   uint32_t seed_rank = 0xFFFFFFFFu) {
+  const bool seed = it.seed, capped = it.capped, wide = it.wide, predicted = it.predicted, committed = it.committed;
+  policy::State& pol = h->pol;
+  const policy::Config& pc = h->pol_cfg;
   const int nq = (int)h->nq;
   KnnArgs a = knn_args(h, T);
   h->dbg_launch_no++;
@@ -648,8 +653,7 @@ static int run_knn(lsgpu_icp* h, const Mat34& T, const IcpState* st, bool seed, 
   if (committed && a.sel_below) { a.sel_hist3w = h->sel_win.p; a.sel_force = 1; }
   a.route_chunks = tn.route_chunks; a.route_dense = tn.route_dense;
   // the search before the first one through the direction index prices the index (lsgpu_knn.hip.h: cone_price)
-  const bool pricing = price_iter && capped && st && !seed && h->cone_ok && (!h->cone_off || h->cone_off_price) && !h->cone_dense &&
-                       tn.cone_heavy_share < 2.f;
+  const bool pricing = pol.pricing(pc, it, st != nullptr);
   if (pricing) {
     constexpr size_t kPriceBytes = (size_t)kPriceSlots * kPriceStride * sizeof(uint32_t);
     HIPC(h->price_cnt.reserve((size_t)kPriceSlots * kPriceStride));
@@ -679,39 +683,34 @@ static int run_knn(lsgpu_icp* h, const Mat34& T, const IcpState* st, bool seed, 
     ev->second = false;
     HIPC(hipEventRecord(ev->a, h->stream));
   }
-  if (capped && cone_iter && st && h->cone_ok && !h->cone_off && !h->cone_decided) {
+  if (pol.wants_occupancy(it, st != nullptr)) {
     // first search through the index for this reference: is it worth it?  The windows of a lane grow with the number of
     // reference points per direction -- measured on local maps of K scans of 1 M points (devtools/cone_density.py), kNN
     // per settled launch: K = 1: 48 us against 82 with the voxel grid, K = 3: 69 / 107, K = 8: 423 / 186.  Points per
     // occupied bin: 2, 3, 8.  (The wait is for a copy queued behind the build; the device is in the first iterations.)
     HIPC(hipEventSynchronize(h->cone_occ_ready));
-    const uint32_t occ = *reinterpret_cast<uint32_t*>(h->h_pinned + 110);
-    h->cone_occupancy = occ ? (float)((double)h->nr / (double)occ) : 1e9f;
-    h->cone_dense = h->cone_occupancy > tn.cone_max_occupancy;
-    h->cone_decided = true;
+    const uint32_t occ = *h->h_cone_occ;
+    pol.set_occupancy(pc, occ ? (float)((double)h->nr / (double)occ) : 1e9f);
+    h->cone_occupancy = pol.cone_occupancy; h->cone_dense = pol.cone_dense; h->cone_decided = true;   // (per reference: a reused reference keeps the verdict)
   }
-  if (cone_iter && h->price_pending) {
+  if (pol.wants_first_price(it)) {
     // ... and what would this align pay for it?  The search before this one counted the lanes whose windows would be long
     // (wide balls next to O: a wall a metre from the sensor; a sparse reading on a dense map that converges in steps of
     // millimetres): the index evaluates each lane's windows alone, the voxel kernel shares one candidate stream among 64
-    // lanes whose balls overlap -- measured on such clouds 1.6-2.0 ms per search against 0.6
+    // lanes whose balls overlap -- measured on such clouds 1.6-2.0 ms per search against 0.6.  A RE-pricing
+    // count (an alignment that was priced off) is not taken here: it belongs to the look it was launched in front of.
     HIPC(hipEventSynchronize(h->price_ready));
-    h->price_pending = false;
-    h->cone_heavy = price_share(h);
-    if (h->cone_heavy > tn.cone_heavy_share) { h->cone_off = true; h->cone_off_price = true; }
+    pol.set_first_price(pc, price_share(h));
   }
-  // (a denser reference also keeps the index out of one more iteration: its third search still has balls of centimetres,
-  // measured 364 us through the index against 179 on the voxel grid on a three-scan map, 143 / 143 on one scan)
-  if (cone_iter && h->cone_decided && h->cone_occupancy > 3.f && dense_wait) cone_iter = false;
-  if (capped && cone_iter && st && h->cone_ok && !h->cone_off && !h->cone_dense) {
+  const policy::KnnKernel kern = pol.kernel(pc, it, st != nullptr);
+  if (kern != policy::KnnKernel::Tile) {
     // settled launch: every lane searches its own windows of the direction-sorted reference (lsgpu_cone.hip.h)
-    h->cone_launches++;
     if (h->cone_pending) {   // (built on the side stream beside the first iterations: lsgpu_icp_compute)
       HIPC(hipStreamWaitEvent(h->stream, h->cone_done, 0));
       h->cone_pending = false;
     }
     a.front_blocks = 0;
-    if (wide && tn.cone_probe)   // balls as wide as the last ICP step: a probe of the query's own direction first
+    if (kern == policy::KnnKernel::ConeProbe)   // balls as wide as the last ICP step: a probe of the query's own direction first
       hipLaunchKernelGGL((k_knn_cone<LSGPU_CONE_WAVES, true>), dim3((a.ntiles + LSGPU_CONE_WAVES - 1) / LSGPU_CONE_WAVES), dim3(LSGPU_CONE_WAVES * 64), 0, h->stream, a, h->cone);
     else
       hipLaunchKernelGGL((k_knn_cone<LSGPU_CONE_WAVES, false>), dim3((a.ntiles + LSGPU_CONE_WAVES - 1) / LSGPU_CONE_WAVES), dim3(LSGPU_CONE_WAVES * 64), 0, h->stream, a, h->cone);
@@ -772,7 +771,7 @@ static int run_knn(lsgpu_icp* h, const Mat34& T, const IcpState* st, bool seed, 
     if (!h->price_ready) HIPC(hipEventCreateWithFlags(&h->price_ready, hipEventDisableTiming));
     HIPC(hipMemcpyAsync(h->h_price, h->price_cnt.p, (size_t)kPriceSlots * kPriceStride * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
     HIPC(hipEventRecord(h->price_ready, h->stream));
-    h->price_pending = true;
+    pol.priced();
   }
   HIPC(hipGetLastError());
   return LSGPU_OK;
@@ -848,7 +847,12 @@ static int build_cone_index(lsgpu_icp* h) {
   // the number of occupied bins travels to the host behind the build; lsgpu_icp_align looks at it before its first
   // search through the index (the device is busy with the first two iterations by then)
   if (!h->cone_occ_ready) HIPC(hipEventCreateWithFlags(&h->cone_occ_ready, hipEventDisableTiming));
-  uint32_t* ho = reinterpret_cast<uint32_t*>(h->h_pinned + 110);
+  // (its own pinned word -- the 128-double staging block also carries the loop state, the scan totals and the grid's
+  // words --, and an earlier build's copy may still be in flight on the side stream when the next one starts: wait for it
+  // before the word is reset)
+  if (!h->h_cone_occ) HIPC(hipHostMalloc((void**)&h->h_cone_occ, 64, hipHostMallocDefault));
+  else if (hipEventSynchronize(h->cone_occ_ready) != hipSuccess) (void)hipGetLastError();
+  uint32_t* ho = h->h_cone_occ;
   *ho = 0u;
   HIPC(hipMemcpyAsync(ho, h->cone_occ.p, sizeof(uint32_t), hipMemcpyDeviceToHost, h->cur));
   HIPC(hipEventRecord(h->cone_occ_ready, h->cur));
@@ -1047,7 +1051,10 @@ int lsgpu_knn(lsgpu_icp* h, const float* query_xyz1, int64_t nq, const float T[1
   const Mat34 Id = to_mat34(I);
   int rc = prepare_queries(h, query_xyz1, nq, Id);
   if (rc) return rc;
-  rc = run_knn(h, Tm, nullptr, true, false, false);
+  policy::Iteration probe;   // a seeded, uncapped, wide search outside any loop
+  probe.seed = true; probe.capped = false; probe.wide = true;
+  h->pol.begin_align(false, false, false, 0.f);
+  rc = run_knn(h, Tm, nullptr, probe, false);
   if (rc) return rc;
   const bool dev_out = is_device_ptr(ids);
   int* ids_o = ids; float* d2_o = d2;
@@ -2048,7 +2055,6 @@ int lsgpu_icp_align(lsgpu_icp* h, const float* reading_xyz1, int64_t nq, const f
   const double t0 = wall_ms();
   h->knn_events_used = 0;
   h->comm_events_used = 0;
-  h->cone_launches = 0;
   h->time_comm = h->comm != nullptr && h->cfg.profile_kernels != 0;
   h->tail_pending = false;   // (from here on everything is behind it on h->stream itself)
 
@@ -2114,7 +2120,6 @@ int lsgpu_icp_align(lsgpu_icp* h, const float* reading_xyz1, int64_t nq, const f
   HIPC(h->spread_flag.reserve((size_t)((nq + 63) / 64))); HIPC(h->spread_list.reserve(kFrontMax)); HIPC(h->spread_cnt.reserve(2));
   HIPC(h->sel_win.reserve((size_t)kSelWinRows * 512));
   h->n_spread_host = 0; h->n_spread_known = false;
-  h->cone_off = false; h->price_pending = false; h->cone_heavy = -1.f; h->cone_off_price = false;
   ia.state = *hst;
   ia.sel0 = SelState{0u, k};   // sel[0] = {0, rank}: constant during an align
   ia.state_dev = h->state.p; ia.chk_hist = h->chk_hist.p; ia.sel = h->sel.p;
@@ -2128,36 +2133,32 @@ int lsgpu_icp_align(lsgpu_icp* h, const float* reading_xyz1, int64_t nq, const f
   const int nb = std::min(kNeBlocks, nblk(nq));
   const bool timed = h->cfg.profile_kernels != 0;
   const Mat34 Tdummy = to_mat34(hst->T_iter);
-  bool first_select = true;
   std::vector<size_t> ev_of_launch;  // event index of every enqueued iteration
   const bool split_update = tuning().split_update;  // (profiling: the update as its own launch)
-  const bool predict_select = tuning().predict_select;
-  const bool commit_select = tuning().commit_select;
-  const bool comm_commit = tuning().comm_commit;
-  bool commit_ok = false;
-  int committed_iterations = 0;
-  int enq = 0;   // iterations enqueued so far = the ordinal of the one being enqueued
-  const int cone_from = tuning().cone_from;   // the direction index serves the launches from this iteration on
-  bool price_next = false;                     // the next launch prices the index again (an align that found it too dear)
-  auto enqueue_iteration = [&](bool seed, bool capped, bool wide, bool knn = true) -> int {
-    // capped launches without a wave-per-query pass may fold the first half of the select into the kNN kernel
-    // (the device decides per iteration, IcpState::sel_mode); not in the RCCL mode (the counts are per shard).
-    // knn == false: only select + normal equations + update on the distances already there (after a missed
-    // prediction)
-    // RCCL mode: the per-shard tables of a *committed* iteration are summed over the ranks in ONE grouped
+  // The launch policy (lsgpu_policy.h) decides what every iteration is made of and when the host looks at the loop
+  // state; this function executes its decisions.  (tests/cpp/policy_check.cpp drives the same state machine on the CPU.)
+  policy::Config& pc = h->pol_cfg;
+  pc = policy::Config();
+  pc.cone_from = tuning().cone_from; pc.wide_iters = tuning().wide_iters; pc.group = 6;
+  pc.enq_limit = 8 * max_it + 64;   // (only guards against a device that never finishes, see below)
+  pc.predict_select = tuning().predict_select; pc.commit_select = tuning().commit_select; pc.comm_commit = tuning().comm_commit;
+  pc.lookahead = tuning().lookahead; pc.comm = h->comm != nullptr;
+  pc.seed_cap = tuning().seed_cap; pc.cap_enabled = h->cfg.reserved[0] == 0;
+  pc.cone_probe = tuning().cone_probe; pc.cone_heavy_share = tuning().cone_heavy_share; pc.cone_max_occupancy = tuning().cone_max_occupancy;
+  policy::State& pol = h->pol;
+  pol.begin_align(h->cone_ok, h->cone_decided, h->cone_dense, h->cone_occupancy);
+  auto enqueue_iteration = [&](const policy::Iteration& itn) -> int {
+    // itn.knn == false: only select + normal equations + update on the distances already there (after a missed
+    // prediction).  RCCL mode: the per-shard tables of a *committed* iteration are summed over the ranks in ONE grouped
     // all-reduce (the host knows beforehand that no select kernel will run: sel_streak comes from the global limit,
     // so every rank takes the same decision); un-committed iterations there run the plain three-pass select.
-    const bool can_commit = commit_select && commit_ok && !first_select && (!h->comm || comm_commit);
-    const bool predicted = predict_select && knn && capped && !wide && (!h->comm || can_commit);
-    const bool committed = predicted && can_commit;
     int r = LSGPU_OK;
-    if (knn) {
-      r = run_knn(h, Tdummy, h->state.p, seed, capped, timed, wide, predicted, seed && capped ? k : 0xFFFFFFFFu, committed,
-                  !seed && capped && enq >= cone_from, enq == cone_from, enq == cone_from - 1 || price_next);  // 6a+6b
+    if (itn.knn) {
+      r = run_knn(h, Tdummy, h->state.p, itn, timed, itn.seed && itn.capped ? k : 0xFFFFFFFFu);  // 6a+6b
       if (r) return r;
       ev_of_launch.push_back(h->knn_events_used ? h->knn_events_used - 1 : 0);
     }
-    if (committed && h->comm) {  // one exchange for the whole select: {counts below, 11-bit histogram, window table}
+    if (itn.committed && h->comm) {  // one exchange for the whole select: {counts below, 11-bit histogram, window table}
       RcclApi* api = rccl_api();
       comm_mark(h, true);
       if (api->GroupStart) RCCLC(api->GroupStart());
@@ -2167,21 +2168,18 @@ int lsgpu_icp_align(lsgpu_icp* h, const float* reading_xyz1, int64_t nq, const f
       if (api->GroupEnd) RCCLC(api->GroupEnd());
       comm_mark(h, false);
     }
-    if (!committed) {
+    if (!itn.committed) {
       r = run_select(h, h->d2.p, (int)nq, k, false /* armed by k_align_init / k_seed_cap / the previous k_normal_eq_loop */,
-                     h->state.p, true, predicted);       // 6c
-      first_select = false;
+                     h->state.p, true, itn.predicted);       // 6c
       if (r) return r;
-    } else {
-      ++committed_iterations;
     }
-    lsgpu_icp::KnnEv* ev = (timed && knn && h->knn_events_used) ? &h->knn_events[h->knn_events_used - 1] : nullptr;
+    lsgpu_icp::KnnEv* ev = (timed && itn.knn && h->knn_events_used) ? &h->knn_events[h->knn_events_used - 1] : nullptr;
     if (ev) HIPC(hipEventRecord(ev->d, h->stream));
     hipLaunchKernelGGL(k_normal_eq_loop, dim3(nb), dim3(256), 0, h->stream, h->rdq.p, (int)nq,
                        h->state.p, h->prev.p, h->d2.p, h->nrm.p, h->hist.p, h->sel.p + 2,
                        h->counters.p + 32, h->ne_tickets.p, h->ne_partials.p, h->ne_gpartials.p, h->ne_out.p,
-                       h->chk_hist.p, h->trace_dev.p, max_it, capped ? 1 : 0, (h->comm || split_update) ? 0 : 1,
-                       h->sel_aux.p, h->sel_win.p, committed ? 1 : 0, h->spread_cnt.p);   // 6d (+6e)
+                       h->chk_hist.p, h->trace_dev.p, max_it, itn.capped ? 1 : 0, (h->comm || split_update) ? 0 : 1,
+                       h->sel_aux.p, h->sel_win.p, itn.committed ? 1 : 0, h->spread_cnt.p);   // 6d (+6e)
     if (h->comm || split_update) {   // split scan: every rank gets the sums over all shards (the limit, slot 29, is already global)
       if (h->comm) comm_mark(h, true);
       if (h->comm && rccl_api()->AllReduce(h->ne_out.p, h->ne_out.p, kNe, ncclDouble, ncclSum, h->comm, h->stream) != ncclSuccess) {
@@ -2190,27 +2188,25 @@ int lsgpu_icp_align(lsgpu_icp* h, const float* reading_xyz1, int64_t nq, const f
       }
       if (h->comm) comm_mark(h, false);
       hipLaunchKernelGGL(k_icp_update, dim3(1), dim3(64), 0, h->stream, h->state.p, h->ne_out.p,
-                         h->chk_hist.p, h->trace_dev.p, max_it, capped ? 1 : 0, h->sel_aux.p);           // 6d+6e
+                         h->chk_hist.p, h->trace_dev.p, max_it, itn.capped ? 1 : 0, h->sel_aux.p);           // 6d+6e
     }
     if (ev) HIPC(hipEventRecord(ev->e, h->stream));
     return hipGetLastError() == hipSuccess ? LSGPU_OK : LSGPU_HIP_ERROR;
   };
-  // A look at the loop state.  `ahead` (not in the split-scan mode): ONE more iteration is enqueued behind the copy before
-  // the host waits for it, so the device works through the round trip instead of idling (~25 us + a cold first launch per
-  // look); that iteration carries the decisions of the previous look, like the later iterations of any group, and exits
-  // at once if the state it finds says `done`.
-  const bool lookahead = tuning().lookahead && !h->comm;
-  if (lookahead && !h->ev_state) HIPC(hipEventCreateWithFlags(&h->ev_state, hipEventDisableTiming));
-  const int wide_iters = tuning().wide_iters;   // the first launches still have wide balls: their spread waves go to the wave-per-query pass
-  const int enq_limit = 8 * max_it + 64;        // (only guards against a device that never finishes, see below)
+  // A look at the loop state.  Look-ahead (not in the split-scan mode): ONE more iteration is enqueued behind the copy
+  // before the host waits for it, so the device works through the round trip instead of idling (~25 us + a cold first
+  // launch per look); that iteration carries the decisions of the previous look, like the later iterations of any group,
+  // and exits at once if the state it finds says `done`.
+  if (pc.lookahead && !pc.comm && !h->ev_state) HIPC(hipEventCreateWithFlags(&h->ev_state, hipEventDisableTiming));
   auto fetch_state = [&](int* enqueued_ahead) -> int {
     *enqueued_ahead = 0;
     HIPC(hipMemcpyAsync(hst, h->state.p, sizeof(IcpState), hipMemcpyDeviceToHost, h->stream));
-    if (lookahead && enq < enq_limit) {
+    policy::Iteration ahead_it;
+    if (pol.lookahead_iteration(pc, &ahead_it)) {
       HIPC(hipEventRecord(h->ev_state, h->stream));
-      const int r = enqueue_iteration(false, true, enq < wide_iters);
+      const int r = enqueue_iteration(ahead_it);
       if (r) return r;
-      ++enq; *enqueued_ahead = 1;
+      *enqueued_ahead = 1;
       HIPC(hipEventSynchronize(h->ev_state));
       return LSGPU_OK;
     }
@@ -2218,71 +2214,50 @@ int lsgpu_icp_align(lsgpu_icp* h, const float* reading_xyz1, int64_t nq, const f
   };
 
   // iteration 0: seeded; capped by the trim quantile of the seed distances (a guaranteed bound: no retry can follow)
-  const bool seed_cap = tuning().seed_cap;
-  rc = enqueue_iteration(true, seed_cap && h->cfg.reserved[0] == 0, true);
+  rc = enqueue_iteration(pol.plan(pc, true, pc.seed_cap && pc.cap_enabled, true, true, false));
   if (rc) return rc;
-  enq = 1;
-  int since_check = 1, sel_retries = 0;
-  int look_iter = 0; unsigned long long look_strag = 0;   // loop state at the previous look (direction-index guard below)
-  std::vector<std::pair<int, size_t>> launch_of_iter;  // (enqueue ordinal -> event) bookkeeping below
-  const int group = 6;
+  pol.enq = 1; pol.since_check = 1;
   // The device decides when the loop ends (CounterTransformationChecker raises `done` after max_iterations at the
   // latest); the host keeps feeding groups of launches until it sees `done`.  Launches enqueued behind an
   // iteration that had to be repeated exit at once, so the number of enqueues is NOT bounded by max_iterations;
-  // the cap below only guards against a device that never finishes.
+  // the policy's enq_limit only guards against a device that never finishes.
   for (;;) {
-    if (enq < enq_limit && since_check < group) {
-      price_next = h->cone_off_price && since_check == group - 1;   // (the counters travel in front of the look's state copy)
-      rc = enqueue_iteration(false, true, enq < wide_iters);
-      price_next = false;
+    policy::Iteration itn;
+    if (pol.next_in_group(pc, &itn)) {
+      rc = enqueue_iteration(itn);
       if (rc) return rc;
-      ++enq; ++since_check;
       continue;
     }
     int ahead = 0;
-    rc = fetch_state(&ahead);
+    const bool repriced = pol.wants_reprice();   // (the last launch in front of this look priced the index again: its counters
+    rc = fetch_state(&ahead);                    //  were copied in front of the state, they are on the host when the state is)
     if (rc) return rc;
-    since_check = ahead;
-    commit_ok = hst->sel_streak >= 1 && hst->status == 0;  // (a miss below clears it until the streak is rebuilt)
     h->n_spread_host = hst->n_spread; h->n_spread_known = true;
-    // k_knn_cone counts the lanes its index could not serve (they search the voxel grid one by one) as stragglers: on
-    // the clouds it is made for they are a handful; where they are not (> 2 % of the queries per settled iteration)
-    // the rest of this align goes back to k_knn_tile
-    if (h->cone_ok && !h->cone_off && look_iter >= std::max(cone_from, wide_iters) && hst->iter > look_iter &&
-        (double)(hst->stragglers - look_strag) > 0.02 * (double)nq * (double)(hst->iter - look_iter))
-      h->cone_off = true;
-    look_iter = hst->iter; look_strag = hst->stragglers;
-    if (h->price_pending && h->cone_off_price) {   // priced again by the last launch in front of this look: cheap enough by now?
-      h->cone_heavy = price_share(h);
-      if (h->cone_heavy <= tuning().cone_heavy_share) { h->cone_off = false; h->cone_off_price = false; }
-      h->price_pending = false;
-    }
-    if (hst->done && hst->status == kStatusCapFailed) {
+    policy::LookInput li;
+    li.done = hst->done; li.status = hst->status; li.iter = hst->iter; li.sel_streak = hst->sel_streak;
+    li.stragglers = hst->stragglers; li.nq = nq; li.status_cap_failed = kStatusCapFailed; li.status_sel_failed = kStatusSelFailed;
+    const policy::LookVerdict verdict = pol.on_look(pc, li, ahead, repriced ? price_share(h) : -1.f);
+    if (verdict == policy::LookVerdict::RepeatUncapped) {
       // the cap prediction failed for iteration hst->iter: repeat it uncapped, then carry on
-      st.cap_retries++;
       hst->done = 0; hst->status = 0;
       HIPC(hipMemcpyAsync(h->state.p, hst, sizeof(IcpState), hipMemcpyHostToDevice, h->stream));
       HIPC(hipStreamSynchronize(h->stream));
-      rc = enqueue_iteration(false, false, true);
+      rc = enqueue_iteration(pol.repeat_uncapped(pc));
       if (rc) return rc;
-      ++enq; since_check = 1;
       continue;
     }
-    if (hst->done && hst->status == kStatusSelFailed) {
+    if (verdict == policy::LookVerdict::RepeatSelect) {
       // the limit left the predicted 12-bit bin in iteration hst->iter: its distances stand, the full select
       // and everything after it run again
-      sel_retries++;
-      commit_ok = false;
       hst->sel_streak = 0;
       hst->done = 0; hst->status = 0;
       HIPC(hipMemcpyAsync(h->state.p, hst, sizeof(IcpState), hipMemcpyHostToDevice, h->stream));
       HIPC(hipStreamSynchronize(h->stream));
-      rc = enqueue_iteration(false, true, false, /*knn*/ false);
+      rc = enqueue_iteration(pol.repeat_select(pc));
       if (rc) return rc;
-      since_check = 1;
       continue;
     }
-    if (hst->done) {
+    if (verdict == policy::LookVerdict::Done) {
       if (ahead) {   // one launch is still queued behind the look that saw `done`
         if (!h->ev_tail) HIPC(hipEventCreateWithFlags(&h->ev_tail, hipEventDisableTiming));
         HIPC(hipEventRecord(h->ev_tail, h->stream));
@@ -2290,11 +2265,13 @@ int lsgpu_icp_align(lsgpu_icp* h, const float* reading_xyz1, int64_t nq, const f
       }
       break;
     }
-    if (enq >= enq_limit) {
+    if (verdict == policy::LookVerdict::GiveUp) {
       h->err = "align: the device loop did not finish";
       return LSGPU_HIP_ERROR;
     }
   }
+  st.cap_retries = pol.cap_retries;
+  const int sel_retries = pol.sel_retries, committed_iterations = pol.committed_iterations;
   const int it = hst->iter;
   rc = hst->status;
   if (rc == LSGPU_NO_CONVERGENCE)
@@ -2344,9 +2321,9 @@ int lsgpu_icp_align(lsgpu_icp* h, const float* reading_xyz1, int64_t nq, const f
       else (void)hipGetLastError();
     }
   }
-  st.direction_index_launches = h->cone_launches;   // (enqueued; those behind the end of the loop exited at once)
+  st.direction_index_launches = h->pol.cone_launches;   // (enqueued; those behind the end of the loop exited at once)
   st.direction_index_occupancy = h->cone_decided ? h->cone_occupancy : 0.f;
-  st.direction_index_heavy_share = h->cone_heavy;
+  st.direction_index_heavy_share = h->pol.cone_heavy;
   st.pad_ = sel_retries;  // (select predictions that missed; informational)
   st.committed_select_iterations = committed_iterations;
   st.spread_tiles = (int)hst->n_spread;
@@ -2417,6 +2394,12 @@ int lsgpu_dev_knn_wave_stats(lsgpu_icp* h, unsigned int* out, int nwaves) {
   return LSGPU_OK;
 }
 #ifdef LSGPU_KNN_STATS
+int lsgpu_dev_tree_phases(lsgpu_icp* h, unsigned long long out[64]) {  // stats build only (devtools/tree_phases.py)
+  if (!h) return LSGPU_BAD_ARG;
+  HIPC(hipStreamSynchronize(h->stream));
+  HIPC(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_tree_dbg), 512));
+  return LSGPU_OK;
+}
 int lsgpu_dev_ne_phases(lsgpu_icp* h, unsigned long long out[16]) {  // stats build only (devtools/ne_phases.py)
   if (!h) return LSGPU_BAD_ARG;
   HIPC(hipStreamSynchronize(h->stream));

@@ -60,12 +60,29 @@ struct SsnTreeLds {
   uint32_t kmin[3], kmax[3];
 };
 
+#ifdef LSGPU_KNN_STATS   // stats build: shader-clock stamps of workgroup 0 (devtools/tree_phases.py)
+__device__ unsigned long long g_tree_dbg[64];
+#define LSGPU_TREE_T(n) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_tree_dbg[n] = (unsigned long long)clock64(); } while (0)
+#else
+#define LSGPU_TREE_T(n) do { } while (0)
+#endif
+
 #ifdef LSGPU_TREE_LDS_BARRIER
 // LDS traffic only: the global loads of the level's cut values stay in flight across the barrier
 #define LSGPU_TREE_SYNC() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 #else
 #define LSGPU_TREE_SYNC() __syncthreads()
 #endif
+
+// the value of the lane before / behind this one (DPP wave shift, no LDS traffic); lane 0 / 63 get 0
+__device__ __forceinline__ uint32_t tree_lane_prev(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x138, 0xF, 0xF, false); }
+__device__ __forceinline__ uint32_t tree_lane_next(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x130, 0xF, 0xF, false); }
+// inclusive prefix sum over the 64 lanes: DPP row scans + the three row totals (no LDS traffic)
+__device__ __forceinline__ uint32_t tree_wave_scan(uint32_t v, int lane) {
+  v = row_scan_incl_u32(v);
+  const uint32_t t0 = rl_u(v, 15), t1 = rl_u(v, 31), t2 = rl_u(v, 47);
+  return v + (lane >= 16 ? t0 : 0u) + (lane >= 32 ? t1 : 0u) + (lane >= 48 ? t2 : 0u);
+}
 
 template <int B>
 __global__ __launch_bounds__(B / 8) void k_ssn_tree(const float4* __restrict__ p, uint32_t* __restrict__ idx,
@@ -81,6 +98,7 @@ __global__ __launch_bounds__(B / 8) void k_ssn_tree(const float4* __restrict__ p
 
   // ---- load: ordered keys of this thread's 8 points, per axis.  Local id of a point = its position in the order the
   // workgroup found the root in (idx[root.start ..]); radix ownership: wave w, group it, lane -> w * 512 + it * 64 + lane
+  LSGPU_TREE_T(0);
   uint32_t kx[8], ky[8], kz[8];
   if (tid < 3) { L.kmin[tid] = 0xFFFFFFFFu; L.kmax[tid] = 0u; }
   {
@@ -108,6 +126,7 @@ __global__ __launch_bounds__(B / 8) void k_ssn_tree(const float4* __restrict__ p
 
   // ---- presort: per axis a stable LSD radix sort of the local ids by (key - min), 8 bits per pass, only the passes
   // the key range needs; the ids ping-pong between list[d] and rank[d], the keys stay where they are
+  LSGPU_TREE_T(1);
 #pragma unroll
   for (int d = 0; d < 3; ++d) {
     const uint32_t kmin = L.kmin[d];
@@ -189,42 +208,47 @@ __global__ __launch_bounds__(B / 8) void k_ssn_tree(const float4* __restrict__ p
       }
       __syncthreads();
     }
-    // dense ranks: thread = 8 consecutive positions of the sorted list
+    LSGPU_TREE_T(2 + 2 * d);
+#ifdef LSGPU_KNN_STATS
+    if (blockIdx.x == 0 && tid == 0) g_tree_dbg[40 + d] = (unsigned long long)P;
+#endif
+    // dense ranks: a wave walks its 512 consecutive positions of the sorted list, 64 at a time
     {
-      const int i0 = tid * 8;
       uint32_t e[8], r[8];
-      uint32_t prevk = 0u, t = 0u;
-      if (i0 > 0 && i0 - 1 < cnt) prevk = L.u.pre.key[L.list[d][i0 - 1]];
+      uint32_t carry = 0u;
 #pragma unroll
       for (int k = 0; k < 8; ++k) {
-        const int i = i0 + k;
+        const int i = w * 512 + k * 64 + lane;
         e[k] = 0u;
-        if (i < cnt) {
-          e[k] = L.list[d][i];
-          const uint32_t kk = L.u.pre.key[e[k]];
-          if (i > 0 && kk != prevk) ++t;
-          prevk = kk;
-        }
-        r[k] = t;
+        uint32_t kk = 0u;
+        if (i < cnt) { e[k] = L.list[d][i]; kk = L.u.pre.key[e[k]]; }
+        uint32_t pk = tree_lane_prev(kk);
+        if (lane == 0 && i > 0 && i < cnt) pk = L.u.pre.key[L.list[d][i - 1]];
+        const uint32_t f = (i < cnt && i > 0 && kk != pk) ? 1u : 0u;
+        const uint32_t incl = tree_wave_scan(f, lane);
+        r[k] = carry + incl;
+        carry += rl_u(incl, 63);
       }
-      const uint32_t incl = wave_scan_incl_u32(t, lane);
-      if (lane == 63) L.wsum[w] = incl;
+      if (lane == 0) L.wsum[w] = carry;
       __syncthreads();
-      uint32_t before = incl - t;
+      uint32_t before = 0u;
       for (int ww = 0; ww < w; ++ww) before += L.wsum[ww];
 #pragma unroll
       for (int k = 0; k < 8; ++k)
-        if (i0 + k < cnt) L.rank[d][e[k]] = (uint16_t)(before + r[k]);
+        if (w * 512 + k * 64 + lane < cnt) L.rank[d][e[k]] = (uint16_t)(before + r[k]);
       __syncthreads();
     }
+    LSGPU_TREE_T(3 + 2 * d);
   }
 
-  // ---- the levels
-  const int i0 = tid * 8;
+  // ---- the levels.  Ownership as in the radix passes: wave w, slab k, lane -> position w * 512 + k * 64 + lane, so that
+  // the 64 lanes of every LDS access by position touch consecutive uint16 (the first version gave a thread 8 consecutive
+  // positions: 16-byte lane stride, 4-way bank conflicts on every access, 27 k cycles per level)
 #pragma unroll
   for (int k = 0; k < 8; ++k) {
-    L.u.tree.cur_pos[i0 + k] = (uint16_t)(i0 + k);
-    L.u.tree.sof[i0 + k] = 0;
+    const int i = w * 512 + k * 64 + lane;
+    L.u.tree.cur_pos[i] = (uint16_t)i;
+    L.u.tree.sof[i] = 0;
   }
   if (tid == 0) {
     TreeSeg r0;
@@ -240,42 +264,47 @@ __global__ __launch_bounds__(B / 8) void k_ssn_tree(const float4* __restrict__ p
   for (int l = 0; l < rem; ++l) {
     const int ns = 1 << l;
     const bool last = l + 1 == rem;
+    LSGPU_TREE_T(8 + l);
     // this thread's 8 positions: their segments
     uint32_t sk[8];
     TreeSeg sg[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
-      sk[k] = L.u.tree.sof[i0 + k];
-      sg[k] = L.seg[i0 + k < cnt ? sk[k] : 0u];
+      const int i = w * 512 + k * 64 + lane;
+      sk[k] = L.u.tree.sof[i];
+      sg[k] = L.seg[i < cnt ? sk[k] : 0u];
     }
     // step 1: tie runs of list[cut] into the segment's current order
     uint32_t ek[8], np[8];
     bool upd[8], fix[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
-      const int i = i0 + k;
+      const int i = w * 512 + k * 64 + lane;
       const bool active = i < cnt && (int)sg[k].count > knn;
       const int a = sg[k].cut;
       upd[k] = active && sg[k].ord != a;
       fix[k] = upd[k] && sg[k].ord != 0xFF;
       ek[k] = 0u; np[k] = (uint32_t)i;
-      if (upd[k]) {
-        const uint16_t* la = L.list[a];
-        const uint16_t* ra = L.rank[a];
-        const uint32_t e = la[i];
-        ek[k] = e;
-        if (fix[k]) {
-          const uint32_t r = ra[e];
-          const int s0 = sg[k].start, s1 = s0 + sg[k].count;
+      const uint16_t* la = L.list[a];
+      const uint16_t* ra = L.rank[a];
+      if (upd[k]) ek[k] = la[i];
+      if (__ballot(fix[k])) {   // (wave-uniform: no segment of this slab re-sorts, nothing to look at)
+        const uint32_t r = fix[k] ? (uint32_t)ra[ek[k]] : 0xFFFFFFFFu;
+        // the neighbours' ranks: lanes of the same segment hold them (same segment -> same cut axis, same `fix`); the
+        // slab's first and last lane read theirs
+        const int s0 = sg[k].start, s1 = s0 + sg[k].count;
+        uint32_t rp = tree_lane_prev(r), rn = tree_lane_next(r);
+        if (lane == 0 && fix[k] && i > s0) rp = ra[la[i - 1]];
+        if (lane == 63 && fix[k] && i + 1 < s1) rn = ra[la[i + 1]];
+        const bool tie = fix[k] && ((i > s0 && rp == r) || (i + 1 < s1 && rn == r));
+        if (tie) {
           int lo = i, hi = i + 1;
           while (lo > s0 && ra[la[lo - 1]] == r) --lo;
           while (hi < s1 && ra[la[hi]] == r) ++hi;
-          if (hi - lo > 1) {
-            const uint32_t cp = L.u.tree.cur_pos[e];
-            uint32_t c = 0u;
-            for (int j = lo; j < hi; ++j) c += L.u.tree.cur_pos[la[j]] < cp ? 1u : 0u;
-            np[k] = (uint32_t)lo + c;
-          }
+          const uint32_t cp = L.u.tree.cur_pos[ek[k]];
+          uint32_t c = 0u;
+          for (int j = lo; j < hi; ++j) c += L.u.tree.cur_pos[la[j]] < cp ? 1u : 0u;
+          np[k] = (uint32_t)lo + c;
         }
       }
     }
@@ -301,10 +330,10 @@ __global__ __launch_bounds__(B / 8) void k_ssn_tree(const float4* __restrict__ p
     }
     // step 3: stable partition of the other two lists by child; one packed scan (low half: axis cut + 1, high: cut + 2)
     uint32_t e1[8], e2[8], xk[8], vk[8];
-    uint32_t t = 0u;
+    uint32_t carry = 0u;
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
-      const int i = i0 + k;
+      const int i = w * 512 + k * 64 + lane;
       const bool active = i < cnt && (int)sg[k].count > knn;
       uint32_t v = 0u;
       e1[k] = e2[k] = 0u;
@@ -318,26 +347,25 @@ __global__ __launch_bounds__(B / 8) void k_ssn_tree(const float4* __restrict__ p
         v = f1 | (f2 << 16);
       }
       vk[k] = v;
-      xk[k] = t;      // exclusive, inside the thread
-      t += v;
+      const uint32_t incl = tree_wave_scan(v, lane);
+      xk[k] = carry + incl - v;      // exclusive, inside the wave's 512 positions
+      carry += rl_u(incl, 63);
     }
-    const uint32_t incl = wave_scan_incl_u32(t, lane);
-    if (lane == 63) L.wsum[w] = incl;
+    if (lane == 0) L.wsum[w] = carry;
     LSGPU_TREE_SYNC();
-    uint32_t before = incl - t;
+    uint32_t before = 0u;
     for (int ww = 0; ww < w; ++ww) before += L.wsum[ww];
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
       xk[k] += before;
-      const int i = i0 + k;
+      const int i = w * 512 + k * 64 + lane;
       if (i < cnt && (int)sg[k].count > knn && i == (int)sg[k].start) L.u.tree.segbase[sk[k]] = xk[k];
     }
     LSGPU_TREE_SYNC();
-    uint32_t nsof[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
-      const int i = i0 + k;
-      nsof[k] = 2u * sk[k];
+      const int i = w * 512 + k * 64 + lane;
+      uint32_t nsof = 2u * sk[k];
       if (i < cnt && (int)sg[k].count > knn) {
         const int a = sg[k].cut;
         const int d1 = a == 2 ? 0 : a + 1, d2 = a == 0 ? 2 : a - 1;
@@ -350,11 +378,10 @@ __global__ __launch_bounds__(B / 8) void k_ssn_tree(const float4* __restrict__ p
         const uint32_t p2 = f2 ? sg[k].start + left + r2 : sg[k].start + (off - r2);
         L.list[d1][p1] = (uint16_t)e1[k];
         L.list[d2][p2] = (uint16_t)e2[k];
-        nsof[k] += off >= left ? 1u : 0u;
+        nsof += off >= left ? 1u : 0u;
       }
+      L.u.tree.sof[i] = (uint16_t)nsof;
     }
-#pragma unroll
-    for (int k = 0; k < 8; ++k) L.u.tree.sof[i0 + k] = (uint16_t)nsof[k];
     // the children (2s, 2s + 1); a finished segment carries over as child 2s
     if (tid < ns) {
       TreeSeg ca = ps, cb = ps;
@@ -394,10 +421,11 @@ __global__ __launch_bounds__(B / 8) void k_ssn_tree(const float4* __restrict__ p
   }
 
   // ---- out: every leaf in its current order; the workgroup's range of idx is read completely before it is written
+  LSGPU_TREE_T(30);
   uint32_t g[8], so[8];
 #pragma unroll
   for (int k = 0; k < 8; ++k) {
-    const int i = i0 + k;
+    const int i = w * 512 + k * 64 + lane;
     g[k] = 0u; so[k] = 0u;
     if (i < cnt) {
       so[k] = L.u.tree.sof[i];
@@ -409,12 +437,13 @@ __global__ __launch_bounds__(B / 8) void k_ssn_tree(const float4* __restrict__ p
   __syncthreads();
 #pragma unroll
   for (int k = 0; k < 8; ++k) {
-    const int i = i0 + k;
+    const int i = w * 512 + k * 64 + lane;
     if (i < cnt) {
       idx[root.start + i] = g[k];
       seg_of[root.start + i] = base_seg + so[k];
     }
   }
+  LSGPU_TREE_T(31);
 }
 
 }  // namespace lsgpu

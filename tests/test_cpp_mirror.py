@@ -44,6 +44,17 @@ def test_cpp_host_checks(tmp_path):
     assert np.array_equal(by_guess, by_solution) and np.allclose(by_guess[:, 0], scan(2)[:, 0] + 0.8, atol=1e-6)
 
 
+def test_launch_policy_state_machine(tmp_path):
+    """csrc/lsgpu_policy.h decides what lsgpu_icp_align enqueues next (no HIP in it): the sequence of an alignment, the
+    hand-over to the direction index, pricing / re-pricing (an alignment priced off the index returns to it once a look
+    finds it cheap -- the defect round 4 shipped), the repeat paths, the split-scan mode.  tests/cpp/policy_check.cpp
+    drives the state machine against a scripted device; no GPU, no library."""
+    exe = str(tmp_path / "policy_check")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall", "-Werror", os.path.join(ROOT, "tests", "cpp", "policy_check.cpp"), "-o", exe])
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 0 and "policy_check ok" in r.stdout, r.stdout + r.stderr
+
+
 def test_gtsam_overlay_parses_and_resolves_the_ros_worker_calls():
     """PARSE check of integration/gtsam/laser_slam_gtsam_overlay.hpp (the `namespace laser_slam` types laser_slam_ros
     compiles against): g++ -fsyntax-only against the declaration-only stand-ins of tests/cpp/mock/ (GTSAM, minkindr,

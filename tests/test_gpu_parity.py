@@ -383,6 +383,37 @@ def test_experiment_switches_do_not_change_results():
             assert res["digest"] == base["digest"], (env_add, res, base)
 
 
+@pytest.mark.timeout(300)
+def test_direction_index_returns_after_a_price_off():
+    """Behaviour, not results (results cannot show it): an alignment whose first price keeps it off the direction index
+    prices the index again with the last launch in front of every look at the loop state and goes BACK to it once a look
+    finds it cheap -- stats.direction_index_launches must grow after that look.  (Round 4 shipped a defect there: the
+    iteration enqueued behind the look consumed the count, the index never came back; csrc/lsgpu_policy.h, whose state
+    machine tests/cpp/policy_check.cpp drives on the CPU.)  Run 1 never refuses the index and reports the share of heavy
+    lanes the first price found (with LSGPU_CONE_HEAVY_STEPS lowered so that the 262 k-point pair has heavy lanes at
+    all); run 2 refuses it at half that share: the balls shrink by more than that within the first group of iterations."""
+    import json
+    import subprocess
+    import sys
+
+    def run(env_add):
+        env = dict(os.environ)
+        env.update(env_add)
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "price_worker.py"), "4096"], env=env, capture_output=True, text=True, timeout=200)
+        line = [ln for ln in r.stdout.splitlines() if ln.startswith("PRICE_RESULT ")]
+        assert r.returncode == 0 and line, (env_add, r.stdout[-1500:], r.stderr[-1500:])
+        return json.loads(line[0][len("PRICE_RESULT "):])
+
+    never_off = run({"LSGPU_CONE_HEAVY_STEPS": "8", "LSGPU_CONE_HEAVY_SHARE": "1.9"})
+    s0 = never_off["heavy_share"]
+    assert never_off["iterations"] >= 12 and never_off["index_launches"] >= never_off["iterations"] - 3, never_off
+    assert s0 > 0.02, never_off                                   # (otherwise nothing would be refused below)
+    back = run({"LSGPU_CONE_HEAVY_STEPS": "8", "LSGPU_CONE_HEAVY_SHARE": repr(0.5 * s0)})
+    assert back["digest"] == never_off["digest"] and back["iterations"] == never_off["iterations"]   # the same alignment, bit for bit
+    assert 0 < back["index_launches"] < never_off["index_launches"], (back, never_off)            # refused at first, back later
+    assert back["heavy_share"] <= 0.5 * s0, (back, never_off)     # the share the look found when it let the index back in
+
+
 def test_full_size_properties(icp_mod):
     """BASELINE configs[1] size (1M-point pair): size-independent properties instead of the oracle.
     (a) kNN distances are self-consistent with the returned ids and no sampled brute-force distance
