@@ -35,6 +35,7 @@
 #include "lsgpu_host_math.h"
 #include "lsgpu_ssn.hip.h"
 #include "lsgpu_ssn_tree.hip.h"
+#include "lsgpu_ssn_levels.hip.h"
 #include "lsgpu_sort.hip.h"
 #include "lsgpu_scan.hip.h"
 #include "lsgpu_rand.h"
@@ -243,6 +244,13 @@ struct lsgpu_icp {
   DevBuf<SegBlock> ssn_blocktab;
   DevBuf<uint32_t> ssn_seg_of, ssn_box_pts, ssn_box_base, ssn_keep, ssn_out_pos, ssn_bb;
   DevBuf<float> ssn_box_normal, ssn_draws;
+  // upper levels of the reference filter from presorted axes (lsgpu_ssn_levels.hip.h)
+  DevBuf<uint32_t> gt_list[6], gt_rank[3], gt_cur[2], gt_cnt, gt_err, gt_hist2, gt_fullnb;
+  DevBuf<char> gt_tmp2;
+  DevBuf<SegBlock> gt_fulltab;
+  hipStream_t gt_stream = nullptr;     // the third axis' presort (the second runs on side_stream)
+  hipEvent_t gt_fork = nullptr, gt_join1 = nullptr, gt_join2 = nullptr;
+  uint32_t* h_gt_err = nullptr;        // pinned: "a tie run was too long for the presorted levels"
   DevBuf<float4> flt_in, flt_in2, flt_ref, flt_rd;
   DevBuf<float> flt_nrm;
   float* draws_pinned = nullptr;  // host staging of the filter draws (pinned: async H2D)
@@ -435,6 +443,15 @@ void lsgpu_icp_destroy(lsgpu_icp* h) {
   if (h->h_pinned) (void)hipHostFree(h->h_pinned);
   if (h->h_price) (void)hipHostFree(h->h_price);
   if (h->h_cone_occ) (void)hipHostFree(h->h_cone_occ);
+  if (h->h_gt_err) (void)hipHostFree(h->h_gt_err);
+  for (auto& b : h->gt_list) b.release();
+  for (auto& b : h->gt_rank) b.release();
+  for (auto& b : h->gt_cur) b.release();
+  h->gt_cnt.release(); h->gt_err.release(); h->gt_hist2.release(); h->gt_fullnb.release(); h->gt_tmp2.release(); h->gt_fulltab.release();
+  if (h->gt_fork) (void)hipEventDestroy(h->gt_fork);
+  if (h->gt_join1) (void)hipEventDestroy(h->gt_join1);
+  if (h->gt_join2) (void)hipEventDestroy(h->gt_join2);
+  if (h->gt_stream) { (void)hipStreamSynchronize(h->gt_stream); (void)hipStreamDestroy(h->gt_stream); }
   if (h->draws_pinned) (void)hipHostFree(h->draws_pinned);
   if (h->copy_done) (void)hipEventDestroy(h->copy_done);
   if (h->ref_up_done) (void)hipEventDestroy(h->ref_up_done);
@@ -1197,6 +1214,17 @@ static int scan_u32(lsgpu_icp* h, const uint32_t* in, uint32_t* out, size_t n, b
   return LSGPU_OK;
 }
 
+// the same on an explicit stream with explicit scratch (the presorts of the three axes run side by side)
+static void scan_u32_on(hipStream_t st, uint32_t* sums, const uint32_t* in, uint32_t* out, size_t n, bool inclusive) {
+  const int nb = (int)((n + kScanTile - 1) / kScanTile);
+  if (nb > 1) {
+    hipLaunchKernelGGL(k_scan_sums, dim3(nb), dim3(256), 0, st, in, n, sums);
+    hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(1024), 0, st, sums, nb);
+  }
+  if (inclusive) hipLaunchKernelGGL(k_scan_write<true>, dim3(nb), dim3(256), 0, st, in, out, n, (const uint32_t*)(nb > 1 ? sums : nullptr));
+  else hipLaunchKernelGGL(k_scan_write<false>, dim3(nb), dim3(256), 0, st, in, out, n, (const uint32_t*)(nb > 1 ? sums : nullptr));
+}
+
 // Up to `kmax` draws of the library stream -> h->ssn_draws, speculatively: the stream stays locked until
 // the caller commits the number the sequential filter would have consumed (DrawStream::commit).
 static int upload_draws_begin(lsgpu_icp* h, int64_t seed, size_t kmax) {
@@ -1314,7 +1342,7 @@ static int scan_totals(lsgpu_icp* h, const uint32_t* in_a, const uint32_t* sc_a,
 // SamplingSurfaceNormal on device memory: src (n points) -> out_xyz1 / out_nrm (device, room for n)
 // (`ahead`: draws begun by the caller, this filter's first at ahead->used; nullptr: the filter draws for itself)
 static int ssn_device(lsgpu_icp* h, const float4* src, int64_t n, int knn, float ratio, int64_t seed,
-                      float4* out_xyz1, float* out_nrm, int64_t* n_out, DrawAhead* ahead = nullptr) {
+                      float4* out_xyz1, float* out_nrm, int64_t* n_out, DrawAhead* ahead = nullptr, bool force_sort_levels = false) {
   *n_out = 0;
   DrawAhead own;
   if (!ahead) {   // at most one draw per point, produced while the levels below are enqueued and run
@@ -1357,6 +1385,7 @@ static int ssn_device(lsgpu_icp* h, const float4* src, int64_t n, int knn, float
     int64_t c = n;
     while (glevels < levels && !(lds_finish && c <= root_max && levels - glevels <= root_levels)) { c -= c / 2; ++glevels; }
   }
+  const bool presorted = !force_sort_levels && !tuning().ssn_sort_levels && !tuning().ssn_full_sort && glevels > 0;
   if (tuning().ssn_full_sort) {   // rounds 1-3: the whole cloud sorted by (segment, coordinate) at every level
     for (int L = 0; L < glevels; ++L) {
       hipLaunchKernelGGL(k_ssn_keys, dim3(nblk(n)), dim3(256), 0, h->stream, src, (int)n, idx,
@@ -1370,6 +1399,89 @@ static int ssn_device(lsgpu_icp* h, const float4* src, int64_t n, int knn, float
       hipLaunchKernelGGL(k_ssn_assign, dim3(nblk(n)), dim3(256), 0, h->stream, (int)n, cur, knn, h->ssn_seg_of.p, L == 0 ? 1 : 0);
       std::swap(cur, nxt);
     }
+  } else if (glevels > 0 && presorted) {
+    // Upper levels from three presorted axes (lsgpu_ssn_levels.hip.h): the axes are sorted side by side on three streams,
+    // a level is a fix-up of tie runs + one stable partition -- 6 launches instead of 16, no sort.
+    const int cap = (int)(n / kSegTile + (int64_t)((size_t)1 << glevels) + 2);
+    const int capf = (int)(n / kSegTile + 2);
+    for (auto& b : h->gt_list) HIPC(b.reserve(n));
+    for (auto& b : h->gt_rank) HIPC(b.reserve(n));
+    for (auto& b : h->gt_cur) HIPC(b.reserve(n));
+    HIPC(h->gt_cnt.reserve((size_t)2 * cap)); HIPC(h->gt_err.reserve(4)); HIPC(h->gt_fullnb.reserve(4));
+    HIPC(h->gt_fulltab.reserve((size_t)capf)); HIPC(h->ssn_blocktab.reserve((size_t)cap));
+    HIPC(h->ssn_axis_a.reserve((size_t)1 << glevels)); HIPC(h->ssn_axis_b.reserve((size_t)1 << glevels));
+    HIPC(h->scr_main.keys.reserve(n)); HIPC(h->scr_main.keys_alt.reserve(n)); HIPC(h->scr_side.keys.reserve(n));
+    HIPC(h->scr_main.sort_hist.reserve((size_t)256 * capf + 260)); HIPC(h->scr_side.sort_hist.reserve((size_t)256 * capf + 260));
+    HIPC(h->gt_hist2.reserve((size_t)256 * capf + 260));
+    const size_t scan_tmp = ((size_t)n / kScanTile + 2) * sizeof(uint32_t);
+    HIPC(h->scr_main.sort_tmp.reserve(scan_tmp)); HIPC(h->scr_side.sort_tmp.reserve(scan_tmp)); HIPC(h->gt_tmp2.reserve(scan_tmp));
+    HIPC(h->sc->vals.reserve(n));
+    if (!h->side_stream) HIPC(hipStreamCreateWithFlags(&h->side_stream, hipStreamNonBlocking));
+    if (!h->gt_stream) HIPC(hipStreamCreateWithFlags(&h->gt_stream, hipStreamNonBlocking));
+    if (!h->gt_fork) { HIPC(hipEventCreateWithFlags(&h->gt_fork, hipEventDisableTiming)); HIPC(hipEventCreateWithFlags(&h->gt_join1, hipEventDisableTiming)); HIPC(hipEventCreateWithFlags(&h->gt_join2, hipEventDisableTiming)); }
+    if (!h->h_gt_err) HIPC(hipHostMalloc((void**)&h->h_gt_err, 64, hipHostMallocDefault));
+    HIPC(hipMemsetAsync(h->gt_err.p, 0, sizeof(uint32_t), h->stream));
+    hipLaunchKernelGGL(k_gt_fulltab, dim3(std::min(nblk(capf), 64)), dim3(256), 0, h->stream, (int)n, h->gt_fulltab.p, h->gt_fullnb.p);
+    HIPC(hipEventRecord(h->gt_fork, h->stream));   // (the cloud, the root and the one-segment block table are behind it)
+    hipStream_t ax_stream[3] = {h->stream, h->side_stream, h->gt_stream};
+    uint32_t* ax_keys[3] = {reinterpret_cast<uint32_t*>(h->scr_main.keys.p), reinterpret_cast<uint32_t*>(h->scr_side.keys.p),
+                            reinterpret_cast<uint32_t*>(h->scr_main.keys_alt.p)};
+    uint32_t* ax_hist[3] = {h->scr_main.sort_hist.p, h->scr_side.sort_hist.p, h->gt_hist2.p};
+    uint32_t* ax_tmp[3] = {reinterpret_cast<uint32_t*>(h->scr_main.sort_tmp.p), reinterpret_cast<uint32_t*>(h->scr_side.sort_tmp.p),
+                           reinterpret_cast<uint32_t*>(h->gt_tmp2.p)};
+    for (int d = 0; d < 3; ++d) {
+      hipStream_t st = ax_stream[d];
+      if (d) HIPC(hipStreamWaitEvent(st, h->gt_fork, 0));
+      uint32_t* keyA = ax_keys[d];
+      uint32_t* keyB = keyA + n;
+      uint32_t* valA = h->gt_list[d].p;        // buffer set 0 ...
+      uint32_t* valB = h->gt_list[3 + d].p;    // ... buffer set 1 as the sort's other half
+      uint32_t* bh = ax_hist[d];
+      uint32_t* dtot = bh + (size_t)256 * capf;
+      hipLaunchKernelGGL(k_gt_keys, dim3(nblk(n)), dim3(256), 0, st, src, (int)n, d, keyA, valA);
+      for (int pass = 0; pass < 4; ++pass) {
+        const uint32_t* kin = (pass & 1) ? keyB : keyA; const uint32_t* vin = (pass & 1) ? valB : valA;
+        uint32_t* kout = (pass & 1) ? keyA : keyB; uint32_t* vout = (pass & 1) ? valA : valB;
+        hipLaunchKernelGGL(k_seg_hist<kSegItems>, dim3(capf), dim3(256), 0, st, kin, h->gt_fulltab.p, h->gt_fullnb.p, 8 * pass, bh, capf);
+        hipLaunchKernelGGL(k_seg_scan, dim3(256), dim3(256), 0, st, bh, capf, h->gt_fullnb.p, dtot);
+        hipLaunchKernelGGL((k_seg_scatter<kSegItems>), dim3(capf), dim3(256), 0, st, kin, vin, kout, vout, h->gt_fulltab.p, h->gt_fullnb.p,
+                           8 * pass, bh, dtot, capf);
+      }
+      // dense ranks: flags where the sorted keys change, inclusive scan, scatter by point
+      hipLaunchKernelGGL(k_gt_rankflags, dim3(nblk(n)), dim3(256), 0, st, keyA, (int)n, keyB);
+      scan_u32_on(st, ax_tmp[d], keyB, keyB, (size_t)n, true);
+      hipLaunchKernelGGL(k_gt_rankscatter, dim3(nblk(n)), dim3(256), 0, st, valA, keyB, (int)n, h->gt_rank[d].p);
+      if (d == 1) HIPC(hipEventRecord(h->gt_join1, st));
+      if (d == 2) HIPC(hipEventRecord(h->gt_join2, st));
+    }
+    HIPC(hipStreamWaitEvent(h->stream, h->gt_join1, 0));
+    HIPC(hipStreamWaitEvent(h->stream, h->gt_join2, 0));
+    HIPC(hipGetLastError());
+    GtLists in, out;
+    for (int d = 0; d < 3; ++d) { in.list[d] = h->gt_list[d].p; out.list[d] = h->gt_list[3 + d].p; }
+    in.cur = h->gt_cur[0].p; out.cur = h->gt_cur[1].p;
+    int* ax_cur = h->ssn_axis_a.p;
+    int* ax_nxt = h->ssn_axis_b.p;
+    uint32_t* nblocks_dev = h->gt_fullnb.p + 1;
+    HIPC(hipMemsetAsync(ax_cur, 0xFF, sizeof(int), h->stream));   // the root's order follows no axis (-1)
+    for (int L = 0; L < glevels; ++L) {
+      const int ns = 1 << L;
+      const int grid = (int)std::min<int64_t>(cap, n / kSegTile + ns + 1);
+      hipLaunchKernelGGL(k_gt_plan, dim3(1), dim3(256), 0, h->stream, cur, ns, knn, h->ssn_blocktab.p, nblocks_dev);
+      hipLaunchKernelGGL(k_gt_fix, dim3(grid), dim3(256), 0, h->stream, h->ssn_blocktab.p, nblocks_dev, cur, (const int*)ax_cur, in, out,
+                         h->gt_rank[0].p, h->gt_rank[1].p, h->gt_rank[2].p, h->gt_err.p);
+      hipLaunchKernelGGL(k_gt_count, dim3(grid), dim3(256), 0, h->stream, h->ssn_blocktab.p, nblocks_dev, cur, in, (const uint32_t*)out.cur, h->gt_cnt.p, cap);
+      hipLaunchKernelGGL(k_gt_scan, dim3(1), dim3(1024), 0, h->stream, h->gt_cnt.p, cap, nblocks_dev);
+      hipLaunchKernelGGL(k_gt_part, dim3(grid), dim3(256), 0, h->stream, h->ssn_blocktab.p, nblocks_dev, cur, in, out, (const uint32_t*)h->gt_cnt.p, cap, h->ssn_seg_of.p);
+      hipLaunchKernelGGL(k_gt_split, dim3(nblk(ns)), dim3(256), 0, h->stream, src, out, cur, ns, knn, nxt, (const int*)ax_cur, ax_nxt);
+      std::swap(in, out);
+      std::swap(cur, nxt);
+      std::swap(ax_cur, ax_nxt);
+    }
+    hipLaunchKernelGGL(k_gt_idx, dim3(nblk(n)), dim3(256), 0, h->stream, (int)n, h->ssn_seg_of.p, (const int*)ax_cur, in, h->sc->vals.p);
+    idx = h->sc->vals.p;
+    HIPC(hipMemcpyAsync(h->h_gt_err, h->gt_err.p, sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
+    HIPC(hipGetLastError());
   } else if (glevels > 0) {
     // segmented sorts (lsgpu_segsort.hip.h): per level only the segments that cut along a new axis, four passes of
     // (uint32 key, uint32 index) pairs, every segment inside its own range of the arrays
@@ -1453,6 +1565,11 @@ static int ssn_device(lsgpu_icp* h, const float4* src, int64_t n, int knn, float
   if (rc == LSGPU_OK)
     rc = scan_totals(h, h->ssn_box_pts.p, h->ssn_box_base.p, nseg, h->ssn_keep.p, h->ssn_out_pos.p, (size_t)n, &n_draws, &kept);
   if (rc) return rc;
+  if (presorted && *h->h_gt_err) {
+    // a run of equal coordinates along a cut axis was too long to be walked element by element (kGtRunCap): the
+    // segmented sorts do not care -- the same filter again with them (same draws: nothing has been consumed yet)
+    return ssn_device(h, src, n, knn, ratio, seed, out_xyz1, out_nrm, n_out, ahead, true);
+  }
   ahead->used = first_draw + (size_t)n_draws;  // dropped boxes drew nothing
   HIPC(hipGetLastError());
   *n_out = kept;
