@@ -26,6 +26,7 @@ constexpr int kHistBins = 2048;
 #define LSGPU_CHUNK_MAX 64
 #endif
 constexpr int kChunkMax = LSGPU_CHUNK_MAX;  // points per chunk (power of two, <= 64)
+constexpr int kChunkGroup = 16;             // consecutive chunks that share one more bounding box (power of two)
 
 struct HashEntry {  // 16 B: one dwordx4 per probe
   uint32_t xy;      // cell x | y << 16

@@ -361,9 +361,24 @@ __global__ __launch_bounds__(256) void k_chunk_boxes(const float4* __restrict__ 
 // away -- so that one ds_read_b128 per coordinate hands four candidates to the packed-pair arithmetic.
 // k_chunk_cnt4: slots per chunk (scanned on the host side of the stream into first slots); k_soa_fill: one wave
 // per chunk, soa_base[c] = float4 index of the block.
+// (also: the bounding box of every GROUP of kChunkGroup consecutive chunks -- a per-lane search that has to walk a cell
+// of hundreds of chunks, a wall a metre from the sensor, skips sixteen chunk boxes per test: lane_ball_search)
 __global__ __launch_bounds__(256) void k_chunk_cnt4(const uint32_t* __restrict__ bounds, uint32_t nchunks,
-                                                    uint32_t* __restrict__ cnt4) {
+                                                    uint32_t* __restrict__ cnt4, const ChunkDesc* __restrict__ chunks,
+                                                    ChunkDesc* __restrict__ groups) {
   const uint32_t c = blockIdx.x * 256u + threadIdx.x;
+  if (c < nchunks && (c & (uint32_t)(kChunkGroup - 1)) == 0u) {
+    ChunkDesc g;
+    g.lox = g.loy = g.loz = INFINITY; g.hix = g.hiy = g.hiz = -INFINITY;
+    g.start = c; g.count = 0u;
+    for (uint32_t k = c; k < min(c + (uint32_t)kChunkGroup, nchunks); ++k) {
+      const ChunkDesc d = chunks[k];
+      g.lox = fminf(g.lox, d.lox); g.loy = fminf(g.loy, d.loy); g.loz = fminf(g.loz, d.loz);
+      g.hix = fmaxf(g.hix, d.hix); g.hiy = fmaxf(g.hiy, d.hiy); g.hiz = fmaxf(g.hiz, d.hiz);
+      g.count += 1u;
+    }
+    groups[c / (uint32_t)kChunkGroup] = g;
+  }
   if (c < nchunks) cnt4[c] = (bounds[c + 1] - bounds[c] + 3u) & ~3u;
 }
 

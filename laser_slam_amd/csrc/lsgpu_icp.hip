@@ -35,7 +35,9 @@
 #include "lsgpu_host_math.h"
 #include "lsgpu_ssn.hip.h"
 #include "lsgpu_ssn_tree.hip.h"
-#include "lsgpu_ssn_levels.hip.h"
+#ifdef LSGPU_EXPERIMENTS
+#include "lsgpu_ssn_levels.hip.h"   // measured slower than the segmented level sorts: kept as the record, experiments build only
+#endif
 #include "lsgpu_sort.hip.h"
 #include "lsgpu_scan.hip.h"
 #include "lsgpu_rand.h"
@@ -176,14 +178,14 @@ struct lsgpu_icp {
   hipStream_t side_stream = nullptr;   // lsgpu_icp_compute: reading filter + query order, beside the grid build
   hipEvent_t side_done = nullptr;
   int side_totals_slot = 0;            // scan_totals staging: the side path uses its own words of h_pinned
-  std::function<int()> hook_before_ref_sync, hook_after_ref_sync;   // set by lsgpu_icp_compute around set_reference
+  std::function<int()> hook_before_ref_sync, hook_after_grid;   // set by lsgpu_icp_compute: before set_reference waits for its cell counts / once the whole grid build is enqueued
   const float* prepared_rd = nullptr;  // queries already ordered by the side path (consumed by the next align)
   int64_t prepared_nq = 0;
   DevBuf<float4> pts, nrm;
   DevBuf<uint32_t> ref_inv;
   DevBuf<HashEntry> tables;
   DevBuf<uint32_t> flags, cidx, bounds;
-  DevBuf<ChunkDesc> chunks;
+  DevBuf<ChunkDesc> chunks, chunk_groups;
   DevBuf<float> soa;            // chunk-blocked SoA copy of pts (k_soa_fill)
   DevBuf<uint32_t> soa_base, soa_cnt4, soa_first;
   uint32_t nchunks = 0;
@@ -194,6 +196,7 @@ struct lsgpu_icp {
   ConeDev cone;
   bool cone_ok = false;       // built (or being built on the side stream: cone_pending) for the current reference
   bool defer_cone = false;    // lsgpu_icp_compute: set_reference leaves the build to the side stream
+  bool cone_build_in_align = false;   // ... and the next align enqueues it there behind its first iteration
   bool cone_pending = false;  // the loop's stream has not yet waited for cone_done
   hipEvent_t cone_done = nullptr;
   DevBuf<uint32_t> cone_occ;          // occupied (row, column) bins of the index
@@ -210,6 +213,10 @@ struct lsgpu_icp {
   // launch policy of the running align (lsgpu_policy.h): every decision about what is enqueued next lives there
   policy::Config pol_cfg;
   policy::State pol;
+  // is the index paying on this handle's clouds?  (policy::index_not_paying; two event pairs per alignment)
+  hipEvent_t ev_pay[4] = {nullptr, nullptr, nullptr, nullptr};
+  bool pay_voxel_timed = false, pay_index_timed = false;
+  int index_rest = 0;         // alignments that still leave the index alone
   DevBuf<uint4> knn_dbg_wave;
   DevBuf<unsigned long long> knn_dbg;  // LSGPU_KNN_STATS builds: 8 counters
   DevBuf<uint2> cell_cache;  // ntiles x 64
@@ -244,13 +251,15 @@ struct lsgpu_icp {
   DevBuf<SegBlock> ssn_blocktab;
   DevBuf<uint32_t> ssn_seg_of, ssn_box_pts, ssn_box_base, ssn_keep, ssn_out_pos, ssn_bb;
   DevBuf<float> ssn_box_normal, ssn_draws;
+#ifdef LSGPU_EXPERIMENTS
   // upper levels of the reference filter from presorted axes (lsgpu_ssn_levels.hip.h)
-  DevBuf<uint32_t> gt_list[6], gt_rank[3], gt_cur[2], gt_cnt, gt_err, gt_hist2, gt_fullnb;
-  DevBuf<char> gt_tmp2;
+  DevBuf<uint32_t> gt_list[6], gt_key[6], gt_cnt, gt_err, gt_hist2, gt_fullnb;   // (points, keys) of the three lists, two buffer sets
+  DevBuf<unsigned char> gt_side;       // per point: right child at this level?
   DevBuf<SegBlock> gt_fulltab;
   hipStream_t gt_stream = nullptr;     // the third axis' presort (the second runs on side_stream)
   hipEvent_t gt_fork = nullptr, gt_join1 = nullptr, gt_join2 = nullptr;
   uint32_t* h_gt_err = nullptr;        // pinned: "a tie run was too long for the presorted levels"
+#endif
   DevBuf<float4> flt_in, flt_in2, flt_ref, flt_rd;
   DevBuf<float> flt_nrm;
   float* draws_pinned = nullptr;  // host staging of the filter draws (pinned: async H2D)
@@ -428,7 +437,7 @@ void lsgpu_icp_destroy(lsgpu_icp* h) {
 #endif
   h->pts.release();
   h->cone_soa.release(); h->cone_occ.release(); h->cone_map.release(); h->cone_tab.release(); h->cone_rowz.release();
-  h->nrm.release(); h->ref_inv.release(); h->tables.release(); h->flags.release(); h->cidx.release(); h->bounds.release(); h->chunks.release(); h->soa.release(); h->soa_base.release(); h->soa_cnt4.release(); h->soa_first.release(); h->prev.release(); h->state.release(); h->lb.release(); h->cell_cache.release(); h->cell_tags.release(); h->ssn_seg_a.release(); h->ssn_seg_b.release(); h->ssn_axis_a.release(); h->ssn_axis_b.release(); h->ssn_seg_fb.release(); h->ssn_blocktab.release(); h->ssn_seg_of.release(); h->ssn_box_pts.release(); h->ssn_box_base.release(); h->ssn_keep.release(); h->ssn_out_pos.release(); h->ssn_bb.release(); h->ssn_box_normal.release(); h->ssn_draws.release(); h->flt_in.release(); h->flt_in2.release(); h->flt_ref.release(); h->flt_rd.release(); h->flt_nrm.release(); h->chk_hist.release(); h->trace_dev.release(); h->knn_dbg.release(); h->knn_dbg_wave.release(); h->stat_partials.release(); h->geom.release();
+  h->nrm.release(); h->ref_inv.release(); h->tables.release(); h->flags.release(); h->cidx.release(); h->bounds.release(); h->chunks.release(); h->chunk_groups.release(); h->soa.release(); h->soa_base.release(); h->soa_cnt4.release(); h->soa_first.release(); h->prev.release(); h->state.release(); h->lb.release(); h->cell_cache.release(); h->cell_tags.release(); h->ssn_seg_a.release(); h->ssn_seg_b.release(); h->ssn_axis_a.release(); h->ssn_axis_b.release(); h->ssn_seg_fb.release(); h->ssn_blocktab.release(); h->ssn_seg_of.release(); h->ssn_box_pts.release(); h->ssn_box_base.release(); h->ssn_keep.release(); h->ssn_out_pos.release(); h->ssn_bb.release(); h->ssn_box_normal.release(); h->ssn_draws.release(); h->flt_in.release(); h->flt_in2.release(); h->flt_ref.release(); h->flt_rd.release(); h->flt_nrm.release(); h->chk_hist.release(); h->trace_dev.release(); h->knn_dbg.release(); h->knn_dbg_wave.release(); h->stat_partials.release(); h->geom.release();
   h->counters.release(); h->price_cnt.release(); h->ang_cells.release(); h->sel_aux.release(); h->sel_win.release(); h->spread_flag.release(); h->spread_list.release(); h->spread_cnt.release(); h->q_in.release(); h->rdq.release(); h->ids.release(); h->d2.release();
   h->ids_io.release(); h->d2_io.release(); h->strag.release(); h->hist.release();
   h->sel.release(); h->ne_partials.release(); h->ne_gpartials.release(); h->ne_tickets.release(); h->ne_out.release(); h->limit_dev.release();
@@ -440,18 +449,21 @@ void lsgpu_icp_destroy(lsgpu_icp* h) {
   if (h->ev_tail) (void)hipEventDestroy(h->ev_tail);
   if (h->cone_done) (void)hipEventDestroy(h->cone_done);
   if (h->cone_occ_ready) (void)hipEventDestroy(h->cone_occ_ready);
+  for (auto& e : h->ev_pay) if (e) (void)hipEventDestroy(e);
   if (h->h_pinned) (void)hipHostFree(h->h_pinned);
   if (h->h_price) (void)hipHostFree(h->h_price);
   if (h->h_cone_occ) (void)hipHostFree(h->h_cone_occ);
+#ifdef LSGPU_EXPERIMENTS
   if (h->h_gt_err) (void)hipHostFree(h->h_gt_err);
   for (auto& b : h->gt_list) b.release();
-  for (auto& b : h->gt_rank) b.release();
-  for (auto& b : h->gt_cur) b.release();
-  h->gt_cnt.release(); h->gt_err.release(); h->gt_hist2.release(); h->gt_fullnb.release(); h->gt_tmp2.release(); h->gt_fulltab.release();
+  for (auto& b : h->gt_key) b.release();
+  h->gt_side.release();
+  h->gt_cnt.release(); h->gt_err.release(); h->gt_hist2.release(); h->gt_fullnb.release(); h->gt_fulltab.release();
   if (h->gt_fork) (void)hipEventDestroy(h->gt_fork);
   if (h->gt_join1) (void)hipEventDestroy(h->gt_join1);
   if (h->gt_join2) (void)hipEventDestroy(h->gt_join2);
   if (h->gt_stream) { (void)hipStreamSynchronize(h->gt_stream); (void)hipStreamDestroy(h->gt_stream); }
+#endif
   if (h->draws_pinned) (void)hipHostFree(h->draws_pinned);
   if (h->copy_done) (void)hipEventDestroy(h->copy_done);
   if (h->ref_up_done) (void)hipEventDestroy(h->ref_up_done);
@@ -599,7 +611,7 @@ static float price_share(const lsgpu_icp* h) {   // heavy lanes / searching lane
 static KnnArgs knn_args(lsgpu_icp* h, const Mat34& T) {
   KnnArgs a;
   a.rdq = h->rdq.p; a.nq = (int)h->nq; a.T = T; a.g = h->grid; a.pts = h->pts.p;
-  a.chunks = h->chunks.p; a.soa = reinterpret_cast<const float4*>(h->soa.p); a.chunk_soa = h->soa_base.p; a.ids = h->ids.p; a.d2 = h->d2.p; a.prev = h->prev.p;
+  a.chunks = h->chunks.p; a.cgroups = h->chunk_groups.p; a.soa = reinterpret_cast<const float4*>(h->soa.p); a.chunk_soa = h->soa_base.p; a.ids = h->ids.p; a.d2 = h->d2.p; a.prev = h->prev.p;
   a.strag = h->strag.p; a.strag_count = h->counters.p + 32;
   a.r_cap = 1.0f; a.group_r = 0.75f; a.cap2 = INFINITY; a.st = nullptr; a.use_state_cap = 0; a.lb = nullptr;
   a.spread_route_r = 0.f; a.route_chunks = 1 << 30; a.route_dense = 1 << 30; a.sel_hist2 = nullptr; a.sel_below = nullptr;
@@ -688,6 +700,10 @@ static int run_knn(lsgpu_icp* h, const Mat34& T, const IcpState* st, const polic
     if (rs) return rs;
     hipLaunchKernelGGL(k_seed_cap, dim3(1), dim3(256), 0, h->stream, h->hist.p, h->sel.p + 2, h->state.p);
   }
+  // two launches of every alignment are timed for policy::index_not_paying (not in profiled runs: they time everything)
+  const bool pay_probe = !timed && st && pol.cone_ok && h->ev_pay[0];
+  const bool pay_voxel = pay_probe && !seed && it.ordinal == pc.cone_from - 1 && !h->pay_voxel_timed;
+  if (pay_voxel) HIPC(hipEventRecord(h->ev_pay[0], h->stream));
   lsgpu_icp::KnnEv* ev = nullptr;
   if (timed) {
     if (h->knn_events_used == h->knn_events.size()) {
@@ -727,11 +743,14 @@ static int run_knn(lsgpu_icp* h, const Mat34& T, const IcpState* st, const polic
       h->cone_pending = false;
     }
     a.front_blocks = 0;
+    const bool pay_index = pay_probe && kern == policy::KnnKernel::Cone && h->pay_voxel_timed && !h->pay_index_timed;
+    if (pay_index) HIPC(hipEventRecord(h->ev_pay[2], h->stream));
     if (kern == policy::KnnKernel::ConeProbe)   // balls as wide as the last ICP step: a probe of the query's own direction first
       hipLaunchKernelGGL((k_knn_cone<LSGPU_CONE_WAVES, true>), dim3((a.ntiles + LSGPU_CONE_WAVES - 1) / LSGPU_CONE_WAVES), dim3(LSGPU_CONE_WAVES * 64), 0, h->stream, a, h->cone);
     else
       hipLaunchKernelGGL((k_knn_cone<LSGPU_CONE_WAVES, false>), dim3((a.ntiles + LSGPU_CONE_WAVES - 1) / LSGPU_CONE_WAVES), dim3(LSGPU_CONE_WAVES * 64), 0, h->stream, a, h->cone);
     if (timed) HIPC(hipEventRecord(ev->b, h->stream));
+    if (pay_index) { HIPC(hipEventRecord(h->ev_pay[3], h->stream)); h->pay_index_timed = true; }
     HIPC(hipGetLastError());
     return LSGPU_OK;
   }
@@ -784,6 +803,7 @@ static int run_knn(lsgpu_icp* h, const Mat34& T, const IcpState* st, const polic
     second = false;
   }
   if (timed && second) { ev->second = true; HIPC(hipEventRecord(ev->c, h->stream)); }   // (an event pair around nothing still reads ~5 us)
+  if (pay_voxel) { HIPC(hipEventRecord(h->ev_pay[1], h->stream)); h->pay_voxel_timed = true; }
   if (pricing) {
     if (!h->price_ready) HIPC(hipEventCreateWithFlags(&h->price_ready, hipEventDisableTiming));
     HIPC(hipMemcpyAsync(h->h_price, h->price_cnt.p, (size_t)kPriceSlots * kPriceStride * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
@@ -829,13 +849,18 @@ static int run_select(lsgpu_icp* h, const float* d2, int n, uint32_t k, bool zer
 
 // Direction index of the current reference (lsgpu_cone.hip.h) on the handle's current stream / sort scratch: keys of
 // the Morton-sorted points, three radix passes, SoA copy + position map + (row, column) table + zeta range per row.
+// is a direction index built for the current reference at all?  (host-side facts only)
+static bool cone_wanted(const lsgpu_icp* h) {
+  const int64_t nr = h->nr;
+  if (!(tuning().cone && h->cone_origin_inside && nr >= 1024)) return false;
+  // a reference with more points than 0.6 x the occupancy limit x the number of bins cannot come out below the limit
+  // (measured: 4.3 / 6.3 / 8.5 points per occupied bin at 3.0 / 4.0 / 5.0 per bin): spare it the build (1.8 ms at 8 M points)
+  return !((double)nr > 0.6 * (double)tuning().cone_max_occupancy * (double)tuning().cone_rows * (double)tuning().cone_cols);
+}
 static int build_cone_index(lsgpu_icp* h) {
   const int64_t nr = h->nr;
   h->cone_ok = false;
-  if (!(tuning().cone && h->cone_origin_inside && nr >= 1024)) return LSGPU_OK;
-  // a reference with more points than 0.6 x the occupancy limit x the number of bins cannot come out below the limit
-  // (measured: 4.3 / 6.3 / 8.5 points per occupied bin at 3.0 / 4.0 / 5.0 per bin): spare it the build (1.8 ms at 8 M points)
-  if ((double)nr > 0.6 * (double)tuning().cone_max_occupancy * (double)tuning().cone_rows * (double)tuning().cone_cols) return LSGPU_OK;
+  if (!cone_wanted(h)) return LSGPU_OK;
   ConeDev c;
   std::memset(&c, 0, sizeof(c));
   c.ox = -h->mean[0]; c.oy = -h->mean[1]; c.oz = -h->mean[2];
@@ -955,10 +980,6 @@ int lsgpu_icp_set_reference(lsgpu_icp* h, const float* ref_xyz1, const float* re
   HIPC(hipStreamSynchronize(h->stream));
   if (hg->bad) { h->err = "set_reference: non-finite coordinates"; return LSGPU_BAD_ARG; }
   for (int d = 0; d < 3; ++d) h->mean[d] = hg->mean[d];
-  if (h->hook_after_ref_sync) {    // (the mean is known: the queries can be moved into the reference's frame)
-    rc = h->hook_after_ref_sync();
-    if (rc) return rc;
-  }
   const int bits = hg->bits, fine = hg->fine;
   const float h0 = hg->h0;
   GridDev g;
@@ -983,8 +1004,9 @@ int lsgpu_icp_set_reference(lsgpu_icp* h, const float* ref_xyz1, const float* re
   // chunk-blocked SoA copy for the broadcast evaluation: <= 3 rounding slots per chunk
   HIPC(h->soa_cnt4.reserve(nchunks)); HIPC(h->soa_first.reserve(nchunks)); HIPC(h->soa_base.reserve(nchunks));
   HIPC(h->soa.reserve(3 * ((size_t)nr + 3 * (size_t)nchunks) + 16));
+  HIPC(h->chunk_groups.reserve((size_t)nchunks / kChunkGroup + 1));
   hipLaunchKernelGGL(k_chunk_cnt4, dim3((nchunks + 255) / 256), dim3(256), 0, h->stream, h->bounds.p, nchunks,
-                     h->soa_cnt4.p);
+                     h->soa_cnt4.p, (const ChunkDesc*)h->chunks.p, h->chunk_groups.p);
   rc = scan_u32(h, h->soa_cnt4.p, h->soa_first.p, nchunks);
   if (rc) return rc;
   hipLaunchKernelGGL(k_soa_fill, dim3((nchunks + 3) / 4), dim3(256), 0, h->stream, h->pts.p, h->bounds.p,
@@ -1003,9 +1025,13 @@ int lsgpu_icp_set_reference(lsgpu_icp* h, const float* ref_xyz1, const float* re
   h->grid = g;
   h->nr = nr;
   h->nchunks = nchunks;
+  if (h->hook_after_grid) {    // lsgpu_icp_compute: the mean is known and this stream is busy -- now the queries' side
+    rc = h->hook_after_grid();
+    if (rc) return rc;
+  }
   // ---- direction index for the settled launches (after k_cells_fill: its sort reuses the Morton keys' buffers).
   // lsgpu_icp_compute builds it on its side stream instead, beside the first iterations of the loop (defer_cone).
-  h->cone_ok = false; h->cone_pending = false;
+  h->cone_ok = false; h->cone_pending = false; h->cone_build_in_align = false;
   h->cone_zeta_lo = hg->zeta_lo; h->cone_zeta_hi = hg->zeta_hi; h->cone_origin_inside = hg->origin_inside != 0;
   if (!h->defer_cone) {
     rc = build_cone_index(h);
@@ -1214,17 +1240,6 @@ static int scan_u32(lsgpu_icp* h, const uint32_t* in, uint32_t* out, size_t n, b
   return LSGPU_OK;
 }
 
-// the same on an explicit stream with explicit scratch (the presorts of the three axes run side by side)
-static void scan_u32_on(hipStream_t st, uint32_t* sums, const uint32_t* in, uint32_t* out, size_t n, bool inclusive) {
-  const int nb = (int)((n + kScanTile - 1) / kScanTile);
-  if (nb > 1) {
-    hipLaunchKernelGGL(k_scan_sums, dim3(nb), dim3(256), 0, st, in, n, sums);
-    hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(1024), 0, st, sums, nb);
-  }
-  if (inclusive) hipLaunchKernelGGL(k_scan_write<true>, dim3(nb), dim3(256), 0, st, in, out, n, (const uint32_t*)(nb > 1 ? sums : nullptr));
-  else hipLaunchKernelGGL(k_scan_write<false>, dim3(nb), dim3(256), 0, st, in, out, n, (const uint32_t*)(nb > 1 ? sums : nullptr));
-}
-
 // Up to `kmax` draws of the library stream -> h->ssn_draws, speculatively: the stream stays locked until
 // the caller commits the number the sequential filter would have consumed (DrawStream::commit).
 static int upload_draws_begin(lsgpu_icp* h, int64_t seed, size_t kmax) {
@@ -1320,23 +1335,31 @@ struct DrawAhead {
   ~DrawAhead() { finish(); }
 };
 
-// totals of two exclusive scans (last scanned value + last input) in one D2H, synchronises the stream
-static int scan_totals(lsgpu_icp* h, const uint32_t* in_a, const uint32_t* sc_a, size_t na,
-                       const uint32_t* in_b, const uint32_t* sc_b, size_t nb, uint32_t* tot_a, uint32_t* tot_b) {
+// totals of two exclusive scans (last scanned value + last input): four 4-byte copies behind the scans ...
+static int scan_totals_enqueue(lsgpu_icp* h, const uint32_t* in_a, const uint32_t* sc_a, size_t na,
+                               const uint32_t* in_b, const uint32_t* sc_b, size_t nb) {
   uint32_t* hp = reinterpret_cast<uint32_t*>(h->h_pinned + 100 + 4 * h->side_totals_slot);
   hp[0] = hp[1] = hp[2] = hp[3] = 0;
-  hipError_t e = hipSuccess;
   if (in_a) {
-    e = hipMemcpyAsync(hp, in_a + (na - 1), 4, hipMemcpyDeviceToHost, h->cur);
-    if (e == hipSuccess) e = hipMemcpyAsync(hp + 1, sc_a + (na - 1), 4, hipMemcpyDeviceToHost, h->cur);
+    HIPC(hipMemcpyAsync(hp, in_a + (na - 1), 4, hipMemcpyDeviceToHost, h->cur));
+    HIPC(hipMemcpyAsync(hp + 1, sc_a + (na - 1), 4, hipMemcpyDeviceToHost, h->cur));
   }
-  if (e == hipSuccess) e = hipMemcpyAsync(hp + 2, in_b + (nb - 1), 4, hipMemcpyDeviceToHost, h->cur);
-  if (e == hipSuccess) e = hipMemcpyAsync(hp + 3, sc_b + (nb - 1), 4, hipMemcpyDeviceToHost, h->cur);
-  if (e == hipSuccess) e = hipStreamSynchronize(h->cur);
+  HIPC(hipMemcpyAsync(hp + 2, in_b + (nb - 1), 4, hipMemcpyDeviceToHost, h->cur));
+  HIPC(hipMemcpyAsync(hp + 3, sc_b + (nb - 1), 4, hipMemcpyDeviceToHost, h->cur));
+  return LSGPU_OK;
+}
+// ... and the host's wait for them (synchronises the current stream)
+static int scan_totals_wait(lsgpu_icp* h, uint32_t* tot_a, uint32_t* tot_b) {
+  const uint32_t* hp = reinterpret_cast<const uint32_t*>(h->h_pinned + 100 + 4 * h->side_totals_slot);
+  HIPC(hipStreamSynchronize(h->cur));
   *tot_a = hp[0] + hp[1];
   *tot_b = hp[2] + hp[3];
-  if (e != hipSuccess) HIPC(e);
   return LSGPU_OK;
+}
+static int scan_totals(lsgpu_icp* h, const uint32_t* in_a, const uint32_t* sc_a, size_t na,
+                       const uint32_t* in_b, const uint32_t* sc_b, size_t nb, uint32_t* tot_a, uint32_t* tot_b) {
+  const int rc = scan_totals_enqueue(h, in_a, sc_a, na, in_b, sc_b, nb);
+  return rc ? rc : scan_totals_wait(h, tot_a, tot_b);
 }
 
 // SamplingSurfaceNormal on device memory: src (n points) -> out_xyz1 / out_nrm (device, room for n)
@@ -1372,6 +1395,7 @@ static int ssn_device(lsgpu_icp* h, const float4* src, int64_t n, int knn, float
   SsnSeg* cur = h->ssn_seg_a.p;
   SsnSeg* nxt = h->ssn_seg_b.p;
   const uint32_t* idx = nullptr;
+  const int* root_axis = nullptr;   // per root of the in-workgroup levels: the axis its order follows (segmented level sorts)
   // levels [0, glevels) with global sorts; the rest inside one workgroup per segment once a segment fits
   // its LDS (<= kSsnLdsMax points, <= kSsnLdsLevels levels to go)
   int glevels = 0;
@@ -1385,7 +1409,11 @@ static int ssn_device(lsgpu_icp* h, const float4* src, int64_t n, int knn, float
     int64_t c = n;
     while (glevels < levels && !(lds_finish && c <= root_max && levels - glevels <= root_levels)) { c -= c / 2; ++glevels; }
   }
-  const bool presorted = !force_sort_levels && !tuning().ssn_sort_levels && !tuning().ssn_full_sort && glevels > 0;
+#ifdef LSGPU_EXPERIMENTS
+  const bool presorted = !force_sort_levels && tuning().ssn_presorted_levels && !tuning().ssn_full_sort && glevels > 0;
+#else
+  (void)force_sort_levels;
+#endif
   if (tuning().ssn_full_sort) {   // rounds 1-3: the whole cloud sorted by (segment, coordinate) at every level
     for (int L = 0; L < glevels; ++L) {
       hipLaunchKernelGGL(k_ssn_keys, dim3(nblk(n)), dim3(256), 0, h->stream, src, (int)n, idx,
@@ -1399,22 +1427,20 @@ static int ssn_device(lsgpu_icp* h, const float4* src, int64_t n, int knn, float
       hipLaunchKernelGGL(k_ssn_assign, dim3(nblk(n)), dim3(256), 0, h->stream, (int)n, cur, knn, h->ssn_seg_of.p, L == 0 ? 1 : 0);
       std::swap(cur, nxt);
     }
+#ifdef LSGPU_EXPERIMENTS
   } else if (glevels > 0 && presorted) {
     // Upper levels from three presorted axes (lsgpu_ssn_levels.hip.h): the axes are sorted side by side on three streams,
     // a level is a fix-up of tie runs + one stable partition -- 6 launches instead of 16, no sort.
     const int cap = (int)(n / kSegTile + (int64_t)((size_t)1 << glevels) + 2);
     const int capf = (int)(n / kSegTile + 2);
     for (auto& b : h->gt_list) HIPC(b.reserve(n));
-    for (auto& b : h->gt_rank) HIPC(b.reserve(n));
-    for (auto& b : h->gt_cur) HIPC(b.reserve(n));
+    for (auto& b : h->gt_key) HIPC(b.reserve(n));
+    HIPC(h->gt_side.reserve(n));
     HIPC(h->gt_cnt.reserve((size_t)2 * cap)); HIPC(h->gt_err.reserve(4)); HIPC(h->gt_fullnb.reserve(4));
     HIPC(h->gt_fulltab.reserve((size_t)capf)); HIPC(h->ssn_blocktab.reserve((size_t)cap));
     HIPC(h->ssn_axis_a.reserve((size_t)1 << glevels)); HIPC(h->ssn_axis_b.reserve((size_t)1 << glevels));
-    HIPC(h->scr_main.keys.reserve(n)); HIPC(h->scr_main.keys_alt.reserve(n)); HIPC(h->scr_side.keys.reserve(n));
     HIPC(h->scr_main.sort_hist.reserve((size_t)256 * capf + 260)); HIPC(h->scr_side.sort_hist.reserve((size_t)256 * capf + 260));
     HIPC(h->gt_hist2.reserve((size_t)256 * capf + 260));
-    const size_t scan_tmp = ((size_t)n / kScanTile + 2) * sizeof(uint32_t);
-    HIPC(h->scr_main.sort_tmp.reserve(scan_tmp)); HIPC(h->scr_side.sort_tmp.reserve(scan_tmp)); HIPC(h->gt_tmp2.reserve(scan_tmp));
     HIPC(h->sc->vals.reserve(n));
     if (!h->side_stream) HIPC(hipStreamCreateWithFlags(&h->side_stream, hipStreamNonBlocking));
     if (!h->gt_stream) HIPC(hipStreamCreateWithFlags(&h->gt_stream, hipStreamNonBlocking));
@@ -1424,18 +1450,15 @@ static int ssn_device(lsgpu_icp* h, const float4* src, int64_t n, int knn, float
     hipLaunchKernelGGL(k_gt_fulltab, dim3(std::min(nblk(capf), 64)), dim3(256), 0, h->stream, (int)n, h->gt_fulltab.p, h->gt_fullnb.p);
     HIPC(hipEventRecord(h->gt_fork, h->stream));   // (the cloud, the root and the one-segment block table are behind it)
     hipStream_t ax_stream[3] = {h->stream, h->side_stream, h->gt_stream};
-    uint32_t* ax_keys[3] = {reinterpret_cast<uint32_t*>(h->scr_main.keys.p), reinterpret_cast<uint32_t*>(h->scr_side.keys.p),
-                            reinterpret_cast<uint32_t*>(h->scr_main.keys_alt.p)};
     uint32_t* ax_hist[3] = {h->scr_main.sort_hist.p, h->scr_side.sort_hist.p, h->gt_hist2.p};
-    uint32_t* ax_tmp[3] = {reinterpret_cast<uint32_t*>(h->scr_main.sort_tmp.p), reinterpret_cast<uint32_t*>(h->scr_side.sort_tmp.p),
-                           reinterpret_cast<uint32_t*>(h->gt_tmp2.p)};
     for (int d = 0; d < 3; ++d) {
       hipStream_t st = ax_stream[d];
       if (d) HIPC(hipStreamWaitEvent(st, h->gt_fork, 0));
-      uint32_t* keyA = ax_keys[d];
-      uint32_t* keyB = keyA + n;
-      uint32_t* valA = h->gt_list[d].p;        // buffer set 0 ...
-      uint32_t* valB = h->gt_list[3 + d].p;    // ... buffer set 1 as the sort's other half
+      // the sort's two halves ARE the two buffer sets of the axis' list: (keys, points) in list order
+      uint32_t* keyA = h->gt_key[d].p;
+      uint32_t* keyB = h->gt_key[3 + d].p;
+      uint32_t* valA = h->gt_list[d].p;
+      uint32_t* valB = h->gt_list[3 + d].p;
       uint32_t* bh = ax_hist[d];
       uint32_t* dtot = bh + (size_t)256 * capf;
       hipLaunchKernelGGL(k_gt_keys, dim3(nblk(n)), dim3(256), 0, st, src, (int)n, d, keyA, valA);
@@ -1447,10 +1470,6 @@ static int ssn_device(lsgpu_icp* h, const float4* src, int64_t n, int knn, float
         hipLaunchKernelGGL((k_seg_scatter<kSegItems>), dim3(capf), dim3(256), 0, st, kin, vin, kout, vout, h->gt_fulltab.p, h->gt_fullnb.p,
                            8 * pass, bh, dtot, capf);
       }
-      // dense ranks: flags where the sorted keys change, inclusive scan, scatter by point
-      hipLaunchKernelGGL(k_gt_rankflags, dim3(nblk(n)), dim3(256), 0, st, keyA, (int)n, keyB);
-      scan_u32_on(st, ax_tmp[d], keyB, keyB, (size_t)n, true);
-      hipLaunchKernelGGL(k_gt_rankscatter, dim3(nblk(n)), dim3(256), 0, st, valA, keyB, (int)n, h->gt_rank[d].p);
       if (d == 1) HIPC(hipEventRecord(h->gt_join1, st));
       if (d == 2) HIPC(hipEventRecord(h->gt_join2, st));
     }
@@ -1458,30 +1477,31 @@ static int ssn_device(lsgpu_icp* h, const float4* src, int64_t n, int knn, float
     HIPC(hipStreamWaitEvent(h->stream, h->gt_join2, 0));
     HIPC(hipGetLastError());
     GtLists in, out;
-    for (int d = 0; d < 3; ++d) { in.list[d] = h->gt_list[d].p; out.list[d] = h->gt_list[3 + d].p; }
-    in.cur = h->gt_cur[0].p; out.cur = h->gt_cur[1].p;
-    int* ax_cur = h->ssn_axis_a.p;
-    int* ax_nxt = h->ssn_axis_b.p;
+    for (int d = 0; d < 3; ++d) { in.e[d] = h->gt_list[d].p; in.k[d] = h->gt_key[d].p; out.e[d] = h->gt_list[3 + d].p; out.k[d] = h->gt_key[3 + d].p; }
+    uint32_t* sig_cur = reinterpret_cast<uint32_t*>(h->ssn_axis_a.p);
+    uint32_t* sig_nxt = reinterpret_cast<uint32_t*>(h->ssn_axis_b.p);
     uint32_t* nblocks_dev = h->gt_fullnb.p + 1;
-    HIPC(hipMemsetAsync(ax_cur, 0xFF, sizeof(int), h->stream));   // the root's order follows no axis (-1)
+    HIPC(hipMemsetAsync(sig_cur, 0xFF, sizeof(uint32_t), h->stream));   // the root was cut along no axis yet
     for (int L = 0; L < glevels; ++L) {
       const int ns = 1 << L;
       const int grid = (int)std::min<int64_t>(cap, n / kSegTile + ns + 1);
       hipLaunchKernelGGL(k_gt_plan, dim3(1), dim3(256), 0, h->stream, cur, ns, knn, h->ssn_blocktab.p, nblocks_dev);
-      hipLaunchKernelGGL(k_gt_fix, dim3(grid), dim3(256), 0, h->stream, h->ssn_blocktab.p, nblocks_dev, cur, (const int*)ax_cur, in, out,
-                         h->gt_rank[0].p, h->gt_rank[1].p, h->gt_rank[2].p, h->gt_err.p);
-      hipLaunchKernelGGL(k_gt_count, dim3(grid), dim3(256), 0, h->stream, h->ssn_blocktab.p, nblocks_dev, cur, in, (const uint32_t*)out.cur, h->gt_cnt.p, cap);
+      hipLaunchKernelGGL(k_gt_fix, dim3(grid), dim3(256), 0, h->stream, h->ssn_blocktab.p, nblocks_dev, cur, (const uint32_t*)sig_cur, in, out,
+                         src, h->gt_side.p, h->gt_err.p);
+      hipLaunchKernelGGL(k_gt_count, dim3(grid), dim3(256), 0, h->stream, h->ssn_blocktab.p, nblocks_dev, cur, in, (const unsigned char*)h->gt_side.p, h->gt_cnt.p, cap);
       hipLaunchKernelGGL(k_gt_scan, dim3(1), dim3(1024), 0, h->stream, h->gt_cnt.p, cap, nblocks_dev);
-      hipLaunchKernelGGL(k_gt_part, dim3(grid), dim3(256), 0, h->stream, h->ssn_blocktab.p, nblocks_dev, cur, in, out, (const uint32_t*)h->gt_cnt.p, cap, h->ssn_seg_of.p);
-      hipLaunchKernelGGL(k_gt_split, dim3(nblk(ns)), dim3(256), 0, h->stream, src, out, cur, ns, knn, nxt, (const int*)ax_cur, ax_nxt);
+      hipLaunchKernelGGL(k_gt_part, dim3(grid), dim3(256), 0, h->stream, h->ssn_blocktab.p, nblocks_dev, cur, in, out, (const unsigned char*)h->gt_side.p,
+                         (const uint32_t*)h->gt_cnt.p, cap, h->ssn_seg_of.p);
+      hipLaunchKernelGGL(k_gt_split, dim3(nblk(ns)), dim3(256), 0, h->stream, src, out, cur, ns, knn, nxt, (const uint32_t*)sig_cur, sig_nxt);
       std::swap(in, out);
       std::swap(cur, nxt);
-      std::swap(ax_cur, ax_nxt);
+      std::swap(sig_cur, sig_nxt);
     }
-    hipLaunchKernelGGL(k_gt_idx, dim3(nblk(n)), dim3(256), 0, h->stream, (int)n, h->ssn_seg_of.p, (const int*)ax_cur, in, h->sc->vals.p);
+    hipLaunchKernelGGL(k_gt_idx, dim3(nblk(n)), dim3(256), 0, h->stream, (int)n, h->ssn_seg_of.p, (const uint32_t*)sig_cur, in, h->sc->vals.p);
     idx = h->sc->vals.p;
     HIPC(hipMemcpyAsync(h->h_gt_err, h->gt_err.p, sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
     HIPC(hipGetLastError());
+#endif
   } else if (glevels > 0) {
     // segmented sorts (lsgpu_segsort.hip.h): per level only the segments that cut along a new axis, four passes of
     // (uint32 key, uint32 index) pairs, every segment inside its own range of the arrays
@@ -1521,6 +1541,7 @@ static int ssn_device(lsgpu_icp* h, const float4* src, int64_t n, int knn, float
       std::swap(cur, nxt);
       std::swap(ax_cur, ax_nxt);
     }
+    root_axis = ax_cur;
     HIPC(hipGetLastError());
   }
   if (glevels < levels) {
@@ -1533,11 +1554,11 @@ static int ssn_device(lsgpu_icp* h, const float4* src, int64_t n, int knn, float
     if (!tree_finish)
       hipLaunchKernelGGL(k_ssn_finish, dim3(1 << glevels), dim3(256), 0, h->stream, src, idx_rw, cur, knn, levels - glevels, h->ssn_seg_of.p, nxt);
     else if (root_max == 8192)
-      hipLaunchKernelGGL(k_ssn_tree<8192>, dim3(1 << glevels), dim3(1024), 0, h->stream, src, idx_rw, cur, knn, levels - glevels, h->ssn_seg_of.p, nxt);
+      hipLaunchKernelGGL(k_ssn_tree<8192>, dim3(1 << glevels), dim3(1024), 0, h->stream, src, idx_rw, cur, knn, levels - glevels, h->ssn_seg_of.p, nxt, root_axis);
     else if (root_max == 4096)
-      hipLaunchKernelGGL(k_ssn_tree<4096>, dim3(1 << glevels), dim3(512), 0, h->stream, src, idx_rw, cur, knn, levels - glevels, h->ssn_seg_of.p, nxt);
+      hipLaunchKernelGGL(k_ssn_tree<4096>, dim3(1 << glevels), dim3(512), 0, h->stream, src, idx_rw, cur, knn, levels - glevels, h->ssn_seg_of.p, nxt, root_axis);
     else
-      hipLaunchKernelGGL(k_ssn_tree<2048>, dim3(1 << glevels), dim3(256), 0, h->stream, src, idx_rw, cur, knn, levels - glevels, h->ssn_seg_of.p, nxt);
+      hipLaunchKernelGGL(k_ssn_tree<2048>, dim3(1 << glevels), dim3(256), 0, h->stream, src, idx_rw, cur, knn, levels - glevels, h->ssn_seg_of.p, nxt, root_axis);
     std::swap(cur, nxt);
   }
   if (levels == 0) {  // a single box: identity order
@@ -1565,11 +1586,13 @@ static int ssn_device(lsgpu_icp* h, const float4* src, int64_t n, int knn, float
   if (rc == LSGPU_OK)
     rc = scan_totals(h, h->ssn_box_pts.p, h->ssn_box_base.p, nseg, h->ssn_keep.p, h->ssn_out_pos.p, (size_t)n, &n_draws, &kept);
   if (rc) return rc;
+#ifdef LSGPU_EXPERIMENTS
   if (presorted && *h->h_gt_err) {
     // a run of equal coordinates along a cut axis was too long to be walked element by element (kGtRunCap): the
     // segmented sorts do not care -- the same filter again with them (same draws: nothing has been consumed yet)
     return ssn_device(h, src, n, knn, ratio, seed, out_xyz1, out_nrm, n_out, ahead, true);
   }
+#endif
   ahead->used = first_draw + (size_t)n_draws;  // dropped boxes drew nothing
   HIPC(hipGetLastError());
   *n_out = kept;
@@ -1577,8 +1600,17 @@ static int ssn_device(lsgpu_icp* h, const float4* src, int64_t n, int knn, float
 }
 
 // RandomSampling on device memory (order preserved)
+// (defer_wait: everything is enqueued, the host's wait for the number of points kept is left to random_sampling_wait --
+// lsgpu_icp_compute puts the rest of the grid build on the other stream in between)
+static int random_sampling_wait(lsgpu_icp* h, int64_t* n_out) {
+  uint32_t unused = 0, kept = 0;
+  const int rc = scan_totals_wait(h, &unused, &kept);
+  if (rc) return rc;
+  *n_out = kept;
+  return LSGPU_OK;
+}
 static int random_sampling_device(lsgpu_icp* h, const float4* src, int64_t n, float prob, int64_t seed,
-                                  float4* out_xyz1, int64_t* n_out, DrawAhead* ahead = nullptr) {
+                                  float4* out_xyz1, int64_t* n_out, DrawAhead* ahead = nullptr, bool defer_wait = false) {
   *n_out = 0;
   HIPC(h->ssn_keep.reserve(n));
   HIPC(h->ssn_out_pos.reserve(n));
@@ -1599,11 +1631,9 @@ static int random_sampling_device(lsgpu_icp* h, const float4* src, int64_t n, fl
   hipLaunchKernelGGL(k_compact_points, dim3(nblk(n)), dim3(256), 0, h->cur, src, (int)n, h->ssn_keep.p,
                      h->ssn_out_pos.p, out_xyz1);
   HIPC(hipGetLastError());
-  uint32_t unused = 0, kept = 0;
-  rc = scan_totals(h, nullptr, nullptr, 0, h->ssn_keep.p, h->ssn_out_pos.p, (size_t)n, &unused, &kept);
-  if (rc) return rc;
-  *n_out = kept;
-  return LSGPU_OK;
+  rc = scan_totals_enqueue(h, nullptr, nullptr, 0, h->ssn_keep.p, h->ssn_out_pos.p, (size_t)n);
+  if (rc || defer_wait) return rc;
+  return random_sampling_wait(h, n_out);
 }
 
 extern "C" {
@@ -1747,7 +1777,7 @@ int lsgpu_icp_compute(lsgpu_icp* h, const float* reading_xyz1, int64_t nq, const
     }
     return LSGPU_OK;
   };
-  auto reading_filter = [&]() -> int {   // step 4: reading filter (yaml:1-3), on h->cur
+  auto reading_filter = [&](bool defer_wait) -> int {   // step 4: reading filter (yaml:1-3), on h->cur
     rd_dev = rd_src;
     if (chain->reading_prob < 0.f) {
       // no readingDataPointsFilters section: upstream runs no module at all -- every point, NO rand() call (a
@@ -1756,7 +1786,7 @@ int lsgpu_icp_compute(lsgpu_icp* h, const float* reading_xyz1, int64_t nq, const
       return LSGPU_OK;
     }
     HIPC(h->flt_rd.reserve(nq));
-    const int r = random_sampling_device(h, rd_src, nq, chain->reading_prob, -1, h->flt_rd.p, &nqf, &draws);
+    const int r = random_sampling_device(h, rd_src, nq, chain->reading_prob, -1, h->flt_rd.p, &nqf, &draws, defer_wait);
     rd_dev = h->flt_rd.p;
     return r;
   };
@@ -1766,7 +1796,7 @@ int lsgpu_icp_compute(lsgpu_icp* h, const float* reading_xyz1, int64_t nq, const
     void leave() { h->cur = h->stream; h->sc = &h->scr_main; h->side_totals_slot = 0; }
     ~SideGuard() {
       leave();
-      h->hook_before_ref_sync = nullptr; h->hook_after_ref_sync = nullptr;
+      h->hook_before_ref_sync = nullptr; h->hook_after_grid = nullptr;
       if (used && h->side_stream) (void)hipStreamSynchronize(h->side_stream);
     }
   } side_guard{h};
@@ -1778,15 +1808,29 @@ int lsgpu_icp_compute(lsgpu_icp* h, const float* reading_xyz1, int64_t nq, const
     if (!h->side_stream) HIPC(hipStreamCreateWithFlags(&h->side_stream, hipStreamNonBlocking));
     if (!h->side_done) HIPC(hipEventCreateWithFlags(&h->side_done, hipEventDisableTiming));
     order_after_tail(h, h->side_stream);
+    // Order of the host's work (round 5, from rocprofv3's timeline of a step).  The host thread that enqueues both chains
+    // is the scarce resource here (~4 us per launch), and what it waits for decides what idles:
+    //   1. the reading's filter goes out NOW, in front of the whole grid build (it only needs the draws and the upload);
+    //   2. the ordering of the queries (~25 launches) goes out while the first half of the grid build runs, right before
+    //      set_reference waits for its cell counts -- the number of reading points kept is long there;
+    //   3. the second half of the grid build goes out right behind that wait;
+    //   4. the move of the queries into the reference's frame (it needs the mean) behind it.
+    // Before, the host enqueued the reading's whole side -- a wait and ~60 launches -- between the grid's two halves: the
+    // loop's stream sat idle for 0.3 ms behind the cell counts, then the loop waited for the queries.
+    side_guard.enter();
+    rc = reading_ready(h->side_stream);
+    if (!rc) rc = reading_filter(/*defer_wait*/ true);
+    side_guard.leave();
+    if (rc) return rc;
     h->hook_before_ref_sync = [&]() -> int {
       side_guard.enter();
-      int r = reading_ready(h->side_stream);
-      if (!r) r = reading_filter();              // (one short host wait on the side stream: the number of points kept)
+      int r = LSGPU_OK;
+      if (chain->reading_prob >= 0.f) r = random_sampling_wait(h, &nqf);   // (the number of points kept)
       if (!r && nqf > 0) r = prepare_queries(h, reinterpret_cast<const float*>(rd_dev), nqf, Mat34{}, /*gather*/ false);
       side_guard.leave();
       return r;
     };
-    h->hook_after_ref_sync = [&]() -> int {
+    h->hook_after_grid = [&]() -> int {
       if (nqf <= 0) return LSGPU_OK;
       float T_rm_in[16];
       std::memcpy(T_rm_in, T_init, sizeof(T_rm_in));
@@ -1801,27 +1845,20 @@ int lsgpu_icp_compute(lsgpu_icp* h, const float* reading_xyz1, int64_t nq, const
   }
   h->defer_cone = side;
   rc = lsgpu_icp_set_reference(h, reinterpret_cast<const float*>(h->flt_ref.p), h->flt_nrm.p, nrf);
-  h->hook_before_ref_sync = nullptr; h->hook_after_ref_sync = nullptr;
+  h->hook_before_ref_sync = nullptr; h->hook_after_grid = nullptr;
   h->defer_cone = false;
   if (rc) return rc;
   if (side) {
-    // the direction index of the reference is not needed before the loop's third search: built on the side stream (behind
-    // the reading's filter and query order, with that stream's sort scratch) it runs beside the first two iterations
-    // instead of in front of the loop (0.16 ms per 1 M-point compute)
+    // the direction index of the reference is not needed before the loop's third search: lsgpu_icp_align enqueues its
+    // build on the side stream (behind the queries' order, with that stream's sort scratch) once the loop's first
+    // iteration is out -- beside the first two iterations instead of in front of the loop (0.16 ms per 1 M-point
+    // compute), and without holding the host back from starting the loop (round 5)
     if (!h->cone_done) HIPC(hipEventCreateWithFlags(&h->cone_done, hipEventDisableTiming));
-    side_guard.enter();
-    rc = build_cone_index(h);
-    if (!rc && h->cone_ok) {
-      const hipError_t e = hipEventRecord(h->cone_done, h->side_stream);
-      if (e != hipSuccess) { (void)hipGetLastError(); rc = LSGPU_HIP_ERROR; h->err = "compute: event record"; }
-      h->cone_pending = true;
-    }
-    side_guard.leave();
-    if (rc) return rc;
+    h->cone_build_in_align = true;
   }
   if (!side) {
     rc = reading_ready(h->stream);
-    if (!rc) rc = reading_filter();
+    if (!rc) rc = reading_filter(false);
     if (rc) return rc;
   }
   draws.finish();
@@ -2263,7 +2300,14 @@ int lsgpu_icp_align(lsgpu_icp* h, const float* reading_xyz1, int64_t nq, const f
   pc.seed_cap = tuning().seed_cap; pc.cap_enabled = h->cfg.reserved[0] == 0;
   pc.cone_probe = tuning().cone_probe; pc.cone_heavy_share = tuning().cone_heavy_share; pc.cone_max_occupancy = tuning().cone_max_occupancy;
   policy::State& pol = h->pol;
-  pol.begin_align(h->cone_ok, h->cone_decided, h->cone_dense, h->cone_occupancy);
+  if (h->cone_build_in_align) { h->cone_ok = cone_wanted(h); h->cone_decided = false; }   // (its build follows the first iteration, below)
+  // a handle whose last alignments found the index slower than the voxel grid leaves it alone for a while (and spares
+  // itself the build when that is still to come)
+  const bool index_rests = h->index_rest > 0 && h->cone_ok;
+  if (index_rests) { --h->index_rest; if (h->cone_build_in_align) { h->cone_build_in_align = false; h->cone_ok = false; } }
+  pol.begin_align(h->cone_ok && !index_rests, h->cone_decided, h->cone_dense, h->cone_occupancy);
+  h->pay_voxel_timed = h->pay_index_timed = false;
+  if (!h->ev_pay[0]) for (auto& e : h->ev_pay) HIPC(hipEventCreate(&e));
   auto enqueue_iteration = [&](const policy::Iteration& itn) -> int {
     // itn.knn == false: only select + normal equations + update on the distances already there (after a missed
     // prediction).  RCCL mode: the per-shard tables of a *committed* iteration are summed over the ranks in ONE grouped
@@ -2334,6 +2378,19 @@ int lsgpu_icp_align(lsgpu_icp* h, const float* reading_xyz1, int64_t nq, const f
   rc = enqueue_iteration(pol.plan(pc, true, pc.seed_cap && pc.cap_enabled, true, true, false));
   if (rc) return rc;
   pol.enq = 1; pol.since_check = 1;
+  if (h->cone_build_in_align) {
+    // lsgpu_icp_compute left the direction index's build to this point: the device is busy with the first search, the
+    // ~15 launches of the build go to the side stream (its own sort scratch) while it is
+    h->cone_build_in_align = false;
+    h->cur = h->side_stream; h->sc = &h->scr_side;
+    int rb = build_cone_index(h);
+    if (!rb && h->cone_ok) {
+      if (hipEventRecord(h->cone_done, h->side_stream) != hipSuccess) { (void)hipGetLastError(); rb = LSGPU_HIP_ERROR; h->err = "align: event record"; }
+      h->cone_pending = true;
+    }
+    h->cur = h->stream; h->sc = &h->scr_main;
+    if (rb) return rb;
+  }
   // The device decides when the loop ends (CounterTransformationChecker raises `done` after max_iterations at the
   // latest); the host keeps feeding groups of launches until it sees `done`.  Launches enqueued behind an
   // iteration that had to be repeated exit at once, so the number of enqueues is NOT bounded by max_iterations;
@@ -2389,6 +2446,14 @@ int lsgpu_icp_align(lsgpu_icp* h, const float* reading_xyz1, int64_t nq, const f
   }
   st.cap_retries = pol.cap_retries;
   const int sel_retries = pol.sel_retries, committed_iterations = pol.committed_iterations;
+  if (h->pay_voxel_timed && h->pay_index_timed) {   // (both launches are long over: the loop's end was seen behind them)
+    float t_voxel = 0.f, t_index = 0.f;
+    if (hipEventElapsedTime(&t_voxel, h->ev_pay[0], h->ev_pay[1]) == hipSuccess && hipEventElapsedTime(&t_index, h->ev_pay[2], h->ev_pay[3]) == hipSuccess) {
+      if (policy::index_not_paying(t_voxel * 1e3f, t_index * 1e3f)) h->index_rest = policy::kIndexRestAligns;
+    } else {
+      (void)hipGetLastError();
+    }
+  }
   const int it = hst->iter;
   rc = hst->status;
   if (rc == LSGPU_NO_CONVERGENCE)

@@ -87,7 +87,8 @@ __device__ __forceinline__ uint32_t tree_wave_scan(uint32_t v, int lane) {
 template <int B>
 __global__ __launch_bounds__(B / 8) void k_ssn_tree(const float4* __restrict__ p, uint32_t* __restrict__ idx,
                                                     const SsnSeg* __restrict__ segs, int knn, int rem,
-                                                    uint32_t* __restrict__ seg_of, SsnSeg* __restrict__ segs_out) {
+                                                    uint32_t* __restrict__ seg_of, SsnSeg* __restrict__ segs_out,
+                                                    const int* __restrict__ root_axis /* nullable */) {
   using Lds = SsnTreeLds<B>;
   constexpr int T = Lds::T, W = Lds::W;
   __shared__ Lds L;
@@ -95,6 +96,9 @@ __global__ __launch_bounds__(B / 8) void k_ssn_tree(const float4* __restrict__ p
   const SsnSeg root = segs[blockIdx.x];
   const int cnt = (int)root.count;
   const unsigned long long lt = (1ull << lane) - 1ull;
+  // the axis the root's order already follows (the upper levels cut along it last): its list is the order the workgroup
+  // finds the points in -- no sort (a third of the presort)
+  const int sorted_axis = root_axis ? root_axis[blockIdx.x] : -1;
 
   // ---- load: ordered keys of this thread's 8 points, per axis.  Local id of a point = its position in the order the
   // workgroup found the root in (idx[root.start ..]); radix ownership: wave w, group it, lane -> w * 512 + it * 64 + lane
@@ -132,7 +136,7 @@ __global__ __launch_bounds__(B / 8) void k_ssn_tree(const float4* __restrict__ p
     const uint32_t kmin = L.kmin[d];
     const uint32_t range = cnt > 0 ? L.kmax[d] - kmin : 0u;
     const int bits = range ? 32 - __clz((int)range) : 0;
-    const int P = (bits + 7) >> 3;
+    const int P = d == sorted_axis ? 0 : (bits + 7) >> 3;
 #pragma unroll
     for (int it = 0; it < 8; ++it) {
       const int e = w * 512 + it * 64 + lane;
@@ -200,7 +204,7 @@ __global__ __launch_bounds__(B / 8) void k_ssn_tree(const float4* __restrict__ p
       }
       __syncthreads();
     }
-    if (P == 0) {   // one value on this axis: the order the workgroup started from
+    if (P == 0) {   // sorted already, or one value on this axis: the order the workgroup started from
 #pragma unroll
       for (int it = 0; it < 8; ++it) {
         const int i = w * 512 + it * 64 + lane;

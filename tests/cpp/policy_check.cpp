@@ -173,6 +173,14 @@ int main() {
     Sim n; n.c = base_config(); n.c.comm = true; n.c.comm_commit = false; n.sel_streak_from = 0; n.align(false);
     for (auto& e : n.log) CHECK(!e.it.predicted && !e.it.committed);
   }
+  {  // ---- is the index paying at all on this handle's clouds?  (two timed launches per alignment, across alignments)
+    CHECK(!index_not_paying(228.f, 60.f));     // the benchmark pair: voxel search of iteration 1 against the index' first settled search
+    CHECK(!index_not_paying(124.f, 53.f));     // an ordinary scan of the track drive
+    CHECK(index_not_paying(425.f, 955.f));     // a wall a metre from the sensor (scan 19 of the drive)
+    CHECK(index_not_paying(344.f, 890.f));
+    CHECK(!index_not_paying(0.f, 50.f));       // nothing timed: nothing decided
+    CHECK(kIndexRestAligns >= 2);
+  }
   std::printf("policy_check ok\n");
   return 0;
 }

@@ -97,3 +97,60 @@ def presorted_lists(pts, knn, lo, hi):
             st, c = s["start"], s["count"]
             leaves.append(np.arange(st, st + c) if s["ord"] == -1 else lists[s["ord"]][st:st + c].copy())
     return leaves
+
+
+def presorted_lists_signature(pts, knn, lo, hi):
+    """lsgpu_ssn_levels.hip.h (upper levels, global memory): the same scheme WITHOUT cur_pos -- the members of a tie run
+    of the cut axis are ordered by comparing their keys on the axes the segment was cut along before, most recent first,
+    then their original index (the "signature" of the segment's current order); the partition's side flag comes from the
+    position in the cut axis' list.  Returns the leaves like presorted_lists."""
+    n = len(pts)
+    keys = [order_key(pts[:, d]) for d in range(3)]
+    lists = [np.argsort(keys[d], kind="stable") for d in range(3)]
+    segs = [dict(start=0, count=n, lo=lo.copy(), hi=hi.copy(), sig=[])]
+    while any(s["count"] > knn for s in segs):
+        new = []
+        side = np.zeros(n, bool)
+        for s in segs:
+            st, c = s["start"], s["count"]
+            if c <= knn:
+                new += [s, dict(start=st + c, count=0, lo=s["lo"], hi=s["hi"], sig=s["sig"])]
+                continue
+            a = cut_axis(s["lo"], s["hi"])
+            la = lists[a]
+            sig = s["sig"]
+            if sig and sig[0] != a:
+                others = [x for x in sig if x != a]
+                seg = la[st:st + c].copy()
+                out = seg.copy()
+                k = keys[a][seg]
+                cmpkey = lambda e: tuple(int(keys[x][e]) for x in others) + (int(e),)
+                for i in range(c):
+                    l, h = i, i + 1
+                    while l > 0 and k[l - 1] == k[i]:
+                        l -= 1
+                    while h < c and k[h] == k[i]:
+                        h += 1
+                    if h - l > 1:
+                        out[l + sum(1 for j in range(l, h) if cmpkey(seg[j]) < cmpkey(seg[i]))] = seg[i]
+                la[st:st + c] = out
+            left = c - c // 2
+            side[la[st + left:st + c]] = True
+            for d in range(3):
+                if d != a:
+                    seg = lists[d][st:st + c]
+                    f = side[seg]
+                    lists[d][st:st + c] = np.concatenate([seg[~f], seg[f]])
+            cutval = pts[la[st + left], a]
+            hi2, lo2 = s["hi"].copy(), s["lo"].copy()
+            hi2[a] = cutval
+            lo2[a] = cutval
+            nsig = [a] + [x for x in sig if x != a]
+            new += [dict(start=st, count=left, lo=s["lo"], hi=hi2, sig=nsig), dict(start=st + left, count=c - left, lo=lo2, hi=s["hi"], sig=nsig)]
+        segs = new
+    leaves = []
+    for s in segs:
+        if s["count"]:
+            st, c = s["start"], s["count"]
+            leaves.append(np.arange(st, st + c) if not s["sig"] else lists[s["sig"][0]][st:st + c].copy())
+    return leaves

@@ -406,6 +406,8 @@ def test_presorted_lists_equal_the_chain_of_stable_sorts():
         a, b = M.chain_of_stable_sorts(pts, knn, lo, hi), M.presorted_lists(pts, knn, lo, hi)
         assert len(a) == len(b), trial
         assert all(np.array_equal(x, y) for x, y in zip(a, b)), trial
+        c = M.presorted_lists_signature(pts, knn, lo, hi)      # the upper levels' variant (no cur_pos: tie runs by signature)
+        assert len(a) == len(c) and all(np.array_equal(x, y) for x, y in zip(a, c)), trial
 
 
 def _check_boxes_against_recursion(pts, boxes, out, nrm):
