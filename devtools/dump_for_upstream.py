@@ -17,9 +17,21 @@ For a synthetic HDL-64E pair (default: the 4 k-point pair of the parity tests, `
   oracle_result.txt                          rc, iterations, converged, final T (4 x 4 row major)
   README.txt                                 what is what, and which file / column each restatement choice would change
 
+With --submap the dump has the REAL call shape of LaserTrack::localScanToSubMap (laser_slam/src/laser_track.cpp:466-519)
+instead of a bare pair: four scans along a trajectory go through the input filter chain (input_filters_.apply, :146), the
+sub-map is assembled from the three older ones in the frame of the newest of them (RigidTransformation::compute with the
+float relative pose + concatenate, :474-486), the guess is T_a^-1 T_b of the odometry poses (:489-491):
+  scan{0..3}.vtk / .csv                      the raw scans           scan{0..3}_input_filtered.csv   after the input chain (one
+                                                                     draw stream over the four scans, srand(1) before the first)
+  poses.txt                                  the four odometry poses T_w_scan (4 x 4 row major each)
+  T_rel{1,2}.txt                             the float relative poses the two older scans are moved by
+  reading.csv / reference.csv / T_init.txt   what icp_.compute is handed: scan 3 filtered, the assembled sub-map, the guess
+  reference_filtered.csv, reading_filtered.csv, oracle_trace.csv, oracle_result.txt   as above (the ICP's own draw stream
+                                             continues the input filters': one process, one rand())
+
 The files regenerate byte for byte (tests/test_oracle.py::test_upstream_dump_regenerates).  INTEGRATION.md has the
 C++ program that replays them on a real PointMatcher<float>::ICP and prints a trace in the same format.
-usage: dump_for_upstream.py OUT_DIR [--n-az 64] [--chain tests/golden/icp_chain_tight.yaml]
+usage: dump_for_upstream.py OUT_DIR [--n-az 64] [--chain tests/golden/icp_chain_tight.yaml] [--submap]
 """
 import argparse
 import os
@@ -86,31 +98,68 @@ def input_filter_chain(path):
     return arr
 
 
-def dump(out_dir, n_az, chain_path):
+def write_mat(path, T):
+    with open(path, "w") as f:
+        for r in range(4):
+            f.write(" ".join(g(T[r, c]) for c in range(4)) + "\n")
+
+
+def submap_inputs(out_dir, n_az):
+    """laser_track.cpp:146, 466-496 on four synthetic scans: input filters, sub-map of three in the frame of scan 2, the
+    odometry guess.  Returns (reading, reference, T_init 4x4 float64, seed for the ICP's first draw)."""
+    scene = synth.Scene(1234)
+    truth = [synth.se3(0.8 * i, 0.05 * i, synth.SENSOR_HEIGHT, yaw=np.deg2rad(2.0 * i)) for i in range(4)]
+    odom = [T @ synth.se3(0.1, -0.05, 0.0, yaw=np.deg2rad(0.5)) for T in truth]     # (the drive of bench.py's value_track)
+    flt = input_filter_chain(os.path.join(ROOT, "tests", "golden", "input_filters.yaml"))
+    filtered = []
+    with open(os.path.join(out_dir, "poses.txt"), "w") as f:
+        for i in range(4):
+            raw = synth.hdl64_scan(scene, truth[i], n_az, 10 + i)
+            cloud_io.save_vtk(os.path.join(out_dir, "scan%d.vtk" % i), raw)
+            cloud_io.save_csv(os.path.join(out_dir, "scan%d.csv" % i), raw)
+            kept = O.apply_point_filters(flt, raw, seed=1 if i == 0 else -1)       # one process, one rand() stream
+            kept = kept if kept is not None else raw[:0]
+            cloud_io.save_csv(os.path.join(out_dir, "scan%d_input_filtered.csv" % i), kept)
+            filtered.append(kept)
+            for r in range(4):
+                f.write(" ".join(g(odom[i][r, c]) for c in range(4)) + "\n")
+    a = 2                                                                           # the sub-map's frame: the newest of its scans
+    parts = [filtered[a]]
+    for n, k in enumerate((1, 0), start=1):
+        Trel = (np.linalg.inv(odom[a]) @ odom[k]).astype(np.float32)               # TransformationParameters are float
+        write_mat(os.path.join(out_dir, "T_rel%d.txt" % n), Trel)
+        parts.append(O.transform_points(synth.colmajor(Trel), filtered[k]))        # RigidTransformation::compute
+    return filtered[3], np.ascontiguousarray(np.concatenate(parts, 0)), np.linalg.inv(odom[a]) @ odom[3], -1
+
+
+def dump(out_dir, n_az, chain_path, submap=False):
     os.makedirs(out_dir, exist_ok=True)
-    ref, rd, T_true, T_init = synth.scan_pair(n_az)
     ch = parse_chain(chain_path)
     shutil.copyfile(chain_path, os.path.join(out_dir, "icp.yaml"))
-    cloud_io.save_vtk(os.path.join(out_dir, "reading.vtk"), rd)
+    if submap:
+        rd, ref, T_init, icp_seed = submap_inputs(out_dir, n_az)
+    else:
+        ref, rd, T_true, T_init = synth.scan_pair(n_az)
+        icp_seed = 1
+        cloud_io.save_vtk(os.path.join(out_dir, "reading.vtk"), rd)
+        cloud_io.save_vtk(os.path.join(out_dir, "reference.vtk"), ref)
     cloud_io.save_csv(os.path.join(out_dir, "reading.csv"), rd)
-    cloud_io.save_vtk(os.path.join(out_dir, "reference.vtk"), ref)
     cloud_io.save_csv(os.path.join(out_dir, "reference.csv"), ref)
     T16 = synth.colmajor(T_init)
-    Tm = T16.reshape(4, 4).T
-    with open(os.path.join(out_dir, "T_init.txt"), "w") as f:
-        for r in range(4):
-            f.write(" ".join(g(Tm[r, c]) for c in range(4)) + "\n")
-    # ICP::compute, steps 1 and 4 with ONE draw stream that starts where an unseeded process starts (srand(1))
-    rf, rn = O.sampling_surface_normal(ref, ch.surface_normal_knn, ch.surface_normal_ratio, 1)
+    write_mat(os.path.join(out_dir, "T_init.txt"), T16.reshape(4, 4).T)
+    # ICP::compute, steps 1 and 4 with ONE draw stream that starts where an unseeded process starts (srand(1)) -- or, in the
+    # sub-map dump, where the input filters of the four scans left it
+    rf, rn = O.sampling_surface_normal(ref, ch.surface_normal_knn, ch.surface_normal_ratio, icp_seed)
     if ch.reading_sampling_prob >= 0:
         rdf = rd[O.random_sampling(rd.shape[0], ch.reading_sampling_prob, -1)]
     else:
         rdf = rd
     cloud_io.save_csv(os.path.join(out_dir, "reference_filtered.csv"), rf, rn)
     cloud_io.save_csv(os.path.join(out_dir, "reading_filtered.csv"), rdf)
-    flt = input_filter_chain(os.path.join(ROOT, "tests", "golden", "input_filters.yaml"))
-    kept = O.apply_point_filters(flt, rd, seed=1)
-    cloud_io.save_csv(os.path.join(out_dir, "input_filtered.csv"), kept if kept is not None else rd[:0])
+    if not submap:
+        flt = input_filter_chain(os.path.join(ROOT, "tests", "golden", "input_filters.yaml"))
+        kept = O.apply_point_filters(flt, rd, seed=1)
+        cloud_io.save_csv(os.path.join(out_dir, "input_filtered.csv"), kept if kept is not None else rd[:0])
     cfg = O.config_yaml(accum_double=0, trim_ratio=ch.trim_ratio, max_iterations=ch.max_iterations,
                         min_diff_rot=ch.min_diff_rot, min_diff_trans=ch.min_diff_trans, smooth_length=ch.smooth_length)
     rc, T, st, tr = O.icp_compute(cfg, rdf, rf, rn, T16, trace_cap=ch.max_iterations)
@@ -124,7 +173,9 @@ def dump(out_dir, n_az, chain_path):
         for r in range(4):
             f.write(" ".join(g(Tf[r, c]) for c in range(4)) + "\n")
     with open(os.path.join(out_dir, "README.txt"), "w") as f:
-        f.write("Synthetic HDL-64E pair, %d azimuth steps: reading %d points, reference %d points; chain %s\n"
+        f.write(("Synthetic HDL-64E drive, LaserTrack::localScanToSubMap's call shape (input filters, sub-map of three scans), "
+                 if submap else "Synthetic HDL-64E pair, ") +
+                "%d azimuth steps: reading %d points, reference %d points; chain %s\n"
                 "(reading_sampling_prob %s, surface normal knn %d ratio %s, trim %s, checkers %d / %s / %s / %d).\n"
                 "Written by devtools/dump_for_upstream.py; the float accumulation of libpointmatcher (accum_double 0).\n"
                 "Replay on libpointmatcher: INTEGRATION.md, \"Diffing against a real libpointmatcher\".\n\n%s"
@@ -139,6 +190,7 @@ if __name__ == "__main__":
     ap.add_argument("out_dir")
     ap.add_argument("--n-az", type=int, default=64)
     ap.add_argument("--chain", default=os.path.join(ROOT, "tests", "golden", "icp_chain.yaml"))
+    ap.add_argument("--submap", action="store_true", help="the call shape of LaserTrack::localScanToSubMap (four scans, input filters, three-scan sub-map)")
     a = ap.parse_args()
-    rc, it = dump(a.out_dir, a.n_az, a.chain)
+    rc, it = dump(a.out_dir, a.n_az, a.chain, a.submap)
     print("wrote %s: oracle rc %d, %d iterations" % (a.out_dir, rc, it))

@@ -434,24 +434,35 @@ def test_upstream_dump_regenerates(tmp_path):
     """devtools/dump_for_upstream.py (round-3 verdict, "make the oracle diffable by someone who has libpointmatcher"): the
     clouds, chain, guess, filter outputs and per-iteration oracle trace of the 4 k pair regenerate byte for byte
     (MANIFEST.sha256 covers the clouds, which are not committed; the small files are), the .vtk loads back bit for bit,
-    and the trace has one row per iteration."""
+    and the trace has one row per iteration.  Round 5: the same for the real call shape of localScanToSubMap
+    (laser_track.cpp:466-519) -- four scans through the input filter chain, a three-scan sub-map assembled with the float
+    relative poses, the odometry guess, one draw stream over input filters and ICP filters."""
     import hashlib
     import importlib.util
     spec = importlib.util.spec_from_file_location("dump_for_upstream", os.path.join(ROOT, "devtools", "dump_for_upstream.py"))
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
-    rc, iters = mod.dump(str(tmp_path), 64, os.path.join(ROOT, "tests", "golden", "icp_chain.yaml"))
-    assert rc == 0 and iters > 5
-    gold = os.path.join(ROOT, "tests", "golden", "upstream_pair4k")
-    want = dict(line.split()[::-1] for line in open(os.path.join(gold, "MANIFEST.sha256")).read().splitlines())
-    assert sorted(want) == sorted(os.listdir(tmp_path))
-    for name, digest in want.items():
-        assert hashlib.sha256(open(tmp_path / name, "rb").read()).hexdigest() == digest, name
-        if os.path.exists(os.path.join(gold, name)):
-            assert open(os.path.join(gold, name), "rb").read() == open(tmp_path / name, "rb").read(), name
+    for sub, gold_name in ((False, "upstream_pair4k"), (True, "upstream_submap3")):
+        out = tmp_path / gold_name
+        rc, iters = mod.dump(str(out), 64, os.path.join(ROOT, "tests", "golden", "icp_chain.yaml"), sub)
+        assert rc == 0 and iters > (2 if sub else 5)
+        gold = os.path.join(ROOT, "tests", "golden", gold_name)
+        want = dict(line.split()[::-1] for line in open(os.path.join(gold, "MANIFEST.sha256")).read().splitlines())
+        assert sorted(want) == sorted(os.listdir(out))
+        for name, digest in want.items():
+            assert hashlib.sha256(open(out / name, "rb").read()).hexdigest() == digest, (gold_name, name)
+            if os.path.exists(os.path.join(gold, name)):
+                assert open(os.path.join(gold, name), "rb").read() == open(out / name, "rb").read(), (gold_name, name)
+        rows = open(out / "oracle_trace.csv").read().splitlines()
+        assert rows[0].startswith("iter,limit,n_used,T00,T10") and len(rows) == iters + 1
     from laser_slam_amd import cloud_io
     ref, rd, _, _ = synth.scan_pair(64)
-    back, nrm = cloud_io.load_vtk(str(tmp_path / "reference.vtk"))
+    back, nrm = cloud_io.load_vtk(str(tmp_path / "upstream_pair4k" / "reference.vtk"))
     assert nrm is None and np.array_equal(back.view(np.uint32), ref.view(np.uint32))
-    rows = open(tmp_path / "oracle_trace.csv").read().splitlines()
-    assert rows[0].startswith("iter,limit,n_used,T00,T10") and len(rows) == iters + 1
+    # the sub-map dump's reference IS the assembly of its own pieces: scan 2's filtered points first, then scans 1 and 0 moved
+    # by the float relative poses (what a replay on libpointmatcher has to reproduce before it calls icp.compute)
+    sm = tmp_path / "upstream_submap3"
+    load = lambda name: np.loadtxt(sm / name, delimiter=",", skiprows=1, dtype=np.float64, ndmin=2)
+    first, ref_sm = load("scan2_input_filtered.csv"), load("reference.csv")
+    assert np.allclose(ref_sm[:first.shape[0], :3], first[:, :3], rtol=0, atol=1e-6)
+    assert ref_sm.shape[0] == first.shape[0] + load("scan1_input_filtered.csv").shape[0] + load("scan0_input_filtered.csv").shape[0]
