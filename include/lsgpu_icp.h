@@ -88,8 +88,9 @@ typedef struct lsgpu_icp_stats {
   float   direction_index_occupancy;    /* reference points per occupied bin of that index (0: not built / not looked at);
                                            above LSGPU_CONE_MAX_OCC (7) the settled searches stay on the voxel grid */
   float   direction_index_heavy_share;  /* share of the searching queries whose windows in that index would be long (priced by the
-                                           search before its first use; -1: not priced); above LSGPU_CONE_HEAVY_SHARE (0.02)
-                                           this alignment stays on the voxel grid */
+                                           search before its first use, again before every later look at the loop state while
+                                           it keeps the alignment off the index; -1: not priced); above LSGPU_CONE_HEAVY_SHARE
+                                           (csrc/lsgpu_tuning.h: 0.07) the alignment stays on the voxel grid */
 } lsgpu_icp_stats;
 
 /* One record per iteration (optional parity/debug trace; replaces the VTKFileInspector dump of

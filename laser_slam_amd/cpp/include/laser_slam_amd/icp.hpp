@@ -320,7 +320,11 @@ class ICP {
                                    const TransformationParameters& T_init) {
     // step 5 of ICP::compute moves the reading by T_refMean_dataIn with RigidTransformation::compute, which refuses a
     // matrix that is not rigid; neither call site corrects its guess (laser_track.cpp:489-496, incremental_estimator.cpp:
-    // 92-108: only the sub-map transforms go through correctTransformationMatrix) and neither catches this exception
+    // 92-108: only the sub-map transforms go through correctTransformationMatrix) and neither catches this exception.
+    // (Checked HERE, before the filters run: upstream throws at step 5, after both filters have consumed their rand()
+    // draws, and so does the C ABI -- lsgpu_icp_align returns LSGPU_BAD_ARG behind the filters.  On this error path the
+    // facade therefore leaves the library's draw stream where it was; a caller that catches the exception and goes on
+    // sees different draws than a libpointmatcher process would.  Neither call site of laser_slam catches it.)
     requireRigid(T_init);
 #ifdef LSGPU_TEST_SEAMS
     if (override_) return override_(*this, reading, reference, T_init);

@@ -393,6 +393,8 @@ class LaserTrack {
     icp.time_a_ns = laser_scans_[n - 2].time_ns;
     // sub-map = scan n-2 plus the (nscan_in_sub_map - 1) scans before it, in the frame of scan n-2
     const SE3 T_w_a = trajectory_.evaluate(icp.time_a_ns);
+    // (nscan_in_sub_map = 0: the reference's `nscan_in_sub_map - 1u` wraps, laser_track.cpp:478, and the loop takes EVERY
+    // earlier scan; the mirror clamps to one scan instead -- the reference's configurations all set >= 1)
     const size_t extra = std::min(n - 2, size_t(std::max(params_.nscan_in_sub_map, 1) - 1));
     std::vector<size_t> members{n - 2};
     std::vector<TransformationParameters> member_T{identityTransformation()};

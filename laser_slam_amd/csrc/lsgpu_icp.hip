@@ -20,7 +20,9 @@
 
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>  // types only: the library is opened lazily (dlopen) by lsgpu_icp_comm_init
-#include <rocprim/device/device_radix_sort.hpp>   // only behind LSGPU_ROCPRIM_SORT: the library sort as a cross-check of lsgpu_sort.hip.h
+#ifdef LSGPU_EXPERIMENTS
+#include <rocprim/device/device_radix_sort.hpp>   // experiments build only, behind LSGPU_ROCPRIM_SORT: the library sort as a cross-check of lsgpu_sort.hip.h
+#endif
 
 #include "../../include/lsgpu_icp.h"
 #include "lsgpu_grid.hip.h"
@@ -499,7 +501,11 @@ static void radix_pass(lsgpu_icp* h, const uint64_t* kin, const uint32_t* vin, u
 static int sort_pairs(lsgpu_icp* h, int64_t n, int nbits) {
   HIPC(h->sc->keys_alt.reserve(n));
   HIPC(h->sc->vals_alt.reserve(n));
+#ifdef LSGPU_EXPERIMENTS
   const bool lib_sort = tuning().rocprim_sort;
+#else
+  const bool lib_sort = false;
+#endif
   if (!lib_sort) {   // own radix sort (lsgpu_sort.hip.h)
     const int items_env = tuning().sort_items;
     const int items = items_env ? items_env : n >= (1 << 21) ? 16 : n >= (1 << 19) ? 8 : 4;
@@ -520,6 +526,7 @@ static int sort_pairs(lsgpu_icp* h, int64_t n, int nbits) {
     if ((passes & 1) == 0) { std::swap(h->sc->keys, h->sc->keys_alt); std::swap(h->sc->vals, h->sc->vals_alt); }  // result is in `keys`
     return LSGPU_OK;
   }
+#ifdef LSGPU_EXPERIMENTS
   size_t bytes = 0;
   HIPC(rocprim::radix_sort_pairs(nullptr, bytes, h->sc->keys.p, h->sc->keys_alt.p, h->sc->vals.p,
                                  h->sc->vals_alt.p, (size_t)n, 0, nbits, h->cur));
@@ -527,6 +534,7 @@ static int sort_pairs(lsgpu_icp* h, int64_t n, int nbits) {
   bytes = h->sc->sort_tmp.cap;
   HIPC(rocprim::radix_sort_pairs((void*)h->sc->sort_tmp.p, bytes, h->sc->keys.p, h->sc->keys_alt.p, h->sc->vals.p,
                                  h->sc->vals_alt.p, (size_t)n, 0, nbits, h->cur));
+#endif
   return LSGPU_OK;  // sorted: keys_alt / vals_alt
 }
 

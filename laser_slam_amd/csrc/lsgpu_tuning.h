@@ -30,7 +30,6 @@
 //   LSGPU_NO_ROUTE_ALL          (with NO_FRONT) settled spread waves search per lane inside the tile kernel
 //   LSGPU_NO_ROWQ               (with NO_FRONT) handed-over queries go to the wave-per-query kernel
 //   LSGPU_ROWQ_BLOCKS     2048  (with NO_FRONT) grid of the row pass
-//   LSGPU_ROCPRIM_SORT          rocPRIM's radix sort instead of lsgpu_sort.hip.h
 //   LSGPU_SORT_ITEMS         0  keys per thread of the radix passes (0: by size; 4, 8, 16)
 //   LSGPU_SSN_FULL_SORT         the reference filter's levels as whole-cloud sorts by (segment, coordinate) (rounds 1-3) instead of segmented sorts
 //   LSGPU_SSN_GLOBAL            every level of the reference filter as a global sort (no in-LDS finish)
@@ -54,6 +53,7 @@
 // Experiment switches, compiled in only with -DLSGPU_EXPERIMENTS (measured-slower variants kept as the record of what was
 // tried: DESIGN.md "Rejected after measurement"); the product build reports them as unknown:
 //   LSGPU_KNN_ROWS (0/1/2), LSGPU_KNN_LANE, LSGPU_SPARSE_LANES, LSGPU_TILE_WAVES (1/4), LSGPU_XCD_SWIZZLE,
+//   LSGPU_ROCPRIM_SORT (rocPRIM's radix sort instead of lsgpu_sort.hip.h: the library sort as a cross-check),
 //   LSGPU_SSN_PRESORTED_LEVELS (the reference filter's upper levels from three presorted axes, lsgpu_ssn_levels.hip.h:
 //   1.22 ms against 1.03 for a 1 M-point scan, 2.75 against 1.98 for 3.1 M, round 5)
 #pragma once
@@ -82,7 +82,6 @@ struct Tuning {
   int front_guess = 2048;
   bool route_all = true, rowq = true;
   int rowq_blocks = 2048;
-  bool rocprim_sort = false;
   int sort_items = 0;
   bool ssn_global = false;
   bool ssn_full_sort = false;
@@ -105,6 +104,7 @@ struct Tuning {
   int tile_waves = 1;
   int xcd_swizzle = 0;
   bool ssn_presorted_levels = false;
+  bool rocprim_sort = false;
 #endif
 };
 
@@ -146,7 +146,6 @@ inline Tuning read() {
   t.route_all = !flag("LSGPU_NO_ROUTE_ALL");
   t.rowq = !flag("LSGPU_NO_ROWQ");
   t.rowq_blocks = (int)number("LSGPU_ROWQ_BLOCKS", 2048, 1, 65535);
-  t.rocprim_sort = flag("LSGPU_ROCPRIM_SORT");
   t.sort_items = (int)number("LSGPU_SORT_ITEMS", 0, 0, 16);
   if (t.sort_items != 0 && t.sort_items != 4 && t.sort_items != 8 && t.sort_items != 16) {
     fprintf(stderr, "liblsgpu_icp: LSGPU_SORT_ITEMS must be 4, 8 or 16; choosing by size\n");
@@ -174,12 +173,12 @@ inline Tuning read() {
   static const char* known[] = {"LSGPU_QUERY_ORDER", "LSGPU_Q_ELEV", "LSGPU_Q_SECT", "LSGPU_GAP", "LSGPU_BUDGET", "LSGPU_BUDGET_WIDE", "LSGPU_WIDE_ITERS",
                                 "LSGPU_ROUTE_R", "LSGPU_ROUTE_CHUNKS", "LSGPU_ROUTE_DENSE", "LSGPU_SPLIT_UPDATE", "LSGPU_NO_PREDICT", "LSGPU_NO_COMMIT",
                                 "LSGPU_NO_COMM_COMMIT", "LSGPU_NO_SEED_CAP", "LSGPU_NO_FRONT", "LSGPU_NO_LAZY", "LSGPU_NO_SIDE_STREAM", "LSGPU_NO_LOOKAHEAD", "LSGPU_FRONT_GUESS", "LSGPU_NO_ROUTE_ALL",
-                                "LSGPU_NO_ROWQ", "LSGPU_ROWQ_BLOCKS", "LSGPU_ROCPRIM_SORT", "LSGPU_SORT_ITEMS", "LSGPU_SSN_GLOBAL", "LSGPU_SSN_FULL_SORT", "LSGPU_SSN_OLD_FINISH", "LSGPU_SSN_ROOT",
+                                "LSGPU_NO_ROWQ", "LSGPU_ROWQ_BLOCKS", "LSGPU_SORT_ITEMS", "LSGPU_SSN_GLOBAL", "LSGPU_SSN_FULL_SORT", "LSGPU_SSN_OLD_FINISH", "LSGPU_SSN_ROOT",
                                 "LSGPU_NE_BLOCKS", "LSGPU_COMM_TIMEOUT_MS", "LSGPU_KNN_DBG", "LSGPU_NO_CONE", "LSGPU_NO_CONE_PROBE", "LSGPU_CONE_ROWS", "LSGPU_CONE_COLS", "LSGPU_CONE_FROM", "LSGPU_CONE_MAX_OCC", "LSGPU_CONE_HEAVY_STEPS", "LSGPU_CONE_HEAVY_SHARE",
                                 // read by the Python / C++ hosts and the test drivers, not by this library:
                                 "LSGPU_SO", "LSGPU_STATS_SO", "LSGPU_GOLDEN_DIR", "LSGPU_SEQ_PERTURB", "LSGPU_SEQ_POSES", "LSGPU_TEST_INPUT_FILTERS",
 #ifdef LSGPU_EXPERIMENTS
-                                "LSGPU_KNN_ROWS", "LSGPU_KNN_LANE", "LSGPU_SPARSE_LANES", "LSGPU_TILE_WAVES", "LSGPU_XCD_SWIZZLE", "LSGPU_SSN_PRESORTED_LEVELS",
+                                "LSGPU_KNN_ROWS", "LSGPU_KNN_LANE", "LSGPU_SPARSE_LANES", "LSGPU_TILE_WAVES", "LSGPU_XCD_SWIZZLE", "LSGPU_SSN_PRESORTED_LEVELS", "LSGPU_ROCPRIM_SORT",
 #endif
                                 nullptr};
 #ifdef LSGPU_EXPERIMENTS
@@ -189,6 +188,7 @@ inline Tuning read() {
   t.tile_waves = (int)number("LSGPU_TILE_WAVES", 1, 1, 4) == 4 ? 4 : 1;
   t.xcd_swizzle = (int)number("LSGPU_XCD_SWIZZLE", 0, 0, 1 << 16);
   t.ssn_presorted_levels = flag("LSGPU_SSN_PRESORTED_LEVELS");
+  t.rocprim_sort = flag("LSGPU_ROCPRIM_SORT");
   // the front rows only exist in the one-wave tile kernel; the row-wise experiment does not fill the window table
   if (t.knn_lane || t.knn_rows != 0 || t.tile_waves == 4 || t.sparse_lanes != 0) t.front = false;
   if (t.knn_rows != 0) t.commit_select = false;

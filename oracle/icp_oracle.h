@@ -55,6 +55,11 @@
  *      consumed in the order reference filter -> reading filter -> (input filters, per scan).  A caller that wants
  *      reproducible runs reseeds per call (seed >= 0); upstream never seeds.  tests: test_draw_stream_is_the_glibc_
  *      rand_sequence; the sequence tests run both "reseed per call" and "one continuing stream".
+ *      On ERROR paths the product's stream position may differ from a libpointmatcher process': lsgpu_icp_compute
+ *      consumes the reading filter's draws as soon as the reference filter has run (the total is known), so a failure
+ *      after that point (HIP error, empty grid) leaves them consumed although the filter never ran; the C++ facade
+ *      rejects a non-rigid guess before any draw, upstream after both filters.  No call site of laser_slam continues
+ *      after either.
  *      [reading_filtered.csv, and reference_filtered.csv for ratio < 1: which rows]
  *   9. MaxDist / MinDist input filters: radial branch compares the norm with |limit| (both), one-axis branch compares
  *      the SIGNED coordinate (MaxDist) / the absolute one (MinDist); an empty cloud into a non-empty chain throws.

@@ -178,6 +178,7 @@ int main() {
     CHECK(!index_not_paying(124.f, 53.f));     // an ordinary scan of the track drive
     CHECK(index_not_paying(425.f, 955.f));     // a wall a metre from the sensor (scan 19 of the drive)
     CHECK(index_not_paying(344.f, 890.f));
+    CHECK(!index_not_paying(250.f, 364.f));    // a dense three-scan map: the index' first search is no faster yet, the later ones are
     CHECK(!index_not_paying(0.f, 50.f));       // nothing timed: nothing decided
     CHECK(kIndexRestAligns >= 2);
   }

@@ -351,7 +351,7 @@ def test_experiment_switches_do_not_change_results():
                 {"LSGPU_CONE_ROWS": "32", "LSGPU_CONE_COLS": "1024"}, {"LSGPU_CONE_ROWS": "512", "LSGPU_CONE_COLS": "32768"},
                 {"LSGPU_NO_CONE_PROBE": "1"}, {"LSGPU_CONE_FROM": "1"}, {"LSGPU_CONE_HEAVY_SHARE": "2"}, dict(tile, LSGPU_ROUTE_DENSE="16"), dict(tile, LSGPU_ROUTE_DENSE="1073741824"),
                 {"LSGPU_CONE_HEAVY_STEPS": "8", "LSGPU_CONE_HEAVY_SHARE": "0.5"},   # (too dear at first, priced again before every look)
-                {"LSGPU_ROCPRIM_SORT": "1"}, {"LSGPU_SORT_ITEMS": "4"}, {"LSGPU_NO_SEED_CAP": "1"}, {"LSGPU_NO_LAZY": "1"}, {"LSGPU_NO_SIDE_STREAM": "1"}, {"LSGPU_NO_LOOKAHEAD": "1"},
+                {"LSGPU_SORT_ITEMS": "4"}, {"LSGPU_NO_SEED_CAP": "1"}, {"LSGPU_NO_LAZY": "1"}, {"LSGPU_NO_SIDE_STREAM": "1"}, {"LSGPU_NO_LOOKAHEAD": "1"},
                 dict(tile, LSGPU_FRONT_GUESS="8"), {"LSGPU_SSN_GLOBAL": "1"}, {"LSGPU_SSN_FULL_SORT": "1"}, {"LSGPU_SSN_FULL_SORT": "1", "LSGPU_SSN_GLOBAL": "1"},
                 {"LSGPU_SSN_OLD_FINISH": "1"}, {"LSGPU_SSN_ROOT": "2048"}, {"LSGPU_SSN_ROOT": "4096"},   # k_ssn_finish / smaller roots of k_ssn_tree
                 {"LSGPU_QUERY_ORDER": "0"}]
@@ -364,7 +364,8 @@ def test_experiment_switches_do_not_change_results():
     if os.path.exists(exp_so) and os.path.getmtime(exp_so) >= os.path.getmtime(os.path.join(ROOT, "laser_slam_amd", "liblsgpu_icp.so")) - 600:   # (a stale build says nothing)
         variants += [dict(v, LSGPU_SO=exp_so) for v in ({}, dict(tile, LSGPU_KNN_ROWS="1"), dict(tile, LSGPU_TILE_WAVES="4"),
                                                         dict(tile, LSGPU_NO_FRONT="1", LSGPU_SPARSE_LANES="16"),
-                                                        {"LSGPU_SSN_PRESORTED_LEVELS": "1"})]   # (the filter's upper levels from presorted axes)
+                                                        {"LSGPU_SSN_PRESORTED_LEVELS": "1"},   # (the filter's upper levels from presorted axes)
+                                                        {"LSGPU_ROCPRIM_SORT": "1"})]          # (the library sort as a cross-check of lsgpu_sort.hip.h)
     results = []
     for env_add in variants:
         env = dict(os.environ)
