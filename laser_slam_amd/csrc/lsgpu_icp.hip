@@ -37,9 +37,7 @@
 #include "lsgpu_host_math.h"
 #include "lsgpu_ssn.hip.h"
 #include "lsgpu_ssn_tree.hip.h"
-#ifdef LSGPU_EXPERIMENTS
-#include "lsgpu_ssn_levels.hip.h"   // measured slower than the segmented level sorts: kept as the record, experiments build only
-#endif
+#include "lsgpu_ssn_select.hip.h"
 #include "lsgpu_sort.hip.h"
 #include "lsgpu_scan.hip.h"
 #include "lsgpu_rand.h"
@@ -253,15 +251,18 @@ struct lsgpu_icp {
   DevBuf<SegBlock> ssn_blocktab;
   DevBuf<uint32_t> ssn_seg_of, ssn_box_pts, ssn_box_base, ssn_keep, ssn_out_pos, ssn_bb;
   DevBuf<float> ssn_box_normal, ssn_draws;
-#ifdef LSGPU_EXPERIMENTS
-  // upper levels of the reference filter from presorted axes (lsgpu_ssn_levels.hip.h)
-  DevBuf<uint32_t> gt_list[6], gt_key[6], gt_cnt, gt_err, gt_hist2, gt_fullnb;   // (points, keys) of the three lists, two buffer sets
-  DevBuf<unsigned char> gt_side;       // per point: right child at this level?
-  DevBuf<SegBlock> gt_fulltab;
-  hipStream_t gt_stream = nullptr;     // the third axis' presort (the second runs on side_stream)
-  hipEvent_t gt_fork = nullptr, gt_join1 = nullptr, gt_join2 = nullptr;
-  uint32_t* h_gt_err = nullptr;        // pinned: "a tie run was too long for the presorted levels"
-#endif
+  // sort-free upper levels of the reference filter (lsgpu_ssn_select.hip.h)
+  DevBuf<uint32_t> gs_e[2], gs_k[6];          // two buffer sets: points + their three ordered keys
+  DevBuf<GsBlock> gs_tab;                     // block tables of all levels (host-computed: segment sizes are static)
+  DevBuf<GsSegBlocks> gs_sblk;
+  DevBuf<uint32_t> gs_hist;                   // per segment 2 x 256 counters, two levels (ping-pong)
+  DevBuf<GsMedian> gs_cand, gs_median;
+  DevBuf<uint32_t> gs_cand_blk, gs_cand_n, gs_cl, gs_err;
+  DevBuf<uint2> gs_rng;                       // per segment: the key range of its points on its cut axis (two levels)
+  uint32_t* h_gs_err = nullptr;               // pinned
+  int64_t gs_plan_n = -1;                     // the cloud size / level count the tables on the device were made for
+  int gs_plan_levels = -1;
+  std::vector<uint32_t> gs_lvl_first, gs_lvl_blocks;
   DevBuf<float4> flt_in, flt_in2, flt_ref, flt_rd;
   DevBuf<float> flt_nrm;
   float* draws_pinned = nullptr;  // host staging of the filter draws (pinned: async H2D)
@@ -455,17 +456,11 @@ void lsgpu_icp_destroy(lsgpu_icp* h) {
   if (h->h_pinned) (void)hipHostFree(h->h_pinned);
   if (h->h_price) (void)hipHostFree(h->h_price);
   if (h->h_cone_occ) (void)hipHostFree(h->h_cone_occ);
-#ifdef LSGPU_EXPERIMENTS
-  if (h->h_gt_err) (void)hipHostFree(h->h_gt_err);
-  for (auto& b : h->gt_list) b.release();
-  for (auto& b : h->gt_key) b.release();
-  h->gt_side.release();
-  h->gt_cnt.release(); h->gt_err.release(); h->gt_hist2.release(); h->gt_fullnb.release(); h->gt_fulltab.release();
-  if (h->gt_fork) (void)hipEventDestroy(h->gt_fork);
-  if (h->gt_join1) (void)hipEventDestroy(h->gt_join1);
-  if (h->gt_join2) (void)hipEventDestroy(h->gt_join2);
-  if (h->gt_stream) { (void)hipStreamSynchronize(h->gt_stream); (void)hipStreamDestroy(h->gt_stream); }
-#endif
+  if (h->h_gs_err) (void)hipHostFree(h->h_gs_err);
+  for (auto& bf : h->gs_e) bf.release();
+  for (auto& bf : h->gs_k) bf.release();
+  h->gs_tab.release(); h->gs_sblk.release(); h->gs_hist.release(); h->gs_cand.release(); h->gs_median.release();
+  h->gs_cand_blk.release(); h->gs_cand_n.release(); h->gs_cl.release(); h->gs_err.release(); h->gs_rng.release();
   if (h->draws_pinned) (void)hipHostFree(h->draws_pinned);
   if (h->copy_done) (void)hipEventDestroy(h->copy_done);
   if (h->ref_up_done) (void)hipEventDestroy(h->ref_up_done);
@@ -1417,11 +1412,8 @@ static int ssn_device(lsgpu_icp* h, const float4* src, int64_t n, int knn, float
     int64_t c = n;
     while (glevels < levels && !(lds_finish && c <= root_max && levels - glevels <= root_levels)) { c -= c / 2; ++glevels; }
   }
-#ifdef LSGPU_EXPERIMENTS
-  const bool presorted = !force_sort_levels && tuning().ssn_presorted_levels && !tuning().ssn_full_sort && glevels > 0;
-#else
-  (void)force_sort_levels;
-#endif
+  const bool select_levels = !force_sort_levels && !tuning().ssn_sort_levels && !tuning().ssn_full_sort && glevels > 0;
+  const uint32_t* root_sig = nullptr;   // per root of the in-workgroup levels: its signature (sort-free upper levels)
   if (tuning().ssn_full_sort) {   // rounds 1-3: the whole cloud sorted by (segment, coordinate) at every level
     for (int L = 0; L < glevels; ++L) {
       hipLaunchKernelGGL(k_ssn_keys, dim3(nblk(n)), dim3(256), 0, h->stream, src, (int)n, idx,
@@ -1435,81 +1427,88 @@ static int ssn_device(lsgpu_icp* h, const float4* src, int64_t n, int knn, float
       hipLaunchKernelGGL(k_ssn_assign, dim3(nblk(n)), dim3(256), 0, h->stream, (int)n, cur, knn, h->ssn_seg_of.p, L == 0 ? 1 : 0);
       std::swap(cur, nxt);
     }
-#ifdef LSGPU_EXPERIMENTS
-  } else if (glevels > 0 && presorted) {
-    // Upper levels from three presorted axes (lsgpu_ssn_levels.hip.h): the axes are sorted side by side on three streams,
-    // a level is a fix-up of tie runs + one stable partition -- 6 launches instead of 16, no sort.
-    const int cap = (int)(n / kSegTile + (int64_t)((size_t)1 << glevels) + 2);
-    const int capf = (int)(n / kSegTile + 2);
-    for (auto& b : h->gt_list) HIPC(b.reserve(n));
-    for (auto& b : h->gt_key) HIPC(b.reserve(n));
-    HIPC(h->gt_side.reserve(n));
-    HIPC(h->gt_cnt.reserve((size_t)2 * cap)); HIPC(h->gt_err.reserve(4)); HIPC(h->gt_fullnb.reserve(4));
-    HIPC(h->gt_fulltab.reserve((size_t)capf)); HIPC(h->ssn_blocktab.reserve((size_t)cap));
-    HIPC(h->ssn_axis_a.reserve((size_t)1 << glevels)); HIPC(h->ssn_axis_b.reserve((size_t)1 << glevels));
-    HIPC(h->scr_main.sort_hist.reserve((size_t)256 * capf + 260)); HIPC(h->scr_side.sort_hist.reserve((size_t)256 * capf + 260));
-    HIPC(h->gt_hist2.reserve((size_t)256 * capf + 260));
-    HIPC(h->sc->vals.reserve(n));
-    if (!h->side_stream) HIPC(hipStreamCreateWithFlags(&h->side_stream, hipStreamNonBlocking));
-    if (!h->gt_stream) HIPC(hipStreamCreateWithFlags(&h->gt_stream, hipStreamNonBlocking));
-    if (!h->gt_fork) { HIPC(hipEventCreateWithFlags(&h->gt_fork, hipEventDisableTiming)); HIPC(hipEventCreateWithFlags(&h->gt_join1, hipEventDisableTiming)); HIPC(hipEventCreateWithFlags(&h->gt_join2, hipEventDisableTiming)); }
-    if (!h->h_gt_err) HIPC(hipHostMalloc((void**)&h->h_gt_err, 64, hipHostMallocDefault));
-    HIPC(hipMemsetAsync(h->gt_err.p, 0, sizeof(uint32_t), h->stream));
-    hipLaunchKernelGGL(k_gt_fulltab, dim3(std::min(nblk(capf), 64)), dim3(256), 0, h->stream, (int)n, h->gt_fulltab.p, h->gt_fullnb.p);
-    HIPC(hipEventRecord(h->gt_fork, h->stream));   // (the cloud, the root and the one-segment block table are behind it)
-    hipStream_t ax_stream[3] = {h->stream, h->side_stream, h->gt_stream};
-    uint32_t* ax_hist[3] = {h->scr_main.sort_hist.p, h->scr_side.sort_hist.p, h->gt_hist2.p};
-    for (int d = 0; d < 3; ++d) {
-      hipStream_t st = ax_stream[d];
-      if (d) HIPC(hipStreamWaitEvent(st, h->gt_fork, 0));
-      // the sort's two halves ARE the two buffer sets of the axis' list: (keys, points) in list order
-      uint32_t* keyA = h->gt_key[d].p;
-      uint32_t* keyB = h->gt_key[3 + d].p;
-      uint32_t* valA = h->gt_list[d].p;
-      uint32_t* valB = h->gt_list[3 + d].p;
-      uint32_t* bh = ax_hist[d];
-      uint32_t* dtot = bh + (size_t)256 * capf;
-      hipLaunchKernelGGL(k_gt_keys, dim3(nblk(n)), dim3(256), 0, st, src, (int)n, d, keyA, valA);
-      for (int pass = 0; pass < 4; ++pass) {
-        const uint32_t* kin = (pass & 1) ? keyB : keyA; const uint32_t* vin = (pass & 1) ? valB : valA;
-        uint32_t* kout = (pass & 1) ? keyA : keyB; uint32_t* vout = (pass & 1) ? valA : valB;
-        hipLaunchKernelGGL(k_seg_hist<kSegItems>, dim3(capf), dim3(256), 0, st, kin, h->gt_fulltab.p, h->gt_fullnb.p, 8 * pass, bh, capf);
-        hipLaunchKernelGGL(k_seg_scan, dim3(256), dim3(256), 0, st, bh, capf, h->gt_fullnb.p, dtot);
-        hipLaunchKernelGGL((k_seg_scatter<kSegItems>), dim3(capf), dim3(256), 0, st, kin, vin, kout, vout, h->gt_fulltab.p, h->gt_fullnb.p,
-                           8 * pass, bh, dtot, capf);
+  } else if (select_levels) {
+    // Sort-free upper levels (lsgpu_ssn_select.hip.h): a segment is a set + a signature, a level is the exact median in the
+    // segment's total order (two 8-bit histogram passes over the box range + a per-segment selection among the few
+    // candidates left) and one stable partition: 7 launches per level, no sort.
+    if (h->gs_plan_n != n || h->gs_plan_levels != glevels) {   // block tables: static for a cloud size
+      std::vector<GsBlock> tab;
+      std::vector<GsSegBlocks> sblk;
+      std::vector<std::pair<uint32_t, uint32_t>> segsz{{0u, (uint32_t)n}};
+      h->gs_lvl_first.clear(); h->gs_lvl_blocks.clear();
+      for (int L = 0; L < glevels; ++L) {
+        h->gs_lvl_first.push_back((uint32_t)tab.size());
+        uint32_t fb = 0;
+        std::vector<std::pair<uint32_t, uint32_t>> next;
+        for (uint32_t sidx = 0; sidx < segsz.size(); ++sidx) {
+          const uint32_t st = segsz[sidx].first, c = segsz[sidx].second;
+          const uint32_t nb = (c + kGsTile - 1u) / kGsTile;
+          sblk.push_back(GsSegBlocks{fb, nb, st, c});
+          for (uint32_t k = 0; k < nb; ++k)
+            tab.push_back(GsBlock{st + k * kGsTile, std::min(kGsTile, c - k * kGsTile), sidx, st, c, fb, nb, 0u});
+          fb += nb;
+          const uint32_t left = c - c / 2u;
+          next.push_back({st, left}); next.push_back({st + left, c - left});
+        }
+        h->gs_lvl_blocks.push_back(fb);
+        segsz.swap(next);
       }
-      if (d == 1) HIPC(hipEventRecord(h->gt_join1, st));
-      if (d == 2) HIPC(hipEventRecord(h->gt_join2, st));
+      HIPC(h->gs_tab.reserve(tab.size())); HIPC(h->gs_sblk.reserve(sblk.size()));
+      // (pageable source: the copy returns when the staging is done; once per cloud size)
+      HIPC(hipMemcpyAsync(h->gs_tab.p, tab.data(), tab.size() * sizeof(GsBlock), hipMemcpyHostToDevice, h->stream));
+      HIPC(hipMemcpyAsync(h->gs_sblk.p, sblk.data(), sblk.size() * sizeof(GsSegBlocks), hipMemcpyHostToDevice, h->stream));
+      HIPC(hipStreamSynchronize(h->stream));
+      h->gs_plan_n = n; h->gs_plan_levels = glevels;
     }
-    HIPC(hipStreamWaitEvent(h->stream, h->gt_join1, 0));
-    HIPC(hipStreamWaitEvent(h->stream, h->gt_join2, 0));
-    HIPC(hipGetLastError());
-    GtLists in, out;
-    for (int d = 0; d < 3; ++d) { in.e[d] = h->gt_list[d].p; in.k[d] = h->gt_key[d].p; out.e[d] = h->gt_list[3 + d].p; out.k[d] = h->gt_key[3 + d].p; }
+    const size_t nseg_g = (size_t)1 << glevels;
+    int cap = 1;
+    for (uint32_t v : h->gs_lvl_blocks) cap = std::max(cap, (int)v);
+    for (auto& bf : h->gs_e) HIPC(bf.reserve(n));
+    for (auto& bf : h->gs_k) HIPC(bf.reserve(n));
+    HIPC(h->gs_hist.reserve(4 * 256 * (nseg_g + 1))); HIPC(h->gs_median.reserve(nseg_g)); HIPC(h->gs_cand_n.reserve(2 * nseg_g + 2));
+    HIPC(h->gs_cand.reserve(nseg_g / 2 * kGsCandCap + kGsCandCap)); HIPC(h->gs_cand_blk.reserve(nseg_g / 2 * kGsCandCap + kGsCandCap));
+    HIPC(h->gs_cl.reserve((size_t)2 * cap)); HIPC(h->gs_err.reserve(8)); HIPC(h->gs_rng.reserve(2 * nseg_g + 2));
+    HIPC(h->ssn_axis_a.reserve(nseg_g)); HIPC(h->ssn_axis_b.reserve(nseg_g));
+    if (!h->h_gs_err) HIPC(hipHostMalloc((void**)&h->h_gs_err, 64, hipHostMallocDefault));
+    uint32_t* cand_n[2] = {h->gs_cand_n.p, h->gs_cand_n.p + nseg_g + 1};
     uint32_t* sig_cur = reinterpret_cast<uint32_t*>(h->ssn_axis_a.p);
     uint32_t* sig_nxt = reinterpret_cast<uint32_t*>(h->ssn_axis_b.p);
-    uint32_t* nblocks_dev = h->gt_fullnb.p + 1;
+    HIPC(hipMemsetAsync(h->gs_err.p, 0, 8 * sizeof(uint32_t), h->stream));
+    HIPC(hipMemsetAsync(cand_n[0], 0, sizeof(uint32_t), h->stream));
     HIPC(hipMemsetAsync(sig_cur, 0xFF, sizeof(uint32_t), h->stream));   // the root was cut along no axis yet
+    GsSet in, out;
+    in.e = h->gs_e[0].p; out.e = h->gs_e[1].p;
+    for (int d = 0; d < 3; ++d) { in.k[d] = h->gs_k[d].p; out.k[d] = h->gs_k[3 + d].p; }
+    uint2* rng_cur = h->gs_rng.p;
+    uint2* rng_nxt = h->gs_rng.p + nseg_g + 1;
+    // per segment two 256-bin histograms; a level zeroes its children's (the root's: here)
+    uint32_t* gh1[2] = {h->gs_hist.p, h->gs_hist.p + 256 * (nseg_g + 1)};
+    uint32_t* gh2[2] = {h->gs_hist.p + 2 * 256 * (nseg_g + 1), h->gs_hist.p + 3 * 256 * (nseg_g + 1)};
+    HIPC(hipMemsetAsync(gh1[0], 0, 256 * sizeof(uint32_t), h->stream));
+    HIPC(hipMemsetAsync(gh2[0], 0, 256 * sizeof(uint32_t), h->stream));
+    hipLaunchKernelGGL(k_gs_init, dim3(nblk(n)), dim3(256), 0, h->stream, src, (int)n, in, out.e, (const SsnSeg*)cur, (const uint32_t*)h->ssn_bb.p, rng_cur);
     for (int L = 0; L < glevels; ++L) {
-      const int ns = 1 << L;
-      const int grid = (int)std::min<int64_t>(cap, n / kSegTile + ns + 1);
-      hipLaunchKernelGGL(k_gt_plan, dim3(1), dim3(256), 0, h->stream, cur, ns, knn, h->ssn_blocktab.p, nblocks_dev);
-      hipLaunchKernelGGL(k_gt_fix, dim3(grid), dim3(256), 0, h->stream, h->ssn_blocktab.p, nblocks_dev, cur, (const uint32_t*)sig_cur, in, out,
-                         src, h->gt_side.p, h->gt_err.p);
-      hipLaunchKernelGGL(k_gt_count, dim3(grid), dim3(256), 0, h->stream, h->ssn_blocktab.p, nblocks_dev, cur, in, (const unsigned char*)h->gt_side.p, h->gt_cnt.p, cap);
-      hipLaunchKernelGGL(k_gt_scan, dim3(1), dim3(1024), 0, h->stream, h->gt_cnt.p, cap, nblocks_dev);
-      hipLaunchKernelGGL(k_gt_part, dim3(grid), dim3(256), 0, h->stream, h->ssn_blocktab.p, nblocks_dev, cur, in, out, (const unsigned char*)h->gt_side.p,
-                         (const uint32_t*)h->gt_cnt.p, cap, h->ssn_seg_of.p);
-      hipLaunchKernelGGL(k_gt_split, dim3(nblk(ns)), dim3(256), 0, h->stream, src, out, cur, ns, knn, nxt, (const uint32_t*)sig_cur, sig_nxt);
+      const int ns = 1 << L, nb = (int)h->gs_lvl_blocks[L], par = L & 1;
+      const GsBlock* tab = h->gs_tab.p + h->gs_lvl_first[L];
+      const GsSegBlocks* sblk = h->gs_sblk.p + (ns - 1);
+      hipLaunchKernelGGL(k_gs_hist<1>, dim3(nb), dim3(256), 0, h->stream, tab, cur, (const uint2*)rng_cur, in, gh1[par], gh2[par], h->gs_err.p);
+      hipLaunchKernelGGL(k_gs_hist<2>, dim3(nb), dim3(256), 0, h->stream, tab, cur, (const uint2*)rng_cur, in, gh1[par], gh2[par], h->gs_err.p);
+      hipLaunchKernelGGL(k_gs_collect, dim3(nb), dim3(256), 0, h->stream, tab, cur, (const uint2*)rng_cur, (const uint32_t*)sig_cur, in,
+                         (const uint32_t*)gh1[par], (const uint32_t*)gh2[par], cand_n[par], h->gs_cand.p, h->gs_cand_blk.p, h->gs_cl.p);
+      hipLaunchKernelGGL(k_gs_select, dim3(ns), dim3(256), 0, h->stream, sblk, src, cur, (const uint32_t*)sig_cur, gh1[par], gh2[par],
+                         gh1[par ^ 1], gh2[par ^ 1], cand_n[par], (const GsMedian*)h->gs_cand.p, (const uint32_t*)h->gs_cand_blk.p, h->gs_cl.p,
+                         h->gs_cl.p + cap, h->gs_median.p, nxt, sig_nxt, cand_n[par ^ 1], rng_nxt, h->gs_err.p);
+      hipLaunchKernelGGL(k_gs_part, dim3(nb), dim3(256), 0, h->stream, tab, cur, (const uint32_t*)sig_cur, in, out,
+                         (const GsMedian*)h->gs_median.p, (const uint32_t*)(h->gs_cl.p + cap), (const SsnSeg*)nxt, rng_nxt, h->gs_err.p);
       std::swap(in, out);
       std::swap(cur, nxt);
       std::swap(sig_cur, sig_nxt);
+      std::swap(rng_cur, rng_nxt);
     }
-    hipLaunchKernelGGL(k_gt_idx, dim3(nblk(n)), dim3(256), 0, h->stream, (int)n, h->ssn_seg_of.p, (const uint32_t*)sig_cur, in, h->sc->vals.p);
-    idx = h->sc->vals.p;
-    HIPC(hipMemcpyAsync(h->h_gt_err, h->gt_err.p, sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
+    idx = in.e;          // every root's points, in original-index order
+    root_sig = sig_cur;
+    HIPC(hipMemcpyAsync(h->h_gs_err, h->gs_err.p, 8 * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
     HIPC(hipGetLastError());
-#endif
   } else if (glevels > 0) {
     // segmented sorts (lsgpu_segsort.hip.h): per level only the segments that cut along a new axis, four passes of
     // (uint32 key, uint32 index) pairs, every segment inside its own range of the arrays
@@ -1562,11 +1561,11 @@ static int ssn_device(lsgpu_icp* h, const float4* src, int64_t n, int knn, float
     if (!tree_finish)
       hipLaunchKernelGGL(k_ssn_finish, dim3(1 << glevels), dim3(256), 0, h->stream, src, idx_rw, cur, knn, levels - glevels, h->ssn_seg_of.p, nxt);
     else if (root_max == 8192)
-      hipLaunchKernelGGL(k_ssn_tree<8192>, dim3(1 << glevels), dim3(1024), 0, h->stream, src, idx_rw, cur, knn, levels - glevels, h->ssn_seg_of.p, nxt, root_axis);
+      hipLaunchKernelGGL(k_ssn_tree<8192>, dim3(1 << glevels), dim3(1024), 0, h->stream, src, idx_rw, cur, knn, levels - glevels, h->ssn_seg_of.p, nxt, root_axis, root_sig);
     else if (root_max == 4096)
-      hipLaunchKernelGGL(k_ssn_tree<4096>, dim3(1 << glevels), dim3(512), 0, h->stream, src, idx_rw, cur, knn, levels - glevels, h->ssn_seg_of.p, nxt, root_axis);
+      hipLaunchKernelGGL(k_ssn_tree<4096>, dim3(1 << glevels), dim3(512), 0, h->stream, src, idx_rw, cur, knn, levels - glevels, h->ssn_seg_of.p, nxt, root_axis, root_sig);
     else
-      hipLaunchKernelGGL(k_ssn_tree<2048>, dim3(1 << glevels), dim3(256), 0, h->stream, src, idx_rw, cur, knn, levels - glevels, h->ssn_seg_of.p, nxt, root_axis);
+      hipLaunchKernelGGL(k_ssn_tree<2048>, dim3(1 << glevels), dim3(256), 0, h->stream, src, idx_rw, cur, knn, levels - glevels, h->ssn_seg_of.p, nxt, root_axis, root_sig);
     std::swap(cur, nxt);
   }
   if (levels == 0) {  // a single box: identity order
@@ -1594,13 +1593,13 @@ static int ssn_device(lsgpu_icp* h, const float4* src, int64_t n, int knn, float
   if (rc == LSGPU_OK)
     rc = scan_totals(h, h->ssn_box_pts.p, h->ssn_box_base.p, nseg, h->ssn_keep.p, h->ssn_out_pos.p, (size_t)n, &n_draws, &kept);
   if (rc) return rc;
-#ifdef LSGPU_EXPERIMENTS
-  if (presorted && *h->h_gt_err) {
-    // a run of equal coordinates along a cut axis was too long to be walked element by element (kGtRunCap): the
-    // segmented sorts do not care -- the same filter again with them (same draws: nothing has been consumed yet)
+  if (select_levels && *h->h_gs_err) {
+    if (getenv("LSGPU_GS_DEBUG")) fprintf(stderr, "lsgpu: sort-free levels gave up (n %lld): code %u seg %u a %u b %u | part %u seg %u dst %u\n", (long long)n,
+                                          h->h_gs_err[1], h->h_gs_err[2], h->h_gs_err[3], h->h_gs_err[4], h->h_gs_err[5], h->h_gs_err[6], h->h_gs_err[7]);
+    // thousands of equal coordinates around a median (more candidates than a workgroup selects among): the segmented
+    // sorts do not care -- the same filter again with them (same draws: nothing has been consumed yet)
     return ssn_device(h, src, n, knn, ratio, seed, out_xyz1, out_nrm, n_out, ahead, true);
   }
-#endif
   ahead->used = first_draw + (size_t)n_draws;  // dropped boxes drew nothing
   HIPC(hipGetLastError());
   *n_out = kept;

@@ -1,0 +1,367 @@
+// lsgpu_ssn_select.hip.h -- the UPPER levels of SamplingSurfaceNormalDataPointsFilter's box tree (segments too large for
+// one workgroup of k_ssn_tree) WITHOUT any sort (icp_default.yaml:5-7; the reference filter of PointMatcher::ICP::compute,
+// laser_slam/src/laser_track.cpp:496).  Round 5.
+//
+// Rounds 1-4 sorted at every level (lsgpu_segsort.hip.h: a segmented stable radix sort of the cut coordinate, 4 passes of 3
+// launches + key / plan / split / assign kernels = 16 dependent launches and ~100 us per level at 1 M points, whatever the
+// amount of data).  What a level actually needs is much less:
+//   * a segment is split at the MEDIAN of its points in the stable order of the cut coordinate;
+//   * the order INSIDE the halves only matters as the tie-break of later levels -- and the chain of stable sorts has a
+//     closed form: a segment's current order is the lexicographic order of (key on the axis it was cut along last, key on
+//     the one before, key on the third, original index): its SIGNATURE, three bytes.
+// So the upper levels keep no order at all.  A segment is a SET of points -- held in original-index order by stable
+// partitions -- with a signature, and a level is
+//   k_gs_hist<1>               256-bin histogram of the cut coordinate over the range the segment's POINTS span (the box can be
+//   k_gs_hist<2>               far wider: a patch of ground keeps the cloud's z range until z is cut), summed per segment with
+//                              one atomic per block and bin; the bin the median falls into is found by every block of the NEXT
+//                              kernel in its prologue (a 256-entry scan: cheaper than a launch); the same again inside that
+//                              bin (16 bits of the range resolved: a handful of candidates per segment remain);
+//   k_gs_collect               the candidates of the last bin -> a small per-segment list; every block's count of points that
+//                              go left for sure;
+//   k_gs_select                ONE workgroup per segment: the exact median of the candidates in the total order above (key on
+//                              the cut axis, keys on the signature's other axes, original index), the children's boxes and
+//                              signatures, the candidates' share of the blocks' left counts;
+//   k_gs_part                  the stable partition by "before the median in that order": points and their three keys move
+//                              to the other buffer set, left half first; on the way the key range of either child on ITS cut
+//                              axis (four atomics per block).
+// Five launches per level, every access by position coalesced, no key ever sorted.  Segment sizes are static (exact
+// halving), so the block tables of all levels are computed on the host once per cloud size.
+// k_ssn_tree takes the sets over: it presorts its three axes anyway; the list of the signature's first axis gets its tie
+// runs ordered by the same comparator once (lsgpu_ssn_tree.hip.h, "initial order"), after which the workgroup's own
+// bookkeeping (cur_pos) carries on.  The scheme is modelled step for step in tests/ssn_tree_model.py (select_then_tree) and
+// checked there against the chain of stable sorts the restatement defines, heavy ties included.
+// Limits: more than kGsCandCap candidates in a segment's last bin (thousands of EQUAL coordinates around a median), or a
+// key outside its segment's box, raise a flag and the host repeats the filter with the segmented sorts
+// (LSGPU_SSN_SORT_LEVELS selects them always).  Bit-identical to them and to the oracle.
+#pragma once
+#include "lsgpu_ssn.hip.h"
+#include "lsgpu_ssn_tree.hip.h"
+
+namespace lsgpu {
+
+constexpr uint32_t kGsTile = 2048u;       // positions per block of the level kernels (256 threads x 8)
+constexpr int kGsItems = 8;
+constexpr uint32_t kGsCandCap = 2048u;    // candidates per segment
+constexpr uint32_t kGsNoAxis = 0xFFu;
+
+struct GsSet {                 // one buffer set: the points of every segment (original-index order inside it) and their keys
+  uint32_t* e;
+  uint32_t* k[3];
+};
+// (selects, not g.k[d]: a dynamically indexed kernel argument would be copied to scratch memory)
+__device__ __forceinline__ uint32_t* gs_k(const GsSet& g, int d) { return d == 0 ? g.k[0] : d == 1 ? g.k[1] : g.k[2]; }
+
+struct GsBlock {               // 32 bytes, computed on the host (segment sizes are static)
+  uint32_t first, count;       // positions [first, first + count)
+  uint32_t seg;                // its segment ...
+  uint32_t seg_start, seg_count;
+  uint32_t fb, nb;             // ... and that segment's blocks [fb, fb + nb)
+  uint32_t pad;
+};
+struct GsSegBlocks { uint32_t fb, nb, start, count; };   // per segment (host)
+
+struct GsMedian { uint32_t ka, k1, k2, e; };   // the median in the segment's total order: cut-axis key, the other keys, index
+
+// a segment's signature: the axes it was cut along, most recent first, one byte each (kGsNoAxis: none); 0xFFFFFFFF at the root
+__host__ __device__ __forceinline__ uint32_t gs_sig_push(uint32_t sig, uint32_t a) {
+  const uint32_t o1 = sig & 0xFFu, o2 = (sig >> 8) & 0xFFu, o3 = (sig >> 16) & 0xFFu;
+  if (o1 == a) return sig;
+  const uint32_t r2 = o2 == a ? o3 : o2;               // the others, a removed (three axes: at most two remain)
+  return a | (o1 << 8) | (r2 << 16) | 0xFF000000u;
+}
+// the two axes that follow the cut axis in the segment's order (kGsNoAxis: none)
+__device__ __forceinline__ void gs_other_axes(uint32_t sig, uint32_t a, uint32_t& x1, uint32_t& x2) {
+  const uint32_t o1 = sig & 0xFFu, o2 = (sig >> 8) & 0xFFu, o3 = (sig >> 16) & 0xFFu;
+  if (o1 == a) { x1 = o2; x2 = o3; }
+  else { x1 = o1; x2 = o2 == a ? o3 : o2; }
+}
+__device__ __forceinline__ bool gs_less(uint32_t ka, uint32_t k1, uint32_t k2, uint32_t e, const GsMedian& m) {
+  return ka != m.ka ? ka < m.ka : k1 != m.k1 ? k1 < m.k1 : k2 != m.k2 ? k2 < m.k2 : e < m.e;
+}
+
+// keys and identity: the root set (the other set's point array gets valid ids too: whatever an aborted level leaves behind
+// must stay dereferenceable for the kernels queued behind it); the root's key range on its cut axis = the cloud's bounds
+__global__ __launch_bounds__(256) void k_gs_init(const float4* __restrict__ p, int n, GsSet out, uint32_t* __restrict__ other_e,
+                                                 const SsnSeg* __restrict__ root, const uint32_t* __restrict__ bb,
+                                                 uint2* __restrict__ rng) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i == 0) { const int a = ssn_cut_axis(root[0]); rng[0] = make_uint2(bb[a], bb[3 + a]); }
+  if (i >= n) return;
+  const float4 v = p[i];
+  out.e[i] = (uint32_t)i; other_e[i] = (uint32_t)i;
+  out.k[0][i] = float_order_key(v.x); out.k[1][i] = float_order_key(v.y); out.k[2][i] = float_order_key(v.z);
+}
+
+// What a block needs to know about its segment's cut: the axis and the map from a key to one of 65536 bins.  The bins are
+// uniform in the COORDINATE over the range the segment's points span, not in the key: keys are float bit patterns, a range
+// that crosses zero or a few binades spends most of its key space where no point is (measured: 3 241 of a segment's 16 349
+// points -- ground returns within two centimetres, the range stretched to 7.7 m by a wall -- in one of 65536 key-space
+// bins; 50 in a coordinate-space bin).  All that exactness needs of the map is that it is monotone: x1 < x2 => bin(x1) <=
+// bin(x2), which float subtraction, multiplication by a positive constant and truncation are.
+struct GsCut { int a; uint32_t klo, khi; float xlo, scale; };
+__device__ __forceinline__ GsCut gs_cut(const SsnSeg& sg, const uint2 rng /* keys of the segment's points on the cut axis: min, max */) {
+  GsCut c;
+  c.a = ssn_cut_axis(sg);
+  c.klo = rng.x; c.khi = rng.y >= rng.x ? rng.y : rng.x;
+  c.xlo = float_from_order_key(c.klo);
+  const float ext = float_from_order_key(c.khi) - c.xlo;
+  c.scale = ext > 0.f ? 65536.0f / ext : 0.f;
+  return c;
+}
+__device__ __forceinline__ uint32_t gs_bin16(const GsCut& c, uint32_t k) {
+  const float t = (float_from_order_key(k) - c.xlo) * c.scale;
+  return (uint32_t)fminf(fmaxf(t, 0.f), 65535.f);
+}
+
+// The bin of a 256-bin segment histogram that holds rank `target`, and the number of points in front of it: every block
+// that needs it computes it itself (whole workgroup of 256 threads; LDS scratch of 8 words; ~1 us).  bin = 0xFFFFFFFF if the
+// rank is not in the histogram (cannot happen unless an earlier kernel failed).
+__device__ __forceinline__ void gs_find_bin(const uint32_t* __restrict__ gh, uint32_t target, uint32_t* sh /* >= 8 */,
+                                            uint32_t& bin, uint32_t& below) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const uint32_t tot = gh[threadIdx.x];
+  const uint32_t incl = wave_scan_incl_u32(tot, lane);
+  if (threadIdx.x == 0) { sh[4] = 0xFFFFFFFFu; sh[5] = 0u; }
+  if (lane == 63) sh[w] = incl;
+  __syncthreads();
+  uint32_t before = 0u;
+  for (int ww = 0; ww < w; ++ww) before += sh[ww];
+  const uint32_t excl = before + incl - tot;
+  if (tot != 0u && excl <= target && target < excl + tot) { sh[4] = threadIdx.x; sh[5] = excl; }
+  __syncthreads();
+  bin = sh[4]; below = sh[5];
+  __syncthreads();
+}
+
+// PASS 1: the upper eight bits of every point's bin; PASS 2: the lower eight of the points inside the median's first bin.
+// gh1 / gh2: per segment 256 counters (zeroed by the level above), one atomic per block and occupied bin.
+template <int PASS>
+__global__ __launch_bounds__(256) void k_gs_hist(const GsBlock* __restrict__ tab, const SsnSeg* __restrict__ segs,
+                                                 const uint2* __restrict__ rng, GsSet in, uint32_t* __restrict__ gh1,
+                                                 uint32_t* __restrict__ gh2, uint32_t* __restrict__ err) {
+  __shared__ uint32_t hist[256];
+  __shared__ uint32_t sh[8];
+  hist[threadIdx.x] = 0u;
+  const GsBlock sb = tab[blockIdx.x];
+  const GsCut c = gs_cut(segs[sb.seg], rng[sb.seg]);
+  const uint32_t* __restrict__ ka = gs_k(in, c.a);
+  uint32_t mb1 = 0u, below1 = 0u;
+  if (PASS == 2) gs_find_bin(gh1 + (size_t)sb.seg * 256u, sb.seg_count - sb.seg_count / 2u, sh, mb1, below1);
+  else __syncthreads();
+  bool bad = PASS == 2 && mb1 == 0xFFFFFFFFu;
+  for (uint32_t j = threadIdx.x; j < sb.count; j += 256u) {
+    const uint32_t k = ka[sb.first + j];
+    bad = bad || k < c.klo || k > c.khi;
+    const uint32_t b16 = gs_bin16(c, k), b1 = b16 >> 8;
+    if (PASS == 1) atomicAdd(&hist[b1], 1u);
+    else if (b1 == mb1) atomicAdd(&hist[b16 & 255u], 1u);
+  }
+  if (bad) { err[0] = 1u; err[1] = 1u; err[2] = sb.seg; }   // a point outside its segment's range / no bin: cannot happen; the host would fall back
+  __syncthreads();
+  const uint32_t v = hist[threadIdx.x];
+  if (v) atomicAdd(&(PASS == 1 ? gh1 : gh2)[(size_t)sb.seg * 256u + threadIdx.x], v);
+}
+
+// candidates of the median's last bin -> the segment's list (tuple + block); the block's count of points that go left for sure
+__global__ __launch_bounds__(256) void k_gs_collect(const GsBlock* __restrict__ tab, const SsnSeg* __restrict__ segs,
+                                                    const uint2* __restrict__ rng,
+                                                    const uint32_t* __restrict__ sig, GsSet in, const uint32_t* __restrict__ gh1,
+                                                    const uint32_t* __restrict__ gh2,
+                                                    uint32_t* __restrict__ cand_n, GsMedian* __restrict__ cand,
+                                                    uint32_t* __restrict__ cand_blk, uint32_t* __restrict__ cl) {
+  __shared__ uint32_t ws[4];
+  __shared__ uint32_t sh[8];
+  const GsBlock sb = tab[blockIdx.x];
+  const GsCut c = gs_cut(segs[sb.seg], rng[sb.seg]);
+  const uint32_t leftn = sb.seg_count - sb.seg_count / 2u;
+  uint32_t mb1, below1, mb2, below2;
+  gs_find_bin(gh1 + (size_t)sb.seg * 256u, leftn, sh, mb1, below1);
+  gs_find_bin(gh2 + (size_t)sb.seg * 256u, leftn - below1, sh, mb2, below2);
+  uint32_t x1, x2;
+  gs_other_axes(sig[sb.seg], (uint32_t)c.a, x1, x2);
+  const uint32_t* __restrict__ ka = gs_k(in, c.a);
+  uint32_t left = 0u;
+  for (uint32_t j = threadIdx.x; j < sb.count; j += 256u) {
+    const uint32_t i = sb.first + j;
+    const uint32_t k = ka[i];
+    const uint32_t b16 = gs_bin16(c, k), b1 = b16 >> 8, b2 = b16 & 255u;
+    if (b1 < mb1 || (b1 == mb1 && b2 < mb2)) {
+      ++left;
+    } else if (b1 == mb1 && b2 == mb2) {
+      const uint32_t slot = atomicAdd(&cand_n[sb.seg], 1u);
+      if (slot < kGsCandCap) {
+        GsMedian m;
+        m.ka = k; m.e = in.e[i];
+        m.k1 = x1 != kGsNoAxis ? gs_k(in, (int)x1)[i] : 0u;
+        m.k2 = x2 != kGsNoAxis ? gs_k(in, (int)x2)[i] : 0u;
+        cand[(size_t)sb.seg * kGsCandCap + slot] = m;
+        cand_blk[(size_t)sb.seg * kGsCandCap + slot] = blockIdx.x;
+      }
+    }
+  }
+  left = wave_sum_u32(left);
+  if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = left;
+  __syncthreads();
+  if (threadIdx.x == 0) cl[blockIdx.x] = ws[0] + ws[1] + ws[2] + ws[3];
+}
+
+// ONE workgroup per segment: the exact median among the candidates, the children, the candidates' share of the left counts
+__global__ __launch_bounds__(256) void k_gs_select(const GsSegBlocks* __restrict__ sblk, const float4* __restrict__ p,
+                                                   const SsnSeg* __restrict__ segs, const uint32_t* __restrict__ sig,
+                                                   uint32_t* __restrict__ gh1, uint32_t* __restrict__ gh2,
+                                                   uint32_t* __restrict__ gh1_next, uint32_t* __restrict__ gh2_next,
+                                                   uint32_t* __restrict__ cand_n,
+                                                   const GsMedian* __restrict__ cand, const uint32_t* __restrict__ cand_blk,
+                                                   uint32_t* __restrict__ cl, uint32_t* __restrict__ clp, GsMedian* __restrict__ median,
+                                                   SsnSeg* __restrict__ out, uint32_t* __restrict__ sig_out,
+                                                   uint32_t* __restrict__ cand_n_next, uint2* __restrict__ rng_next,
+                                                   uint32_t* __restrict__ err) {
+  __shared__ GsMedian lc[kGsCandCap];    // 32 KB
+  __shared__ uint32_t med_slot;
+  __shared__ uint32_t sh[8];
+  const uint32_t s = blockIdx.x;
+  const GsSegBlocks q = sblk[s];
+  const uint32_t n = cand_n[s];
+  const uint32_t left = q.count - q.count / 2u;
+  uint32_t mb1, below1, mb2, below2;
+  gs_find_bin(gh1 + (size_t)s * 256u, left, sh, mb1, below1);
+  gs_find_bin(gh2 + (size_t)s * 256u, left - below1, sh, mb2, below2);
+  const uint32_t target = left - below1 - below2;    // rank of the median among the candidates
+  // the children's histograms for the next level (this segment's own have been read by every kernel that needs them)
+  gh1_next[(size_t)(2u * s) * 256u + threadIdx.x] = 0u; gh1_next[(size_t)(2u * s + 1u) * 256u + threadIdx.x] = 0u;
+  gh2_next[(size_t)(2u * s) * 256u + threadIdx.x] = 0u; gh2_next[(size_t)(2u * s + 1u) * 256u + threadIdx.x] = 0u;
+  if (threadIdx.x == 0) {
+    med_slot = 0xFFFFFFFFu;
+    cand_n_next[2u * s] = 0u; cand_n_next[2u * s + 1u] = 0u;
+    rng_next[2u * s] = make_uint2(0xFFFFFFFFu, 0u); rng_next[2u * s + 1u] = make_uint2(0xFFFFFFFFu, 0u);   // (k_gs_part fills them)
+    if (n > kGsCandCap || target >= n || mb1 == 0xFFFFFFFFu || mb2 == 0xFFFFFFFFu) { err[0] = 1u; err[1] = 3u; err[2] = s; err[3] = n; err[4] = target; }   // too many equal keys around the median: the host falls back
+  }
+  const uint32_t c = min(n, kGsCandCap);
+  for (uint32_t i = threadIdx.x; i < c; i += 256u) lc[i] = cand[(size_t)s * kGsCandCap + i];
+  __syncthreads();
+  for (uint32_t i = threadIdx.x; i < c; i += 256u) {
+    const GsMedian me = lc[i];
+    uint32_t r = 0u;
+    for (uint32_t j = 0; j < c; ++j) {
+      const GsMedian o = lc[j];
+      r += gs_less(o.ka, o.k1, o.k2, o.e, me) ? 1u : 0u;
+    }
+    if (r < target) atomicAdd(&cl[cand_blk[(size_t)s * kGsCandCap + i]], 1u);   // this candidate goes left
+    if (r == target) med_slot = i;
+  }
+  __threadfence();
+  __syncthreads();
+  // the blocks' left counts are complete: their exclusive prefix over the segment's blocks, for k_gs_part
+  {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    uint32_t carry = 0u;
+    for (uint32_t b0 = 0; b0 < q.nb; b0 += 256u) {
+      const uint32_t b = b0 + threadIdx.x;
+      const uint32_t v = b < q.nb ? __hip_atomic_load(&cl[q.fb + b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+      const uint32_t incl = wave_scan_incl_u32(v, lane);
+      if (lane == 63) sh[w] = incl;
+      __syncthreads();
+      uint32_t before = carry;
+      for (int ww = 0; ww < w; ++ww) before += sh[ww];
+      if (b < q.nb) clp[q.fb + b] = before + incl - v;
+      carry += sh[0] + sh[1] + sh[2] + sh[3];
+      __syncthreads();
+    }
+  }
+  if (threadIdx.x == 0 && med_slot != 0xFFFFFFFFu) {
+    const GsMedian m = lc[med_slot];
+    median[s] = m;
+    const SsnSeg sg = segs[s];
+    const int cut = ssn_cut_axis(sg);
+    SsnSeg a = sg, b = sg;
+    const float cutval = coord_of(p[m.e], cut);
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+      a.hi[d] = d == cut ? cutval : a.hi[d];
+      b.lo[d] = d == cut ? cutval : b.lo[d];
+    }
+    a.start = q.start; a.count = left;
+    b.start = q.start + left; b.count = q.count - left;
+    out[2u * s] = a; out[2u * s + 1u] = b;
+    const uint32_t sv = gs_sig_push(sig[s], (uint32_t)cut);
+    sig_out[2u * s] = sv; sig_out[2u * s + 1u] = sv;
+  }
+}
+
+// the stable partition: every point (and its three keys) to its child's range of the OUT buffers, left half first
+__global__ __launch_bounds__(256) void k_gs_part(const GsBlock* __restrict__ tab, const SsnSeg* __restrict__ segs,
+                                                 const uint32_t* __restrict__ sig, GsSet in, GsSet out,
+                                                 const GsMedian* __restrict__ median, const uint32_t* __restrict__ clp,
+                                                 const SsnSeg* __restrict__ segs_next, uint2* __restrict__ rng_next,
+                                                 uint32_t* __restrict__ err) {
+  __shared__ uint32_t ws[4];
+  __shared__ uint32_t rr[4][4];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const GsBlock sb = tab[blockIdx.x];
+  const SsnSeg sg = segs[sb.seg];
+  const int a = ssn_cut_axis(sg);
+  uint32_t x1, x2;
+  gs_other_axes(sig[sb.seg], (uint32_t)a, x1, x2);
+  const GsMedian m = median[sb.seg];
+  const uint32_t base_left = clp[blockIdx.x];     // left points of the segment's earlier blocks (k_gs_select)
+  const uint32_t left_total = sb.seg_count - sb.seg_count / 2u;
+  const uint32_t base_right = (sb.first - sb.seg_start) - base_left;
+  // wave w owns 1024 consecutive positions of the block, 64 at a time: stable ranks need positions in order
+  uint32_t ev[kGsItems], kx[kGsItems], ky[kGsItems], kz[kGsItems], xl[kGsItems];
+  uint32_t carry = 0u;
+  // the children's own cut axes (k_gs_select has written their boxes): the key range of either child's points on it
+  const int aL = ssn_cut_axis(segs_next[2u * sb.seg]), aR = ssn_cut_axis(segs_next[2u * sb.seg + 1u]);
+  uint32_t mnL = 0xFFFFFFFFu, mxL = 0u, mnR = 0xFFFFFFFFu, mxR = 0u;
+#pragma unroll
+  for (int k = 0; k < kGsItems; ++k) {
+    const uint32_t j = (uint32_t)(w * (64 * kGsItems) + k * 64 + lane);
+    uint32_t v = 0u;
+    ev[k] = kx[k] = ky[k] = kz[k] = 0u;
+    if (j < sb.count) {
+      const uint32_t i = sb.first + j;
+      ev[k] = in.e[i]; kx[k] = in.k[0][i]; ky[k] = in.k[1][i]; kz[k] = in.k[2][i];
+      const uint32_t ka = a == 0 ? kx[k] : a == 1 ? ky[k] : kz[k];
+      const uint32_t k1 = x1 == kGsNoAxis ? 0u : x1 == 0u ? kx[k] : x1 == 1u ? ky[k] : kz[k];
+      const uint32_t k2 = x2 == kGsNoAxis ? 0u : x2 == 0u ? kx[k] : x2 == 1u ? ky[k] : kz[k];
+      v = gs_less(ka, k1, k2, ev[k], m) ? 1u : 0u;
+      if (v) { const uint32_t kc = aL == 0 ? kx[k] : aL == 1 ? ky[k] : kz[k]; mnL = min(mnL, kc); mxL = max(mxL, kc); }
+      else   { const uint32_t kc = aR == 0 ? kx[k] : aR == 1 ? ky[k] : kz[k]; mnR = min(mnR, kc); mxR = max(mxR, kc); }
+    }
+    const uint32_t incl = tree_wave_scan(v, lane);
+    xl[k] = ((carry + incl - v) << 1) | v;      // left points in front of this one inside the wave's range; its own side
+    carry += rl_u(incl, 63);
+  }
+  __syncthreads();
+  mnL = ~wave_max_u32(~mnL); mxL = wave_max_u32(mxL); mnR = ~wave_max_u32(~mnR); mxR = wave_max_u32(mxR);
+  if (lane == 0) { ws[w] = carry; rr[w][0] = mnL; rr[w][1] = mxL; rr[w][2] = mnR; rr[w][3] = mxR; }
+  __syncthreads();
+  if (threadIdx.x < 4) {
+    // (an atomic only where this block improves on what it can see of the range so far: hundreds of blocks of one segment
+    // on the same four words serialise in the L2 otherwise; a stale look costs an atomic that changes nothing)
+    const int q = (int)threadIdx.x;
+    const bool is_min = (q & 1) == 0;
+    const uint32_t v = is_min ? min(min(rr[0][q], rr[1][q]), min(rr[2][q], rr[3][q])) : max(max(rr[0][q], rr[1][q]), max(rr[2][q], rr[3][q]));
+    uint32_t* word = reinterpret_cast<uint32_t*>(&rng_next[2u * sb.seg + (uint32_t)(q >> 1)]) + (q & 1);
+    const uint32_t seen = __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (is_min ? v < seen : v > seen) { if (is_min) atomicMin(word, v); else atomicMax(word, v); }
+  }
+  uint32_t before = 0u;
+  for (int ww = 0; ww < w; ++ww) before += ws[ww];
+#pragma unroll
+  for (int k = 0; k < kGsItems; ++k) {
+    const uint32_t j = (uint32_t)(w * (64 * kGsItems) + k * 64 + lane);
+    if (j < sb.count) {
+      const uint32_t lbefore = before + (xl[k] >> 1);            // left points of this block in front of j
+      const uint32_t dst = (xl[k] & 1u) ? sb.seg_start + base_left + lbefore
+                                        : sb.seg_start + left_total + base_right + (j - lbefore);
+      uint32_t d = dst;
+      if (d - sb.seg_start >= sb.seg_count) {   // (only behind an error the earlier kernels have flagged: stay inside the segment, the
+        err[0] = 1u; err[5] = 4u; err[6] = sb.seg; err[7] = dst;   //  host repeats the filter, the kernels queued behind this one must find valid ids)
+        d = sb.seg_start + (d - sb.seg_start) % sb.seg_count;
+      }
+      out.e[d] = ev[k]; out.k[0][d] = kx[k]; out.k[1][d] = ky[k]; out.k[2][d] = kz[k];
+    }
+  }
+}
+
+}  // namespace lsgpu

@@ -85,7 +85,8 @@ template <int B>
 __global__ __launch_bounds__(B / 8) void k_ssn_tree(const float4* __restrict__ p, uint32_t* __restrict__ idx,
                                                     const SsnSeg* __restrict__ segs, int knn, int rem,
                                                     uint32_t* __restrict__ seg_of, SsnSeg* __restrict__ segs_out,
-                                                    const int* __restrict__ root_axis /* nullable */) {
+                                                    const int* __restrict__ root_axis /* nullable */,
+                                                    const uint32_t* __restrict__ root_sig /* nullable */) {
   using Lds = SsnTreeLds<B>;
   constexpr int T = Lds::T, W = Lds::W;
   __shared__ Lds L;
@@ -261,6 +262,54 @@ __global__ __launch_bounds__(B / 8) void k_ssn_tree(const float4* __restrict__ p
     L.u.tree.box[0] = b0;
   }
   __syncthreads();
+  // ---- the initial order.  Roots that come from the sort-free upper levels (lsgpu_ssn_select.hip.h) arrive as SETS in
+  // original-index order with a signature: the axes they were cut along, most recent first.  Their current order -- what
+  // the chain of stable sorts would have left -- is (key on the signature's first axis, on its second, on its third, index):
+  // the list of the first axis is that order up to its tie runs, which are put right here by the same comparator (dense
+  // ranks stand in for the keys); cur_pos is taken from it and the levels below carry on as for any other segment.
+  const uint32_t rsig = root_sig ? root_sig[blockIdx.x] : 0xFFFFFFFFu;
+  const uint32_t ro1 = rsig & 0xFFu, ro2 = (rsig >> 8) & 0xFFu, ro3 = (rsig >> 16) & 0xFFu;
+  if (ro1 < 3u) {     // (the same for every thread of the workgroup)
+    uint16_t* la = L.list[ro1];
+    const uint16_t* ra = L.rank[ro1];
+    const uint16_t* r2 = L.rank[ro2 < 3u ? ro2 : 0u];
+    const uint16_t* r3 = L.rank[ro3 < 3u ? ro3 : 0u];
+    uint32_t ek[8], np[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int i = w * 512 + k * 64 + lane;
+      ek[k] = 0u; np[k] = (uint32_t)i;
+      const bool act = i < cnt;
+      if (act) ek[k] = la[i];
+      const uint32_t r = act ? (uint32_t)ra[ek[k]] : 0xFFFFFFFFu;
+      uint32_t rp = tree_lane_prev(r), rn = tree_lane_next(r);
+      if (lane == 0 && act && i > 0) rp = ra[la[i - 1]];
+      if (lane == 63 && act && i + 1 < cnt) rn = ra[la[i + 1]];
+      if (act && ((i > 0 && rp == r) || (i + 1 < cnt && rn == r))) {
+        int lo = i, hi = i + 1;
+        while (lo > 0 && ra[la[lo - 1]] == r) --lo;
+        while (hi < cnt && ra[la[hi]] == r) ++hi;
+        const uint32_t e = ek[k];
+        const uint32_t e2 = ro2 < 3u ? (uint32_t)r2[e] : 0u, e3 = ro3 < 3u ? (uint32_t)r3[e] : 0u;
+        uint32_t c = 0u;
+        for (int j = lo; j < hi; ++j) {
+          const uint32_t f = la[j];
+          const uint32_t f2 = ro2 < 3u ? (uint32_t)r2[f] : 0u, f3 = ro3 < 3u ? (uint32_t)r3[f] : 0u;
+          const bool less = f2 != e2 ? f2 < e2 : f3 != e3 ? f3 < e3 : f < e;
+          c += less ? 1u : 0u;
+        }
+        np[k] = (uint32_t)lo + c;
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int i = w * 512 + k * 64 + lane;
+      if (i < cnt) { la[np[k]] = (uint16_t)ek[k]; L.u.tree.cur_pos[ek[k]] = (uint16_t)np[k]; }
+    }
+    if (tid == 0) L.seg[0].ord = (uint8_t)ro1;
+    __syncthreads();
+  }
   const uint32_t base_seg = (uint32_t)blockIdx.x << rem;
   for (int l = 0; l < rem; ++l) {
     const int ns = 1 << l;

@@ -33,6 +33,8 @@
 //   LSGPU_SORT_ITEMS         0  keys per thread of the radix passes (0: by size; 4, 8, 16)
 //   LSGPU_SSN_FULL_SORT         the reference filter's levels as whole-cloud sorts by (segment, coordinate) (rounds 1-3) instead of segmented sorts
 //   LSGPU_SSN_GLOBAL            every level of the reference filter as a global sort (no in-LDS finish)
+//   LSGPU_SSN_SORT_LEVELS       the upper levels of the reference filter with a segmented sort per level (round 4, lsgpu_segsort.hip.h) instead of
+//                               the sort-free levels of lsgpu_ssn_select.hip.h (exact median by selection + one stable partition)
 //   LSGPU_SSN_OLD_FINISH        the last levels with k_ssn_finish (rounds 2-4: 2048 points per workgroup, a radix sort per level) instead of
 //                               k_ssn_tree (presorted axes, a stable partition per level)
 //   LSGPU_SSN_ROOT        8192  points per workgroup of k_ssn_tree (2048, 4096, 8192)
@@ -53,9 +55,8 @@
 // Experiment switches, compiled in only with -DLSGPU_EXPERIMENTS (measured-slower variants kept as the record of what was
 // tried: DESIGN.md "Rejected after measurement"); the product build reports them as unknown:
 //   LSGPU_KNN_ROWS (0/1/2), LSGPU_KNN_LANE, LSGPU_SPARSE_LANES, LSGPU_TILE_WAVES (1/4), LSGPU_XCD_SWIZZLE,
-//   LSGPU_ROCPRIM_SORT (rocPRIM's radix sort instead of lsgpu_sort.hip.h: the library sort as a cross-check),
-//   LSGPU_SSN_PRESORTED_LEVELS (the reference filter's upper levels from three presorted axes, lsgpu_ssn_levels.hip.h:
-//   1.22 ms against 1.03 for a 1 M-point scan, 2.75 against 1.98 for 3.1 M, round 5)
+//   LSGPU_ROCPRIM_SORT (rocPRIM's radix sort instead of lsgpu_sort.hip.h: the library sort as a cross-check)
+
 #pragma once
 #include <cstdio>
 #include <cstdlib>
@@ -86,6 +87,7 @@ struct Tuning {
   bool ssn_global = false;
   bool ssn_full_sort = false;
   bool ssn_old_finish = false;
+  bool ssn_sort_levels = false;
   int ssn_root = 8192;
   int ne_blocks = 256;
   bool split_update = false;
@@ -103,7 +105,6 @@ struct Tuning {
   int sparse_lanes = 0;
   int tile_waves = 1;
   int xcd_swizzle = 0;
-  bool ssn_presorted_levels = false;
   bool rocprim_sort = false;
 #endif
 };
@@ -154,6 +155,7 @@ inline Tuning read() {
   t.ssn_global = flag("LSGPU_SSN_GLOBAL");
   t.ssn_full_sort = flag("LSGPU_SSN_FULL_SORT");
   t.ssn_old_finish = flag("LSGPU_SSN_OLD_FINISH");
+  t.ssn_sort_levels = flag("LSGPU_SSN_SORT_LEVELS");
   t.ssn_root = (int)number("LSGPU_SSN_ROOT", 8192, 2048, 8192);
   if (t.ssn_root != 2048 && t.ssn_root != 4096 && t.ssn_root != 8192) {
     fprintf(stderr, "liblsgpu_icp: LSGPU_SSN_ROOT must be 2048, 4096 or 8192; using 8192\n");
@@ -173,12 +175,12 @@ inline Tuning read() {
   static const char* known[] = {"LSGPU_QUERY_ORDER", "LSGPU_Q_ELEV", "LSGPU_Q_SECT", "LSGPU_GAP", "LSGPU_BUDGET", "LSGPU_BUDGET_WIDE", "LSGPU_WIDE_ITERS",
                                 "LSGPU_ROUTE_R", "LSGPU_ROUTE_CHUNKS", "LSGPU_ROUTE_DENSE", "LSGPU_SPLIT_UPDATE", "LSGPU_NO_PREDICT", "LSGPU_NO_COMMIT",
                                 "LSGPU_NO_COMM_COMMIT", "LSGPU_NO_SEED_CAP", "LSGPU_NO_FRONT", "LSGPU_NO_LAZY", "LSGPU_NO_SIDE_STREAM", "LSGPU_NO_LOOKAHEAD", "LSGPU_FRONT_GUESS", "LSGPU_NO_ROUTE_ALL",
-                                "LSGPU_NO_ROWQ", "LSGPU_ROWQ_BLOCKS", "LSGPU_SORT_ITEMS", "LSGPU_SSN_GLOBAL", "LSGPU_SSN_FULL_SORT", "LSGPU_SSN_OLD_FINISH", "LSGPU_SSN_ROOT",
+                                "LSGPU_NO_ROWQ", "LSGPU_ROWQ_BLOCKS", "LSGPU_SORT_ITEMS", "LSGPU_SSN_GLOBAL", "LSGPU_SSN_FULL_SORT", "LSGPU_SSN_OLD_FINISH", "LSGPU_SSN_ROOT", "LSGPU_SSN_SORT_LEVELS",
                                 "LSGPU_NE_BLOCKS", "LSGPU_COMM_TIMEOUT_MS", "LSGPU_KNN_DBG", "LSGPU_NO_CONE", "LSGPU_NO_CONE_PROBE", "LSGPU_CONE_ROWS", "LSGPU_CONE_COLS", "LSGPU_CONE_FROM", "LSGPU_CONE_MAX_OCC", "LSGPU_CONE_HEAVY_STEPS", "LSGPU_CONE_HEAVY_SHARE",
                                 // read by the Python / C++ hosts and the test drivers, not by this library:
-                                "LSGPU_SO", "LSGPU_STATS_SO", "LSGPU_GOLDEN_DIR", "LSGPU_SEQ_PERTURB", "LSGPU_SEQ_POSES", "LSGPU_TEST_INPUT_FILTERS",
+                                "LSGPU_SO", "LSGPU_STATS_SO", "LSGPU_GS_DEBUG", "LSGPU_GOLDEN_DIR", "LSGPU_SEQ_PERTURB", "LSGPU_SEQ_POSES", "LSGPU_TEST_INPUT_FILTERS",
 #ifdef LSGPU_EXPERIMENTS
-                                "LSGPU_KNN_ROWS", "LSGPU_KNN_LANE", "LSGPU_SPARSE_LANES", "LSGPU_TILE_WAVES", "LSGPU_XCD_SWIZZLE", "LSGPU_SSN_PRESORTED_LEVELS", "LSGPU_ROCPRIM_SORT",
+                                "LSGPU_KNN_ROWS", "LSGPU_KNN_LANE", "LSGPU_SPARSE_LANES", "LSGPU_TILE_WAVES", "LSGPU_XCD_SWIZZLE", "LSGPU_ROCPRIM_SORT",
 #endif
                                 nullptr};
 #ifdef LSGPU_EXPERIMENTS
@@ -187,7 +189,6 @@ inline Tuning read() {
   t.sparse_lanes = (int)number("LSGPU_SPARSE_LANES", 0, 0, 64);
   t.tile_waves = (int)number("LSGPU_TILE_WAVES", 1, 1, 4) == 4 ? 4 : 1;
   t.xcd_swizzle = (int)number("LSGPU_XCD_SWIZZLE", 0, 0, 1 << 16);
-  t.ssn_presorted_levels = flag("LSGPU_SSN_PRESORTED_LEVELS");
   t.rocprim_sort = flag("LSGPU_ROCPRIM_SORT");
   // the front rows only exist in the one-wave tile kernel; the row-wise experiment does not fill the window table
   if (t.knn_lane || t.knn_rows != 0 || t.tile_waves == 4 || t.sparse_lanes != 0) t.front = false;

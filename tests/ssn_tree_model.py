@@ -99,58 +99,112 @@ def presorted_lists(pts, knn, lo, hi):
     return leaves
 
 
-def presorted_lists_signature(pts, knn, lo, hi):
-    """lsgpu_ssn_levels.hip.h (upper levels, global memory): the same scheme WITHOUT cur_pos -- the members of a tie run
-    of the cut axis are ordered by comparing their keys on the axes the segment was cut along before, most recent first,
-    then their original index (the "signature" of the segment's current order); the partition's side flag comes from the
-    position in the cut axis' list.  Returns the leaves like presorted_lists."""
+def select_then_tree(pts, knn, lo, hi, root_size):
+    """Round 5, lsgpu_ssn_select.hip.h + k_ssn_tree: the UPPER levels keep no order at all.  A segment is a SET of points
+    (kept in original-index order by stable partitions) with a signature -- the axes it was cut along, most recent first --
+    and is halved at the median of the total order  (key on the cut axis, keys on the signature's other axes in order,
+    original index),  which is exactly the order the chain of stable sorts would have put it in.  Once a segment holds
+    <= root_size points it goes to the workgroup kernel: local ids in arrival (= original-index) order, three lists
+    presorted by (key, local id); the list of the signature's first axis is put into the segment's current order by the
+    same comparator (one fix-up of its tie runs), cur_pos is taken from it, and the levels run as in presorted_lists."""
     n = len(pts)
     keys = [order_key(pts[:, d]) for d in range(3)]
-    lists = [np.argsort(keys[d], kind="stable") for d in range(3)]
-    segs = [dict(start=0, count=n, lo=lo.copy(), hi=hi.copy(), sig=[])]
-    while any(s["count"] > knn for s in segs):
-        new = []
-        side = np.zeros(n, bool)
-        for s in segs:
-            st, c = s["start"], s["count"]
-            if c <= knn:
-                new += [s, dict(start=st + c, count=0, lo=s["lo"], hi=s["hi"], sig=s["sig"])]
-                continue
-            a = cut_axis(s["lo"], s["hi"])
-            la = lists[a]
-            sig = s["sig"]
-            if sig and sig[0] != a:
-                others = [x for x in sig if x != a]
-                seg = la[st:st + c].copy()
-                out = seg.copy()
-                k = keys[a][seg]
-                cmpkey = lambda e: tuple(int(keys[x][e]) for x in others) + (int(e),)
-                for i in range(c):
-                    l, h = i, i + 1
-                    while l > 0 and k[l - 1] == k[i]:
-                        l -= 1
-                    while h < c and k[h] == k[i]:
-                        h += 1
-                    if h - l > 1:
-                        out[l + sum(1 for j in range(l, h) if cmpkey(seg[j]) < cmpkey(seg[i]))] = seg[i]
-                la[st:st + c] = out
-            left = c - c // 2
-            side[la[st + left:st + c]] = True
-            for d in range(3):
-                if d != a:
-                    seg = lists[d][st:st + c]
-                    f = side[seg]
-                    lists[d][st:st + c] = np.concatenate([seg[~f], seg[f]])
-            cutval = pts[la[st + left], a]
-            hi2, lo2 = s["hi"].copy(), s["lo"].copy()
-            hi2[a] = cutval
-            lo2[a] = cutval
-            nsig = [a] + [x for x in sig if x != a]
-            new += [dict(start=st, count=left, lo=s["lo"], hi=hi2, sig=nsig), dict(start=st + left, count=c - left, lo=lo2, hi=s["hi"], sig=nsig)]
-        segs = new
     leaves = []
-    for s in segs:
-        if s["count"]:
-            st, c = s["start"], s["count"]
-            leaves.append(np.arange(st, st + c) if not s["sig"] else lists[s["sig"][0]][st:st + c].copy())
+
+    def tuple_of(e, a, sig):
+        others = [x for x in sig if x != a]
+        return (int(keys[a][e]),) + tuple(int(keys[x][e]) for x in others) + (int(e),)
+
+    def tree(ids, lo, hi, sig):
+        """k_ssn_tree on one root: ids in original-index order."""
+        m = len(ids)
+        k = [keys[d][ids] for d in range(3)]
+        lists = [np.argsort(k[d], kind="stable") for d in range(3)]          # local ids, ties by local id
+        rank = []
+        for d in range(3):
+            ks = k[d][lists[d]]
+            r = np.empty(m, np.int64)
+            r[lists[d]] = np.cumsum(np.concatenate([[0], (ks[1:] != ks[:-1]).astype(np.int64)]))
+            rank.append(r)
+        cur_pos = np.arange(m)
+        root_ord = -1
+        if sig:   # the initial fix-up: list[sig[0]] into the root's current order
+            o1 = sig[0]
+            others = [x for x in sig if x != o1]
+            l1 = lists[o1]
+            out = l1.copy()
+            r = rank[o1][l1]
+            ck = lambda e: tuple(int(rank[x][e]) for x in others) + (int(e),)
+            for i in range(m):
+                a0, b0 = i, i + 1
+                while a0 > 0 and r[a0 - 1] == r[i]:
+                    a0 -= 1
+                while b0 < m and r[b0] == r[i]:
+                    b0 += 1
+                if b0 - a0 > 1:
+                    out[a0 + sum(1 for j in range(a0, b0) if ck(l1[j]) < ck(l1[i]))] = l1[i]
+            lists[o1] = out
+            cur_pos[out] = np.arange(m)
+            root_ord = o1
+        segs = [dict(start=0, count=m, lo=lo.copy(), hi=hi.copy(), ord=root_ord)]
+        while any(s["count"] > knn for s in segs):
+            new = []
+            for s in segs:
+                st, c = s["start"], s["count"]
+                if c <= knn:
+                    new += [s, dict(start=st + c, count=0, lo=s["lo"], hi=s["hi"], ord=s["ord"])]
+                    continue
+                a = cut_axis(s["lo"], s["hi"])
+                la = lists[a]
+                if s["ord"] != -1 and s["ord"] != a:
+                    seg = la[st:st + c].copy()
+                    out = seg.copy()
+                    r = rank[a][seg]
+                    for i in range(c):
+                        a0, b0 = i, i + 1
+                        while a0 > 0 and r[a0 - 1] == r[i]:
+                            a0 -= 1
+                        while b0 < c and r[b0] == r[i]:
+                            b0 += 1
+                        if b0 - a0 > 1:
+                            out[a0 + sum(1 for j in range(a0, b0) if cur_pos[seg[j]] < cur_pos[seg[i]])] = seg[i]
+                    la[st:st + c] = out
+                cur_pos[la[st:st + c]] = np.arange(st, st + c)
+                left = c - c // 2
+                for d in range(3):
+                    if d != a:
+                        seg = lists[d][st:st + c]
+                        f = cur_pos[seg] - st >= left
+                        lists[d][st:st + c] = np.concatenate([seg[~f], seg[f]])
+                cutval = pts[ids[la[st + left]], a]
+                hi2, lo2 = s["hi"].copy(), s["lo"].copy()
+                hi2[a] = cutval
+                lo2[a] = cutval
+                new += [dict(start=st, count=left, lo=s["lo"], hi=hi2, ord=a), dict(start=st + left, count=c - left, lo=lo2, hi=s["hi"], ord=a)]
+            segs = new
+        for s in segs:
+            if s["count"]:
+                st, c = s["start"], s["count"]
+                loc = np.arange(st, st + c) if s["ord"] == -1 else lists[s["ord"]][st:st + c]
+                leaves.append(ids[loc])
+
+    def upper(ids, lo, hi, sig):
+        c = len(ids)
+        if c <= root_size or c <= knn:
+            tree(ids, lo, hi, sig)
+            return
+        a = cut_axis(lo, hi)
+        left = c - c // 2
+        order = sorted(ids.tolist(), key=lambda e: tuple_of(e, a, sig))   # (the device SELECTS the median of this order)
+        median = tuple_of(order[left], a, sig)
+        side = np.array([tuple_of(e, a, sig) >= median for e in ids])
+        cutval = pts[order[left], a]
+        hi2, lo2 = hi.copy(), lo.copy()
+        hi2[a] = cutval
+        lo2[a] = cutval
+        nsig = [a] + [x for x in sig if x != a]
+        upper(ids[~side], lo, hi2, nsig)       # stable: original-index order kept
+        upper(ids[side], lo2, hi, nsig)
+
+    upper(np.arange(n), lo.copy(), hi.copy(), [])
     return leaves

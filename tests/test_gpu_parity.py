@@ -354,6 +354,7 @@ def test_experiment_switches_do_not_change_results():
                 {"LSGPU_SORT_ITEMS": "4"}, {"LSGPU_NO_SEED_CAP": "1"}, {"LSGPU_NO_LAZY": "1"}, {"LSGPU_NO_SIDE_STREAM": "1"}, {"LSGPU_NO_LOOKAHEAD": "1"},
                 dict(tile, LSGPU_FRONT_GUESS="8"), {"LSGPU_SSN_GLOBAL": "1"}, {"LSGPU_SSN_FULL_SORT": "1"}, {"LSGPU_SSN_FULL_SORT": "1", "LSGPU_SSN_GLOBAL": "1"},
                 {"LSGPU_SSN_OLD_FINISH": "1"}, {"LSGPU_SSN_ROOT": "2048"}, {"LSGPU_SSN_ROOT": "4096"},   # k_ssn_finish / smaller roots of k_ssn_tree
+                {"LSGPU_SSN_SORT_LEVELS": "1"}, {"LSGPU_SSN_SORT_LEVELS": "1", "LSGPU_SSN_OLD_FINISH": "1"},   # a segmented sort per upper level (round 4) / all of round 4's filter
                 {"LSGPU_QUERY_ORDER": "0"}]
     # the measured-slower variants only exist in the -DLSGPU_EXPERIMENTS build (devtools/build.sh); when that build is
     # around it has to give the same bits as the product, switch by switch
@@ -364,7 +365,6 @@ def test_experiment_switches_do_not_change_results():
     if os.path.exists(exp_so) and os.path.getmtime(exp_so) >= os.path.getmtime(os.path.join(ROOT, "laser_slam_amd", "liblsgpu_icp.so")) - 600:   # (a stale build says nothing)
         variants += [dict(v, LSGPU_SO=exp_so) for v in ({}, dict(tile, LSGPU_KNN_ROWS="1"), dict(tile, LSGPU_TILE_WAVES="4"),
                                                         dict(tile, LSGPU_NO_FRONT="1", LSGPU_SPARSE_LANES="16"),
-                                                        {"LSGPU_SSN_PRESORTED_LEVELS": "1"},   # (the filter's upper levels from presorted axes)
                                                         {"LSGPU_ROCPRIM_SORT": "1"})]          # (the library sort as a cross-check of lsgpu_sort.hip.h)
     results = []
     for env_add in variants:
@@ -667,7 +667,8 @@ def test_device_reference_filter_edge_cases(icp_mod, oracle):
         grid[:, :3] = (np.round(rng.normal(size=(40000, 3)) * np.array([40.0, 25.0, 6.0])) / 4).astype(np.float32)
         # ... and one constant axis on top (a sheet): every cut alternates between the two others
         sheet = grid[:20000].copy(); sheet[:, 2] = np.float32(1.5)
-        # few distinct values along the two widest axes: runs of thousands of equal coordinates at the upper levels
+        # few distinct values along the two widest axes: thousands of equal coordinates around the upper levels' medians -- more
+        # than the sort-free levels select among (kGsCandCap): the filter falls back to the segmented sorts, same output
         coarse = np.ones((40000, 4), np.float32)
         coarse[:, 0] = 10.0 * rng.integers(0, 8, size=40000); coarse[:, 1] = 8.0 * rng.integers(0, 4, size=40000)
         coarse[:, 2] = rng.normal(size=40000)

@@ -383,9 +383,10 @@ def test_surface_normal_filter_boxes_against_a_numpy_recursion(oracle):
 
 def test_presorted_lists_equal_the_chain_of_stable_sorts():
     """k_ssn_tree (csrc/lsgpu_ssn_tree.hip.h) builds the filter's lower levels from three presorted axes and stable
-    partitions instead of a sort per level.  Its scheme, modelled step for step in tests/ssn_tree_model.py, must give the
-    leaves of the restatement's chain of stable sorts -- also where equal coordinates make the stable order matter (grids
-    of few values, a constant axis, duplicates)."""
+    partitions instead of a sort per level; the upper levels (csrc/lsgpu_ssn_select.hip.h) keep no order at all -- sets with
+    a signature, halved at the exact median of the order the chain of stable sorts would have left.  Both schemes, modelled
+    step for step in tests/ssn_tree_model.py, must give the leaves of the restatement's chain of stable sorts -- also where
+    equal coordinates make the stable order matter (grids of few values, a constant axis, duplicates)."""
     import ssn_tree_model as M
     rng = np.random.default_rng(1)
     for trial in range(240):
@@ -406,8 +407,9 @@ def test_presorted_lists_equal_the_chain_of_stable_sorts():
         a, b = M.chain_of_stable_sorts(pts, knn, lo, hi), M.presorted_lists(pts, knn, lo, hi)
         assert len(a) == len(b), trial
         assert all(np.array_equal(x, y) for x, y in zip(a, b)), trial
-        c = M.presorted_lists_signature(pts, knn, lo, hi)      # the upper levels' variant (no cur_pos: tie runs by signature)
-        assert len(a) == len(c) and all(np.array_equal(x, y) for x, y in zip(a, c)), trial
+        for root in (16, 64):      # the sort-free upper levels down to roots of this size, k_ssn_tree's scheme below (select_then_tree)
+            c = M.select_then_tree(pts, knn, lo, hi, root)
+            assert len(a) == len(c) and all(np.array_equal(x, y) for x, y in zip(a, c)), (trial, root)
 
 
 def _check_boxes_against_recursion(pts, boxes, out, nrm):
