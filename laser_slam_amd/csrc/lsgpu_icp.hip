@@ -118,6 +118,20 @@ bool is_device_ptr(const void* p) {
   return a.type == hipMemoryTypeDevice || a.type == hipMemoryTypeManaged;
 }
 
+// A few words for the host, in ONE launch: the kernel stores into the pinned (host-coherent, device-mapped) staging words
+// themselves.  (Each hipMemcpyAsync of four bytes is a 4 - 5 us slot of its own on the stream: four of them behind the
+// reference filter, three behind the cell counts -- on chains of 0.8 and 0.25 ms.)
+struct ToHost { const uint32_t* src[6]; uint32_t* dst[6]; uint32_t n[6]; };
+__global__ __launch_bounds__(64) void k_to_host(ToHost c) {
+#pragma unroll
+  for (int e = 0; e < 6; ++e)
+    for (uint32_t i = threadIdx.x; i < c.n[e]; i += 64u) c.dst[e][i] = c.src[e][i];
+}
+static void to_host_add(ToHost* c, int* used, const void* src, void* dst, size_t bytes) {
+  c->src[*used] = static_cast<const uint32_t*>(src); c->dst[*used] = static_cast<uint32_t*>(dst); c->n[*used] = (uint32_t)(bytes / 4);
+  ++*used;
+}
+
 // (Uploading a PINNED cloud with a copy kernel over its device mapping instead of hipMemcpyAsync was measured slower:
 // 5.93 vs 5.48 ms per 1 M-point compute from host buffers; what had made the pinned path the slower one was two copies
 // sharing the link -- lsgpu_icp_compute now queues the reading's copy behind the reference's.)
@@ -249,7 +263,7 @@ struct lsgpu_icp {
   DevBuf<int> ssn_axis_a, ssn_axis_b;       // per segment: the axis its current order follows (segmented level sorts)
   DevBuf<uint32_t> ssn_seg_fb;
   DevBuf<SegBlock> ssn_blocktab;
-  DevBuf<uint32_t> ssn_seg_of, ssn_box_pts, ssn_box_base, ssn_keep, ssn_out_pos, ssn_bb;
+  DevBuf<uint32_t> ssn_seg_of, ssn_box_pts, ssn_box_base, ssn_keep, ssn_out_pos, ssn_bb, ssn_bounds_ws;
   DevBuf<float> ssn_box_normal, ssn_draws;
   // sort-free upper levels of the reference filter (lsgpu_ssn_select.hip.h)
   DevBuf<uint32_t> gs_e[2], gs_k[6];          // two buffer sets: points + their three ordered keys
@@ -440,7 +454,7 @@ void lsgpu_icp_destroy(lsgpu_icp* h) {
 #endif
   h->pts.release();
   h->cone_soa.release(); h->cone_occ.release(); h->cone_map.release(); h->cone_tab.release(); h->cone_rowz.release();
-  h->nrm.release(); h->ref_inv.release(); h->tables.release(); h->flags.release(); h->cidx.release(); h->bounds.release(); h->chunks.release(); h->chunk_groups.release(); h->soa.release(); h->soa_base.release(); h->soa_cnt4.release(); h->soa_first.release(); h->prev.release(); h->state.release(); h->lb.release(); h->cell_cache.release(); h->cell_tags.release(); h->ssn_seg_a.release(); h->ssn_seg_b.release(); h->ssn_axis_a.release(); h->ssn_axis_b.release(); h->ssn_seg_fb.release(); h->ssn_blocktab.release(); h->ssn_seg_of.release(); h->ssn_box_pts.release(); h->ssn_box_base.release(); h->ssn_keep.release(); h->ssn_out_pos.release(); h->ssn_bb.release(); h->ssn_box_normal.release(); h->ssn_draws.release(); h->flt_in.release(); h->flt_in2.release(); h->flt_ref.release(); h->flt_rd.release(); h->flt_nrm.release(); h->chk_hist.release(); h->trace_dev.release(); h->knn_dbg.release(); h->knn_dbg_wave.release(); h->stat_partials.release(); h->geom.release();
+  h->nrm.release(); h->ref_inv.release(); h->tables.release(); h->flags.release(); h->cidx.release(); h->bounds.release(); h->chunks.release(); h->chunk_groups.release(); h->soa.release(); h->soa_base.release(); h->soa_cnt4.release(); h->soa_first.release(); h->prev.release(); h->state.release(); h->lb.release(); h->cell_cache.release(); h->cell_tags.release(); h->ssn_seg_a.release(); h->ssn_seg_b.release(); h->ssn_axis_a.release(); h->ssn_axis_b.release(); h->ssn_seg_fb.release(); h->ssn_blocktab.release(); h->ssn_seg_of.release(); h->ssn_box_pts.release(); h->ssn_box_base.release(); h->ssn_keep.release(); h->ssn_out_pos.release(); h->ssn_bb.release(); h->ssn_bounds_ws.release(); h->ssn_box_normal.release(); h->ssn_draws.release(); h->flt_in.release(); h->flt_in2.release(); h->flt_ref.release(); h->flt_rd.release(); h->flt_nrm.release(); h->chk_hist.release(); h->trace_dev.release(); h->knn_dbg.release(); h->knn_dbg_wave.release(); h->stat_partials.release(); h->geom.release();
   h->counters.release(); h->price_cnt.release(); h->ang_cells.release(); h->sel_aux.release(); h->sel_win.release(); h->spread_flag.release(); h->spread_list.release(); h->spread_cnt.release(); h->q_in.release(); h->rdq.release(); h->ids.release(); h->d2.release();
   h->ids_io.release(); h->d2_io.release(); h->strag.release(); h->hist.release();
   h->sel.release(); h->ne_partials.release(); h->ne_gpartials.release(); h->ne_tickets.release(); h->ne_out.release(); h->limit_dev.release();
@@ -973,9 +987,15 @@ int lsgpu_icp_set_reference(lsgpu_icp* h, const float* ref_xyz1, const float* re
   uint32_t* hc = reinterpret_cast<uint32_t*>(h->h_pinned);
   GeomDev* hg = reinterpret_cast<GeomDev*>(h->h_pinned + 16);
   static_assert(sizeof(GeomDev) <= 16 * sizeof(double), "geometry staging");
-  HIPC(hipMemcpyAsync(hc, h->counters.p, kMaxLevels * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
-  HIPC(hipMemcpyAsync(hc + 20, h->cidx.p + (nr - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
-  HIPC(hipMemcpyAsync(hg, h->geom.p, sizeof(GeomDev), hipMemcpyDeviceToHost, h->stream));
+  {
+    static_assert(sizeof(GeomDev) % 4 == 0, "copied word by word");
+    ToHost c{}; int used = 0;
+    to_host_add(&c, &used, h->counters.p, hc, kMaxLevels * sizeof(uint32_t));
+    to_host_add(&c, &used, h->cidx.p + (nr - 1), hc + 20, sizeof(uint32_t));
+    to_host_add(&c, &used, h->geom.p, hg, sizeof(GeomDev));
+    hipLaunchKernelGGL(k_to_host, dim3(1), dim3(64), 0, h->stream, c);
+    HIPC(hipGetLastError());
+  }
   if (h->hook_before_ref_sync) {   // lsgpu_icp_compute: the reading's side of the work is enqueued on its own stream now
     rc = h->hook_before_ref_sync();
     if (rc) return rc;
@@ -1338,17 +1358,23 @@ struct DrawAhead {
   ~DrawAhead() { finish(); }
 };
 
-// totals of two exclusive scans (last scanned value + last input): four 4-byte copies behind the scans ...
+// totals of two exclusive scans (last scanned value + last input) -> four pinned words, behind the scans ...
+// (`extra`: up to two more ranges that travel with them)
 static int scan_totals_enqueue(lsgpu_icp* h, const uint32_t* in_a, const uint32_t* sc_a, size_t na,
-                               const uint32_t* in_b, const uint32_t* sc_b, size_t nb) {
+                               const uint32_t* in_b, const uint32_t* sc_b, size_t nb,
+                               const void* extra_src = nullptr, void* extra_dst = nullptr, size_t extra_bytes = 0) {
   uint32_t* hp = reinterpret_cast<uint32_t*>(h->h_pinned + 100 + 4 * h->side_totals_slot);
   hp[0] = hp[1] = hp[2] = hp[3] = 0;
+  ToHost c{}; int used = 0;
   if (in_a) {
-    HIPC(hipMemcpyAsync(hp, in_a + (na - 1), 4, hipMemcpyDeviceToHost, h->cur));
-    HIPC(hipMemcpyAsync(hp + 1, sc_a + (na - 1), 4, hipMemcpyDeviceToHost, h->cur));
+    to_host_add(&c, &used, in_a + (na - 1), hp, 4);
+    to_host_add(&c, &used, sc_a + (na - 1), hp + 1, 4);
   }
-  HIPC(hipMemcpyAsync(hp + 2, in_b + (nb - 1), 4, hipMemcpyDeviceToHost, h->cur));
-  HIPC(hipMemcpyAsync(hp + 3, sc_b + (nb - 1), 4, hipMemcpyDeviceToHost, h->cur));
+  to_host_add(&c, &used, in_b + (nb - 1), hp + 2, 4);
+  to_host_add(&c, &used, sc_b + (nb - 1), hp + 3, 4);
+  if (extra_src) to_host_add(&c, &used, extra_src, extra_dst, extra_bytes);
+  hipLaunchKernelGGL(k_to_host, dim3(1), dim3(64), 0, h->cur, c);
+  HIPC(hipGetLastError());
   return LSGPU_OK;
 }
 // ... and the host's wait for them (synchronises the current stream)
@@ -1360,8 +1386,9 @@ static int scan_totals_wait(lsgpu_icp* h, uint32_t* tot_a, uint32_t* tot_b) {
   return LSGPU_OK;
 }
 static int scan_totals(lsgpu_icp* h, const uint32_t* in_a, const uint32_t* sc_a, size_t na,
-                       const uint32_t* in_b, const uint32_t* sc_b, size_t nb, uint32_t* tot_a, uint32_t* tot_b) {
-  const int rc = scan_totals_enqueue(h, in_a, sc_a, na, in_b, sc_b, nb);
+                       const uint32_t* in_b, const uint32_t* sc_b, size_t nb, uint32_t* tot_a, uint32_t* tot_b,
+                       const void* extra_src = nullptr, void* extra_dst = nullptr, size_t extra_bytes = 0) {
+  const int rc = scan_totals_enqueue(h, in_a, sc_a, na, in_b, sc_b, nb, extra_src, extra_dst, extra_bytes);
   return rc ? rc : scan_totals_wait(h, tot_a, tot_b);
 }
 
@@ -1391,10 +1418,13 @@ static int ssn_device(lsgpu_icp* h, const float4* src, int64_t n, int knn, float
   HIPC(h->ssn_bb.reserve(8));
   HIPC(h->sc->keys.reserve(n));
   HIPC(h->sc->vals.reserve(n));
-  HIPC(hipMemsetAsync(h->ssn_bb.p, 0xFF, 12, h->stream));
-  HIPC(hipMemsetAsync(h->ssn_bb.p + 3, 0, 12, h->stream));
-  hipLaunchKernelGGL(k_ssn_bounds, dim3(std::min(nblk(n), 256)), dim3(256), 0, h->stream, src, (int)n, h->ssn_bb.p);
-  hipLaunchKernelGGL(k_ssn_root, dim3(1), dim3(1), 0, h->stream, h->ssn_bb.p, (int)n, h->ssn_seg_a.p, (uint32_t*)nullptr);
+  {   // the cloud's bounds and the root segment in one launch (k_ssn_bounds_root: a ticket that is zero between calls)
+    const bool fresh = h->ssn_bounds_ws.cap == 0;
+    HIPC(h->ssn_bounds_ws.reserve(8 + 6 * 256));
+    if (fresh) HIPC(hipMemsetAsync(h->ssn_bounds_ws.p, 0, 8 * sizeof(uint32_t), h->stream));
+    hipLaunchKernelGGL(k_ssn_bounds_root, dim3(std::min(nblk(n), 256)), dim3(256), 0, h->stream, src, (int)n, h->ssn_bounds_ws.p,
+                       h->ssn_bb.p, h->ssn_seg_a.p);
+  }
   SsnSeg* cur = h->ssn_seg_a.p;
   SsnSeg* nxt = h->ssn_seg_b.p;
   const uint32_t* idx = nullptr;
@@ -1412,7 +1442,10 @@ static int ssn_device(lsgpu_icp* h, const float4* src, int64_t n, int knn, float
     int64_t c = n;
     while (glevels < levels && !(lds_finish && c <= root_max && levels - glevels <= root_levels)) { c -= c / 2; ++glevels; }
   }
-  const bool select_levels = !force_sort_levels && !tuning().ssn_sort_levels && !tuning().ssn_full_sort && glevels > 0;
+  // the sort-free levels hand SETS over (points in original-index order + a signature): only k_ssn_tree knows how to take
+  // them; the round-4 finish kernel and the all-global mode continue a sorted order, so they imply the sorted levels
+  const bool select_levels = !force_sort_levels && !tuning().ssn_sort_levels && !tuning().ssn_full_sort && tree_finish &&
+                             !tuning().ssn_global && glevels > 0;
   const uint32_t* root_sig = nullptr;   // per root of the in-workgroup levels: its signature (sort-free upper levels)
   if (tuning().ssn_full_sort) {   // rounds 1-3: the whole cloud sorted by (segment, coordinate) at every level
     for (int L = 0; L < glevels; ++L) {
@@ -1473,9 +1506,6 @@ static int ssn_device(lsgpu_icp* h, const float4* src, int64_t n, int knn, float
     uint32_t* cand_n[2] = {h->gs_cand_n.p, h->gs_cand_n.p + nseg_g + 1};
     uint32_t* sig_cur = reinterpret_cast<uint32_t*>(h->ssn_axis_a.p);
     uint32_t* sig_nxt = reinterpret_cast<uint32_t*>(h->ssn_axis_b.p);
-    HIPC(hipMemsetAsync(h->gs_err.p, 0, 8 * sizeof(uint32_t), h->stream));
-    HIPC(hipMemsetAsync(cand_n[0], 0, sizeof(uint32_t), h->stream));
-    HIPC(hipMemsetAsync(sig_cur, 0xFF, sizeof(uint32_t), h->stream));   // the root was cut along no axis yet
     GsSet in, out;
     in.e = h->gs_e[0].p; out.e = h->gs_e[1].p;
     for (int d = 0; d < 3; ++d) { in.k[d] = h->gs_k[d].p; out.k[d] = h->gs_k[3 + d].p; }
@@ -1484,9 +1514,8 @@ static int ssn_device(lsgpu_icp* h, const float4* src, int64_t n, int knn, float
     // per segment two 256-bin histograms; a level zeroes its children's (the root's: here)
     uint32_t* gh1[2] = {h->gs_hist.p, h->gs_hist.p + 256 * (nseg_g + 1)};
     uint32_t* gh2[2] = {h->gs_hist.p + 2 * 256 * (nseg_g + 1), h->gs_hist.p + 3 * 256 * (nseg_g + 1)};
-    HIPC(hipMemsetAsync(gh1[0], 0, 256 * sizeof(uint32_t), h->stream));
-    HIPC(hipMemsetAsync(gh2[0], 0, 256 * sizeof(uint32_t), h->stream));
-    hipLaunchKernelGGL(k_gs_init, dim3(nblk(n)), dim3(256), 0, h->stream, src, (int)n, in, out.e, (const SsnSeg*)cur, (const uint32_t*)h->ssn_bb.p, rng_cur);
+    hipLaunchKernelGGL(k_gs_init, dim3(nblk(n)), dim3(256), 0, h->stream, src, (int)n, in, out.e, (const SsnSeg*)cur, (const uint32_t*)h->ssn_bb.p, rng_cur,
+                       gh1[0], gh2[0], cand_n[0], sig_cur, h->gs_err.p);
     for (int L = 0; L < glevels; ++L) {
       const int ns = 1 << L, nb = (int)h->gs_lvl_blocks[L], par = L & 1;
       const GsBlock* tab = h->gs_tab.p + h->gs_lvl_first[L];
@@ -1507,7 +1536,6 @@ static int ssn_device(lsgpu_icp* h, const float4* src, int64_t n, int knn, float
     }
     idx = in.e;          // every root's points, in original-index order
     root_sig = sig_cur;
-    HIPC(hipMemcpyAsync(h->h_gs_err, h->gs_err.p, 8 * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
     HIPC(hipGetLastError());
   } else if (glevels > 0) {
     // segmented sorts (lsgpu_segsort.hip.h): per level only the segments that cut along a new axis, four passes of
@@ -1591,7 +1619,9 @@ static int ssn_device(lsgpu_icp* h, const float4* src, int64_t n, int knn, float
   }
   uint32_t n_draws = 0, kept = 0;
   if (rc == LSGPU_OK)
-    rc = scan_totals(h, h->ssn_box_pts.p, h->ssn_box_base.p, nseg, h->ssn_keep.p, h->ssn_out_pos.p, (size_t)n, &n_draws, &kept);
+    // (the sort-free levels' error words travel with the totals)
+    rc = scan_totals(h, h->ssn_box_pts.p, h->ssn_box_base.p, nseg, h->ssn_keep.p, h->ssn_out_pos.p, (size_t)n, &n_draws, &kept,
+                     select_levels ? h->gs_err.p : nullptr, h->h_gs_err, 8 * sizeof(uint32_t));
   if (rc) return rc;
   if (select_levels && *h->h_gs_err) {
     if (getenv("LSGPU_GS_DEBUG")) fprintf(stderr, "lsgpu: sort-free levels gave up (n %lld): code %u seg %u a %u b %u | part %u seg %u dst %u\n", (long long)n,

@@ -77,6 +77,71 @@ __global__ void k_ssn_root(const uint32_t* __restrict__ bb, int n, SsnSeg* __res
   seg[0] = s;
 }
 
+// The same two in ONE launch and without the two fills in front of them (round 5: the reference filter's chain is short
+// enough for four 3 - 5 us launches to show): every block stores its six partial bounds, the block that draws the last
+// ticket reduces them, writes bb[0..6) and the root segment and puts the ticket back to zero for the next call.
+// ws: [0] the ticket (zero when the buffer is made), [8 + 6 b + d] block b's partial.  gridDim.x <= 256.
+__global__ __launch_bounds__(256) void k_ssn_bounds_root(const float4* __restrict__ p, int n, uint32_t* __restrict__ ws,
+                                                         uint32_t* __restrict__ bb, SsnSeg* __restrict__ seg) {
+  uint32_t lo[3] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu}, hi[3] = {0u, 0u, 0u};
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+    const float4 v = p[i];
+    const uint32_t k[3] = {float_order_key(v.x), float_order_key(v.y), float_order_key(v.z)};
+#pragma unroll
+    for (int d = 0; d < 3; ++d) { lo[d] = min(lo[d], k[d]); hi[d] = max(hi[d], k[d]); }
+  }
+  __shared__ uint32_t red[4][6];
+  __shared__ uint32_t last;
+#pragma unroll
+  for (int d = 0; d < 3; ++d) {
+    for (int o = 32; o; o >>= 1) {
+      lo[d] = min(lo[d], (uint32_t)__shfl_xor((int)lo[d], o));
+      hi[d] = max(hi[d], (uint32_t)__shfl_xor((int)hi[d], o));
+    }
+    if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6][d] = lo[d]; red[threadIdx.x >> 6][3 + d] = hi[d]; }
+  }
+  __syncthreads();
+  if (threadIdx.x < 6) {
+    const int d = threadIdx.x;
+    const uint32_t v = d < 3 ? min(min(red[0][d], red[1][d]), min(red[2][d], red[3][d]))
+                             : max(max(red[0][d], red[1][d]), max(red[2][d], red[3][d]));
+    __hip_atomic_store(&ws[8 + 6 * blockIdx.x + d], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  __threadfence();
+  __syncthreads();
+  if (threadIdx.x == 0) last = atomicAdd(&ws[0], 1u) == gridDim.x - 1u ? 1u : 0u;
+  __syncthreads();
+  if (!last) return;
+  __threadfence();
+#pragma unroll
+  for (int d = 0; d < 3; ++d) {
+    lo[d] = 0xFFFFFFFFu; hi[d] = 0u;
+    if (threadIdx.x < gridDim.x) {
+      lo[d] = __hip_atomic_load(&ws[8 + 6 * threadIdx.x + d], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      hi[d] = __hip_atomic_load(&ws[8 + 6 * threadIdx.x + 3 + d], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    for (int o = 32; o; o >>= 1) {
+      lo[d] = min(lo[d], (uint32_t)__shfl_xor((int)lo[d], o));
+      hi[d] = max(hi[d], (uint32_t)__shfl_xor((int)hi[d], o));
+    }
+    if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6][d] = lo[d]; red[threadIdx.x >> 6][3 + d] = hi[d]; }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    SsnSeg s;
+    s.start = 0; s.count = (uint32_t)n;
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+      const uint32_t l = min(min(red[0][d], red[1][d]), min(red[2][d], red[3][d]));
+      const uint32_t u = max(max(red[0][3 + d], red[1][3 + d]), max(red[2][3 + d], red[3][3 + d]));
+      bb[d] = l; bb[3 + d] = u;
+      s.lo[d] = float_from_order_key(l); s.hi[d] = float_from_order_key(u);
+    }
+    seg[0] = s;
+    __hip_atomic_store(&ws[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
 // level keys: (segment << 32) | ordered cut coordinate for segments that still split, (segment << 32) |
 // rank for finished ones (they keep their order).  idx_in == nullptr: identity (level 0).
 __global__ __launch_bounds__(256) void k_ssn_keys(const float4* __restrict__ p, int n,

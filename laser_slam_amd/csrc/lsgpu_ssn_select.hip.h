@@ -80,12 +80,23 @@ __device__ __forceinline__ bool gs_less(uint32_t ka, uint32_t k1, uint32_t k2, u
 }
 
 // keys and identity: the root set (the other set's point array gets valid ids too: whatever an aborted level leaves behind
-// must stay dereferenceable for the kernels queued behind it); the root's key range on its cut axis = the cloud's bounds
+// must stay dereferenceable for the kernels queued behind it); the root's key range on its cut axis = the cloud's bounds;
+// block 0 also clears what the first level accumulates into (its two histograms, its candidate count, the error words)
+// and gives the root its empty signature -- five fills in front of the first level otherwise
 __global__ __launch_bounds__(256) void k_gs_init(const float4* __restrict__ p, int n, GsSet out, uint32_t* __restrict__ other_e,
                                                  const SsnSeg* __restrict__ root, const uint32_t* __restrict__ bb,
-                                                 uint2* __restrict__ rng) {
+                                                 uint2* __restrict__ rng, uint32_t* __restrict__ gh1_root,
+                                                 uint32_t* __restrict__ gh2_root, uint32_t* __restrict__ cand_n_root,
+                                                 uint32_t* __restrict__ sig_root, uint32_t* __restrict__ err) {
   const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i == 0) { const int a = ssn_cut_axis(root[0]); rng[0] = make_uint2(bb[a], bb[3 + a]); }
+  if (blockIdx.x == 0) {
+    gh1_root[threadIdx.x] = 0u; gh2_root[threadIdx.x] = 0u;
+    if (threadIdx.x < 8) err[threadIdx.x] = 0u;
+    if (threadIdx.x == 0) {
+      const int a = ssn_cut_axis(root[0]); rng[0] = make_uint2(bb[a], bb[3 + a]);
+      cand_n_root[0] = 0u; sig_root[0] = 0xFFFFFFFFu;   // the root was cut along no axis yet
+    }
+  }
   if (i >= n) return;
   const float4 v = p[i];
   out.e[i] = (uint32_t)i; other_e[i] = (uint32_t)i;
@@ -296,6 +307,7 @@ __global__ __launch_bounds__(256) void k_gs_part(const GsBlock* __restrict__ tab
                                                  uint32_t* __restrict__ err) {
   __shared__ uint32_t ws[4];
   __shared__ uint32_t rr[4][4];
+  __shared__ uint32_t stage[4][kGsTile];   // 32 KB
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const GsBlock sb = tab[blockIdx.x];
   const SsnSeg sg = segs[sb.seg];
@@ -347,19 +359,38 @@ __global__ __launch_bounds__(256) void k_gs_part(const GsBlock* __restrict__ tab
   }
   uint32_t before = 0u;
   for (int ww = 0; ww < w; ++ww) before += ws[ww];
+  const uint32_t nleft = ws[0] + ws[1] + ws[2] + ws[3];       // this block's left points
+  // through LDS: the block's left points first, then its right ones, each in order -- the stores below are then two runs
+  // of consecutive addresses per array instead of 64 lanes alternating between two places
 #pragma unroll
   for (int k = 0; k < kGsItems; ++k) {
     const uint32_t j = (uint32_t)(w * (64 * kGsItems) + k * 64 + lane);
     if (j < sb.count) {
       const uint32_t lbefore = before + (xl[k] >> 1);            // left points of this block in front of j
-      const uint32_t dst = (xl[k] & 1u) ? sb.seg_start + base_left + lbefore
-                                        : sb.seg_start + left_total + base_right + (j - lbefore);
-      uint32_t d = dst;
-      if (d - sb.seg_start >= sb.seg_count) {   // (only behind an error the earlier kernels have flagged: stay inside the segment, the
-        err[0] = 1u; err[5] = 4u; err[6] = sb.seg; err[7] = dst;   //  host repeats the filter, the kernels queued behind this one must find valid ids)
-        d = sb.seg_start + (d - sb.seg_start) % sb.seg_count;
-      }
-      out.e[d] = ev[k]; out.k[0][d] = kx[k]; out.k[1][d] = ky[k]; out.k[2][d] = kz[k];
+      const uint32_t slot = (xl[k] & 1u) ? lbefore : nleft + (j - lbefore);
+      stage[0][slot] = ev[k]; stage[1][slot] = kx[k]; stage[2][slot] = ky[k]; stage[3][slot] = kz[k];
+    }
+  }
+  __syncthreads();
+  const uint32_t dst_left = sb.seg_start + base_left, dst_right = sb.seg_start + left_total + base_right;
+  const uint32_t pos0 = sb.first - sb.seg_start;   // (the counts of a consistent level: nothing below can leave the segment)
+  const bool bad = base_left > pos0 || base_left + nleft > left_total ||
+                   (pos0 - base_left) + (sb.count - nleft) > sb.seg_count - left_total;
+  if (bad) {   // (only behind an error the earlier kernels have flagged: stay inside the segment -- the host repeats the filter, the
+               //  kernels queued behind this one must find valid ids)
+    if (threadIdx.x == 0) { err[0] = 1u; err[5] = 4u; err[6] = sb.seg; err[7] = dst_left; }
+    for (uint32_t t = threadIdx.x; t < sb.count; t += 256u) {
+      const uint32_t d = sb.first + t;
+      out.e[d] = stage[0][t]; out.k[0][d] = stage[1][t]; out.k[1][d] = stage[2][t]; out.k[2][d] = stage[3][t];
+    }
+    return;
+  }
+#pragma unroll
+  for (int k = 0; k < kGsItems; ++k) {
+    const uint32_t t = (uint32_t)(k * 256) + threadIdx.x;
+    if (t < sb.count) {
+      const uint32_t d = t < nleft ? dst_left + t : dst_right + (t - nleft);
+      out.e[d] = stage[0][t]; out.k[0][d] = stage[1][t]; out.k[1][d] = stage[2][t]; out.k[2][d] = stage[3][t];
     }
   }
 }
