@@ -29,3 +29,4 @@ for a, b in zip(lv[:-1], lv[1:]):
     print("  level %d %.1f" % (a, us(8 + a, 8 + b)))
 print("  level %d %.1f" % (lv[-1], us(8 + lv[-1], 30)))
 print("  output %.1f   total %.1f" % (us(30, 31), us(0, 31)))
+print("first level's k_gs_select (%d candidates); us: bins %.1f, candidates to LDS %.1f, median + left counts %.1f, prefix %.1f, children %.1f" % (int(t[54]), us(48, 49), us(49, 50), us(50, 51), us(51, 52), us(52, 53)))

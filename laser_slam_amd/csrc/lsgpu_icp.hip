@@ -1420,9 +1420,9 @@ static int ssn_device(lsgpu_icp* h, const float4* src, int64_t n, int knn, float
   HIPC(h->sc->vals.reserve(n));
   {   // the cloud's bounds and the root segment in one launch (k_ssn_bounds_root: a ticket that is zero between calls)
     const bool fresh = h->ssn_bounds_ws.cap == 0;
-    HIPC(h->ssn_bounds_ws.reserve(8 + 6 * 256));
+    HIPC(h->ssn_bounds_ws.reserve(8 + 6 * kSsnBoundsBlocks));
     if (fresh) HIPC(hipMemsetAsync(h->ssn_bounds_ws.p, 0, 8 * sizeof(uint32_t), h->stream));
-    hipLaunchKernelGGL(k_ssn_bounds_root, dim3(std::min(nblk(n), 256)), dim3(256), 0, h->stream, src, (int)n, h->ssn_bounds_ws.p,
+    hipLaunchKernelGGL(k_ssn_bounds_root, dim3(std::min(nblk(n), kSsnBoundsBlocks)), dim3(256), 0, h->stream, src, (int)n, h->ssn_bounds_ws.p,
                        h->ssn_bb.p, h->ssn_seg_a.p);
   }
   SsnSeg* cur = h->ssn_seg_a.p;
@@ -1524,10 +1524,10 @@ static int ssn_device(lsgpu_icp* h, const float4* src, int64_t n, int knn, float
       hipLaunchKernelGGL(k_gs_hist<2>, dim3(nb), dim3(256), 0, h->stream, tab, cur, (const uint2*)rng_cur, in, gh1[par], gh2[par], h->gs_err.p);
       hipLaunchKernelGGL(k_gs_collect, dim3(nb), dim3(256), 0, h->stream, tab, cur, (const uint2*)rng_cur, (const uint32_t*)sig_cur, in,
                          (const uint32_t*)gh1[par], (const uint32_t*)gh2[par], cand_n[par], h->gs_cand.p, h->gs_cand_blk.p, h->gs_cl.p);
-      hipLaunchKernelGGL(k_gs_select, dim3(ns), dim3(256), 0, h->stream, sblk, src, cur, (const uint32_t*)sig_cur, gh1[par], gh2[par],
+      hipLaunchKernelGGL(k_gs_select, dim3(ns), dim3(L < 3 ? 1024 : 256), 0, h->stream, sblk, src, cur, (const uint32_t*)sig_cur, gh1[par], gh2[par],
                          gh1[par ^ 1], gh2[par ^ 1], cand_n[par], (const GsMedian*)h->gs_cand.p, (const uint32_t*)h->gs_cand_blk.p, h->gs_cl.p,
                          h->gs_cl.p + cap, h->gs_median.p, nxt, sig_nxt, cand_n[par ^ 1], rng_nxt, h->gs_err.p);
-      hipLaunchKernelGGL(k_gs_part, dim3(nb), dim3(256), 0, h->stream, tab, cur, (const uint32_t*)sig_cur, in, out,
+      hipLaunchKernelGGL(k_gs_part, dim3(nb), dim3(kGsPartThreads), 0, h->stream, tab, cur, (const uint32_t*)sig_cur, in, out,
                          (const GsMedian*)h->gs_median.p, (const uint32_t*)(h->gs_cl.p + cap), (const SsnSeg*)nxt, rng_nxt, h->gs_err.p);
       std::swap(in, out);
       std::swap(cur, nxt);

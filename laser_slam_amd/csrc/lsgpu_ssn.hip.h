@@ -80,11 +80,23 @@ __global__ void k_ssn_root(const uint32_t* __restrict__ bb, int n, SsnSeg* __res
 // The same two in ONE launch and without the two fills in front of them (round 5: the reference filter's chain is short
 // enough for four 3 - 5 us launches to show): every block stores its six partial bounds, the block that draws the last
 // ticket reduces them, writes bb[0..6) and the root segment and puts the ticket back to zero for the next call.
-// ws: [0] the ticket (zero when the buffer is made), [8 + 6 b + d] block b's partial.  gridDim.x <= 256.
+// ws: [0] the ticket (zero when the buffer is made), [8 + 6 b + d] block b's partial (kSsnBoundsBlocks of them at most).
+constexpr int kSsnBoundsBlocks = 256;
 __global__ __launch_bounds__(256) void k_ssn_bounds_root(const float4* __restrict__ p, int n, uint32_t* __restrict__ ws,
                                                          uint32_t* __restrict__ bb, SsnSeg* __restrict__ seg) {
   uint32_t lo[3] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu}, hi[3] = {0u, 0u, 0u};
-  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+  const int stride = gridDim.x * 256;
+  int i = blockIdx.x * 256 + threadIdx.x;
+  for (; i + 3 * stride < n; i += 4 * stride) {     // four loads in flight per thread (256 blocks: a ticket costs ~50 ns)
+    const float4 v[4] = {p[i], p[i + stride], p[i + 2 * stride], p[i + 3 * stride]};
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const uint32_t k[3] = {float_order_key(v[u].x), float_order_key(v[u].y), float_order_key(v[u].z)};
+#pragma unroll
+      for (int d = 0; d < 3; ++d) { lo[d] = min(lo[d], k[d]); hi[d] = max(hi[d], k[d]); }
+    }
+  }
+  for (; i < n; i += stride) {
     const float4 v = p[i];
     const uint32_t k[3] = {float_order_key(v.x), float_order_key(v.y), float_order_key(v.z)};
 #pragma unroll
@@ -105,20 +117,22 @@ __global__ __launch_bounds__(256) void k_ssn_bounds_root(const float4* __restric
     const int d = threadIdx.x;
     const uint32_t v = d < 3 ? min(min(red[0][d], red[1][d]), min(red[2][d], red[3][d]))
                              : max(max(red[0][d], red[1][d]), max(red[2][d], red[3][d]));
-    __hip_atomic_store(&ws[8 + 6 * blockIdx.x + d], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // (an exchange, and its old value waited for: the partial has reached the memory side when the ticket is drawn.
+    //  __threadfence() would do, at the price of writing this XCD's whole L2 back and invalidating it -- buffer_wbl2 sc1 +
+    //  buffer_inv sc1 on gfx950, measured ~10 us in this kernel)
+    const uint32_t old = __hip_atomic_exchange(&ws[8 + 6 * blockIdx.x + d], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("" ::"v"(old));
   }
-  __threadfence();
   __syncthreads();
   if (threadIdx.x == 0) last = atomicAdd(&ws[0], 1u) == gridDim.x - 1u ? 1u : 0u;
   __syncthreads();
   if (!last) return;
-  __threadfence();
 #pragma unroll
   for (int d = 0; d < 3; ++d) {
     lo[d] = 0xFFFFFFFFu; hi[d] = 0u;
-    if (threadIdx.x < gridDim.x) {
-      lo[d] = __hip_atomic_load(&ws[8 + 6 * threadIdx.x + d], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      hi[d] = __hip_atomic_load(&ws[8 + 6 * threadIdx.x + 3 + d], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (uint32_t b = threadIdx.x; b < gridDim.x; b += 256u) {
+      lo[d] = min(lo[d], __hip_atomic_load(&ws[8 + 6 * b + d], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+      hi[d] = max(hi[d], __hip_atomic_load(&ws[8 + 6 * b + 3 + d], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
     }
     for (int o = 32; o; o >>= 1) {
       lo[d] = min(lo[d], (uint32_t)__shfl_xor((int)lo[d], o));

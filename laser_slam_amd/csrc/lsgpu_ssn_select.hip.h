@@ -39,10 +39,18 @@
 
 namespace lsgpu {
 
+// (stats build: stamps of the first level's k_gs_select, g_tree_dbg[48..55]; devtools/tree_phases.py)
+#ifdef LSGPU_KNN_STATS
+#define LSGPU_SEL_T(n) do { if (gridDim.x == 1 && threadIdx.x == 0) g_tree_dbg[n] = (unsigned long long)clock64(); } while (0)
+#else
+#define LSGPU_SEL_T(n) do { } while (0)
+#endif
+
 constexpr uint32_t kGsTile = 2048u;       // positions per block of the level kernels (256 threads x 8)
-constexpr int kGsItems = 8;
+constexpr int kGsPartThreads = 512;        // k_gs_part: 4 positions per thread (512 blocks of 256 threads left a 1 M-point level two waves per SIMD)
 constexpr uint32_t kGsCandCap = 2048u;    // candidates per segment
 constexpr uint32_t kGsNoAxis = 0xFFu;
+constexpr uint32_t kGsSelBlocks = 8192u;  // k_gs_select counts in LDS for segments of up to this many blocks (16.7 M points)
 
 struct GsSet {                 // one buffer set: the points of every segment (original-index order inside it) and their keys
   uint32_t* e;
@@ -130,15 +138,16 @@ __device__ __forceinline__ uint32_t gs_bin16(const GsCut& c, uint32_t k) {
 __device__ __forceinline__ void gs_find_bin(const uint32_t* __restrict__ gh, uint32_t target, uint32_t* sh /* >= 8 */,
                                             uint32_t& bin, uint32_t& below) {
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const uint32_t tot = gh[threadIdx.x];
+  const bool act = threadIdx.x < 256u;           // (workgroups of more than 256 threads: the first four waves do it)
+  const uint32_t tot = act ? gh[threadIdx.x] : 0u;
   const uint32_t incl = wave_scan_incl_u32(tot, lane);
   if (threadIdx.x == 0) { sh[4] = 0xFFFFFFFFu; sh[5] = 0u; }
-  if (lane == 63) sh[w] = incl;
+  if (act && lane == 63) sh[w] = incl;
   __syncthreads();
   uint32_t before = 0u;
-  for (int ww = 0; ww < w; ++ww) before += sh[ww];
+  for (int ww = 0; ww < w && ww < 4; ++ww) before += sh[ww];
   const uint32_t excl = before + incl - tot;
-  if (tot != 0u && excl <= target && target < excl + tot) { sh[4] = threadIdx.x; sh[5] = excl; }
+  if (act && tot != 0u && excl <= target && target < excl + tot) { sh[4] = threadIdx.x; sh[5] = excl; }
   __syncthreads();
   bin = sh[4]; below = sh[5];
   __syncthreads();
@@ -217,7 +226,7 @@ __global__ __launch_bounds__(256) void k_gs_collect(const GsBlock* __restrict__ 
 }
 
 // ONE workgroup per segment: the exact median among the candidates, the children, the candidates' share of the left counts
-__global__ __launch_bounds__(256) void k_gs_select(const GsSegBlocks* __restrict__ sblk, const float4* __restrict__ p,
+__global__ __launch_bounds__(1024) void k_gs_select(const GsSegBlocks* __restrict__ sblk, const float4* __restrict__ p,
                                                    const SsnSeg* __restrict__ segs, const uint32_t* __restrict__ sig,
                                                    uint32_t* __restrict__ gh1, uint32_t* __restrict__ gh2,
                                                    uint32_t* __restrict__ gh1_next, uint32_t* __restrict__ gh2_next,
@@ -230,6 +239,10 @@ __global__ __launch_bounds__(256) void k_gs_select(const GsSegBlocks* __restrict
   __shared__ GsMedian lc[kGsCandCap];    // 32 KB
   __shared__ uint32_t med_slot;
   __shared__ uint32_t sh[8];
+  __shared__ uint32_t rh[256];
+  __shared__ uint32_t lcnt[kGsSelBlocks];   // candidates that go left, per block of the segment (32 KB)
+  __shared__ uint32_t lblk[kGsCandCap];     // the candidates' blocks (a global load per candidate inside the rank loops: 2 us each, one after the other)
+  LSGPU_SEL_T(48);
   const uint32_t s = blockIdx.x;
   const GsSegBlocks q = sblk[s];
   const uint32_t n = cand_n[s];
@@ -238,9 +251,12 @@ __global__ __launch_bounds__(256) void k_gs_select(const GsSegBlocks* __restrict
   gs_find_bin(gh1 + (size_t)s * 256u, left, sh, mb1, below1);
   gs_find_bin(gh2 + (size_t)s * 256u, left - below1, sh, mb2, below2);
   const uint32_t target = left - below1 - below2;    // rank of the median among the candidates
+  LSGPU_SEL_T(49);
   // the children's histograms for the next level (this segment's own have been read by every kernel that needs them)
-  gh1_next[(size_t)(2u * s) * 256u + threadIdx.x] = 0u; gh1_next[(size_t)(2u * s + 1u) * 256u + threadIdx.x] = 0u;
-  gh2_next[(size_t)(2u * s) * 256u + threadIdx.x] = 0u; gh2_next[(size_t)(2u * s + 1u) * 256u + threadIdx.x] = 0u;
+  if (threadIdx.x < 256u) {
+    gh1_next[(size_t)(2u * s) * 256u + threadIdx.x] = 0u; gh1_next[(size_t)(2u * s + 1u) * 256u + threadIdx.x] = 0u;
+    gh2_next[(size_t)(2u * s) * 256u + threadIdx.x] = 0u; gh2_next[(size_t)(2u * s + 1u) * 256u + threadIdx.x] = 0u;
+  }
   if (threadIdx.x == 0) {
     med_slot = 0xFFFFFFFFu;
     cand_n_next[2u * s] = 0u; cand_n_next[2u * s + 1u] = 0u;
@@ -248,44 +264,126 @@ __global__ __launch_bounds__(256) void k_gs_select(const GsSegBlocks* __restrict
     if (n > kGsCandCap || target >= n || mb1 == 0xFFFFFFFFu || mb2 == 0xFFFFFFFFu) { err[0] = 1u; err[1] = 3u; err[2] = s; err[3] = n; err[4] = target; }   // too many equal keys around the median: the host falls back
   }
   const uint32_t c = min(n, kGsCandCap);
-  for (uint32_t i = threadIdx.x; i < c; i += 256u) lc[i] = cand[(size_t)s * kGsCandCap + i];
+  // the candidates that go left are counted per block of the segment: in LDS (a few hundred device-scope atomics from this
+  // one CU, their old values waited for, were ~10 us of the first two levels), in the global counts only for a segment of
+  // more blocks than the LDS array has words
+  const bool lds_counts = q.nb <= kGsSelBlocks;
+  if (lds_counts) for (uint32_t b = threadIdx.x; b < q.nb; b += blockDim.x) lcnt[b] = 0u;
+  for (uint32_t i = threadIdx.x; i < c; i += blockDim.x) { lc[i] = cand[(size_t)s * kGsCandCap + i]; lblk[i] = cand_blk[(size_t)s * kGsCandCap + i]; }
   __syncthreads();
-  for (uint32_t i = threadIdx.x; i < c; i += 256u) {
-    const GsMedian me = lc[i];
-    uint32_t r = 0u;
-    for (uint32_t j = 0; j < c; ++j) {
-      const GsMedian o = lc[j];
-      r += gs_less(o.ka, o.k1, o.k2, o.e, me) ? 1u : 0u;
+  LSGPU_SEL_T(50);
+#ifdef LSGPU_KNN_STATS
+  if (gridDim.x == 1 && threadIdx.x == 0) g_tree_dbg[54] = c;
+#endif
+  uint32_t arrived = 0u;
+  if (c <= 256u) {
+    // up to 256 candidates (all but the first levels of a sub-map): ranks by c x c comparisons, the LANES over the other
+    // candidate (registers), a wave per candidate, counted by ballots.  (One thread per candidate looping over the others
+    // in LDS was 12 us at 181 candidates: three waves, nothing to hide the LDS latency behind.)
+    const int lane = threadIdx.x & 63;
+    const uint32_t w = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    GsMedian oj[4];
+#pragma unroll
+    for (int ch = 0; ch < 4; ++ch) {
+      const uint32_t j = (uint32_t)(ch * 64 + lane);
+      oj[ch] = j < c ? lc[j] : GsMedian{0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};   // (less than nothing)
     }
-    if (r < target) atomicAdd(&cl[cand_blk[(size_t)s * kGsCandCap + i]], 1u);   // this candidate goes left
-    if (r == target) med_slot = i;
+    for (uint32_t i = w; i < c; i += nw) {
+      const GsMedian me = lc[i];
+      uint32_t r = 0u;
+#pragma unroll
+      for (int ch = 0; ch < 4; ++ch)
+        if ((uint32_t)(ch * 64) < c) r += (uint32_t)__popcll(__ballot(gs_less(oj[ch].ka, oj[ch].k1, oj[ch].k2, oj[ch].e, me)));
+      if (lane == 0) {
+        if (r < target) {                                                                      // this candidate goes left
+          const uint32_t blk = lblk[i];
+          if (lds_counts) atomicAdd(&lcnt[blk - q.fb], 1u); else arrived ^= atomicAdd(&cl[blk], 1u);
+        }
+        if (r == target) med_slot = i;
+      }
+    }
+  } else {
+    // a thousand and more (a 1 M-point segment has 16 points per bin on average, many more where the sensor stands): the
+    // comparisons all run on this one CU -- 17 us at 1 000 candidates, 75 at 2 000, whatever the number of threads.
+    // Instead: the candidate of rank `target` by a radix select over the 16 bytes of the tuple (cut-axis key, the two
+    // other keys, index; most significant first; it stops as soon as one candidate is left: after the third or fourth
+    // byte unless the keys tie), then ONE comparison per candidate.
+    uint32_t alive = 0u;     // bit k: candidate threadIdx.x + k * blockDim.x still has the median's leading bytes
+    for (uint32_t i = threadIdx.x, k = 0; i < c; i += blockDim.x, ++k) alive |= 1u << k;
+    uint32_t rem = target;
+    for (int pass = 0; pass < 16; ++pass) {
+      const int field = pass >> 2, shift = 24 - 8 * (pass & 3);
+      if (threadIdx.x < 256u) rh[threadIdx.x] = 0u;
+      __syncthreads();
+      for (uint32_t i = threadIdx.x, k = 0; i < c; i += blockDim.x, ++k)
+        if ((alive >> k) & 1u) {
+          const GsMedian o = lc[i];
+          const uint32_t f = field == 0 ? o.ka : field == 1 ? o.k1 : field == 2 ? o.k2 : o.e;
+          atomicAdd(&rh[(f >> shift) & 255u], 1u);
+        }
+      __syncthreads();
+      uint32_t bin, below;
+      gs_find_bin(rh, rem, sh, bin, below);
+      if (bin == 0xFFFFFFFFu) { alive = 0u; break; }     // (rank outside the candidates: flagged above)
+      rem -= below;
+      const uint32_t left_in_bin = rh[bin];
+      for (uint32_t i = threadIdx.x, k = 0; i < c; i += blockDim.x, ++k)
+        if ((alive >> k) & 1u) {
+          const GsMedian o = lc[i];
+          const uint32_t f = field == 0 ? o.ka : field == 1 ? o.k1 : field == 2 ? o.k2 : o.e;
+          if (((f >> shift) & 255u) != bin) alive &= ~(1u << k);
+        }
+      __syncthreads();                                   // (rh is cleared again at the top)
+      if (left_in_bin == 1u) break;
+    }
+    for (uint32_t i = threadIdx.x, k = 0; i < c; i += blockDim.x, ++k)
+      if ((alive >> k) & 1u) med_slot = i;               // (one candidate: the indices are distinct)
+    __syncthreads();
+    if (med_slot != 0xFFFFFFFFu) {
+      const GsMedian m = lc[med_slot];
+      for (uint32_t i = threadIdx.x; i < c; i += blockDim.x) {
+        const GsMedian o = lc[i];
+        if (gs_less(o.ka, o.k1, o.k2, o.e, m)) {
+          const uint32_t blk = lblk[i];
+          if (lds_counts) atomicAdd(&lcnt[blk - q.fb], 1u); else arrived ^= atomicAdd(&cl[blk], 1u);
+        }
+      }
+    }
   }
-  __threadfence();
+  // (the atomics' old values waited for = they have been performed where the loads below look; no __threadfence(): on
+  //  gfx950 that is a write-back and an invalidation of the XCD's whole L2)
+  asm volatile("" ::"v"(arrived));
   __syncthreads();
+  LSGPU_SEL_T(51);
   // the blocks' left counts are complete: their exclusive prefix over the segment's blocks, for k_gs_part
   {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const bool act = threadIdx.x < 256u;
     uint32_t carry = 0u;
     for (uint32_t b0 = 0; b0 < q.nb; b0 += 256u) {
       const uint32_t b = b0 + threadIdx.x;
-      const uint32_t v = b < q.nb ? __hip_atomic_load(&cl[q.fb + b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+      const uint32_t v = act && b < q.nb ? (lds_counts ? cl[q.fb + b] + lcnt[b] : __hip_atomic_load(&cl[q.fb + b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) : 0u;
       const uint32_t incl = wave_scan_incl_u32(v, lane);
-      if (lane == 63) sh[w] = incl;
+      if (act && lane == 63) sh[w] = incl;
       __syncthreads();
       uint32_t before = carry;
-      for (int ww = 0; ww < w; ++ww) before += sh[ww];
-      if (b < q.nb) clp[q.fb + b] = before + incl - v;
+      for (int ww = 0; ww < w && ww < 4; ++ww) before += sh[ww];
+      if (act && b < q.nb) clp[q.fb + b] = before + incl - v;
       carry += sh[0] + sh[1] + sh[2] + sh[3];
       __syncthreads();
     }
   }
-  if (threadIdx.x == 0 && med_slot != 0xFFFFFFFFu) {
-    const GsMedian m = lc[med_slot];
+  LSGPU_SEL_T(52);
+  if (threadIdx.x == 0) {
+    // (no median: an error has been flagged above and the host repeats the filter -- but everything queued behind this
+    //  level, k_ssn_tree included, runs first and must find segments that are what the static halving says they are)
+    const bool have = med_slot != 0xFFFFFFFFu;
+    const GsMedian m = have ? lc[med_slot] : GsMedian{0u, 0u, 0u, 0u};
     median[s] = m;
     const SsnSeg sg = segs[s];
     const int cut = ssn_cut_axis(sg);
     SsnSeg a = sg, b = sg;
-    const float cutval = coord_of(p[m.e], cut);
+    const float cutval = have ? coord_of(p[m.e], cut) : coord_of(make_float4(sg.hi[0], sg.hi[1], sg.hi[2], 0.f), cut);
 #pragma unroll
     for (int d = 0; d < 3; ++d) {
       a.hi[d] = d == cut ? cutval : a.hi[d];
@@ -297,16 +395,18 @@ __global__ __launch_bounds__(256) void k_gs_select(const GsSegBlocks* __restrict
     const uint32_t sv = gs_sig_push(sig[s], (uint32_t)cut);
     sig_out[2u * s] = sv; sig_out[2u * s + 1u] = sv;
   }
+  LSGPU_SEL_T(53);
 }
 
 // the stable partition: every point (and its three keys) to its child's range of the OUT buffers, left half first
-__global__ __launch_bounds__(256) void k_gs_part(const GsBlock* __restrict__ tab, const SsnSeg* __restrict__ segs,
+__global__ __launch_bounds__(kGsPartThreads) void k_gs_part(const GsBlock* __restrict__ tab, const SsnSeg* __restrict__ segs,
                                                  const uint32_t* __restrict__ sig, GsSet in, GsSet out,
                                                  const GsMedian* __restrict__ median, const uint32_t* __restrict__ clp,
                                                  const SsnSeg* __restrict__ segs_next, uint2* __restrict__ rng_next,
                                                  uint32_t* __restrict__ err) {
-  __shared__ uint32_t ws[4];
-  __shared__ uint32_t rr[4][4];
+  constexpr int kW = kGsPartThreads / 64, kI = (int)kGsTile / kGsPartThreads;   // waves; positions per thread
+  __shared__ uint32_t ws[kW];
+  __shared__ uint32_t rr[kW][4];
   __shared__ uint32_t stage[4][kGsTile];   // 32 KB
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const GsBlock sb = tab[blockIdx.x];
@@ -318,15 +418,15 @@ __global__ __launch_bounds__(256) void k_gs_part(const GsBlock* __restrict__ tab
   const uint32_t base_left = clp[blockIdx.x];     // left points of the segment's earlier blocks (k_gs_select)
   const uint32_t left_total = sb.seg_count - sb.seg_count / 2u;
   const uint32_t base_right = (sb.first - sb.seg_start) - base_left;
-  // wave w owns 1024 consecutive positions of the block, 64 at a time: stable ranks need positions in order
-  uint32_t ev[kGsItems], kx[kGsItems], ky[kGsItems], kz[kGsItems], xl[kGsItems];
+  // wave w owns 64 kI consecutive positions of the block, 64 at a time: stable ranks need positions in order
+  uint32_t ev[kI], kx[kI], ky[kI], kz[kI], xl[kI];
   uint32_t carry = 0u;
   // the children's own cut axes (k_gs_select has written their boxes): the key range of either child's points on it
   const int aL = ssn_cut_axis(segs_next[2u * sb.seg]), aR = ssn_cut_axis(segs_next[2u * sb.seg + 1u]);
   uint32_t mnL = 0xFFFFFFFFu, mxL = 0u, mnR = 0xFFFFFFFFu, mxR = 0u;
 #pragma unroll
-  for (int k = 0; k < kGsItems; ++k) {
-    const uint32_t j = (uint32_t)(w * (64 * kGsItems) + k * 64 + lane);
+  for (int k = 0; k < kI; ++k) {
+    const uint32_t j = (uint32_t)(w * (64 * kI) + k * 64 + lane);
     uint32_t v = 0u;
     ev[k] = kx[k] = ky[k] = kz[k] = 0u;
     if (j < sb.count) {
@@ -352,19 +452,21 @@ __global__ __launch_bounds__(256) void k_gs_part(const GsBlock* __restrict__ tab
     // on the same four words serialise in the L2 otherwise; a stale look costs an atomic that changes nothing)
     const int q = (int)threadIdx.x;
     const bool is_min = (q & 1) == 0;
-    const uint32_t v = is_min ? min(min(rr[0][q], rr[1][q]), min(rr[2][q], rr[3][q])) : max(max(rr[0][q], rr[1][q]), max(rr[2][q], rr[3][q]));
+    uint32_t v = rr[0][q];
+    for (int ww = 1; ww < kW; ++ww) v = is_min ? min(v, rr[ww][q]) : max(v, rr[ww][q]);
     uint32_t* word = reinterpret_cast<uint32_t*>(&rng_next[2u * sb.seg + (uint32_t)(q >> 1)]) + (q & 1);
     const uint32_t seen = __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (is_min ? v < seen : v > seen) { if (is_min) atomicMin(word, v); else atomicMax(word, v); }
   }
   uint32_t before = 0u;
   for (int ww = 0; ww < w; ++ww) before += ws[ww];
-  const uint32_t nleft = ws[0] + ws[1] + ws[2] + ws[3];       // this block's left points
+  uint32_t nleft = 0u;                                         // this block's left points
+  for (int ww = 0; ww < kW; ++ww) nleft += ws[ww];
   // through LDS: the block's left points first, then its right ones, each in order -- the stores below are then two runs
   // of consecutive addresses per array instead of 64 lanes alternating between two places
 #pragma unroll
-  for (int k = 0; k < kGsItems; ++k) {
-    const uint32_t j = (uint32_t)(w * (64 * kGsItems) + k * 64 + lane);
+  for (int k = 0; k < kI; ++k) {
+    const uint32_t j = (uint32_t)(w * (64 * kI) + k * 64 + lane);
     if (j < sb.count) {
       const uint32_t lbefore = before + (xl[k] >> 1);            // left points of this block in front of j
       const uint32_t slot = (xl[k] & 1u) ? lbefore : nleft + (j - lbefore);
@@ -379,15 +481,15 @@ __global__ __launch_bounds__(256) void k_gs_part(const GsBlock* __restrict__ tab
   if (bad) {   // (only behind an error the earlier kernels have flagged: stay inside the segment -- the host repeats the filter, the
                //  kernels queued behind this one must find valid ids)
     if (threadIdx.x == 0) { err[0] = 1u; err[5] = 4u; err[6] = sb.seg; err[7] = dst_left; }
-    for (uint32_t t = threadIdx.x; t < sb.count; t += 256u) {
+    for (uint32_t t = threadIdx.x; t < sb.count; t += (uint32_t)kGsPartThreads) {
       const uint32_t d = sb.first + t;
       out.e[d] = stage[0][t]; out.k[0][d] = stage[1][t]; out.k[1][d] = stage[2][t]; out.k[2][d] = stage[3][t];
     }
     return;
   }
 #pragma unroll
-  for (int k = 0; k < kGsItems; ++k) {
-    const uint32_t t = (uint32_t)(k * 256) + threadIdx.x;
+  for (int k = 0; k < kI; ++k) {
+    const uint32_t t = (uint32_t)(k * kGsPartThreads) + threadIdx.x;
     if (t < sb.count) {
       const uint32_t d = t < nleft ? dst_left + t : dst_right + (t - nleft);
       out.e[d] = stage[0][t]; out.k[0][d] = stage[1][t]; out.k[1][d] = stage[2][t]; out.k[2][d] = stage[3][t];
