@@ -130,6 +130,8 @@ def track_section(n_az: int, n_scans: int, cpu_threads: int):
                                env=dict(os.environ, LSGPU_TRACK_STAGES="1"))
             if r.returncode != 0:
                 raise RuntimeError("track_driver failed: " + r.stdout[-500:] + r.stderr[-500:])
+            if os.environ.get("LSGPU_GS_DEBUG"):   # (dev: the library's diagnostics of the driver process)
+                sys.stderr.write(r.stderr)
             return r.stdout.splitlines()
         lines = run([])
         ms = [float(l.split()[-1]) for l in lines if l.startswith("icp_iterations")]          # scans 1 .. n-1

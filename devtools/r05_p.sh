@@ -13,10 +13,10 @@ rows = db.execute("select name, start, end from kernels order by start").fetchal
 # first occurrence of k_gs_init -> timeline of one filter at 1M
 names=[re.sub(r"^void |lsgpu::","",re.sub(r"\(.*","",r[0]))[:34] for r in rows]
 idx=[i for i,n in enumerate(names) if n.startswith("k_gs_init")]
-i0=idx[3]
+import os; i0=idx[int(os.environ.get("IDX","3"))]
 t0=rows[i0][1]
 prev=rows[i0][2]
-for j in range(i0, min(i0+75, len(rows))):
+for j in range(i0, min(i0+int(os.environ.get("NROWS","75")), len(rows))):
     print("%8.1f +%6.1f gap %5.1f %s" % ((rows[j][1]-t0)/1e3, (rows[j][2]-rows[j][1])/1e3, (rows[j][1]-prev)/1e3, names[j]))
     prev=rows[j][2]
 PY

@@ -1465,32 +1465,51 @@ static int ssn_device(lsgpu_icp* h, const float4* src, int64_t n, int knn, float
     // segment's total order (two 8-bit histogram passes over the box range + a per-segment selection among the few
     // candidates left) and one stable partition: 7 launches per level, no sort.
     if (h->gs_plan_n != n || h->gs_plan_levels != glevels) {   // block tables: static for a cloud size
-      std::vector<GsBlock> tab;
-      std::vector<GsSegBlocks> sblk;
-      std::vector<std::pair<uint32_t, uint32_t>> segsz{{0u, (uint32_t)n}};
+      // every level's number of blocks and first row (sizes of a level: c -> c - c / 2, c / 2)
+      std::vector<uint32_t> sizes{(uint32_t)n}, next;
       h->gs_lvl_first.clear(); h->gs_lvl_blocks.clear();
+      uint32_t rows = 0, segs = 0;
       for (int L = 0; L < glevels; ++L) {
-        h->gs_lvl_first.push_back((uint32_t)tab.size());
         uint32_t fb = 0;
-        std::vector<std::pair<uint32_t, uint32_t>> next;
-        for (uint32_t sidx = 0; sidx < segsz.size(); ++sidx) {
-          const uint32_t st = segsz[sidx].first, c = segsz[sidx].second;
-          const uint32_t nb = (c + kGsTile - 1u) / kGsTile;
-          sblk.push_back(GsSegBlocks{fb, nb, st, c});
-          for (uint32_t k = 0; k < nb; ++k)
-            tab.push_back(GsBlock{st + k * kGsTile, std::min(kGsTile, c - k * kGsTile), sidx, st, c, fb, nb, 0u});
-          fb += nb;
-          const uint32_t left = c - c / 2u;
-          next.push_back({st, left}); next.push_back({st + left, c - left});
+        next.clear();
+        for (uint32_t c : sizes) {
+          fb += (c + kGsTile - 1u) / kGsTile;
+          next.push_back(c - c / 2u); next.push_back(c / 2u);
         }
-        h->gs_lvl_blocks.push_back(fb);
-        segsz.swap(next);
+        h->gs_lvl_first.push_back(rows); h->gs_lvl_blocks.push_back(fb);
+        rows += fb; segs += (uint32_t)sizes.size();
+        sizes.swap(next);
       }
-      HIPC(h->gs_tab.reserve(tab.size())); HIPC(h->gs_sblk.reserve(sblk.size()));
-      // (pageable source: the copy returns when the staging is done; once per cloud size)
-      HIPC(hipMemcpyAsync(h->gs_tab.p, tab.data(), tab.size() * sizeof(GsBlock), hipMemcpyHostToDevice, h->stream));
-      HIPC(hipMemcpyAsync(h->gs_sblk.p, sblk.data(), sblk.size() * sizeof(GsSegBlocks), hipMemcpyHostToDevice, h->stream));
-      HIPC(hipStreamSynchronize(h->stream));
+      HIPC(h->gs_tab.reserve(rows)); HIPC(h->gs_sblk.reserve(segs));
+      if (glevels <= kGsPlanLevels && ((size_t)1 << (glevels - 1)) <= kGsPlanSegs) {   // the rows themselves: on the device
+        GsPlanArgs pa{};
+        for (int L = 0; L < glevels; ++L) pa.first[L] = h->gs_lvl_first[L];
+        hipLaunchKernelGGL(k_gs_plan, dim3(glevels), dim3(1024), 0, h->stream, (uint32_t)n, pa, h->gs_tab.p, h->gs_sblk.p);
+        HIPC(hipGetLastError());
+      } else {                                            // (more than 8192 segments in a level: 67 M points)
+        std::vector<GsBlock> tab;
+        std::vector<GsSegBlocks> sblk;
+        std::vector<std::pair<uint32_t, uint32_t>> segsz{{0u, (uint32_t)n}};
+        for (int L = 0; L < glevels; ++L) {
+          uint32_t fb = 0;
+          std::vector<std::pair<uint32_t, uint32_t>> nx;
+          for (uint32_t sidx = 0; sidx < segsz.size(); ++sidx) {
+            const uint32_t st = segsz[sidx].first, c = segsz[sidx].second;
+            const uint32_t nb = (c + kGsTile - 1u) / kGsTile;
+            sblk.push_back(GsSegBlocks{fb, nb, st, c});
+            for (uint32_t k = 0; k < nb; ++k)
+              tab.push_back(GsBlock{st + k * kGsTile, std::min(kGsTile, c - k * kGsTile), sidx, st, c, fb, nb, 0u});
+            fb += nb;
+            const uint32_t left = c - c / 2u;
+            nx.push_back({st, left}); nx.push_back({st + left, c - left});
+          }
+          segsz.swap(nx);
+        }
+        // (pageable source: the copy returns when the staging is done)
+        HIPC(hipMemcpyAsync(h->gs_tab.p, tab.data(), tab.size() * sizeof(GsBlock), hipMemcpyHostToDevice, h->stream));
+        HIPC(hipMemcpyAsync(h->gs_sblk.p, sblk.data(), sblk.size() * sizeof(GsSegBlocks), hipMemcpyHostToDevice, h->stream));
+        HIPC(hipStreamSynchronize(h->stream));
+      }
       h->gs_plan_n = n; h->gs_plan_levels = glevels;
     }
     const size_t nseg_g = (size_t)1 << glevels;
@@ -1499,7 +1518,8 @@ static int ssn_device(lsgpu_icp* h, const float4* src, int64_t n, int knn, float
     for (auto& bf : h->gs_e) HIPC(bf.reserve(n));
     for (auto& bf : h->gs_k) HIPC(bf.reserve(n));
     HIPC(h->gs_hist.reserve(4 * 256 * (nseg_g + 1))); HIPC(h->gs_median.reserve(nseg_g)); HIPC(h->gs_cand_n.reserve(2 * nseg_g + 2));
-    HIPC(h->gs_cand.reserve(nseg_g / 2 * kGsCandCap + kGsCandCap)); HIPC(h->gs_cand_blk.reserve(nseg_g / 2 * kGsCandCap + kGsCandCap));
+    const size_t cand_room = std::max<size_t>(nseg_g / 2, 1) * kGsCandCap;
+    HIPC(h->gs_cand.reserve(cand_room)); HIPC(h->gs_cand_blk.reserve(cand_room));
     HIPC(h->gs_cl.reserve((size_t)2 * cap)); HIPC(h->gs_err.reserve(8)); HIPC(h->gs_rng.reserve(2 * nseg_g + 2));
     HIPC(h->ssn_axis_a.reserve(nseg_g)); HIPC(h->ssn_axis_b.reserve(nseg_g));
     if (!h->h_gs_err) HIPC(hipHostMalloc((void**)&h->h_gs_err, 64, hipHostMallocDefault));
@@ -1522,10 +1542,13 @@ static int ssn_device(lsgpu_icp* h, const float4* src, int64_t n, int knn, float
       const GsSegBlocks* sblk = h->gs_sblk.p + (ns - 1);
       hipLaunchKernelGGL(k_gs_hist<1>, dim3(nb), dim3(256), 0, h->stream, tab, cur, (const uint2*)rng_cur, in, gh1[par], gh2[par], h->gs_err.p);
       hipLaunchKernelGGL(k_gs_hist<2>, dim3(nb), dim3(256), 0, h->stream, tab, cur, (const uint2*)rng_cur, in, gh1[par], gh2[par], h->gs_err.p);
+      // (candidates per segment: the list's room shared out among the level's segments -- 2048 at the last level, half a
+      //  million at the first: a wall square to a frame axis puts 12 000 points of a sub-map into one bin of the first levels)
+      const uint32_t lvl_cap = (uint32_t)std::min<size_t>(cand_room / (size_t)ns, (size_t)1 << 22);
       hipLaunchKernelGGL(k_gs_collect, dim3(nb), dim3(256), 0, h->stream, tab, cur, (const uint2*)rng_cur, (const uint32_t*)sig_cur, in,
-                         (const uint32_t*)gh1[par], (const uint32_t*)gh2[par], cand_n[par], h->gs_cand.p, h->gs_cand_blk.p, h->gs_cl.p);
+                         (const uint32_t*)gh1[par], (const uint32_t*)gh2[par], cand_n[par], h->gs_cand.p, h->gs_cand_blk.p, lvl_cap, h->gs_cl.p);
       hipLaunchKernelGGL(k_gs_select, dim3(ns), dim3(L < 3 ? 1024 : 256), 0, h->stream, sblk, src, cur, (const uint32_t*)sig_cur, gh1[par], gh2[par],
-                         gh1[par ^ 1], gh2[par ^ 1], cand_n[par], (const GsMedian*)h->gs_cand.p, (const uint32_t*)h->gs_cand_blk.p, h->gs_cl.p,
+                         gh1[par ^ 1], gh2[par ^ 1], cand_n[par], (const GsMedian*)h->gs_cand.p, (const uint32_t*)h->gs_cand_blk.p, lvl_cap, h->gs_cl.p,
                          h->gs_cl.p + cap, h->gs_median.p, nxt, sig_nxt, cand_n[par ^ 1], rng_nxt, h->gs_err.p);
       hipLaunchKernelGGL(k_gs_part, dim3(nb), dim3(kGsPartThreads), 0, h->stream, tab, cur, (const uint32_t*)sig_cur, in, out,
                          (const GsMedian*)h->gs_median.p, (const uint32_t*)(h->gs_cl.p + cap), (const SsnSeg*)nxt, rng_nxt, h->gs_err.p);

@@ -87,6 +87,54 @@ __device__ __forceinline__ bool gs_less(uint32_t ka, uint32_t k1, uint32_t k2, u
   return ka != m.ka ? ka < m.ka : k1 != m.k1 ? k1 < m.k1 : k2 != m.k2 ? k2 < m.k2 : e < m.e;
 }
 
+// The block tables of all levels, on the device (one workgroup per level).  Segment sizes are static -- a segment of c
+// points splits into c - c / 2 and c / 2 -- so the host knows every level's number of blocks (a few hundred integer
+// operations) and where its rows start; writing the 14 000 rows of a 3.1 M-point cloud on the host and copying them was
+// 0.10 - 0.12 ms per call with the device idle, and a track's sub-map has another size at every scan.
+constexpr int kGsPlanLevels = 24;
+constexpr uint32_t kGsPlanSegs = 8192u;    // segments per level this kernel handles (LDS); more: host tables
+struct GsPlanArgs { uint32_t first[kGsPlanLevels]; };
+__global__ __launch_bounds__(1024) void k_gs_plan(uint32_t n, GsPlanArgs lvl, GsBlock* __restrict__ tab, GsSegBlocks* __restrict__ sblk) {
+  __shared__ uint32_t fbs[kGsPlanSegs + 1];     // first block of every segment of this level (+ the total)
+  __shared__ uint2 sc[kGsPlanSegs];             // (start, count)
+  __shared__ uint32_t wsum[16], carry_sh;
+  const uint32_t L = blockIdx.x, ns = 1u << L;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  if (threadIdx.x == 0) carry_sh = 0u;
+  __syncthreads();
+  for (uint32_t s0 = 0; s0 < ns; s0 += 1024u) {
+    const uint32_t sg = s0 + threadIdx.x;
+    uint32_t st = 0u, c = n;
+    for (int bit = (int)L - 1; bit >= 0; --bit) {   // the path from the root: left child first
+      const uint32_t left = c - c / 2u;
+      if ((sg >> bit) & 1u) { st += left; c -= left; } else c = left;
+    }
+    const uint32_t nb = sg < ns ? (c + kGsTile - 1u) / kGsTile : 0u;
+    const uint32_t incl = wave_scan_incl_u32(nb, lane);
+    if (lane == 63) wsum[w] = incl;
+    __syncthreads();
+    uint32_t before = carry_sh;
+    for (int ww = 0; ww < w; ++ww) before += wsum[ww];
+    if (sg < ns) { fbs[sg] = before + incl - nb; sc[sg] = make_uint2(st, c); }
+    __syncthreads();
+    if (threadIdx.x == 1023) carry_sh = before + incl;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) fbs[ns] = carry_sh;
+  __syncthreads();
+  const uint32_t total = fbs[ns];
+  for (uint32_t sg = threadIdx.x; sg < ns; sg += 1024u)
+    sblk[(ns - 1u) + sg] = GsSegBlocks{fbs[sg], fbs[sg + 1u] - fbs[sg], sc[sg].x, sc[sg].y};
+  GsBlock* __restrict__ t = tab + lvl.first[L];
+  for (uint32_t j = threadIdx.x; j < total; j += 1024u) {
+    uint32_t lo = 0u, hi = ns;                    // the segment whose blocks hold row j: fbs[lo] <= j < fbs[lo + 1]
+    while (hi - lo > 1u) { const uint32_t mid = (lo + hi) >> 1; if (fbs[mid] <= j) lo = mid; else hi = mid; }
+    const uint32_t k = j - fbs[lo], st = sc[lo].x, c = sc[lo].y;
+    const uint32_t off = k * kGsTile;
+    t[j] = GsBlock{st + off, min(kGsTile, c - off), lo, st, c, fbs[lo], fbs[lo + 1u] - fbs[lo], 0u};
+  }
+}
+
 // keys and identity: the root set (the other set's point array gets valid ids too: whatever an aborted level leaves behind
 // must stay dereferenceable for the kernels queued behind it); the root's key range on its cut axis = the cloud's bounds;
 // block 0 also clears what the first level accumulates into (its two histograms, its candidate count, the error words)
@@ -188,7 +236,8 @@ __global__ __launch_bounds__(256) void k_gs_collect(const GsBlock* __restrict__ 
                                                     const uint32_t* __restrict__ sig, GsSet in, const uint32_t* __restrict__ gh1,
                                                     const uint32_t* __restrict__ gh2,
                                                     uint32_t* __restrict__ cand_n, GsMedian* __restrict__ cand,
-                                                    uint32_t* __restrict__ cand_blk, uint32_t* __restrict__ cl) {
+                                                    uint32_t* __restrict__ cand_blk, uint32_t cap /* candidates per segment at this level */,
+                                                    uint32_t* __restrict__ cl) {
   __shared__ uint32_t ws[4];
   __shared__ uint32_t sh[8];
   const GsBlock sb = tab[blockIdx.x];
@@ -209,13 +258,13 @@ __global__ __launch_bounds__(256) void k_gs_collect(const GsBlock* __restrict__ 
       ++left;
     } else if (b1 == mb1 && b2 == mb2) {
       const uint32_t slot = atomicAdd(&cand_n[sb.seg], 1u);
-      if (slot < kGsCandCap) {
+      if (slot < cap) {
         GsMedian m;
         m.ka = k; m.e = in.e[i];
         m.k1 = x1 != kGsNoAxis ? gs_k(in, (int)x1)[i] : 0u;
         m.k2 = x2 != kGsNoAxis ? gs_k(in, (int)x2)[i] : 0u;
-        cand[(size_t)sb.seg * kGsCandCap + slot] = m;
-        cand_blk[(size_t)sb.seg * kGsCandCap + slot] = blockIdx.x;
+        cand[(size_t)sb.seg * cap + slot] = m;
+        cand_blk[(size_t)sb.seg * cap + slot] = blockIdx.x;
       }
     }
   }
@@ -231,13 +280,14 @@ __global__ __launch_bounds__(1024) void k_gs_select(const GsSegBlocks* __restric
                                                    uint32_t* __restrict__ gh1, uint32_t* __restrict__ gh2,
                                                    uint32_t* __restrict__ gh1_next, uint32_t* __restrict__ gh2_next,
                                                    uint32_t* __restrict__ cand_n,
-                                                   const GsMedian* __restrict__ cand, const uint32_t* __restrict__ cand_blk,
+                                                   const GsMedian* __restrict__ cand, const uint32_t* __restrict__ cand_blk, uint32_t cap,
                                                    uint32_t* __restrict__ cl, uint32_t* __restrict__ clp, GsMedian* __restrict__ median,
                                                    SsnSeg* __restrict__ out, uint32_t* __restrict__ sig_out,
                                                    uint32_t* __restrict__ cand_n_next, uint2* __restrict__ rng_next,
                                                    uint32_t* __restrict__ err) {
   __shared__ GsMedian lc[kGsCandCap];    // 32 KB
   __shared__ uint32_t med_slot;
+  __shared__ GsMedian med_sh;
   __shared__ uint32_t sh[8];
   __shared__ uint32_t rh[256];
   __shared__ uint32_t lcnt[kGsSelBlocks];   // candidates that go left, per block of the segment (32 KB)
@@ -261,15 +311,18 @@ __global__ __launch_bounds__(1024) void k_gs_select(const GsSegBlocks* __restric
     med_slot = 0xFFFFFFFFu;
     cand_n_next[2u * s] = 0u; cand_n_next[2u * s + 1u] = 0u;
     rng_next[2u * s] = make_uint2(0xFFFFFFFFu, 0u); rng_next[2u * s + 1u] = make_uint2(0xFFFFFFFFu, 0u);   // (k_gs_part fills them)
-    if (n > kGsCandCap || target >= n || mb1 == 0xFFFFFFFFu || mb2 == 0xFFFFFFFFu) { err[0] = 1u; err[1] = 3u; err[2] = s; err[3] = n; err[4] = target; }   // too many equal keys around the median: the host falls back
+    if (n > cap || target >= n || mb1 == 0xFFFFFFFFu || mb2 == 0xFFFFFFFFu) { err[0] = 1u; err[1] = 3u; err[2] = s; err[3] = n; err[4] = target; }   // too many equal keys around the median: the host falls back
   }
-  const uint32_t c = min(n, kGsCandCap);
+  const uint32_t c = min(n, cap);
+  const GsMedian* __restrict__ gc = cand + (size_t)s * cap;          // this segment's candidates ...
+  const uint32_t* __restrict__ gb = cand_blk + (size_t)s * cap;     // ... and their blocks
+  const bool in_lds = c <= kGsCandCap;                               // (more: the radix select below works on the global list)
   // the candidates that go left are counted per block of the segment: in LDS (a few hundred device-scope atomics from this
   // one CU, their old values waited for, were ~10 us of the first two levels), in the global counts only for a segment of
   // more blocks than the LDS array has words
   const bool lds_counts = q.nb <= kGsSelBlocks;
   if (lds_counts) for (uint32_t b = threadIdx.x; b < q.nb; b += blockDim.x) lcnt[b] = 0u;
-  for (uint32_t i = threadIdx.x; i < c; i += blockDim.x) { lc[i] = cand[(size_t)s * kGsCandCap + i]; lblk[i] = cand_blk[(size_t)s * kGsCandCap + i]; }
+  if (in_lds) for (uint32_t i = threadIdx.x; i < c; i += blockDim.x) { lc[i] = gc[i]; lblk[i] = gb[i]; }
   __syncthreads();
   LSGPU_SEL_T(50);
 #ifdef LSGPU_KNN_STATS
@@ -299,52 +352,58 @@ __global__ __launch_bounds__(1024) void k_gs_select(const GsSegBlocks* __restric
           const uint32_t blk = lblk[i];
           if (lds_counts) atomicAdd(&lcnt[blk - q.fb], 1u); else arrived ^= atomicAdd(&cl[blk], 1u);
         }
-        if (r == target) med_slot = i;
+        if (r == target) { med_slot = i; med_sh = me; }
       }
     }
   } else {
-    // a thousand and more (a 1 M-point segment has 16 points per bin on average, many more where the sensor stands): the
+    // a thousand and more (a 1 M-point segment has 16 points per bin on average, many more where the sensor stands; a wall
+    // square to an axis of the frame puts ten thousand points of a three-scan sub-map into one 3.7 mm bin): the c x c
     // comparisons all run on this one CU -- 17 us at 1 000 candidates, 75 at 2 000, whatever the number of threads.
     // Instead: the candidate of rank `target` by a radix select over the 16 bytes of the tuple (cut-axis key, the two
     // other keys, index; most significant first; it stops as soon as one candidate is left: after the third or fourth
-    // byte unless the keys tie), then ONE comparison per candidate.
-    uint32_t alive = 0u;     // bit k: candidate threadIdx.x + k * blockDim.x still has the median's leading bytes
-    for (uint32_t i = threadIdx.x, k = 0; i < c; i += blockDim.x, ++k) alive |= 1u << k;
+    // byte unless the keys tie), then ONE comparison per candidate.  A candidate is still in the running while its
+    // leading bytes are the ones chosen so far; up to kGsCandCap candidates are read from LDS, more from the global list.
+    GsMedian ch{0u, 0u, 0u, 0u};                         // the bytes chosen so far
     uint32_t rem = target;
-    for (int pass = 0; pass < 16; ++pass) {
+    bool found = false;
+    for (int pass = 0; pass < 16 && !found; ++pass) {
       const int field = pass >> 2, shift = 24 - 8 * (pass & 3);
+      const uint32_t himask = shift == 24 ? 0u : 0xFFFFFFFFu << (shift + 8);   // the current field's bytes already chosen
       if (threadIdx.x < 256u) rh[threadIdx.x] = 0u;
       __syncthreads();
-      for (uint32_t i = threadIdx.x, k = 0; i < c; i += blockDim.x, ++k)
-        if ((alive >> k) & 1u) {
-          const GsMedian o = lc[i];
-          const uint32_t f = field == 0 ? o.ka : field == 1 ? o.k1 : field == 2 ? o.k2 : o.e;
-          atomicAdd(&rh[(f >> shift) & 255u], 1u);
-        }
+      for (uint32_t i = threadIdx.x; i < c; i += blockDim.x) {
+        const GsMedian o = in_lds ? lc[i] : gc[i];
+        const bool before_ok = (field < 1 || o.ka == ch.ka) && (field < 2 || o.k1 == ch.k1) && (field < 3 || o.k2 == ch.k2);
+        const uint32_t f = field == 0 ? o.ka : field == 1 ? o.k1 : field == 2 ? o.k2 : o.e;
+        const uint32_t cf = field == 0 ? ch.ka : field == 1 ? ch.k1 : field == 2 ? ch.k2 : ch.e;
+        if (before_ok && ((f ^ cf) & himask) == 0u) atomicAdd(&rh[(f >> shift) & 255u], 1u);
+      }
       __syncthreads();
       uint32_t bin, below;
       gs_find_bin(rh, rem, sh, bin, below);
-      if (bin == 0xFFFFFFFFu) { alive = 0u; break; }     // (rank outside the candidates: flagged above)
+      if (bin == 0xFFFFFFFFu) break;                     // (rank outside the candidates: flagged above)
       rem -= below;
-      const uint32_t left_in_bin = rh[bin];
-      for (uint32_t i = threadIdx.x, k = 0; i < c; i += blockDim.x, ++k)
-        if ((alive >> k) & 1u) {
-          const GsMedian o = lc[i];
+      found = rh[bin] == 1u;
+      const uint32_t add = bin << shift;
+      if (field == 0) ch.ka |= add; else if (field == 1) ch.k1 |= add; else if (field == 2) ch.k2 |= add; else ch.e |= add;
+      if (found) {                                       // one candidate has these leading bytes: the median
+        const uint32_t lomask = shift == 0 ? 0xFFFFFFFFu : 0xFFFFFFFFu << shift;
+        for (uint32_t i = threadIdx.x; i < c; i += blockDim.x) {
+          const GsMedian o = in_lds ? lc[i] : gc[i];
+          const bool before_ok = (field < 1 || o.ka == ch.ka) && (field < 2 || o.k1 == ch.k1) && (field < 3 || o.k2 == ch.k2);
           const uint32_t f = field == 0 ? o.ka : field == 1 ? o.k1 : field == 2 ? o.k2 : o.e;
-          if (((f >> shift) & 255u) != bin) alive &= ~(1u << k);
+          const uint32_t cf = field == 0 ? ch.ka : field == 1 ? ch.k1 : field == 2 ? ch.k2 : ch.e;
+          if (before_ok && ((f ^ cf) & lomask) == 0u) { med_slot = i; med_sh = o; }
         }
-      __syncthreads();                                   // (rh is cleared again at the top)
-      if (left_in_bin == 1u) break;
+      }
+      __syncthreads();                                   // (rh is cleared again at the top; med_sh is complete)
     }
-    for (uint32_t i = threadIdx.x, k = 0; i < c; i += blockDim.x, ++k)
-      if ((alive >> k) & 1u) med_slot = i;               // (one candidate: the indices are distinct)
-    __syncthreads();
     if (med_slot != 0xFFFFFFFFu) {
-      const GsMedian m = lc[med_slot];
+      const GsMedian m = med_sh;
       for (uint32_t i = threadIdx.x; i < c; i += blockDim.x) {
-        const GsMedian o = lc[i];
+        const GsMedian o = in_lds ? lc[i] : gc[i];
         if (gs_less(o.ka, o.k1, o.k2, o.e, m)) {
-          const uint32_t blk = lblk[i];
+          const uint32_t blk = in_lds ? lblk[i] : gb[i];
           if (lds_counts) atomicAdd(&lcnt[blk - q.fb], 1u); else arrived ^= atomicAdd(&cl[blk], 1u);
         }
       }
@@ -378,7 +437,7 @@ __global__ __launch_bounds__(1024) void k_gs_select(const GsSegBlocks* __restric
     // (no median: an error has been flagged above and the host repeats the filter -- but everything queued behind this
     //  level, k_ssn_tree included, runs first and must find segments that are what the static halving says they are)
     const bool have = med_slot != 0xFFFFFFFFu;
-    const GsMedian m = have ? lc[med_slot] : GsMedian{0u, 0u, 0u, 0u};
+    const GsMedian m = have ? med_sh : GsMedian{0u, 0u, 0u, 0u};
     median[s] = m;
     const SsnSeg sg = segs[s];
     const int cut = ssn_cut_axis(sg);
