@@ -1,4 +1,5 @@
 #!/bin/bash
+# dev helper (GPU box): the bit-exact filter tests (REPS="1 2 3": repeated, to catch a race), then devtools/filter_time.py
 cd "$(dirname "$0")/.." || exit 1
 export TMPDIR=/tmp
 ulimit -c 0

@@ -1,7 +1,9 @@
 #!/bin/bash
+# dev helper (GPU box): rocprofv3 kernel stats of devtools/filter_time.py and the timeline of one reference filter
+# (IDX: which k_gs_init to start from -- 3: a 1 M-point filter, 9: a 3.1 M-point one; NROWS: kernels to print)
 cd "$(dirname "$0")/.." || exit 1
 mkdir -p gpurun_out; export TMPDIR=/tmp
-tag=${1:-r05p}
+tag=${1:-fprof}
 rm -rf gpurun_out/prof_${tag}
 (cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats -d $OLDPWD/gpurun_out/prof_${tag} -- python $OLDPWD/devtools/filter_time.py > /dev/null 2> $OLDPWD/gpurun_out/${tag}_prof.err)
 db=$(find gpurun_out/prof_${tag} -name "*results.db" | head -1)

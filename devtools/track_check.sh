@@ -1,7 +1,8 @@
 #!/bin/bash
+# dev helper (GPU box): bench.py's value_track section alone, per-scan stages printed (LSGPU_GS_DEBUG=1: the library's diagnostics)
 cd "$(dirname "$0")/.." || exit 1
 mkdir -p gpurun_out; export TMPDIR=/tmp
-tag=${1:-r05trk}
+tag=${1:-trk}
 timeout 900 python devtools/track_only.py > gpurun_out/${tag}_track.json 2> gpurun_out/${tag}_track.err; echo "track rc=$?"
 python - <<PY
 import json
