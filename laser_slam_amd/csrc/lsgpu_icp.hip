@@ -1462,8 +1462,8 @@ static int ssn_device(lsgpu_icp* h, const float4* src, int64_t n, int knn, float
     }
   } else if (select_levels) {
     // Sort-free upper levels (lsgpu_ssn_select.hip.h): a segment is a set + a signature, a level is the exact median in the
-    // segment's total order (two 8-bit histogram passes over the box range + a per-segment selection among the few
-    // candidates left) and one stable partition: 7 launches per level, no sort.
+    // segment's total order (two 8-bit histogram passes over the range its points span + a per-segment selection among the
+    // candidates left) and one stable partition: five launches per level, no sort.
     if (h->gs_plan_n != n || h->gs_plan_levels != glevels) {   // block tables: static for a cloud size
       // every level's number of blocks and first row (sizes of a level: c -> c - c / 2, c / 2)
       std::vector<uint32_t> sizes{(uint32_t)n}, next;

@@ -19,20 +19,23 @@
 //   k_gs_collect               the candidates of the last bin -> a small per-segment list; every block's count of points that
 //                              go left for sure;
 //   k_gs_select                ONE workgroup per segment: the exact median of the candidates in the total order above (key on
-//                              the cut axis, keys on the signature's other axes, original index), the children's boxes and
-//                              signatures, the candidates' share of the blocks' left counts;
+//                              the cut axis, keys on the signature's other axes, original index) -- ranks by ballots up to 256
+//                              candidates, a radix select over the tuple's bytes beyond --, the children's boxes and
+//                              signatures, the candidates' share of the blocks' left counts and their exclusive prefix;
 //   k_gs_part                  the stable partition by "before the median in that order": points and their three keys move
 //                              to the other buffer set, left half first; on the way the key range of either child on ITS cut
 //                              axis (four atomics per block).
 // Five launches per level, every access by position coalesced, no key ever sorted.  Segment sizes are static (exact
-// halving), so the block tables of all levels are computed on the host once per cloud size.
+// halving): the host knows every level's number of blocks, k_gs_plan writes the block tables when the cloud's size changes.
 // k_ssn_tree takes the sets over: it presorts its three axes anyway; the list of the signature's first axis gets its tie
 // runs ordered by the same comparator once (lsgpu_ssn_tree.hip.h, "initial order"), after which the workgroup's own
 // bookkeeping (cur_pos) carries on.  The scheme is modelled step for step in tests/ssn_tree_model.py (select_then_tree) and
 // checked there against the chain of stable sorts the restatement defines, heavy ties included.
-// Limits: more than kGsCandCap candidates in a segment's last bin (thousands of EQUAL coordinates around a median), or a
-// key outside its segment's box, raise a flag and the host repeats the filter with the segmented sorts
-// (LSGPU_SSN_SORT_LEVELS selects them always).  Bit-identical to them and to the oracle.
+// Limits: more candidates in a segment's last bin than the level's share of the candidate list (kGsCandCap per segment of
+// the last level, the same room shared out among the fewer segments of the levels above: a wall square to a frame axis puts
+// 12 000 points of a sub-map into one bin of the first level), or a key outside its segment's range, raise a flag and the
+// host repeats the filter with the segmented sorts (LSGPU_SSN_SORT_LEVELS selects them always; LSGPU_GS_DEBUG prints the
+// reason).  Bit-identical to them and to the oracle.
 #pragma once
 #include "lsgpu_ssn.hip.h"
 #include "lsgpu_ssn_tree.hip.h"
@@ -48,7 +51,7 @@ namespace lsgpu {
 
 constexpr uint32_t kGsTile = 2048u;       // positions per block of the level kernels (256 threads x 8)
 constexpr int kGsPartThreads = 512;        // k_gs_part: 4 positions per thread (512 blocks of 256 threads left a 1 M-point level two waves per SIMD)
-constexpr uint32_t kGsCandCap = 2048u;    // candidates per segment
+constexpr uint32_t kGsCandCap = 2048u;    // candidates per segment of the LAST level (and what k_gs_select holds in LDS)
 constexpr uint32_t kGsNoAxis = 0xFFu;
 constexpr uint32_t kGsSelBlocks = 8192u;  // k_gs_select counts in LDS for segments of up to this many blocks (16.7 M points)
 

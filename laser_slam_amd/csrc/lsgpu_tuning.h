@@ -32,11 +32,11 @@
 //   LSGPU_ROWQ_BLOCKS     2048  (with NO_FRONT) grid of the row pass
 //   LSGPU_SORT_ITEMS         0  keys per thread of the radix passes (0: by size; 4, 8, 16)
 //   LSGPU_SSN_FULL_SORT         the reference filter's levels as whole-cloud sorts by (segment, coordinate) (rounds 1-3) instead of segmented sorts
-//   LSGPU_SSN_GLOBAL            every level of the reference filter as a global sort (no in-LDS finish)
+//   LSGPU_SSN_GLOBAL            every level of the reference filter as a global sort (no in-LDS finish; implies LSGPU_SSN_SORT_LEVELS)
 //   LSGPU_SSN_SORT_LEVELS       the upper levels of the reference filter with a segmented sort per level (round 4, lsgpu_segsort.hip.h) instead of
 //                               the sort-free levels of lsgpu_ssn_select.hip.h (exact median by selection + one stable partition)
 //   LSGPU_SSN_OLD_FINISH        the last levels with k_ssn_finish (rounds 2-4: 2048 points per workgroup, a radix sort per level) instead of
-//                               k_ssn_tree (presorted axes, a stable partition per level)
+//                               k_ssn_tree (presorted axes, a stable partition per level); continues a sorted order: implies LSGPU_SSN_SORT_LEVELS
 //   LSGPU_SSN_ROOT        8192  points per workgroup of k_ssn_tree (2048, 4096, 8192)
 //   LSGPU_NE_BLOCKS        256  blocks of k_normal_eq_loop (64 .. 2048)
 //   LSGPU_SPLIT_UPDATE          the per-iteration update as its own launch (profiling)
