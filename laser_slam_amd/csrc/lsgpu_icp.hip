@@ -1518,7 +1518,7 @@ static int ssn_device(lsgpu_icp* h, const float4* src, int64_t n, int knn, float
     for (auto& bf : h->gs_e) HIPC(bf.reserve(n));
     for (auto& bf : h->gs_k) HIPC(bf.reserve(n));
     HIPC(h->gs_hist.reserve(4 * 256 * (nseg_g + 1))); HIPC(h->gs_median.reserve(nseg_g)); HIPC(h->gs_cand_n.reserve(2 * nseg_g + 2));
-    const size_t cand_room = std::max<size_t>(nseg_g / 2, 1) * kGsCandCap;
+    const size_t cand_room = std::max<size_t>(nseg_g / 2, 1) * kGsCandRoom;
     HIPC(h->gs_cand.reserve(cand_room)); HIPC(h->gs_cand_blk.reserve(cand_room));
     HIPC(h->gs_cl.reserve((size_t)2 * cap)); HIPC(h->gs_err.reserve(8)); HIPC(h->gs_rng.reserve(2 * nseg_g + 2));
     HIPC(h->ssn_axis_a.reserve(nseg_g)); HIPC(h->ssn_axis_b.reserve(nseg_g));
@@ -1542,8 +1542,9 @@ static int ssn_device(lsgpu_icp* h, const float4* src, int64_t n, int knn, float
       const GsSegBlocks* sblk = h->gs_sblk.p + (ns - 1);
       hipLaunchKernelGGL(k_gs_hist<1>, dim3(nb), dim3(256), 0, h->stream, tab, cur, (const uint2*)rng_cur, in, gh1[par], gh2[par], h->gs_err.p);
       hipLaunchKernelGGL(k_gs_hist<2>, dim3(nb), dim3(256), 0, h->stream, tab, cur, (const uint2*)rng_cur, in, gh1[par], gh2[par], h->gs_err.p);
-      // (candidates per segment: the list's room shared out among the level's segments -- 2048 at the last level, half a
-      //  million at the first: a wall square to a frame axis puts 12 000 points of a sub-map into one bin of the first levels)
+      // (candidates per segment: the list's room shared out among the level's segments -- kGsCandRoom at the last level, i.e.
+      //  as many as the segment has points, and so at every level above it: a wall square to a frame axis puts 12 000 points
+      //  of a sub-map into one bin of the first levels, a lattice a fifth of a segment)
       const uint32_t lvl_cap = (uint32_t)std::min<size_t>(cand_room / (size_t)ns, (size_t)1 << 22);
       hipLaunchKernelGGL(k_gs_collect, dim3(nb), dim3(256), 0, h->stream, tab, cur, (const uint2*)rng_cur, (const uint32_t*)sig_cur, in,
                          (const uint32_t*)gh1[par], (const uint32_t*)gh2[par], cand_n[par], h->gs_cand.p, h->gs_cand_blk.p, lvl_cap, h->gs_cl.p);

@@ -31,9 +31,10 @@
 // runs ordered by the same comparator once (lsgpu_ssn_tree.hip.h, "initial order"), after which the workgroup's own
 // bookkeeping (cur_pos) carries on.  The scheme is modelled step for step in tests/ssn_tree_model.py (select_then_tree) and
 // checked there against the chain of stable sorts the restatement defines, heavy ties included.
-// Limits: more candidates in a segment's last bin than the level's share of the candidate list (kGsCandCap per segment of
-// the last level, the same room shared out among the fewer segments of the levels above: a wall square to a frame axis puts
-// 12 000 points of a sub-map into one bin of the first level), or a key outside its segment's range, raise a flag and the
+// Limits: the candidate list has room for kGsCandRoom candidates per segment of the LAST level -- as many as such a segment
+// has points -- and the levels above share the same total, so a segment's candidates always fit (a wall square to a frame
+// axis puts 12 000 points of a sub-map into one bin of the first level; a lattice a fifth of a segment).  What cannot
+// happen -- more candidates than room, a key outside its segment's range, counts that do not add up -- raises a flag and the
 // host repeats the filter with the segmented sorts (LSGPU_SSN_SORT_LEVELS selects them always; LSGPU_GS_DEBUG prints the
 // reason).  Bit-identical to them and to the oracle.
 #pragma once
@@ -51,7 +52,9 @@ namespace lsgpu {
 
 constexpr uint32_t kGsTile = 2048u;       // positions per block of the level kernels (256 threads x 8)
 constexpr int kGsPartThreads = 512;        // k_gs_part: 4 positions per thread (512 blocks of 256 threads left a 1 M-point level two waves per SIMD)
-constexpr uint32_t kGsCandCap = 2048u;    // candidates per segment of the LAST level (and what k_gs_select holds in LDS)
+constexpr uint32_t kGsCandCap = 2048u;    // candidates k_gs_select holds in LDS (more: it works on the global list)
+constexpr uint32_t kGsCandRoom = 16384u;  // room in the candidate list per segment of the LAST level (>= its points: it cannot
+                                          // overflow; the levels above share the same total, i.e. their segments' sizes too)
 constexpr uint32_t kGsNoAxis = 0xFFu;
 constexpr uint32_t kGsSelBlocks = 8192u;  // k_gs_select counts in LDS for segments of up to this many blocks (16.7 M points)
 
@@ -253,20 +256,30 @@ __global__ __launch_bounds__(256) void k_gs_collect(const GsBlock* __restrict__ 
   gs_other_axes(sig[sb.seg], (uint32_t)c.a, x1, x2);
   const uint32_t* __restrict__ ka = gs_k(in, c.a);
   uint32_t left = 0u;
-  for (uint32_t j = threadIdx.x; j < sb.count; j += 256u) {
-    const uint32_t i = sb.first + j;
-    const uint32_t k = ka[i];
+  // (uniform trip count: the waves allocate their candidates' slots together -- ONE atomic on the segment's counter per
+  //  wave and round instead of one per candidate: a wall square to the cut axis is twelve thousand candidates in one
+  //  segment, and same-address atomics are served one after the other, ~12 ns each)
+  const int lane = threadIdx.x & 63;
+  for (uint32_t j0 = 0; j0 < sb.count; j0 += 256u) {
+    const uint32_t j = j0 + threadIdx.x;
+    const bool live = j < sb.count;
+    const uint32_t i = sb.first + (live ? j : 0u);
+    const uint32_t k = live ? ka[i] : 0u;
     const uint32_t b16 = gs_bin16(c, k), b1 = b16 >> 8, b2 = b16 & 255u;
-    if (b1 < mb1 || (b1 == mb1 && b2 < mb2)) {
-      ++left;
-    } else if (b1 == mb1 && b2 == mb2) {
-      const uint32_t slot = atomicAdd(&cand_n[sb.seg], 1u);
-      if (slot < cap) {
-        GsMedian m;
-        m.ka = k; m.e = in.e[i];
-        m.k1 = x1 != kGsNoAxis ? gs_k(in, (int)x1)[i] : 0u;
-        m.k2 = x2 != kGsNoAxis ? gs_k(in, (int)x2)[i] : 0u;
-        cand[(size_t)sb.seg * cap + slot] = m;
+    const bool is_cand = live && b1 == mb1 && b2 == mb2;
+    if (live && (b1 < mb1 || (b1 == mb1 && b2 < mb2))) ++left;
+    const unsigned long long m = __ballot(is_cand);
+    if (m != 0ull) {
+      uint32_t base = 0u;
+      if (lane == 0) base = atomicAdd(&cand_n[sb.seg], (uint32_t)__popcll(m));
+      base = (uint32_t)__shfl((int)base, 0);
+      const uint32_t slot = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+      if (is_cand && slot < cap) {
+        GsMedian md;
+        md.ka = k; md.e = in.e[i];
+        md.k1 = x1 != kGsNoAxis ? gs_k(in, (int)x1)[i] : 0u;
+        md.k2 = x2 != kGsNoAxis ? gs_k(in, (int)x2)[i] : 0u;
+        cand[(size_t)sb.seg * cap + slot] = md;
         cand_blk[(size_t)sb.seg * cap + slot] = blockIdx.x;
       }
     }

@@ -416,6 +416,32 @@ def test_direction_index_returns_after_a_price_off():
     assert back["heavy_share"] <= 0.5 * s0, (back, never_off)     # the share the look found when it let the index back in
 
 
+def test_sort_free_levels_keep_walls_and_lattices():
+    """Behaviour beside results: the box tree's sort-free upper levels (csrc/lsgpu_ssn_select.hip.h) must KEEP clouds that
+    put thousands of equal coordinates around a median -- a wall square to a frame axis (scans 18-19 of the track drive put
+    12 246 points into one bin and a fixed capacity of 2048 candidates sent both filters to the segmented sorts, at twice the
+    time), a lattice -- and still give the oracle's bits.  The library reports a hand-over on stderr under LSGPU_GS_DEBUG;
+    with LSGPU_SSN_SORT_LEVELS the same clouds go through the segmented sorts and give the same result."""
+    import json
+    import subprocess
+    import sys
+
+    def run(kind, env_add):
+        env = dict(os.environ, LSGPU_GS_DEBUG="1")
+        env.update(env_add)
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "levels_worker.py"), kind], env=env, capture_output=True, text=True, timeout=300)
+        line = [ln for ln in r.stdout.splitlines() if ln.startswith("LEVELS_RESULT ")]
+        assert r.returncode == 0 and line, (kind, r.stdout[-1500:], r.stderr[-1500:])
+        return json.loads(line[0][len("LEVELS_RESULT "):]), r.stderr
+
+    for kind in ("wall", "lattice"):
+        res, err = run(kind, {})
+        assert res["equal"] and res["kept"] > 0, (kind, res)     # (the lattice's boxes are mostly lines in x, y: few survive the rank test)
+        assert "gave up" not in err, (kind, err[-800:])            # the sort-free levels did the whole tree
+        res2, _ = run(kind, {"LSGPU_SSN_SORT_LEVELS": "1"})
+        assert res2 == res, (kind, res, res2)
+
+
 def test_full_size_properties(icp_mod):
     """BASELINE configs[1] size (1M-point pair): size-independent properties instead of the oracle.
     (a) kNN distances are self-consistent with the returned ids and no sampled brute-force distance
@@ -668,7 +694,7 @@ def test_device_reference_filter_edge_cases(icp_mod, oracle):
         # ... and one constant axis on top (a sheet): every cut alternates between the two others
         sheet = grid[:20000].copy(); sheet[:, 2] = np.float32(1.5)
         # few distinct values along the two widest axes: thousands of equal coordinates around the upper levels' medians -- more
-        # than the sort-free levels select among (kGsCandCap): the filter falls back to the segmented sorts, same output
+        # than k_gs_select holds in LDS (kGsCandCap): it selects among them on the global list, same output
         coarse = np.ones((40000, 4), np.float32)
         coarse[:, 0] = 10.0 * rng.integers(0, 8, size=40000); coarse[:, 1] = 8.0 * rng.integers(0, 4, size=40000)
         coarse[:, 2] = rng.normal(size=40000)
