@@ -321,25 +321,32 @@ class ICP {
     // step 5 of ICP::compute moves the reading by T_refMean_dataIn with RigidTransformation::compute, which refuses a
     // matrix that is not rigid; neither call site corrects its guess (laser_track.cpp:489-496, incremental_estimator.cpp:
     // 92-108: only the sub-map transforms go through correctTransformationMatrix) and neither catches this exception.
-    // (Checked HERE, before the filters run: upstream throws at step 5, after both filters have consumed their rand()
-    // draws, and so does the C ABI -- lsgpu_icp_align returns LSGPU_BAD_ARG behind the filters.  On this error path the
-    // facade therefore leaves the library's draw stream where it was; a caller that catches the exception and goes on
-    // sees different draws than a libpointmatcher process would.  Neither call site of laser_slam catches it.)
-    requireRigid(T_init);
+    // Upstream throws at its step 5, AFTER both filters have consumed their rand() draws.  So does the C ABI
+    // (lsgpu_icp_align rejects the guess behind the filters), and so does this facade: a guess that is not rigid is handed
+    // to the device all the same, whose filters run and whose step 5 refuses it; only then the exception is thrown.  A
+    // caller that catches it and goes on sees the draws a libpointmatcher process would see.  (Without a device there is
+    // no draw stream to keep in step: the exception is thrown at once.)
+    const bool rigid = RigidTransformation::checkParameters(T_init);
 #ifdef LSGPU_TEST_SEAMS
-    if (override_) return override_(*this, reading, reference, T_init);
+    if (override_) { requireRigid(T_init); return override_(*this, reading, reference, T_init); }
 #endif
-    ensureHandle();
+    if (!rigid) {
+      try { ensureHandle(); } catch (const DeviceError&) { requireRigid(T_init); }
+    } else {
+      ensureHandle();
+    }
     const int64_t nr = reference.getNbPoints(), nq = reading.getNbPoints();
-    if (nr <= 0 || nq <= 0) throw ConvergenceError("empty cloud");
+    if (nr <= 0 || nq <= 0) { requireRigid(T_init); throw ConvergenceError("empty cloud"); }
     // ICP::compute steps 1-7 on the device: referenceDataPointsFilters, centring + grid,
     // readingDataPointsFilters, the loop (lsgpu_icp_compute)
     lsgpu_chain_config chain;
     lsgpu_chain_config_default(&chain);
     chain.reading_prob = prob_; chain.ssn_knn = knn_; chain.ssn_ratio = ratio_; chain.seed = seed_;
     TransformationParameters T = T_init;
-    check(lsgpu_icp_compute(h_, reading.features.data(), nq, reference.features.data(), nr, T_init.data(),
-                            &chain, T.data(), &stats_), "lsgpu_icp_compute");
+    const int rc = lsgpu_icp_compute(h_, reading.features.data(), nq, reference.features.data(), nr, T_init.data(),
+                                     &chain, T.data(), &stats_);
+    if (!rigid) requireRigid(T_init);          // (rc is LSGPU_BAD_ARG from step 5, the filters have run)
+    check(rc, "lsgpu_icp_compute");
 #ifdef LSGPU_TEST_SEAMS
     if (observer_) observer_(*this, reading, reference, T_init, T);
 #endif
@@ -365,8 +372,12 @@ class ICP {
   TransformationParameters computeClouds(int reading, const std::vector<int>& refs,
                                          const std::vector<TransformationParameters>& ref_T,
                                          const TransformationParameters& T_init) {
-    requireRigid(T_init);
-    ensureHandle();
+    const bool rigid = RigidTransformation::checkParameters(T_init);   // (refused at step 5, behind the filters: see compute())
+    if (!rigid) {
+      try { ensureHandle(); } catch (const DeviceError&) { requireRigid(T_init); }
+    } else {
+      ensureHandle();
+    }
     if (refs.size() != ref_T.size()) throw std::logic_error("one transform per reference cloud");
     lsgpu_chain_config chain;
     lsgpu_chain_config_default(&chain);
@@ -374,8 +385,10 @@ class ICP {
     std::vector<float> flat(16 * refs.size());
     for (size_t i = 0; i < refs.size(); ++i) std::memcpy(&flat[16 * i], ref_T[i].data(), 16 * sizeof(float));
     TransformationParameters T = T_init;
-    check(lsgpu_icp_compute_clouds(h_, reading, refs.data(), flat.data(), (int)refs.size(), T_init.data(), &chain,
-                                   T.data(), &stats_), "lsgpu_icp_compute_clouds");
+    const int rc = lsgpu_icp_compute_clouds(h_, reading, refs.data(), flat.data(), (int)refs.size(), T_init.data(), &chain,
+                                            T.data(), &stats_);
+    if (!rigid) requireRigid(T_init);
+    check(rc, "lsgpu_icp_compute_clouds");
     return T;
   }
 

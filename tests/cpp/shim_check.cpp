@@ -46,6 +46,30 @@ int main(int argc, char** argv) {
   bool threw = false;
   try { DataPoints empty; shim.compute(empty, ref, T_init); } catch (const ConvergenceError&) { threw = true; }
   CHECK(threw);
+  // a guess that is not rigid is refused at step 5 of ICP::compute, i.e. AFTER both filters have consumed their rand()
+  // draws (upstream throws TransformationError out of RigidTransformation::compute there): a caller that catches the
+  // exception and goes on must see the draws it would have seen after a successful call with the same clouds
+  {
+    ICP a, b;
+    { std::ifstream y(argv[1]); a.loadFromYaml(y); }
+    { std::ifstream y(argv[1]); b.loadFromYaml(y); }
+    TransformationParameters T_bad = T_init;
+    T_bad[0] = 1.1f;                                           // det 1.1
+    a.setSeed(9);
+    threw = false;
+    try { a.compute(rd, ref, T_bad); } catch (const TransformationError&) { threw = true; }
+    CHECK(threw);
+    a.setSeed(-1);                                             // continue the stream
+    const TransformationParameters Tc = a.compute(rd, ref, T_init);
+    b.setSeed(9);
+    (void)b.compute(rd, ref, T_init);                          // the same filters on the same clouds: the same draws consumed
+    b.setSeed(-1);
+    const TransformationParameters Td = b.compute(rd, ref, T_init);
+    CHECK(std::memcmp(Tc.data(), Td.data(), sizeof(float) * 16) == 0);
+    b.setSeed(9);
+    const TransformationParameters Te = b.compute(rd, ref, T_init);   // (and the draws matter: from the stream's start the result differs)
+    CHECK(std::memcmp(Tc.data(), Te.data(), sizeof(float) * 16) != 0);
+  }
   threw = false;
   try { std::istringstream bad("matcher:\n  NullMatcher\n"); shim.loadFromYaml(bad); } catch (const std::runtime_error&) { threw = true; }
   CHECK(threw);
