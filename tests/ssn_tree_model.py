@@ -208,3 +208,88 @@ def select_then_tree(pts, knn, lo, hi, root_size):
 
     upper(np.arange(n), lo.copy(), hi.copy(), [])
     return leaves
+
+
+# ---- the upper levels' bookkeeping (csrc/lsgpu_ssn_select.hip.h) ------------------------------------------------------------
+def block_tables_by_halving(n, levels, tile=2048):
+    """What the host used to build and copy: per level the list of (first, count, segment, seg_start, seg_count, fb, nb)
+    rows, from the recursion c -> (c - c // 2, c // 2), left child first."""
+    out = []
+    segs = [(0, n)]
+    for _ in range(levels):
+        rows, fb, nxt = [], 0, []
+        for s, (st, c) in enumerate(segs):
+            nb = (c + tile - 1) // tile
+            for k in range(nb):
+                rows.append((st + k * tile, min(tile, c - k * tile), s, st, c, fb, nb))
+            fb += nb
+            left = c - c // 2
+            nxt += [(st, left), (st + left, c - left)]
+        out.append(rows)
+        segs = nxt
+    return out
+
+
+def block_tables_by_bit_path(n, levels, tile=2048):
+    """k_gs_plan: every segment finds its (start, count) on its own from the bits of its index -- the path from the root,
+    most significant bit first, 1 = right child -- then an exclusive scan of the block counts and, per row, a binary search
+    for the segment that owns it."""
+    out = []
+    for L in range(levels):
+        ns = 1 << L
+        st_c = []
+        for sg in range(ns):
+            st, c = 0, n
+            for bit in range(L - 1, -1, -1):
+                left = c - c // 2
+                if (sg >> bit) & 1:
+                    st += left; c -= left
+                else:
+                    c = left
+            st_c.append((st, c))
+        nb = [(c + tile - 1) // tile for _, c in st_c]
+        fbs = np.concatenate([[0], np.cumsum(nb)]).astype(np.int64)
+        rows = []
+        for j in range(int(fbs[-1])):
+            lo, hi = 0, ns
+            while hi - lo > 1:
+                mid = (lo + hi) >> 1
+                if fbs[mid] <= j:
+                    lo = mid
+                else:
+                    hi = mid
+            k = j - int(fbs[lo]); st, c = st_c[lo]
+            rows.append((st + k * tile, min(tile, c - k * tile), lo, st, c, int(fbs[lo]), int(fbs[lo + 1] - fbs[lo])))
+        out.append(rows)
+    return out
+
+
+def radix_select_tuple(cands, target):
+    """k_gs_select above 256 candidates: the tuple of rank `target` (0-based) among distinct 4-word tuples, by a radix select
+    over their 16 bytes, most significant first, that stops as soon as one candidate has the chosen leading bytes.
+    cands: (c, 4) uint32.  Returns the row index."""
+    c = np.asarray(cands, np.uint64)
+    chosen = [0, 0, 0, 0]
+    rem = int(target)
+    for p in range(16):
+        field, shift = p >> 2, 24 - 8 * (p & 3)
+        himask = 0 if shift == 24 else (0xFFFFFFFF << (shift + 8)) & 0xFFFFFFFF
+        alive = np.ones(len(c), bool)
+        for f in range(field):
+            alive &= c[:, f] == chosen[f]
+        alive &= ((c[:, field] ^ chosen[field]) & himask) == 0
+        byte = ((c[:, field] >> shift) & 255).astype(np.int64)
+        hist = np.bincount(byte[alive], minlength=256)
+        excl = np.concatenate([[0], np.cumsum(hist)[:-1]])
+        b = int(np.nonzero((hist > 0) & (excl <= rem) & (rem < excl + hist))[0][0])
+        rem -= int(excl[b])
+        chosen[field] |= b << shift
+        if hist[b] == 1:
+            lomask = (0xFFFFFFFF << shift) & 0xFFFFFFFF
+            m = np.ones(len(c), bool)
+            for f in range(field):
+                m &= c[:, f] == chosen[f]
+            m &= ((c[:, field] ^ chosen[field]) & lomask) == 0
+            (i,) = np.nonzero(m)
+            return int(i[0])
+    raise AssertionError("equal tuples")

@@ -412,6 +412,29 @@ def test_presorted_lists_equal_the_chain_of_stable_sorts():
             assert len(a) == len(c) and all(np.array_equal(x, y) for x, y in zip(a, c)), (trial, root)
 
 
+def test_upper_level_bookkeeping_models():
+    """Two pieces of the sort-free levels that no result can single out, modelled in tests/ssn_tree_model.py the way the
+    kernels do them: (a) k_gs_plan's block tables -- every segment finds its start and size from the bits of its index, rows
+    find their segment by binary search -- against the rows the halving recursion gives; (b) k_gs_select's radix select of
+    the median tuple against a sort, with heavy ties on the leading words (a wall: thousands of equal cut keys, resolved by
+    the index)."""
+    import ssn_tree_model as M
+    rng = np.random.default_rng(3)
+    for n, levels, tile in ((1, 1, 4), (37, 3, 4), (1000, 5, 16), (1046319, 7, 2048), (3139020, 9, 2048), (65537, 4, 2048)):
+        assert M.block_tables_by_bit_path(n, levels, tile) == M.block_tables_by_halving(n, levels, tile), n
+    for trial in range(60):
+        c = int(rng.integers(1, 700))
+        mode = trial % 3
+        t = np.zeros((c, 4), np.uint32)
+        t[:, 0] = rng.integers(0, 2 ** 32, size=c) if mode == 0 else (0x41000000 + rng.integers(0, 3, size=c))
+        t[:, 1] = rng.integers(0, 2 ** 32, size=c) if mode != 2 else 0
+        t[:, 2] = rng.integers(0, 5, size=c) if mode != 2 else 0
+        t[:, 3] = rng.permutation(c) * 7 + 1                   # distinct indices
+        order = np.lexsort((t[:, 3], t[:, 2], t[:, 1], t[:, 0]))
+        for target in {0, c - 1, c // 2, int(rng.integers(0, c))}:
+            assert M.radix_select_tuple(t, target) == int(order[target]), (trial, target)
+
+
 def _check_boxes_against_recursion(pts, boxes, out, nrm):
     pos = 0
     checked = 0
