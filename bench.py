@@ -151,8 +151,9 @@ def track_section(n_az: int, n_scans: int, cpu_threads: int):
         if stages:
             out["stages_ms_median"] = {k[:-3]: round(float(np.median([st[k] for st in stages])), 3) for k in stages[0] if k.endswith("_ms")}
             out["stages_ms"] = {k[:-3] if k.endswith("_ms") else k: [round(st[k], 2) for st in all_stages] for k in all_stages[0]}
-            out["stages_are"] = ("copy = the call's working copy of the scan + input filters (host); upload = the new scan's H2D into its HBM slot; "
-                                 "icp = icp_.compute on the resident clouds (device_filters / device_total: the C ABI's own clocks inside it)")
+            out["stages_are"] = ("copy = the call's working copy of the scan + input filters (host); upload = H2D of sub-map scans that are not resident "
+                                 "(none in steady state; the NEW scan's H2D goes out with icp_.compute -- lsgpu_icp_compute_clouds_upload -- and crosses PCIe "
+                                 "while the sub-map is filtered); icp = icp_.compute (device_filters / device_total: the C ABI's own clocks inside it)")
         if sh:
             t = sh[0]
             kv = {t[i]: t[i + 1] for i in range(1, len(t) - 1, 2)}

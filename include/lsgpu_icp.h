@@ -235,6 +235,17 @@ int lsgpu_cloud_size(lsgpu_icp* h, int slot, int64_t* n);   /* n = -1: empty slo
 int lsgpu_icp_compute_clouds(lsgpu_icp* h, int reading_slot, const int* ref_slots, const float* ref_T,
                              int n_ref, const float T_init[16], const lsgpu_chain_config* chain,
                              float T_out[16], lsgpu_icp_stats* stats);
+/* lsgpu_cloud_upload(h, reading_slot, reading_xyz1, nq) followed by lsgpu_icp_compute_clouds(h, reading_slot, ...), in one
+ * call: the new scan (host memory) crosses PCIe WHILE the sub-map is assembled and filtered.  This is the call shape of
+ * LaserTrack::processLaserScan -> localScanToSubMap (laser_slam/src/laser_track.cpp:112-119, 466-519): every scan is matched
+ * exactly once, right after it arrived, against scans that are already resident; uploaded first and matched afterwards, a
+ * 1 M-point scan's copy is 0.3 ms of idle device inside the reference's own timed region (scan_matching_times_,
+ * laser_track.cpp:128, 208-209).  Same results, same draws, same return codes as the two calls one after the other; the
+ * slot holds the scan on return whatever the registration's outcome.  `reading_slot` must not be one of `ref_slots`
+ * (then, and for a device pointer or an empty cloud, the two calls are simply made one after the other). */
+int lsgpu_icp_compute_clouds_upload(lsgpu_icp* h, int reading_slot, const float* reading_xyz1, int64_t nq,
+                                    const int* ref_slots, const float* ref_T, int n_ref, const float T_init[16],
+                                    const lsgpu_chain_config* chain, float T_out[16], lsgpu_icp_stats* stats);
 
 /* ---- local-map maintenance on the device --------------------------------------------
  * What the ROS worker does to its local map between scans (laser_slam_ros/src/laser_slam_worker.cpp:415-488,

@@ -20,7 +20,7 @@ ABI_SYMBOLS = [
     "lsgpu_icp_set_reference", "lsgpu_icp_align", "lsgpu_icp_align_batch", "lsgpu_icp_get_trace",
     "lsgpu_chain_config_yaml", "lsgpu_chain_config_default", "lsgpu_icp_filter_reference",
     "lsgpu_icp_filter_reading", "lsgpu_icp_compute", "lsgpu_cloud_upload", "lsgpu_cloud_release",
-    "lsgpu_cloud_size", "lsgpu_icp_compute_clouds", "lsgpu_filter_cylinder", "lsgpu_filter_voxel_grid",
+    "lsgpu_cloud_size", "lsgpu_icp_compute_clouds", "lsgpu_icp_compute_clouds_upload", "lsgpu_filter_cylinder", "lsgpu_filter_voxel_grid",
     "lsgpu_icp_get_reference_mean", "lsgpu_icp_get_info", "lsgpu_comm_get_unique_id", "lsgpu_icp_comm_init", "lsgpu_knn", "lsgpu_trim_limit", "lsgpu_normal_eq",
     "lsgpu_transform_points", "lsgpu_rotate_descriptors", "lsgpu_filter_random_sampling",
     "lsgpu_filter_sampling_surface_normal", "lsgpu_check_rigid", "lsgpu_correct_rigid", "lsgpu_rotation_distance",
@@ -174,6 +174,9 @@ def lib() -> C.CDLL:
     L.lsgpu_icp_compute_clouds.argtypes = [vp, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_float), C.c_int,
                                            C.POINTER(C.c_float), C.POINTER(ChainCfg), C.POINTER(C.c_float),
                                            C.POINTER(IcpStats)]
+    L.lsgpu_icp_compute_clouds_upload.argtypes = [vp, C.c_int, fp, i64, C.POINTER(C.c_int), C.POINTER(C.c_float), C.c_int,
+                                                  C.POINTER(C.c_float), C.POINTER(ChainCfg), C.POINTER(C.c_float),
+                                                  C.POINTER(IcpStats)]
     L.lsgpu_icp_get_trace.argtypes = [vp, C.POINTER(IterTrace), C.c_int]
     L.lsgpu_icp_get_reference_mean.argtypes = [vp, C.POINTER(C.c_float)]
     L.lsgpu_icp_get_info.argtypes = [vp, C.POINTER(IcpInfo)]

@@ -392,6 +392,31 @@ class ICP {
     return T;
   }
 
+  // uploadCloud(reading, cloud) + computeClouds(reading, ...) in one call: the new scan crosses PCIe while the sub-map is
+  // assembled and filtered (lsgpu_icp_compute_clouds_upload).  The slot holds the scan afterwards, also when this throws.
+  TransformationParameters computeCloudsUploading(int reading, const DataPoints& cloud, const std::vector<int>& refs,
+                                                  const std::vector<TransformationParameters>& ref_T,
+                                                  const TransformationParameters& T_init) {
+    const bool rigid = RigidTransformation::checkParameters(T_init);   // (refused at step 5, behind the filters: see compute())
+    if (!rigid) {
+      try { ensureHandle(); } catch (const DeviceError&) { requireRigid(T_init); }
+    } else {
+      ensureHandle();
+    }
+    if (refs.size() != ref_T.size()) throw std::logic_error("one transform per reference cloud");
+    lsgpu_chain_config chain;
+    lsgpu_chain_config_default(&chain);
+    chain.reading_prob = prob_; chain.ssn_knn = knn_; chain.ssn_ratio = ratio_; chain.seed = seed_;
+    std::vector<float> flat(16 * refs.size());
+    for (size_t i = 0; i < refs.size(); ++i) std::memcpy(&flat[16 * i], ref_T[i].data(), 16 * sizeof(float));
+    TransformationParameters T = T_init;
+    const int rc = lsgpu_icp_compute_clouds_upload(h_, reading, cloud.features.data(), cloud.getNbPoints(), refs.data(),
+                                                   flat.data(), (int)refs.size(), T_init.data(), &chain, T.data(), &stats_);
+    if (!rigid) requireRigid(T_init);
+    check(rc, "lsgpu_icp_compute_clouds_upload");
+    return T;
+  }
+
   // >= 0: reseed the filters' draw stream at every compute() (reproducible runs); < 0: continue it
   void setSeed(int64_t seed) { seed_ = seed; }
   int64_t seed() const { return seed_; }

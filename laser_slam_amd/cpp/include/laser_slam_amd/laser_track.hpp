@@ -416,10 +416,14 @@ class LaserTrack {
         const auto t_up = std::chrono::steady_clock::now();
         std::vector<int> slots;
         for (size_t m : members) slots.push_back(deviceSlot(m));
-        const int reading_slot = deviceSlot(n - 1);
+        // the new scan is matched exactly once, right after it arrived: its upload goes out WITH the registration and
+        // crosses PCIe while the sub-map -- scans already in HBM -- is assembled and filtered
+        const bool reading_resident = slotHolds(n - 1);
+        const int reading_slot = reading_resident ? deviceSlot(n - 1) : claimSlot(n - 1);
         stage_times_.upload_ms = msSince(t_up);
         const auto t_icp = std::chrono::steady_clock::now();
-        solution = icp_.computeClouds(reading_slot, slots, member_T, T_init);
+        solution = reading_resident ? icp_.computeClouds(reading_slot, slots, member_T, T_init)
+                                    : icp_.computeCloudsUploading(reading_slot, reading, slots, member_T, T_init);
         stage_times_.icp_ms = msSince(t_icp);
 #ifdef LSGPU_TEST_SEAMS
         if (icp_.hasComputeObserver()) {   // parity drivers: hand the observer the clouds the device just matched
@@ -458,6 +462,19 @@ class LaserTrack {
     icp_transformations_.push_back(icp);
   }
 
+  // (is scan `index` in its slot already?  /  its slot, marked as holding it: the caller uploads, lsgpu_icp_compute_clouds_upload)
+  bool slotHolds(size_t index) {
+    const int slot = (int)(index % (size_t)params_.scans_on_device);
+    return slot_generation_ == icp_.generation() && (size_t)slot < slot_owner_.size() && slot_owner_[(size_t)slot] == index &&
+           icp_.hasCloud(slot);
+  }
+  int claimSlot(size_t index) {
+    const int slot = (int)(index % (size_t)params_.scans_on_device);
+    if (slot_generation_ != icp_.generation()) { slot_owner_.clear(); slot_generation_ = icp_.generation(); }
+    if ((int)slot_owner_.size() < params_.scans_on_device) slot_owner_.resize((size_t)params_.scans_on_device, (size_t)-1);
+    slot_owner_[(size_t)slot] = index;
+    return slot;
+  }
   // Device slot of scan `index`: scan i lives in slot i % scans_on_device while it is among the most recent
   // ones; anything else (or everything, after the ICP object was reconfigured) is uploaded on demand.
   int deviceSlot(size_t index) {

@@ -164,6 +164,8 @@ struct lsgpu_icp {
   int device = 0;
   hipStream_t stream = nullptr;
   hipStream_t copy_stream = nullptr;   // lsgpu_icp_compute: the reading's H2D, overlapped with the reference filter
+  float4* upload_into = nullptr;       // lsgpu_icp_compute_clouds_upload: that H2D goes into the reading's slot instead of the staging buffer
+  bool upload_done = false;            // ... and has been enqueued (every return path of lsgpu_icp_compute drains the copy stream)
   hipEvent_t copy_done = nullptr;
   hipEvent_t ref_up_done = nullptr;    // the reference's H2D on `stream`: the reading's copy queues behind it
   std::string err;
@@ -1780,7 +1782,8 @@ int lsgpu_icp_compute(lsgpu_icp* h, const float* reading_xyz1, int64_t nq, const
   if (overlap_upload) {
     if (!h->copy_stream) HIPC(hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking));
     if (!h->copy_done) HIPC(hipEventCreateWithFlags(&h->copy_done, hipEventDisableTiming));
-    HIPC(h->flt_in2.reserve(nq));
+    float4* up_dst = h->upload_into;     // (a cloud slot: lsgpu_icp_compute_clouds_upload)
+    if (!up_dst) { HIPC(h->flt_in2.reserve(nq)); up_dst = h->flt_in2.p; }
     order_after_tail(h, h->copy_stream);
     // the reference's own upload goes first: it is in front of everything, the reading is not needed before the reading
     // filter, and two copies at once share the link (from pinned buffers they did: the pinned path was the slower one)
@@ -1789,11 +1792,12 @@ int lsgpu_icp_compute(lsgpu_icp* h, const float* reading_xyz1, int64_t nq, const
       HIPC(hipEventRecord(h->ref_up_done, h->stream));
       HIPC(hipStreamWaitEvent(h->copy_stream, h->ref_up_done, 0));
     }
-    auto upload = [&] {
+    auto upload = [&, up_dst] {
       hipError_t e = hipSetDevice(h->device);
-      if (e == hipSuccess) e = hipMemcpyAsync(h->flt_in2.p, reading_xyz1, (size_t)nq * 16, hipMemcpyHostToDevice, h->copy_stream);
+      if (e == hipSuccess) e = hipMemcpyAsync(up_dst, reading_xyz1, (size_t)nq * 16, hipMemcpyHostToDevice, h->copy_stream);
       if (e == hipSuccess) e = hipEventRecord(h->copy_done, h->copy_stream);
       upload_err = e;
+      if (e == hipSuccess) h->upload_done = true;
     };
     try {
       uploader = std::thread(upload);
@@ -1832,7 +1836,7 @@ int lsgpu_icp_compute(lsgpu_icp* h, const float* reading_xyz1, int64_t nq, const
       if (uploader.joinable()) uploader.join();
       if (upload_err != hipSuccess) { h->err = std::string("compute: reading upload: ") + hipGetErrorString(upload_err); (void)hipGetLastError(); return LSGPU_HIP_ERROR; }
       HIPC(hipStreamWaitEvent(on, h->copy_done, 0));
-      rd_src = h->flt_in2.p;
+      rd_src = h->upload_into ? h->upload_into : h->flt_in2.p;
     } else {
       rd_src = reinterpret_cast<const float4*>(reading_xyz1);
     }
@@ -2194,28 +2198,8 @@ int lsgpu_cloud_size(lsgpu_icp* h, int slot, int64_t* n) {
   return LSGPU_OK;
 }
 
-int lsgpu_icp_compute_clouds(lsgpu_icp* h, int reading_slot, const int* ref_slots, const float* ref_T,
-                             int n_ref, const float T_init[16], const lsgpu_chain_config* chain,
-                             float T_out[16], lsgpu_icp_stats* stats) {
-  if (!h || !T_init || !T_out || !chain || n_ref < 0 || (n_ref > 0 && !ref_slots)) return LSGPU_BAD_ARG;
-  h->err.clear();
-  std::memcpy(T_out, T_init, 16 * sizeof(float));
-  if (stats) std::memset(stats, 0, sizeof(*stats));
-  auto have = [&](int s) { return s >= 0 && (size_t)s < h->clouds.size() && h->cloud_n[s] >= 0; };
-  if (!have(reading_slot)) { h->err = "compute_clouds: empty reading slot"; return LSGPU_BAD_ARG; }
-  int64_t total = 0;
-  for (int i = 0; i < n_ref; ++i) {
-    if (!have(ref_slots[i])) { h->err = "compute_clouds: empty reference slot"; return LSGPU_BAD_ARG; }
-    total += h->cloud_n[ref_slots[i]];
-  }
-  if (total > 0x7FFFFFF0ll) return LSGPU_BAD_ARG;
-  if (total <= 0 || h->cloud_n[reading_slot] <= 0) {
-    if (chain->seed >= 0) DrawStream::global().take(chain->seed, 0, nullptr);
-    h->err = "compute: empty cloud";
-    return LSGPU_NO_CONVERGENCE;
-  }
-  HIPC(hipSetDevice(h->device));
-  // sub-map assembly (laser_track.cpp:474-486) on the device
+// sub-map assembly (laser_track.cpp:474-486) on the device: submap = concat_i ( T_i * cloud ref_slots[i] ), `total` points
+static int assemble_submap(lsgpu_icp* h, const int* ref_slots, const float* ref_T, int n_ref, int64_t total) {
   HIPC(h->submap.reserve(total));
   int64_t off = 0;
   for (int i = 0; i < n_ref; ++i) {
@@ -2237,9 +2221,92 @@ int lsgpu_icp_compute_clouds(lsgpu_icp* h, int reading_slot, const int* ref_slot
     off += n;
   }
   HIPC(hipGetLastError());
+  return LSGPU_OK;
+}
+
+int lsgpu_icp_compute_clouds(lsgpu_icp* h, int reading_slot, const int* ref_slots, const float* ref_T,
+                             int n_ref, const float T_init[16], const lsgpu_chain_config* chain,
+                             float T_out[16], lsgpu_icp_stats* stats) {
+  if (!h || !T_init || !T_out || !chain || n_ref < 0 || (n_ref > 0 && !ref_slots)) return LSGPU_BAD_ARG;
+  h->err.clear();
+  std::memcpy(T_out, T_init, 16 * sizeof(float));
+  if (stats) std::memset(stats, 0, sizeof(*stats));
+  auto have = [&](int s) { return s >= 0 && (size_t)s < h->clouds.size() && h->cloud_n[s] >= 0; };
+  if (!have(reading_slot)) { h->err = "compute_clouds: empty reading slot"; return LSGPU_BAD_ARG; }
+  int64_t total = 0;
+  for (int i = 0; i < n_ref; ++i) {
+    if (!have(ref_slots[i])) { h->err = "compute_clouds: empty reference slot"; return LSGPU_BAD_ARG; }
+    total += h->cloud_n[ref_slots[i]];
+  }
+  if (total > 0x7FFFFFF0ll) return LSGPU_BAD_ARG;
+  if (total <= 0 || h->cloud_n[reading_slot] <= 0) {
+    if (chain->seed >= 0) DrawStream::global().take(chain->seed, 0, nullptr);
+    h->err = "compute: empty cloud";
+    return LSGPU_NO_CONVERGENCE;
+  }
+  HIPC(hipSetDevice(h->device));
+  {
+    const int rca = assemble_submap(h, ref_slots, ref_T, n_ref, total);
+    if (rca) return rca;
+  }
   const int rc = lsgpu_icp_compute(h, reinterpret_cast<const float*>(h->clouds[reading_slot].p), h->cloud_n[reading_slot],
                                    reinterpret_cast<const float*>(h->submap.p), total, T_init, chain, T_out, stats);
   return rc;  // (the assembly is stream-ordered: its time is part of compute's filter time, stats->t_reserved[0])
+}
+
+// lsgpu_cloud_upload(reading_slot) + lsgpu_icp_compute_clouds in one call: the new scan crosses PCIe WHILE the sub-map --
+// the scans already in HBM -- is assembled and filtered (its own stream and host thread, as the host reading of
+// lsgpu_icp_compute).  LaserTrack::localScanToSubMap matches every new scan exactly once, right after it arrived
+// (laser_track.cpp:112-119, 466-519): uploaded first and matched afterwards, the 0.3 ms of a 1 M-point scan's copy were
+// spent with the device idle, inside the reference's own timed region (scan_matching_times_).  The slot holds the scan on
+// return whatever the registration's outcome, like the two calls one after the other.
+int lsgpu_icp_compute_clouds_upload(lsgpu_icp* h, int reading_slot, const float* reading_xyz1, int64_t nq,
+                                    const int* ref_slots, const float* ref_T, int n_ref, const float T_init[16],
+                                    const lsgpu_chain_config* chain, float T_out[16], lsgpu_icp_stats* stats) {
+  if (!h || !T_init || !T_out || !chain || n_ref < 0 || (n_ref > 0 && !ref_slots)) return LSGPU_BAD_ARG;
+  if (reading_slot < 0 || reading_slot >= (1 << 20) || nq < 0 || nq > 0x7FFFFFF0ll || (nq > 0 && !reading_xyz1)) return LSGPU_BAD_ARG;
+  auto have = [&](int s) { return s >= 0 && (size_t)s < h->clouds.size() && h->cloud_n[s] >= 0; };
+  bool fused = nq > 0 && !is_device_ptr(reading_xyz1);
+  int64_t total = 0;
+  for (int i = 0; i < n_ref && fused; ++i) {
+    fused = have(ref_slots[i]) && ref_slots[i] != reading_slot;
+    if (fused) total += h->cloud_n[ref_slots[i]];
+  }
+  fused = fused && total > 0 && total <= 0x7FFFFFF0ll && chain->ssn_knn >= 3 && chain->ssn_knn <= kSsnMaxKnn;
+  if (!fused) {   // nothing to overlap (or nothing to match against): the two calls, one after the other
+    const int rcu = lsgpu_cloud_upload(h, reading_slot, reading_xyz1, nq);
+    if (rcu) return rcu;
+    return lsgpu_icp_compute_clouds(h, reading_slot, ref_slots, ref_T, n_ref, T_init, chain, T_out, stats);
+  }
+  h->err.clear();
+  std::memcpy(T_out, T_init, 16 * sizeof(float));
+  if (stats) std::memset(stats, 0, sizeof(*stats));
+  HIPC(hipSetDevice(h->device));
+  if ((size_t)reading_slot >= h->clouds.size()) { h->clouds.resize((size_t)reading_slot + 1); h->cloud_n.resize((size_t)reading_slot + 1, -1); }
+  h->cloud_n[reading_slot] = -1;
+  HIPC(h->clouds[reading_slot].reserve(nq));
+  {
+    const int rca = assemble_submap(h, ref_slots, ref_T, n_ref, total);
+    if (rca) {   // (a sub-map transform that is not rigid: the scan is stored all the same)
+      const std::string why = h->err;
+      const int rcu = lsgpu_cloud_upload(h, reading_slot, reading_xyz1, nq);
+      h->err = why;
+      return rcu ? rcu : rca;
+    }
+  }
+  h->upload_into = h->clouds[reading_slot].p;
+  h->upload_done = false;
+  const int rc = lsgpu_icp_compute(h, reading_xyz1, nq, reinterpret_cast<const float*>(h->submap.p), total, T_init, chain, T_out, stats);
+  h->upload_into = nullptr;
+  if (!h->upload_done) {   // the call returned before its upload went out: the plain copy, so that the slot holds the scan
+    const std::string why = h->err;
+    HIPC(hipMemcpyAsync(h->clouds[reading_slot].p, reading_xyz1, (size_t)nq * 16, hipMemcpyDefault, h->stream));
+    HIPC(hipStreamSynchronize(h->stream));
+    h->err = why;
+  }
+  h->upload_done = false;
+  h->cloud_n[reading_slot] = nq;
+  return rc;
 }
 
 int lsgpu_icp_align(lsgpu_icp* h, const float* reading_xyz1, int64_t nq, const float T_init[16],

@@ -310,6 +310,27 @@ class IcpHandle:
             _raise(rc, "lsgpu_icp_compute_clouds", self._h)
         return to.reshape(4, 4).T.copy(), st
 
+    def compute_clouds_upload(self, reading_slot: int, reading_xyz1, ref_slots, ref_T, T_init, reading_prob: float = 0.5,
+                              ssn_knn: int = 10, ssn_ratio: float = 0.5, seed: int = -1):
+        """upload_cloud(reading_slot, reading) + compute_clouds(reading_slot, ...) in one call: the host reading crosses
+        PCIe while the sub-map is assembled and filtered (the call shape of LaserTrack::localScanToSubMap)."""
+        rd = np.ascontiguousarray(reading_xyz1, np.float32)
+        k = len(ref_slots)
+        slots = (C.c_int * max(k, 1))(*ref_slots)
+        Ts = None
+        if ref_T is not None:
+            Ts = np.concatenate([_t16(T) for T in ref_T]) if k else np.zeros(0, np.float32)
+        ch = _lib.ChainCfg(reading_prob, ssn_knn, ssn_ratio, 0, seed)
+        ti = _t16(T_init)
+        to = np.empty(16, np.float32)
+        st = IcpStats()
+        rc = _lib.lib().lsgpu_icp_compute_clouds_upload(self._h, reading_slot, _fp(rd), rd.shape[0], slots,
+                                                        _fp(Ts) if Ts is not None else None, k, _fp(ti), C.byref(ch),
+                                                        _fp(to), C.byref(st))
+        if rc != _lib.OK:
+            _raise(rc, "lsgpu_icp_compute_clouds_upload", self._h)
+        return to.reshape(4, 4).T.copy(), st
+
     def trace(self, cap: int = 64):
         buf = (IterTrace * cap)()
         n = _lib.lib().lsgpu_icp_get_trace(self._h, buf, cap)

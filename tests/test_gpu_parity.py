@@ -764,6 +764,23 @@ def test_compute_clouds_assembles_the_submap_on_the_device(icp_mod):
         want = np.linalg.inv(poses[2]) @ poses[3]
         et, er = synth.pose_error(T_dev, want)
         assert et < 0.03 and er < 3e-3
+        # upload + compute in one call (the new scan crosses PCIe while the sub-map is filtered): the same transform, the
+        # same draws, and the slot holds the scan afterwards -- also when the registration itself is refused
+        h.cloud_release(3)
+        T_up, st_up = h.compute_clouds_upload(3, scans[3], [2, 1, 0], rel, T_init, 0.5, 10, 0.5, seed=6)
+        assert np.array_equal(T_up, T_dev) and st_up.iterations == st_dev.iterations and h.cloud_size(3) == len(scans[3])
+        T_again, _ = h.compute_clouds(3, [2, 1, 0], rel, T_init, 0.5, 10, 0.5, seed=6)     # (from the slot the fused call filled)
+        assert np.array_equal(T_again, T_dev)
+        h.cloud_release(3)
+        with pytest.raises(LsgpuError):
+            bad_guess = T_init.copy(); bad_guess[0, 0] = 1.5
+            h.compute_clouds_upload(3, scans[3], [2], None, bad_guess)
+        assert h.cloud_size(3) == len(scans[3])
+        T_c, _ = h.compute_clouds(3, [2], None, T_init, 0.5, 10, 0.5, seed=6)
+        assert np.array_equal(T_c, T_a)
+        T_d, _ = h.compute_clouds_upload(2, scans[2], [2], None, T_init, 0.5, 10, 0.5, seed=6)   # reading slot among the references: the two calls in a row
+        T_e, _ = h.compute(scans[2], scans[2], T_init, 0.5, 10, 0.5, seed=6)
+        assert np.array_equal(T_d, T_e)
         h.cloud_release(1)
         with pytest.raises(LsgpuError):
             h.compute_clouds(3, [2, 1], None, T_init)
