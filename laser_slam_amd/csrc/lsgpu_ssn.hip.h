@@ -69,16 +69,8 @@ __global__ __launch_bounds__(256) void k_ssn_bounds(const float4* __restrict__ p
   }
 }
 
-__global__ void k_ssn_root(const uint32_t* __restrict__ bb, int n, SsnSeg* __restrict__ seg,
-                           uint32_t* __restrict__ seg_of_fill /*unused*/) {
-  SsnSeg s;
-  s.start = 0; s.count = (uint32_t)n;
-  for (int d = 0; d < 3; ++d) { s.lo[d] = float_from_order_key(bb[d]); s.hi[d] = float_from_order_key(bb[3 + d]); }
-  seg[0] = s;
-}
-
-// The same two in ONE launch and without the two fills in front of them (round 5: the reference filter's chain is short
-// enough for four 3 - 5 us launches to show): every block stores its six partial bounds, the block that draws the last
+// The cloud's bounds AND the root segment in ONE launch, without fills in front of it (round 5: the reference filter's chain
+// is short enough for four 3 - 5 us launches -- two fills, the bounds, a one-thread root kernel -- to show): every block stores its six partial bounds, the block that draws the last
 // ticket reduces them, writes bb[0..6) and the root segment and puts the ticket back to zero for the next call.
 // ws: [0] the ticket (zero when the buffer is made), [8 + 6 b + d] block b's partial (kSsnBoundsBlocks of them at most).
 constexpr int kSsnBoundsBlocks = 256;
