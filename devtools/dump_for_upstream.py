@@ -9,7 +9,7 @@ For a synthetic HDL-64E pair (default: the 4 k-point pair of the parity tests, `
   icp.yaml                                   the module chain (tests/golden/icp_chain*.yaml, loadable by
                                              PointMatcher::ICP::loadFromYaml; checked here with this repo's own loader)
   T_init.txt                                 4 x 4, row major, "%.9g"
-  reference_filtered.csv                     what SamplingSurfaceNormalDataPointsFilter leaves (x,y,z,nx,ny,nz): choices 1, 2, 8
+  reference_filtered.csv                     what SamplingSurfaceNormalDataPointsFilter leaves (x,y,z,nx,ny,nz): choices 1, 2, 8, 10, 11
   reading_filtered.csv                       what RandomSamplingDataPointsFilter leaves: choice 8 (the draws continue the
                                              reference filter's; the process starts at srand(1) like an unseeded one)
   input_filtered.csv                         reading.csv through tests/golden/input_filters.yaml (srand(1) again): choice 9
@@ -47,7 +47,7 @@ from oracle import oracle_py as O  # noqa: E402
 
 CHOICES = """Restatement choices of oracle/icp_oracle.h and where a different upstream behaviour shows:
  1 box rank test (FullPivHouseholderQR, eps * 3)      reference_filtered.csv: number of rows (thin boxes kept / dropped)
- 2 box split (stable sort, split at the median)      reference_filtered.csv: row ORDER and the normals of boxes with tied coordinates
+ 2 box split (stable sort, split at the median)      reference_filtered.csv: normals of boxes with tied coordinates; for ratio < 1 WHICH rows
  3 kd-tree ties (any nearest point)                  nothing: oracle_trace.csv is the same for every valid tie order
  4 TrimmedDist: index floor(n * ratio), d2 <= limit  oracle_trace.csv: columns limit and n_used
  5 reference mean in double, rounded to float        oracle_trace.csv: last digits of T_iter (1e-6 level)
@@ -55,6 +55,8 @@ CHOICES = """Restatement choices of oracle/icp_oracle.h and where a different up
  7 differential checker: 2 atan2(|vec|, |w|)         oracle_trace.csv: number of rows (the iteration it stops at)
  8 rand(): glibc sequence, draw < prob keeps         reading_filtered.csv (and reference_filtered.csv for ratio < 1): WHICH rows
  9 MaxDist signed on one axis, MinDist absolute      input_filtered.csv: rows
+10 kept points in ascending ORIGINAL index             reference_filtered.csv: row order (upstream sorts indicesToKeep before it compacts)
+11 box eigenvectors: Jacobi in double on the float C   reference_filtered.csv: last digits of nx, ny, nz (upstream: EigenSolver in float)
 """
 
 

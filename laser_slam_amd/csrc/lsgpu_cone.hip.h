@@ -38,9 +38,10 @@ struct ConeDev {
   float z0, rs;            // row = floor((zeta - z0) * rs), clamped to [0, rows)
   float cs;                // column = floor(p * cs), cs = cols / 4
   int rows, cols;
-  const float4* soa;       // direction-sorted copy of the reference in groups of four points: group g = {x0..x3}{y0..y3}{z0..z3}
-                           // (48 bytes, one cache line for all three loads of an evaluation step); + kConePad far points
-  const uint32_t* map;     // direction-sorted position -> index in the Morton-sorted reference (pts)
+  const float4* soa;       // direction-sorted copy of the reference in groups of four points: group g = {x0..x3}{y0..y3}{z0..z3}{m0..m3},
+                           // m = index of the point in the Morton-sorted reference (pts) -- 64 bytes, ONE aligned cache line for the
+                           // four loads of an evaluation step (round 6; rounds 4-5: 48-byte groups + a separate position map, whose
+                           // read was one more dependent round trip per searching lane); + kConePad far points
   const uint32_t* tab;     // rows * cols + 1: first position whose key is >= row * cols + column
   const float4* rowz;      // per row: {min zeta, max zeta, 1 / (4 min cos(elevation)), -} over its points; empty row: min > max
 };
@@ -87,8 +88,7 @@ __global__ __launch_bounds__(256) void k_cone_keys(const float4* __restrict__ pt
 // long -- 16 k waves waiting 15 us each for 50 MB of traffic)
 __global__ __launch_bounds__(256) void k_cone_gather(const float4* __restrict__ pts, const uint32_t* __restrict__ perm,
                                                      const uint64_t* __restrict__ keys, int64_t n, ConeDev c,
-                                                     float* __restrict__ soa,
-                                                     uint32_t* __restrict__ map, uint32_t* __restrict__ tab) {
+                                                     float* __restrict__ soa, uint32_t* __restrict__ tab) {
   const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
   const int lane = threadIdx.x & 63;
   const int64_t npad = ((n + 3) & ~(int64_t)3) + kConePad;
@@ -99,15 +99,15 @@ __global__ __launch_bounds__(256) void k_cone_gather(const float4* __restrict__ 
   if (valid) {
     const uint32_t i = perm[j];
     const float4 p = pts[i];
-    float* g = soa + 12 * (j >> 2) + (j & 3);
-    g[0] = p.x; g[4] = p.y; g[8] = p.z; map[j] = i;
+    float* g = soa + 16 * (j >> 2) + (j & 3);
+    g[0] = p.x; g[4] = p.y; g[8] = p.z; g[12] = __uint_as_float(i);
     const uint32_t key = (uint32_t)keys[j];
     gap_lo = j > 0 ? (uint32_t)keys[j - 1] + 1u : 0u;
     gap_hi = key + 1u;
     pos = (uint32_t)j;
   } else if (j < npad) {
-    float* g = soa + 12 * (j >> 2) + (j & 3);
-    g[0] = kPadCoord; g[4] = kPadCoord; g[8] = kPadCoord; map[j] = 0u;
+    float* g = soa + 16 * (j >> 2) + (j & 3);
+    g[0] = kPadCoord; g[4] = kPadCoord; g[8] = kPadCoord; g[12] = __uint_as_float(0u);
     if (j == n) { gap_lo = (uint32_t)keys[n - 1] + 1u; gap_hi = nkeys + 1u; pos = (uint32_t)n; }   // everything behind the last key
   }
   // ---- table: a thread whose key follows its predecessor's closely writes the few entries in between itself; longer
@@ -139,7 +139,7 @@ __global__ __launch_bounds__(256) void k_cone_rows(ConeDev c, float4* __restrict
   const float* __restrict__ soa = reinterpret_cast<const float*>(c.soa);
   float mn = INFINITY, mx = -INFINITY;
   for (uint32_t p = st + threadIdx.x; p < en; p += 256u) {
-    const float* g = soa + 12u * (size_t)(p >> 2) + (p & 3u);
+    const float* g = soa + 16u * (size_t)(p >> 2) + (p & 3u);
     float inv_rho, zeta, pa, rxy, inv_h;
     cone_dir(g[0] - c.ox, g[4] - c.oy, g[8] - c.oz, inv_rho, zeta, pa, rxy, inv_h);
     if (!(fabsf(zeta) <= 1.5f)) zeta = 0.f;   // (as k_cone_keys)
@@ -167,63 +167,101 @@ __global__ __launch_bounds__(256) void k_cone_rows(ConeDev c, float4* __restrict
 }
 
 // ---------------------------------------------------------------- search
-// One window of one lane: groups [g0, g0 + len) of four consecutive direction-sorted points.  All lanes run until the
-// wave's longest window is through; a lane past its own end sits the step out (no load is issued for it).
+#ifdef LSGPU_KNN_STATS
+// stats build (devtools/cone_phases.py): one 16-word record per wave and ICP iteration of k_knn_cone (no atomics: sixteen
+// thousand waves adding to the same words made a 30 us launch 1.5 ms long)
+__device__ uint32_t* g_cone_rec;   // [kConeRecIters][ntiles][16], set by lsgpu_dev_cone_phases
+constexpr int kConeRecIters = 48;
+struct ConeStat { long long t_eval = 0, t_rows = 0; uint32_t steps = 0, items = 0, batches = 0; };
+#define CONE_STAT_ARG , ConeStat& cs
+#define CONE_STAT_PASS , cs
+#else
+#define CONE_STAT_ARG
+#define CONE_STAT_PASS
+#endif
+
+// One window of one lane, evaluated by that lane alone: groups [g0, g0 + len) of four consecutive direction-sorted points
+// (the probe of the first search through the index; the search proper shares its windows out over the wave, below).  All
+// lanes run until the wave's longest window is through; a lane past its own end sits the step out.
 __device__ __forceinline__ void cone_eval_window(const ConeDev& c, uint32_t g0, uint32_t len, float qx, float qy, float qz,
-                                                 float& best, float& sec, uint32_t& bgrp) {
+                                                 float& best, float& sec) {
   const f32x2 q2x = {qx, qx}, q2y = {qy, qy}, q2z = {qz, qz};
-  // two groups per step: six loads in flight, one memory round trip for eight candidates
+  // two groups per step, all six loads issued before the first is waited for: one memory round trip for eight candidates
   for (uint32_t t = 0; __ballot(t < len); t += 2u) {
     if (t < len) {
-      const uint32_t g = g0 + t;
-      const bool two = t + 1u < len;
-      const float4* __restrict__ p = c.soa + 3u * (size_t)g;
+      const float4* __restrict__ p = c.soa + 4u * (size_t)(g0 + t);
+      const float4* __restrict__ p1 = t + 1u < len ? p + 4 : p;   // (no second group: the first once more, it changes nothing)
       const float4 X = p[0], Y = p[1], Z = p[2];
-      float4 X1 = X, Y1 = Y, Z1 = Z;
-      if (two) { X1 = p[3]; Y1 = p[4]; Z1 = p[5]; }
+      const float4 X1 = p1[0], Y1 = p1[1], Z1 = p1[2];
       const f32x2 d0 = dist2_pair(q2x, q2y, q2z, f32x2{X.x, X.y}, f32x2{Y.x, Y.y}, f32x2{Z.x, Z.y});
       const f32x2 d1 = dist2_pair(q2x, q2y, q2z, f32x2{X.z, X.w}, f32x2{Y.z, Y.w}, f32x2{Z.z, Z.w});
+      const f32x2 e0 = dist2_pair(q2x, q2y, q2z, f32x2{X1.x, X1.y}, f32x2{Y1.x, Y1.y}, f32x2{Z1.x, Z1.y});
+      const f32x2 e1 = dist2_pair(q2x, q2y, q2z, f32x2{X1.z, X1.w}, f32x2{Y1.z, Y1.w}, f32x2{Z1.z, Z1.w});
       const float m4 = fminf(fminf(fminf(d0.x, d0.y), d1.x), d1.y);
+      const float n4 = fminf(fminf(fminf(e0.x, e0.y), e1.x), e1.y);
       sec = __builtin_amdgcn_fmed3f(best, m4, sec);
-      bgrp = m4 < best ? g : bgrp;
       best = fminf(best, m4);
-      if (two) {
-        const f32x2 e0 = dist2_pair(q2x, q2y, q2z, f32x2{X1.x, X1.y}, f32x2{Y1.x, Y1.y}, f32x2{Z1.x, Z1.y});
-        const f32x2 e1 = dist2_pair(q2x, q2y, q2z, f32x2{X1.z, X1.w}, f32x2{Y1.z, Y1.w}, f32x2{Z1.z, Z1.w});
-        const float n4 = fminf(fminf(fminf(e0.x, e0.y), e1.x), e1.y);
-        sec = __builtin_amdgcn_fmed3f(best, n4, sec);
-        bgrp = n4 < best ? g + 1u : bgrp;
-        best = fminf(best, n4);
-      }
+      sec = __builtin_amdgcn_fmed3f(best, n4, sec);
+      best = fminf(best, n4);
     }
   }
 }
 
-// The kernel.  A workgroup takes WAVES consecutive tiles of 64 queries.  Phase 1, every wave for its own tile: the query,
+// ---- the kernel.  A workgroup takes WAVES consecutive tiles of 64 queries.  Phase 1, every wave for its own tile: the query,
 // its warm-start distance, the keep / far skips (as k_knn_tile); lanes that do not search are finished here.  The
 // searching lanes of all WAVES tiles are then packed through LDS (in query order) and phase 2 -- cone, rows, windows,
 // evaluation, results -- runs on full waves of searching lanes only: what a wave pays per row and per window it pays
-// for 64 lanes that need it, and the waves left without lanes exit.  (Per-tile waves spent 22-25 us of a 36 us launch
-// on that skeleton, whatever the number of lanes that searched: 80 % of them in iteration 3, 10 % in iteration 31, but
-// 83 % of the TILES still had one.)  Per-lane windows do not care who the neighbours in the wave are.
+// for 64 lanes that need it, and the waves left without lanes exit.  Per-lane windows do not care who the neighbours in
+// the wave are.
+// Round 6, from per-wave records of where the cycles go (devtools/cone_phases.py, profiles/r06_cone_phases_*.txt: a
+// searching wave lived 29 k cycles in a 29 us launch whose vector units idled 70 % of the time -- a chain of ~15
+// dependent memory round trips of 1.6-2.5 k cycles each, and the launch ends with its slowest wave):
+//   * the barriers of the pack wait for the LDS only -- __syncthreads() also waited for the stores and select atomics of
+//     the lanes that were done (4.3 k -> 2 k cycles between the loads' arrival and the pack);
+//   * the loop state's words arrive in one batch of scalar loads; the rows' zeta ranges travel to LDS beside the queries,
+//     with one occupancy bit per row: empty rows (between the rings of a spinning lidar) cost a shift, not a load;
+//   * the table reads of the NEXT row are in flight while the current row's windows are evaluated (a table round trip per
+//     row was 3.5 k cycles);
+//   * both groups of an evaluation step are loaded before the first is waited for (the conditional second load used to
+//     follow the first one's wait: two round trips per step);
+//   * a group's record carries its points' Morton indices (64-byte groups, one aligned cache line for a step's loads):
+//     the re-read of the winning group needs no second, dependent read of a position map.
+// Built and measured on the way, and dropped (same results, slower launches): every lane's windows cut into groups and
+// shared out over the wave through an LDS list with per-owner LDS minima (balanced lanes, three round trips per wave --
+// but 27 KB of LDS per workgroup held until its slowest wave ends: 35-38 us per late launch against 25-28); the union of
+// a row's windows staged into LDS with LDS-DMA and every lane stepping through its window there (coalesced loads, a few
+// dozen cache lines per wave instead of hundreds -- but 64 lanes gathering 48 bytes each per step make the LDS the
+// bottleneck: 800 cycles per step, 42-50 us per late launch).
 #ifndef LSGPU_CONE_WAVES
 #define LSGPU_CONE_WAVES 4
 #endif
+#ifndef LSGPU_CONE_OCC
+#define LSGPU_CONE_OCC 8   // waves per SIMD the register budget is cut for
+#endif
+constexpr int kConeRowSlots = 4;           // occupied rows a wave looks up per table round trip
+
 struct ConeRec { float qx, qy, qz, ub, lbn; int id_in, j; uint32_t pad; };   // 32 B: one searching query on its way to phase 2
 
-#ifndef LSGPU_CONE_OCC
-#define LSGPU_CONE_OCC 7   // waves per SIMD the register budget is cut for
-#endif
+__device__ __forceinline__ void cone_barrier_lds() {   // workgroup barrier that waits for the LDS only: the stores and
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // atomics of phase 1 need not have landed
+}
+__device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) { return ~wave_max_u32(~v); }
+
 template <int WAVES, bool PROBE = false>
 __global__ __launch_bounds__(WAVES * 64, LSGPU_CONE_OCC) void k_knn_cone(KnnArgs a, ConeDev c) {
-  __shared__ ConeRec rec[WAVES * 64];
+  __shared__ ConeRec rec[WAVES * 64];          // the searching queries of the block's tiles, packed
+  __shared__ unsigned long long ne_mask[16];   // occupied rows, one bit each (<= 1024 rows)
   __shared__ uint32_t wcount[WAVES];
+  extern __shared__ float4 rowz_sh[];          // the rows' records {min zeta, max zeta, 1 / (4 min cos e), -}
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#ifdef LSGPU_KNN_STATS
+  const long long ts0 = clock64();
+  long long t_rows = 0, t_stage = 0, t_eval = 0;
+  uint32_t n_chunks = 0, n_steps = 0, n_groups = 0, n_rowslots = 0;
+#endif
   // (tiles go to the XCDs round robin, in dispatch order.  One contiguous eighth of the tiles per XCD -- whose L2 would then
   // hold just the stretch of the index its tiles read -- was measured slower, 39-55 us per launch against 30-42: the tiles
   // of near range cost several times those of the far field, and the launch ends with the slowest XCD.)
-  // (Dispatch order is not what the launch's tail is made of: last tiles first, or a stride of 1031 blocks through the grid,
-  // changed nothing -- 25-74 us per settled launch either way, round 5.)
   const uint32_t tile = blockIdx.x * (uint32_t)WAVES + (uint32_t)w;
   int j = (int)(tile * 64u) + lane;
   const bool act = j < a.nq;
@@ -234,13 +272,42 @@ __global__ __launch_bounds__(WAVES * 64, LSGPU_CONE_OCC) void k_knn_cone(KnnArgs
     mp = a.prev[j];
     lb_in = a.lb[j];
   }
+  // the rows' records and their occupancy mask go to LDS beside those loads
+  const uint32_t nrows = (uint32_t)c.rows;
+  for (uint32_t r0 = 0; r0 < nrows; r0 += (uint32_t)(WAVES * 64)) {
+    const uint32_t r = r0 + threadIdx.x;
+    float4 rz = make_float4(INFINITY, -INFINITY, INFINITY, 0.f);
+    if (r < nrows) { rz = c.rowz[r]; rowz_sh[r] = rz; }
+    const unsigned long long occ = __ballot(rz.x <= rz.y);
+    if (lane == 0 && (r0 >> 6) + (uint32_t)w < 16u) ne_mask[(r0 >> 6) + (uint32_t)w] = occ;
+  }
   int id_in = __float_as_int(mp.w);
-  Mat34 T; float cap2;
-  if (!iter_params(a.st, a.T, a.cap2, 1, T, cap2)) return;   // (the same answer in every wave of the block)
+  // the loop state: everything this launch reads of it, in one go
+  const IcpState* __restrict__ st = a.st;
+  if (st->done) return;   // (the same answer in every wave of the block)
+  Mat34 T, To;
+#pragma unroll
+  for (int i = 0; i < 12; ++i) { T.m[i] = st->T_rows[i]; To.m[i] = st->T_rows_prev[i]; }
+  const float cap2 = st->cap2;
+  const bool sel_on = a.sel_below && (st->sel_mode || a.sel_force);
+  const uint32_t sel_b1 = sel_on ? st->sel_bin1 : 0u;
+  const uint32_t sel_b2 = sel_on ? st->sel_bin2 : 0u;
   const float cap2s = cap2 * kCapSearchMargin2;
   const float gap = a.gap;
-  const bool sel_on = a.sel_below && (a.st->sel_mode || a.sel_force);
-  const uint32_t sel_b1 = sel_on ? a.st->sel_bin1 : 0u;
+#ifdef LSGPU_KNN_STATS
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  const long long ts1 = clock64();
+  uint32_t* const dbg = g_cone_rec ? g_cone_rec + ((size_t)min(max(st->iter, 0), kConeRecIters - 1) * (size_t)a.ntiles + tile) * 16u : nullptr;
+#endif
+  // one final distance's share of the predicted / committed select (as sel_count_inside, the state's words already here)
+  auto sel_inside = [&](uint32_t bits) {
+    const uint32_t bin2 = (bits >> 9) & 0x7FFu;
+    atomicAdd(&a.sel_hist2[bin2], 1u);
+    if (a.sel_hist3w) {
+      const uint32_t d = bin2 - sel_b2 + (uint32_t)kSelWinHalf;
+      if (d < (uint32_t)kSelWinRows) atomicAdd(&a.sel_hist3w[d * 512u + (bits & 0x1FFu)], 1u);
+    }
+  };
   // ---- phase 1
   float qx = 0.f, qy = 0.f, qz = 0.f, ub = 0.f, lbn = 0.f;
   bool skip = false;
@@ -248,9 +315,6 @@ __global__ __launch_bounds__(WAVES * 64, LSGPU_CONE_OCC) void k_knn_cone(KnnArgs
     const float3 q = xform(T, rraw.x, rraw.y, rraw.z);
     qx = q.x; qy = q.y; qz = q.z;
     ub = dist2(qx - mp.x, qy - mp.y, qz - mp.z);
-    Mat34 To;
-#pragma unroll
-    for (int i = 0; i < 12; ++i) To.m[i] = a.st->T_rows_prev[i];
     const float3 qo = xform(To, rraw.x, rraw.y, rraw.z);
     const float ddx = qx - qo.x, ddy = qy - qo.y, ddz = qz - qo.z;
     const float delta = __builtin_amdgcn_sqrtf(ddx * ddx + ddy * ddy + ddz * ddz) * (1.0f + 1e-5f) + 1e-7f;   // (hardware square root, 1 ulp: the factor covers it)
@@ -267,27 +331,38 @@ __global__ __launch_bounds__(WAVES * 64, LSGPU_CONE_OCC) void k_knn_cone(KnnArgs
   if (sel_on) {   // the skipped lanes' share of the trimmed-distance select (first two passes, as k_knn_tile)
     const uint32_t bits = __float_as_uint(ub), top = bits >> 20;
     const unsigned long long below = __ballot(act && skip && top < sel_b1);
-    if (act && skip && top == sel_b1) sel_count_inside(a, bits);
+    if (act && skip && top == sel_b1) sel_inside(bits);
     if (lane == 0 && below) atomicAdd(&a.sel_below[(tile & (kSelBelowSlots - 1)) * kSelBelowStride], (uint32_t)__popcll(below));
   }
-  // ---- pack the searching lanes of the block
+  // ---- pack the searching lanes of the block: slot s of the block goes to wave s / 64, entry s % 64 of its area
+#ifdef LSGPU_KNN_STATS
+  const long long ts2 = clock64();
+#endif
   const unsigned long long sm = __ballot(act && !skip);
   if (lane == 0) wcount[w] = (uint32_t)__popcll(sm);
-  __syncthreads();
+  cone_barrier_lds();
   uint32_t before = 0, total = 0;
 #pragma unroll
   for (int k = 0; k < WAVES; ++k) { const uint32_t n = wcount[k]; before += k < w ? n : 0u; total += n; }
   if (act && !skip) {
     ConeRec r;
     r.qx = qx; r.qy = qy; r.qz = qz; r.ub = ub; r.lbn = lbn; r.id_in = id_in; r.j = j; r.pad = 0u;
-    rec[before + (uint32_t)__popcll(sm & ((1ull << lane) - 1ull))] = r;
+    const uint32_t at = before + (uint32_t)__popcll(sm & ((1ull << lane) - 1ull));
+    rec[at] = r;
   }
-  __syncthreads();
-  const uint32_t slot = (uint32_t)(w * 64 + lane);
+  cone_barrier_lds();
+#ifdef LSGPU_KNN_STATS
+  const long long ts3 = clock64();
+  if (lane == 0 && dbg) {
+    dbg[0] = (uint32_t)(ts1 - ts0); dbg[1] = (uint32_t)(ts2 - ts1); dbg[2] = (uint32_t)(ts3 - ts2);
+    dbg[3] = 1u; dbg[10] = (uint32_t)(ts3 - ts0); dbg[11] = (uint32_t)ts0; dbg[12] = (uint32_t)ts3;
+    dbg[13] = (uint32_t)__popcll(sm);
+  }
+#endif
   if ((uint32_t)(w * 64) >= total) return;
-  const bool ing = slot < total;
-  if (ing) {
-    const ConeRec r = rec[slot];
+  const bool ing = (uint32_t)(w * 64 + lane) < total;
+  {
+    const ConeRec r = rec[w * 64 + lane];   // (beyond `total`: stale or uninitialised words, never used)
     qx = r.qx; qy = r.qy; qz = r.qz; ub = r.ub; lbn = r.lbn; id_in = r.id_in; j = r.j;
   }
   // ---- phase 2: the searching lanes
@@ -306,27 +381,28 @@ __global__ __launch_bounds__(WAVES * 64, LSGPU_CONE_OCC) void k_knn_cone(KnnArgs
     const uint32_t p_first = (uint32_t)__builtin_amdgcn_readfirstlane((int)wave_max_u32(pr ? ~(uint32_t)max(rq - 2, 0) : 0u));
     const uint32_t p_last = wave_max_u32(pr ? (uint32_t)min(rq + 2, c.rows - 1) + 1u : 0u);
     float pb = INFINITY, ps = INFINITY;
-    uint32_t pg = 0u;
     for (uint32_t row = ~p_first; row < p_last; ++row) {
-      const float4 rz = c.rowz[row];
+      const float4 rz = rowz_sh[row];
       if (!(rz.x <= rz.y)) continue;
       const bool in = pr && (int)row >= rq - 2 && (int)row <= rq + 2;
       const uint32_t base = row * (uint32_t)c.cols;
-      uint32_t st = 0u, en = 0u;
+      uint32_t st_ = 0u, en_ = 0u;
       if (in) {
-        st = c.tab[base + (uint32_t)max(cq - 1, 0)];
-        en = c.tab[base + (uint32_t)min(cq + 1, c.cols - 1) + 1u];
+        st_ = c.tab[base + (uint32_t)max(cq - 1, 0)];
+        en_ = c.tab[base + (uint32_t)min(cq + 1, c.cols - 1) + 1u];
       }
-      const uint32_t g0 = st >> 2;
-      const uint32_t len = en > st ? min(((en + 3u) >> 2) - g0, 4u) : 0u;   // (a bound needs no more than a few groups)
-      cone_eval_window(c, g0, len, qx, qy, qz, pb, ps, pg);
+      const uint32_t g0 = st_ >> 2;
+      const uint32_t len = en_ > st_ ? min(((en_ + 3u) >> 2) - g0, 4u) : 0u;   // (a bound needs no more than a few groups)
+      cone_eval_window(c, g0, len, qx, qy, qz, pb, ps);
     }
     ubs = fminf(ub, pb);
   }
   const float lim0 = prune_lim(ubs, gap, cap2s);                // squared search radius: every point inside is evaluated
   const float R = __builtin_amdgcn_sqrtf(lim0) * (1.0f + 1e-5f) + 1e-7f;
   bool fb = false;                 // this lane searches the voxel grid instead
-  float best = INFINITY, sec = INFINITY;
+  float best = INFINITY, sec = INFINITY, bs4 = INFINITY;   // evaluated minimum, second smallest group minimum, runner-up inside the leading group
+  float4 bpt = make_float4(0.f, 0.f, 0.f, 0.f);            // the point at the minimum {x, y, z, Morton index}
+  bool found = false;
   uint32_t bgrp = 0xFFFFFFFFu;     // group of four direction-sorted points that holds the evaluated minimum
   {
     // ---- the lane's cone.  sin(alpha) = R / rho.  A point within R of q is seen from O under an angle <= alpha from q.
@@ -342,51 +418,131 @@ __global__ __launch_bounds__(WAVES * 64, LSGPU_CONE_OCC) void k_knn_cone(KnnArgs
     const uint32_t r_lo = cone_clampu(floorf((zeta - dz - c.z0) * c.rs), c.rows - 1);
     const uint32_t r_hi = cone_clampu(floorf((zeta + dz - c.z0) * c.rs), c.rows - 1);
     fb = ing && !cone;
-    // rows of the wave, one after the other (wave-uniform: the row's record is a scalar load, an empty row costs a compare)
-    const uint32_t row_first = (uint32_t)__builtin_amdgcn_readfirstlane((int)wave_max_u32(cone ? ~r_lo : 0u));   // ~min = max~
+    const int cols = c.cols;
+    const f32x2 q2x = {qx, qx}, q2y = {qy, qy}, q2z = {qz, qz};
+    // rows of the wave, one after the other (wave-uniform; the occupancy mask skips the empty ones between the rings of a
+    // spinning lidar).  The table reads of the NEXT row some lane's cone reaches are issued before the current row's run
+    // is staged and evaluated, so only the first row's table round trip is waited for; a row with windows that cross
+    // column 0 comes twice, the second time for the wrapped parts.
+    uint32_t row = (uint32_t)__builtin_amdgcn_readfirstlane((int)wave_min_u32(cone ? r_lo : 0xFFFFFFFFu));
     const uint32_t row_last = wave_max_u32(cone ? r_hi + 1u : 0u);
-    for (uint32_t row = ~row_first; row < row_last; ++row) {
-      const float4 rz = c.rowz[row];
-      if (!(rz.x <= rz.y)) continue;                             // empty row (between the rings of a spinning lidar)
-      // distance in zeta between q and the row's points: a LOWER bound of their difference in elevation
-      // (|sin a - sin b| <= |a - b|)
-      const float dzr = fmaxf(fmaxf(fmaxf(rz.x - zeta, zeta - rz.y), 0.f) - 1e-6f, 0.f);
-      bool in = cone && row >= r_lo && row <= r_hi && dzr <= alpha;
-      if (!__ballot(in)) continue;
-      // azimuth: cos(theta) = cos(de) - cos(e_q) cos(e_p) (1 - cos(da)), theta <= alpha  =>
-      //   sin^2(da / 2) <= (cos(de) - cos(alpha)) / (2 ce ce_p) <= (alpha^2 - de^2) / (4 ce ce_p)
-      const float u2 = __fmaf_rn(-dzr, dzr, alpha2) * inv_ce * rz.z;
-      const bool polar = in && !(u2 <= 0.25f);                  // the cone reaches (or nears) the polar axis at this row
-      const float u = __builtin_amdgcn_sqrtf(fmaxf(u2, 0.f)) * (1.0f + 1e-6f);
-      const float da = 2.f * u * (1.0f + 0.2f * u * u);         // >= 2 asin(u)
-      // pseudo-azimuth: its derivative is Lipschitz (2 sqrt 2), so |d pa| <= gq da + 1.42 da^2
-      const float dp = __fmaf_rn(gq, da, 1.42f * da * da) + 4e-6f;
-      const int clo = (int)floorf((pa - dp) * c.cs), chi = (int)floorf((pa + dp) * c.cs);
-      const bool wide = in && !polar && chi - clo >= (c.cols >> 2);
-      if (polar || wide) { fb = true; cone = false; }
-      in = in && cone;
-      const uint32_t base = row * (uint32_t)c.cols;
-      // pass 0: the part of the window inside [0, cols); pass 1: the wrapped part of the windows that have one
-      bool more = in;
-      for (int pass = 0; pass < 2 && __ballot(more); ++pass) {
-        int a0 = max(clo, 0), a1 = min(chi, c.cols - 1);
+    int pass = 0;
+    uint32_t n_st = 0u, n_en = 0u;   // the next slot's window, its loads in flight
+    bool n_in = false;
+    auto next_slot = [&]() -> bool {
+      n_st = 0u; n_en = 0u; n_in = false;
+      while (row < row_last) {
+        if (pass == 0) {
+          const unsigned long long wd = ne_mask[row >> 6] >> (row & 63u);
+          if (!wd) { row = (row | 63u) + 1u; continue; }
+          row += (uint32_t)__ffsll((long long)wd) - 1u;
+          if (row >= row_last) break;
+        }
+        const float4 rz = rowz_sh[row];
+        // distance in zeta between q and the row's points: a LOWER bound of their difference in elevation
+        // (|sin a - sin b| <= |a - b|)
+        const float dzr = fmaxf(fmaxf(fmaxf(rz.x - zeta, zeta - rz.y), 0.f) - 1e-6f, 0.f);
+        bool in = cone && row >= r_lo && row <= r_hi && dzr <= alpha;
+        if (!__ballot(in)) { ++row; pass = 0; continue; }
+        // azimuth: cos(theta) = cos(de) - cos(e_q) cos(e_p) (1 - cos(da)), theta <= alpha  =>
+        //   sin^2(da / 2) <= (cos(de) - cos(alpha)) / (2 ce ce_p) <= (alpha^2 - de^2) / (4 ce ce_p)
+        const float u2 = __fmaf_rn(-dzr, dzr, alpha2) * inv_ce * rz.z;
+        const bool polar = in && !(u2 <= 0.25f);                  // the cone reaches (or nears) the polar axis at this row
+        const float u = __builtin_amdgcn_sqrtf(fmaxf(u2, 0.f)) * (1.0f + 1e-6f);
+        const float da = 2.f * u * (1.0f + 0.2f * u * u);         // >= 2 asin(u)
+        // pseudo-azimuth: its derivative is Lipschitz (2 sqrt 2), so |d pa| <= gq da + 1.42 da^2
+        const float dp = __fmaf_rn(gq, da, 1.42f * da * da) + 4e-6f;
+        const int clo = (int)floorf((pa - dp) * c.cs), chi = (int)floorf((pa + dp) * c.cs);
+        const bool wide = in && !polar && chi - clo >= (cols >> 2);
+        if (polar || wide) { fb = true; cone = false; }
+        in = in && cone;
+        // pass 0: the part of the window inside [0, cols); pass 1: the wrapped part of the windows that have one
+        int a0 = max(clo, 0), a1 = min(chi, cols - 1);
+        const bool wraps = in && (clo < 0 || chi >= cols);
         if (pass == 1) {
           const bool wl = clo < 0;
-          a0 = wl ? clo + c.cols : 0; a1 = wl ? c.cols - 1 : chi - c.cols;
+          a0 = wl ? clo + cols : 0; a1 = wl ? cols - 1 : chi - cols;
+          in = wraps;
         }
-        uint32_t st = 0u, en = 0u;
-        if (more) {
-          st = c.tab[base + (uint32_t)a0];
-          en = c.tab[base + (uint32_t)a1 + 1u];
+        const uint32_t base = row * (uint32_t)cols;
+        if (in) {
+          n_st = c.tab[base + (uint32_t)a0];
+          n_en = c.tab[base + (uint32_t)a1 + 1u];
         }
-        if (en - st > kConeMaxWin) { fb = true; cone = false; }
-        const bool w = more && cone && en > st;
-        const uint32_t g0 = st >> 2, len = w ? ((en + 3u) >> 2) - g0 : 0u;
-        cone_eval_window(c, g0, len, qx, qy, qz, best, sec, bgrp);
-        more = in && cone && pass == 0 && (clo < 0 || chi >= c.cols);
+        n_in = in;
+        if (pass == 0 && __ballot(wraps)) pass = 1;   // the same row once more, for the wrapped parts
+        else { pass = 0; ++row; }
+        return true;
       }
+      return false;
+    };
+#ifdef LSGPU_KNN_STATS
+    const long long t_r0 = clock64();
+#endif
+    bool got = next_slot();
+    while (got) {
+      const uint32_t w_st = n_st, w_en = n_en;
+      const bool w_in = n_in;
+      got = next_slot();
+#ifdef LSGPU_KNN_STATS
+      if (!n_rowslots) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); t_rows += clock64() - t_r0; }
+#endif
+      // ---- every lane steps through its own window, two groups per step: all six loads of a step are issued before the
+      // first is waited for (one memory round trip for eight candidates), a lane past its own end sits the step out
+      if (w_in && w_en - w_st > kConeMaxWin) { fb = true; cone = false; }
+      const bool wv = w_in && cone && w_en > w_st;
+      const uint32_t g0 = w_st >> 2, g1 = wv ? (w_en + 3u) >> 2 : 0u;   // this lane's groups [g0, g1)
+      if (!__ballot(wv)) continue;
+#ifdef LSGPU_KNN_STATS
+      ++n_rowslots; n_groups += wave_sum_u32(wv ? g1 - g0 : 0u);
+      const long long t_s1 = clock64();
+#endif
+      for (uint32_t t = g0; __ballot(wv && t < g1); t += 2u) {
+#ifdef LSGPU_KNN_STATS
+        ++n_steps;
+#endif
+        if (wv && t < g1) {
+          const bool two = t + 1u < g1;
+          const float4* __restrict__ p0 = c.soa + 4u * (size_t)t;
+          const float4* __restrict__ p1 = two ? p0 + 4 : p0;   // (no second group: the first once more, left out of the minimum below)
+          const float4 X = p0[0], Y = p0[1], Z = p0[2];
+          const float4 X1 = p1[0], Y1 = p1[1], Z1 = p1[2];
+          const f32x2 d0 = dist2_pair(q2x, q2y, q2z, f32x2{X.x, X.y}, f32x2{Y.x, Y.y}, f32x2{Z.x, Z.y});
+          const f32x2 d1 = dist2_pair(q2x, q2y, q2z, f32x2{X.z, X.w}, f32x2{Y.z, Y.w}, f32x2{Z.z, Z.w});
+          const f32x2 e0 = dist2_pair(q2x, q2y, q2z, f32x2{X1.x, X1.y}, f32x2{Y1.x, Y1.y}, f32x2{Z1.x, Z1.y});
+          const f32x2 e1 = dist2_pair(q2x, q2y, q2z, f32x2{X1.z, X1.w}, f32x2{Y1.z, Y1.w}, f32x2{Z1.z, Z1.w});
+          const float m4 = fminf(fminf(fminf(d0.x, d0.y), d1.x), d1.y);
+          const float n4 = two ? fminf(fminf(fminf(e0.x, e0.y), e1.x), e1.y) : INFINITY;
+          sec = __builtin_amdgcn_fmed3f(best, m4, sec);
+          bgrp = m4 < best ? t : bgrp;
+          best = fminf(best, m4);
+          sec = __builtin_amdgcn_fmed3f(best, n4, sec);
+          bgrp = n4 < best ? t + 1u : bgrp;
+          best = fminf(best, n4);
+        }
+      }
+#ifdef LSGPU_KNN_STATS
+      t_eval += clock64() - t_s1;
+#endif
     }
   }
+  // ---- the group that holds the evaluated minimum, once more: which of its points, the runner-up inside the group, the
+  // point's Morton index (the group minima of all other groups are in `sec` already)
+  if (bgrp != 0xFFFFFFFFu) {
+    const float4* __restrict__ p = c.soa + 4u * (size_t)bgrp;
+    const float4 X = p[0], Y = p[1], Z = p[2], M = p[3];
+    const float e0 = dist2(qx - X.x, qy - Y.x, qz - Z.x), e1 = dist2(qx - X.y, qy - Y.y, qz - Z.y);
+    const float e2 = dist2(qx - X.z, qy - Y.z, qz - Z.z), e3 = dist2(qx - X.w, qy - Y.w, qz - Z.w);
+    if (e3 == best) bpt = make_float4(X.w, Y.w, Z.w, M.w);
+    if (e2 == best) bpt = make_float4(X.z, Y.z, Z.z, M.z);
+    if (e1 == best) bpt = make_float4(X.y, Y.y, Z.y, M.y);
+    if (e0 == best) bpt = make_float4(X.x, Y.x, Z.x, M.x);
+    bs4 = fminf(fmaxf(fminf(e0, e1), fminf(e2, e3)), fminf(fmaxf(e0, e1), fmaxf(e2, e3)));
+    found = true;
+  }
+#ifdef LSGPU_KNN_STATS
+  const long long ts5 = clock64();
+#endif
   // ---- lanes the index could not serve: the voxel grid (same search as a spread wave's lanes in k_knn_tile)
   int bi = id_in;
   mp = make_float4(0.f, 0.f, 0.f, __int_as_float(id_in));   // (only the index of the old match matters from here on)
@@ -403,20 +559,10 @@ __global__ __launch_bounds__(WAVES * 64, LSGPU_CONE_OCC) void k_knn_cone(KnnArgs
     float nb;  // new lower bound on the distance to every point other than the (new) match
     if (fb) {
       nb = best <= cap2s ? sqrtf(best) * (1.0f - 1e-6f) : fmaxf(lbn, sqrtf(cap2s) * (1.0f - 1e-5f));
-    } else if (bgrp != 0xFFFFFFFFu && best <= ub) {
-      // the evaluated minimum (the warm-start point itself unless something beat it): which point of its group, and
-      // the runner-up inside the group (the group minima of all other groups are in `sec` already)
-      const float4* __restrict__ p = c.soa + 3u * (size_t)bgrp;
-      const float4 X = p[0], Y = p[1], Z = p[2];
-      const uint4 M = reinterpret_cast<const uint4*>(c.map)[bgrp];
-      const float e0 = dist2(qx - X.x, qy - Y.x, qz - Z.x), e1 = dist2(qx - X.y, qy - Y.y, qz - Z.y);
-      const float e2 = dist2(qx - X.z, qy - Y.z, qz - Z.z), e3 = dist2(qx - X.w, qy - Y.w, qz - Z.w);
-      if (e3 == best) mp = make_float4(X.w, Y.w, Z.w, __uint_as_float(M.w));
-      if (e2 == best) mp = make_float4(X.z, Y.z, Z.z, __uint_as_float(M.z));
-      if (e1 == best) mp = make_float4(X.y, Y.y, Z.y, __uint_as_float(M.y));
-      if (e0 == best) mp = make_float4(X.x, Y.x, Z.x, __uint_as_float(M.x));
-      const float s4 = fminf(fmaxf(fminf(e0, e1), fminf(e2, e3)), fminf(fmaxf(e0, e1), fmaxf(e2, e3)));
-      sec = fminf(sec, s4);
+    } else if (found && best <= ub) {
+      // the evaluated minimum (the warm-start point itself unless something beat it)
+      mp = bpt;
+      sec = fminf(sec, bs4);
       float others = fminf(sec, lim0);   // every point that was not evaluated lies beyond the search radius
       bool same = __float_as_int(mp.w) == id_in;
       if (sec == best || (!same && best == ub)) {  // a second point at exactly this distance: smallest Morton index
@@ -440,9 +586,20 @@ __global__ __launch_bounds__(WAVES * 64, LSGPU_CONE_OCC) void k_knn_cone(KnnArgs
   if (sel_on) {   // the searching lanes' share of the select
     const uint32_t bits = __float_as_uint(best), top = bits >> 20;
     const unsigned long long below = __ballot(ing && top < sel_b1);
-    if (ing && top == sel_b1) sel_count_inside(a, bits);
+    if (ing && top == sel_b1) sel_inside(bits);
     if (lane == 0 && below) atomicAdd(&a.sel_below[((tile + 32u) & (kSelBelowSlots - 1)) * kSelBelowStride], (uint32_t)__popcll(below));
   }
+#ifdef LSGPU_KNN_STATS
+  {
+    const long long ts9 = clock64();
+    const uint32_t n_ing = (uint32_t)__popcll(__ballot(ing)), n_fb = (uint32_t)__popcll(fbm);
+    if (lane == 0 && dbg) {
+      dbg[3] = 2u | (n_ing << 8) | (n_fb << 16); dbg[4] = (uint32_t)t_rows; dbg[5] = (uint32_t)t_eval; dbg[6] = n_chunks;
+      dbg[7] = n_steps; dbg[8] = n_groups; dbg[15] = (uint32_t)t_stage | 0u; dbg[13] = n_rowslots;
+      dbg[9] = (uint32_t)(ts9 - ts5); dbg[10] = (uint32_t)(ts9 - ts0); dbg[12] = (uint32_t)ts9; dbg[14] = (uint32_t)(ts5 - ts3);
+    }
+  }
+#endif
 }
 
 }  // namespace lsgpu

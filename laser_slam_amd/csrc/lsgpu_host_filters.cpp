@@ -31,6 +31,18 @@ struct SurfaceNormalBuilder {
   float* out_xyz1;
   float* out_nrm;
   int64_t n_out = 0;
+  std::vector<unsigned char> keep;   // per ORIGINAL index: kept (the draws are taken in box-traversal order)
+  std::vector<float> nrm_of;         // per original index: its box's normal
+
+  // upstream sorts indicesToKeep ascending before it compacts the cloud in place: the output is in original index order
+  void emit(int64_t n) {
+    for (int64_t i = 0; i < n; ++i)
+      if (keep[(size_t)i]) {
+        const int64_t o = n_out++;
+        std::memcpy(out_xyz1 + 4 * o, xyz1 + 4 * i, 16);
+        std::memcpy(out_nrm + 3 * o, nrm_of.data() + 3 * i, 12);
+      }
+  }
 
   float coord(int32_t i, int d) const { return xyz1[4 * (int64_t)i + d]; }
 
@@ -45,10 +57,10 @@ struct SurfaceNormalBuilder {
       const int64_t k = (i - first) % 64;
       if (k == 0) lsgpu::DrawStream::global().take(-1, (size_t)std::min<int64_t>(64, last - i), draws);
       const float r = draws[k];
-      if (r < ratio) {
-        const int64_t o = n_out++;
-        std::memcpy(out_xyz1 + 4 * o, xyz1 + 4 * (int64_t)idx[i], 16);
-        for (int d = 0; d < 3; ++d) out_nrm[3 * o + d] = n[d];
+      if (r < ratio) {   // indicesToKeep.push_back(k); normals->col(k) = normal: compacted by original index in emit()
+        const int64_t k_orig = idx[i];
+        keep[(size_t)k_orig] = 1;
+        for (int d = 0; d < 3; ++d) nrm_of[3 * (size_t)k_orig + d] = n[d];
       }
     }
   }
@@ -116,7 +128,10 @@ int64_t lsgpu_filter_sampling_surface_normal(const float* xyz1, int64_t n, int k
       mn[d] = std::min(mn[d], xyz1[4 * i + d]);
       mx[d] = std::max(mx[d], xyz1[4 * i + d]);
     }
+  b.keep.assign((size_t)n, 0);
+  b.nrm_of.resize(3 * (size_t)n);
   b.build(0, n, mn, mx);
+  b.emit(n);
   return b.n_out;
 }
 

@@ -207,7 +207,7 @@ struct lsgpu_icp {
   uint32_t nchunks = 0;
   // direction index of the reference (lsgpu_cone.hip.h): the settled launches of an align search it instead of the voxel grid
   DevBuf<float> cone_soa;
-  DevBuf<uint32_t> cone_map, cone_tab;
+  DevBuf<uint32_t> cone_tab;
   DevBuf<float4> cone_rowz;
   ConeDev cone;
   bool cone_ok = false;       // built (or being built on the side stream: cone_pending) for the current reference
@@ -265,6 +265,7 @@ struct lsgpu_icp {
   DevBuf<int> ssn_axis_a, ssn_axis_b;       // per segment: the axis its current order follows (segmented level sorts)
   DevBuf<uint32_t> ssn_seg_fb;
   DevBuf<SegBlock> ssn_blocktab;
+  DevBuf<uint32_t> ssn_seg_orig;
   DevBuf<uint32_t> ssn_seg_of, ssn_box_pts, ssn_box_base, ssn_keep, ssn_out_pos, ssn_bb, ssn_bounds_ws;
   DevBuf<float> ssn_box_normal, ssn_draws;
   // sort-free upper levels of the reference filter (lsgpu_ssn_select.hip.h)
@@ -455,8 +456,8 @@ void lsgpu_icp_destroy(lsgpu_icp* h) {
   h->work.release();
 #endif
   h->pts.release();
-  h->cone_soa.release(); h->cone_occ.release(); h->cone_map.release(); h->cone_tab.release(); h->cone_rowz.release();
-  h->nrm.release(); h->ref_inv.release(); h->tables.release(); h->flags.release(); h->cidx.release(); h->bounds.release(); h->chunks.release(); h->chunk_groups.release(); h->soa.release(); h->soa_base.release(); h->soa_cnt4.release(); h->soa_first.release(); h->prev.release(); h->state.release(); h->lb.release(); h->cell_cache.release(); h->cell_tags.release(); h->ssn_seg_a.release(); h->ssn_seg_b.release(); h->ssn_axis_a.release(); h->ssn_axis_b.release(); h->ssn_seg_fb.release(); h->ssn_blocktab.release(); h->ssn_seg_of.release(); h->ssn_box_pts.release(); h->ssn_box_base.release(); h->ssn_keep.release(); h->ssn_out_pos.release(); h->ssn_bb.release(); h->ssn_bounds_ws.release(); h->ssn_box_normal.release(); h->ssn_draws.release(); h->flt_in.release(); h->flt_in2.release(); h->flt_ref.release(); h->flt_rd.release(); h->flt_nrm.release(); h->chk_hist.release(); h->trace_dev.release(); h->knn_dbg.release(); h->knn_dbg_wave.release(); h->stat_partials.release(); h->geom.release();
+  h->cone_soa.release(); h->cone_occ.release(); h->cone_tab.release(); h->cone_rowz.release();
+  h->nrm.release(); h->ref_inv.release(); h->tables.release(); h->flags.release(); h->cidx.release(); h->bounds.release(); h->chunks.release(); h->chunk_groups.release(); h->soa.release(); h->soa_base.release(); h->soa_cnt4.release(); h->soa_first.release(); h->prev.release(); h->state.release(); h->lb.release(); h->cell_cache.release(); h->cell_tags.release(); h->ssn_seg_a.release(); h->ssn_seg_b.release(); h->ssn_axis_a.release(); h->ssn_axis_b.release(); h->ssn_seg_fb.release(); h->ssn_blocktab.release(); h->ssn_seg_of.release(); h->ssn_seg_orig.release(); h->ssn_box_pts.release(); h->ssn_box_base.release(); h->ssn_keep.release(); h->ssn_out_pos.release(); h->ssn_bb.release(); h->ssn_bounds_ws.release(); h->ssn_box_normal.release(); h->ssn_draws.release(); h->flt_in.release(); h->flt_in2.release(); h->flt_ref.release(); h->flt_rd.release(); h->flt_nrm.release(); h->chk_hist.release(); h->trace_dev.release(); h->knn_dbg.release(); h->knn_dbg_wave.release(); h->stat_partials.release(); h->geom.release();
   h->counters.release(); h->price_cnt.release(); h->ang_cells.release(); h->sel_aux.release(); h->sel_win.release(); h->spread_flag.release(); h->spread_list.release(); h->spread_cnt.release(); h->q_in.release(); h->rdq.release(); h->ids.release(); h->d2.release();
   h->ids_io.release(); h->d2_io.release(); h->strag.release(); h->hist.release();
   h->sel.release(); h->ne_partials.release(); h->ne_gpartials.release(); h->ne_tickets.release(); h->ne_out.release(); h->limit_dev.release();
@@ -765,9 +766,9 @@ static int run_knn(lsgpu_icp* h, const Mat34& T, const IcpState* st, const polic
     const bool pay_index = pay_probe && kern == policy::KnnKernel::Cone && h->pay_voxel_timed && !h->pay_index_timed;
     if (pay_index) HIPC(hipEventRecord(h->ev_pay[2], h->stream));
     if (kern == policy::KnnKernel::ConeProbe)   // balls as wide as the last ICP step: a probe of the query's own direction first
-      hipLaunchKernelGGL((k_knn_cone<LSGPU_CONE_WAVES, true>), dim3((a.ntiles + LSGPU_CONE_WAVES - 1) / LSGPU_CONE_WAVES), dim3(LSGPU_CONE_WAVES * 64), 0, h->stream, a, h->cone);
+      hipLaunchKernelGGL((k_knn_cone<LSGPU_CONE_WAVES, true>), dim3((a.ntiles + LSGPU_CONE_WAVES - 1) / LSGPU_CONE_WAVES), dim3(LSGPU_CONE_WAVES * 64), (size_t)h->cone.rows * sizeof(float4), h->stream, a, h->cone);
     else
-      hipLaunchKernelGGL((k_knn_cone<LSGPU_CONE_WAVES, false>), dim3((a.ntiles + LSGPU_CONE_WAVES - 1) / LSGPU_CONE_WAVES), dim3(LSGPU_CONE_WAVES * 64), 0, h->stream, a, h->cone);
+      hipLaunchKernelGGL((k_knn_cone<LSGPU_CONE_WAVES, false>), dim3((a.ntiles + LSGPU_CONE_WAVES - 1) / LSGPU_CONE_WAVES), dim3(LSGPU_CONE_WAVES * 64), (size_t)h->cone.rows * sizeof(float4), h->stream, a, h->cone);
     if (timed) HIPC(hipEventRecord(ev->b, h->stream));
     if (pay_index) { HIPC(hipEventRecord(h->ev_pay[3], h->stream)); h->pay_index_timed = true; }
     HIPC(hipGetLastError());
@@ -889,10 +890,10 @@ static int build_cone_index(lsgpu_icp* h) {
   c.rs = (float)c.rows / (zr * 1.0002f + 2e-5f);
   c.cs = (float)c.cols * 0.25f;
   const size_t npad = (((size_t)nr + 3) & ~(size_t)3) + kConePad, nkeys = (size_t)c.rows * (size_t)c.cols;
-  HIPC(h->cone_soa.reserve(3 * npad)); HIPC(h->cone_map.reserve(npad));
+  HIPC(h->cone_soa.reserve(4 * npad));
   HIPC(h->cone_tab.reserve(nkeys + 1)); HIPC(h->cone_rowz.reserve((size_t)c.rows));
   HIPC(h->sc->keys.reserve(nr)); HIPC(h->sc->vals.reserve(nr));
-  c.soa = reinterpret_cast<const float4*>(h->cone_soa.p); c.map = h->cone_map.p; c.tab = h->cone_tab.p; c.rowz = h->cone_rowz.p;
+  c.soa = reinterpret_cast<const float4*>(h->cone_soa.p); c.tab = h->cone_tab.p; c.rowz = h->cone_rowz.p;
   hipLaunchKernelGGL(k_cone_keys, dim3(nblk(nr)), dim3(256), 0, h->cur, h->pts.p, nr, c,
                      h->sc->keys.p, h->sc->vals.p);
   int nbits = 1;
@@ -902,7 +903,7 @@ static int build_cone_index(lsgpu_icp* h) {
   HIPC(h->cone_occ.reserve(1));
   HIPC(hipMemsetAsync(h->cone_occ.p, 0, sizeof(uint32_t), h->cur));
   hipLaunchKernelGGL(k_cone_gather, dim3(nblk((int64_t)npad)), dim3(256), 0, h->cur, h->pts.p, h->sc->vals_alt.p,
-                     h->sc->keys_alt.p, nr, c, h->cone_soa.p, h->cone_map.p, h->cone_tab.p);
+                     h->sc->keys_alt.p, nr, c, h->cone_soa.p, h->cone_tab.p);
   hipLaunchKernelGGL(k_cone_rows, dim3(c.rows), dim3(256), 0, h->cur, c, h->cone_rowz.p, h->cone_occ.p);
   HIPC(hipGetLastError());
   // the number of occupied bins travels to the host behind the build; lsgpu_icp_align looks at it before its first
@@ -1412,6 +1413,7 @@ static int ssn_device(lsgpu_icp* h, const float4* src, int64_t n, int knn, float
   HIPC(h->ssn_seg_a.reserve(nseg));
   HIPC(h->ssn_seg_b.reserve(nseg));
   HIPC(h->ssn_seg_of.reserve(n));
+  HIPC(h->ssn_seg_orig.reserve(n));
   HIPC(h->ssn_box_pts.reserve(nseg));
   HIPC(h->ssn_box_base.reserve(nseg));
   HIPC(h->ssn_box_normal.reserve(3 * nseg));
@@ -1636,11 +1638,11 @@ static int ssn_device(lsgpu_icp* h, const float4* src, int64_t n, int knn, float
   // the draws: at most one per point; produced on the helper thread while the kernels above were enqueued
   rc = ahead->ready();
   if (rc) return rc;
-  hipLaunchKernelGGL(k_ssn_select, dim3(nblk(n)), dim3(256), 0, h->stream, (int)n, h->ssn_seg_of.p, cur,
-                     h->ssn_box_pts.p, h->ssn_box_base.p, h->ssn_draws.p + first_draw, ratio, h->ssn_keep.p);
+  hipLaunchKernelGGL(k_ssn_select, dim3(nblk(n)), dim3(256), 0, h->stream, (int)n, idx, h->ssn_seg_of.p, cur,
+                     h->ssn_box_pts.p, h->ssn_box_base.p, h->ssn_draws.p + first_draw, ratio, h->ssn_keep.p, h->ssn_seg_orig.p);
   rc = scan_u32(h, h->ssn_keep.p, h->ssn_out_pos.p, (size_t)n);
   if (rc == LSGPU_OK) {
-    hipLaunchKernelGGL(k_ssn_emit, dim3(nblk(n)), dim3(256), 0, h->stream, src, (int)n, idx, h->ssn_seg_of.p,
+    hipLaunchKernelGGL(k_ssn_emit, dim3(nblk(n)), dim3(256), 0, h->stream, src, (int)n, h->ssn_seg_orig.p,
                        h->ssn_box_normal.p, h->ssn_keep.p, h->ssn_out_pos.p, out_xyz1, out_nrm);
   }
   uint32_t n_draws = 0, kept = 0;
@@ -2708,6 +2710,23 @@ int lsgpu_dev_tree_phases(lsgpu_icp* h, unsigned long long out[64]) {  // stats 
   if (!h) return LSGPU_BAD_ARG;
   HIPC(hipStreamSynchronize(h->stream));
   HIPC(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_tree_dbg), 512));
+  return LSGPU_OK;
+}
+int lsgpu_dev_cone_phases(lsgpu_icp* h, unsigned int* out, int ntiles) {  // stats build only (devtools/cone_phases.py)
+  // out == nullptr: (re)arm the record buffer for `ntiles` waves per iteration; otherwise copy the records back
+  if (!h || ntiles <= 0) return LSGPU_BAD_ARG;
+  static uint32_t* rec = nullptr;
+  static size_t rec_words = 0;
+  const size_t words = (size_t)kConeRecIters * (size_t)ntiles * 16;
+  HIPC(hipStreamSynchronize(h->stream));
+  if (!out) {
+    if (words > rec_words) { if (rec) HIPC(hipFree(rec)); HIPC(hipMalloc((void**)&rec, words * 4)); rec_words = words; }
+    HIPC(hipMemset(rec, 0, words * 4));
+    HIPC(hipMemcpyToSymbol(HIP_SYMBOL(g_cone_rec), &rec, sizeof(rec)));
+    return LSGPU_OK;
+  }
+  if (!rec || words > rec_words) return LSGPU_BAD_ARG;
+  HIPC(hipMemcpy(out, rec, words * 4, hipMemcpyDeviceToHost));
   return LSGPU_OK;
 }
 int lsgpu_dev_ne_phases(lsgpu_icp* h, unsigned long long out[16]) {  // stats build only (devtools/ne_phases.py)

@@ -231,6 +231,8 @@ typedef struct ssn_ctx {
   float* out_xyz1;
   float* out_nrm;
   int64_t n_out;
+  unsigned char* keep; /* per ORIGINAL index: in indicesToKeep */
+  float* nrm_of;       /* per original index: the normal of its box */
 } ssn_ctx;
 
 /* Jacobi eigen-decomposition of a symmetric 3x3 (double).  V columns = eigenvectors. */
@@ -337,14 +339,16 @@ static void ssn_fuse(ssn_ctx* s, int64_t first, int64_t last) {
   double nx = v[0][k], ny = v[1][k], nz = v[2][k];
   const double nl = sqrt(nx * nx + ny * ny + nz * nz);
   nx /= nl; ny /= nl; nz /= nl;
-  for (int64_t i = first; i < last; ++i) { /* samplingMethod 0 */
+  for (int64_t i = first; i < last; ++i) { /* samplingMethod 0: the draws are taken in box-traversal order */
     const float r = (float)rand() / (float)RAND_MAX;
     if (r < s->ratio) {
-      const int64_t src = s->idx[i], o = s->n_out++;
-      memcpy(s->out_xyz1 + 4 * o, s->xyz1 + 4 * src, 4 * sizeof(float));
-      s->out_nrm[3 * o + 0] = (float)nx;
-      s->out_nrm[3 * o + 1] = (float)ny;
-      s->out_nrm[3 * o + 2] = (float)nz;
+      /* indicesToKeep.push_back(k); normals->col(k) = normal -- the point keeps its ORIGINAL column until the
+       * final compaction (lso_sampling_surface_normal below) */
+      const int64_t src = s->idx[i];
+      s->keep[src] = 1;
+      s->nrm_of[3 * src + 0] = (float)nx;
+      s->nrm_of[3 * src + 1] = (float)ny;
+      s->nrm_of[3 * src + 2] = (float)nz;
     }
   }
 }
@@ -385,7 +389,20 @@ int64_t lso_sampling_surface_normal(const float* xyz1, int64_t n, int knn, float
       if (v > maxb[d]) maxb[d] = v;
     }
   }
+  s.keep = (unsigned char*)calloc((size_t)n, 1);
+  s.nrm_of = (float*)malloc(sizeof(float) * 3 * (size_t)n);
   ssn_build(&s, 0, n, minb, maxb);
+  /* "Bring the data we keep to the front of the arrays": upstream sorts indicesToKeep ascending before it compacts
+   * (std::sort in inPlaceFilter; from knowledge of libpointmatcher, restatement choice 10 in icp_oracle.h), so the
+   * filtered cloud is in ORIGINAL index order, every point with its box's normal */
+  for (int64_t i = 0; i < n; ++i)
+    if (s.keep[i]) {
+      const int64_t o = s.n_out++;
+      memcpy(s.out_xyz1 + 4 * o, xyz1 + 4 * i, 4 * sizeof(float));
+      memcpy(s.out_nrm + 3 * o, s.nrm_of + 3 * i, 3 * sizeof(float));
+    }
+  free(s.keep);
+  free(s.nrm_of);
   free(s.idx);
   free(s.tmp);
   return s.n_out;

@@ -32,8 +32,8 @@
  *      dropped differently (a few points of 1 M).  tests: test_independent_known_answers (collinear boxes dropped,
  *      planar ones kept, normals == numpy.linalg.eigh).  [reference_filtered.csv: number of rows]
  *   2. split of a box: std::nth_element leaves ties and the order inside the halves unspecified; here "stable sort,
- *      split at the median".  Wrong => other box memberships where coordinates tie, other output ORDER of the kept
- *      points (which permutes the rand() draws of ratio < 1).  tests: test_filter_golden_vectors_reproduce,
+ *      split at the median".  Wrong => other box memberships where coordinates tie, another order in which the boxes'
+ *      points take their rand() draws (ratio < 1: other points kept).  tests: test_filter_golden_vectors_reproduce,
  *      test_device_reference_filter_is_bit_identical (pin device == host == oracle, not upstream);
  *      test_surface_normal_filter_boxes_against_a_numpy_recursion (the stated rule as a plain numpy recursion).  [reference_filtered.csv: row order, normals]
  *   3. kd-tree ties (libnabo): implementation defined => any nearest point is valid; the product returns the
@@ -57,13 +57,29 @@
  *      rand_sequence; the sequence tests run both "reseed per call" and "one continuing stream".
  *      On ERROR paths the product's stream position may differ from a libpointmatcher process': lsgpu_icp_compute
  *      consumes the reading filter's draws as soon as the reference filter has run (the total is known), so a failure
- *      after that point (HIP error, empty grid) leaves them consumed although the filter never ran; the C++ facade
- *      rejects a non-rigid guess before any draw, upstream after both filters.  No call site of laser_slam continues
- *      after either.
+ *      after that point (HIP error, empty grid) leaves them consumed although the filter never ran.  A guess that is not
+ *      rigid is refused AFTER both filters have consumed their draws, as upstream does (the C++ facade hands it to the
+ *      device all the same; tests/cpp/shim_check.cpp compares the stream positions); only a facade without a device, or with
+ *      the LSGPU_TEST_SEAMS compute override, refuses it before any draw.  No call site of laser_slam continues after either.
  *      [reading_filtered.csv, and reference_filtered.csv for ratio < 1: which rows]
  *   9. MaxDist / MinDist input filters: radial branch compares the norm with |limit| (both), one-axis branch compares
  *      the SIGNED coordinate (MaxDist) / the absolute one (MinDist); an empty cloud into a non-empty chain throws.
  *      tests: test_input_filters_upstream_asymmetries.  [input_filtered.csv: rows]
+ *  10. output order of SamplingSurfaceNormal: upstream's inPlaceFilter takes the draws in box-traversal order, collects the
+ *      kept indices, then does std::sort(indicesToKeep) and compacts the cloud in place ("bring the data we keep to the
+ *      front of the arrays") -- the filtered cloud is in ascending ORIGINAL index, every point with its box's normal
+ *      (from knowledge of libpointmatcher, like choice 1; rounds 1-5 emitted in traversal order, the round-5 verdict's
+ *      catch).  Wrong => the same points in another row order: other ids, another float order of the reference mean
+ *      (T at the 1e-6 level).  tests: test_surface_normal_filter_boxes_against_a_numpy_recursion (point for point against
+ *      a numpy recursion that sorts the kept indices), test_filter_golden_vectors_reproduce, test_device_reference_filter_
+ *      is_bit_identical.  [reference_filtered.csv: row order]
+ *  11. eigenvectors of a box: upstream runs Eigen::EigenSolver<Matrix3f> (general real solver, float) on C and takes the
+ *      real part of the eigenvector of the smallest eigenvalue; here a cyclic Jacobi iteration in double on the float C,
+ *      normalised in double, rounded to float (lsgpu_box_normal.h / jacobi3: the same source on host and device).  The
+ *      two agree to float rounding (1e-6 in the normal's components, sign included only up to the solver's convention:
+ *      the point-to-plane error is even in the normal); a near-isotropic box (two or three equal eigenvalues) may pick
+ *      another vector of the degenerate eigenspace.  tests: test_independent_known_answers (numpy.linalg.eigh).
+ *      [reference_filtered.csv: columns nx, ny, nz]
  * The COMPOSITION of ICP::compute (frames, left-multiplied update, checker window, steps 1-7 of SURVEY.md A.1) is pinned
  * against a float64 numpy / scipy ICP that shares no code with this file:
  * test_oracle_loop_against_an_independent_numpy_icp.

@@ -436,23 +436,33 @@ def test_upper_level_bookkeeping_models():
 
 
 def _check_boxes_against_recursion(pts, boxes, out, nrm):
-    pos = 0
-    checked = 0
-    for b in boxes:                         # (a box is dropped only if its points are collinear / coincident)
+    """`boxes` in traversal order; the filter's output is the kept points in ascending ORIGINAL index (upstream sorts
+    indicesToKeep before it compacts, restatement choice 10), every point with the normal of its box."""
+    box_of = np.full(pts.shape[0], -1, np.int64)
+    kept_boxes = []
+    for k, b in enumerate(boxes):           # (a box is dropped only if its points are collinear / coincident)
         d = pts[b, :3].astype(np.float64)
         c = d - d.mean(0)
         if np.linalg.matrix_rank(c.T @ c, tol=None) < 2:
             continue                        # dropped by the rank test: nothing of it in the output
-        got = out[pos:pos + b.size]
-        assert np.array_equal(got[:, :3], pts[b, :3]), (pos, b[:4])
+        box_of[b] = k
+        kept_boxes.append(k)
+    kept = np.flatnonzero(box_of >= 0)      # ascending original index
+    assert out.shape[0] == kept.size
+    assert np.array_equal(out[:, :3], pts[kept, :3])
+    checked = 0
+    for k in kept_boxes:
+        b = boxes[k]
+        rows = np.searchsorted(kept, np.sort(b))
+        nn = nrm[rows[0]]
+        assert np.array_equal(nrm[rows], np.repeat(nn[None], b.size, 0)), k
+        d = pts[b, :3].astype(np.float64)
+        c = d - d.mean(0)
         evals, evecs = np.linalg.eigh(c.T @ c)
-        nn = nrm[pos]
         if evals[1] > 1e-3 * evals[2] and evals[0] < 0.5 * evals[1]:   # a well separated smallest eigenvalue
             assert abs(abs(float(nn @ evecs[:, 0])) - 1.0) < 1e-3
             checked += 1
-        assert np.array_equal(nrm[pos:pos + b.size], np.repeat(nn[None], b.size, 0))
-        pos += b.size
-    assert pos == out.shape[0] and checked > 300
+    assert checked > 300
 
 
 def test_upstream_dump_regenerates(tmp_path):
