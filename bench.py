@@ -167,6 +167,100 @@ def track_section(n_az: int, n_scans: int, cpu_threads: int):
         shutil.rmtree(d, ignore_errors=True)
 
 
+def dry_run(args, rank, world):
+    """`--dry-run`: everything of a multi-rank run that is NOT the device -- the rendezvous the driver's launcher sets up, the
+    shards every mode derives from (rank, world), the unique-id broadcast and the entry handshake of the split-scan mode, the
+    per-iteration exchange pattern (sums of per-shard tables -> the same decision on every rank), the max-over-ranks clock and
+    the JSON line -- on the gloo backend with a 4 k-point host workload.  No search, no ICP: nothing here is a measurement.
+    Returns the process' exit code (non-zero: a peer was missing and this rank gave up in bounded time)."""
+    import datetime
+    import torch
+    import torch.distributed as dist
+    from laser_slam_amd import synth, sharding
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo", timeout=datetime.timedelta(seconds=60))
+    wait_s = float(os.environ.get("LSGPU_COMM_TIMEOUT_MS", "5000")) / 1e3   # (the library bounds its stream waits with the same variable)
+    if rank == args.dry_run_dead_rank:
+        return 0                                   # a peer that died before the first exchange
+    out = {"dry_run": True, "backend": "gloo", "n_gpus": world, "mode": "batch" if args.batch else "split" if args.split else "default"}
+
+    def bounded(work):                             # a collective that a dead peer cannot turn into a hang
+        try:
+            work.wait(datetime.timedelta(seconds=wait_s))
+            return True
+        except Exception as e:                     # (gloo raises on the timeout; RCCL's counterpart is the bounded stream wait)
+            print("bench.py --dry-run rank %d: peer missing, giving up (%s)" % (rank, str(e)[:80]), file=sys.stderr)
+            return False
+
+    def allreduce(t, op=None):
+        if world == 1:
+            return True
+        return bounded(dist.all_reduce(t, op=op or dist.ReduceOp.SUM, async_op=True))
+
+    t0 = time.perf_counter()
+    if args.batch:
+        mine = sharding.pairs_of_rank(args.batch_pairs, rank, world)
+        owner = torch.zeros(args.batch_pairs, dtype=torch.int64)
+        owner[mine] = 1
+        if not allreduce(owner):
+            return 3
+        out["pairs_owned_exactly_once"] = bool((owner == 1).all().item())
+        out["pairs_of_rank0"] = len(sharding.pairs_of_rank(args.batch_pairs, 0, world))
+    else:
+        data_rank = 0 if args.split else rank
+        ref, rd, T_true, T_init = synth.scan_pair(64, noise_seeds=(1 + 2 * data_rank, 2 + 2 * data_rank), guess_seed=7 + data_rank)
+        if args.split:
+            sl = sharding.split_shard(rd.shape[0], rank, world)
+
+            class _Handle:                         # stands where an IcpHandle would: records what comm_init was given
+                def comm_init(self, r, w, uid):
+                    self.got = (r, w, bytes(uid))
+            hnd = _Handle()
+            import laser_slam_amd.icp as icp_mod
+            real_uid = icp_mod.comm_unique_id
+            icp_mod.comm_unique_id = lambda: bytes((7 * i + 3) % 256 for i in range(128))   # (no librccl here)
+            try:
+                sharding.init_split_comm(hnd, device=None)
+            finally:
+                icp_mod.comm_unique_id = real_uid
+            uid_sum = torch.tensor([float(sum(hnd.got[2]))], dtype=torch.float64)
+            uid_max = uid_sum.clone()
+            # entry handshake of lsgpu_icp_align in the split-scan mode: {shard size, cannot-start flag} summed over the ranks
+            hs = torch.tensor([sl.stop - sl.start, 0], dtype=torch.int64)
+            if not (allreduce(hs) and allreduce(uid_max, dist.ReduceOp.MAX) and allreduce(uid_sum)):
+                return 3
+            out["handshake"] = {"points_total": int(hs[0]), "cannot_start": int(hs[1]), "covers_the_reading": int(hs[0]) == rd.shape[0]}
+            out["unique_id_equal_on_all_ranks"] = bool(abs(uid_sum.item() - world * uid_max.item()) < 0.5) and hnd.got[:2] == (rank, world)
+            # the exchange pattern of an iteration: per-shard tables summed, every rank derives the same trim rank / decision
+            decisions = []
+            for it in range(3):
+                x = rd[sl, :3].astype(np.float64) + 0.01 * it
+                d2 = (x ** 2).sum(1).astype(np.float32)
+                hist = torch.from_numpy(np.bincount(d2.view(np.uint32) >> 20, minlength=4096).astype(np.int64))
+                if not allreduce(hist):
+                    return 3
+                k = int(np.float32(int(hs[0])) * np.float32(0.75))
+                b1 = int(np.searchsorted(np.cumsum(hist.numpy()), k, side="right"))
+                decisions.append(b1)
+            dec = torch.tensor(decisions, dtype=torch.int64)
+            dmin, dmax = dec.clone(), dec.clone()
+            if not (allreduce(dmin, dist.ReduceOp.MIN) and allreduce(dmax, dist.ReduceOp.MAX)):
+                return 3
+            out["decisions_equal_on_all_ranks"] = bool((dmin == dmax).all().item())
+        else:
+            out["pair_of_this_rank_differs_from_rank0s"] = bool(rank == 0 or not np.array_equal(rd, synth.scan_pair(64)[1]))
+    el = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    if not allreduce(el, dist.ReduceOp.MAX if world > 1 else None):
+        return 3
+    out["max_elapsed_s_over_ranks"] = float(el.item())
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -185,6 +279,10 @@ def main():
     ap.add_argument("--batch-handles", type=int, default=16)
     ap.add_argument("--split", action="store_true", help="BASELINE configs[3]: one 8.4 M local map vs one 1 M scan, reading sharded, RCCL")
     ap.add_argument("--split-pair", action="store_true", help="(with --split) the configs[1] pair instead of the 8-scan local map")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="no GPU: the launch / rendezvous / sharding / handshake / reduction plumbing of the chosen mode on the gloo\n"
+                         "backend with a small host workload, so that a multi-GPU lease is not spent finding a typo in it")
+    ap.add_argument("--dry-run-dead-rank", type=int, default=-1, help="(with --dry-run) this rank leaves before the first exchange: the others must give up, not hang")
     args = ap.parse_args()
 
     if needs_relaunch(args.gpus, os.environ):
@@ -202,6 +300,13 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus != world and rank == 0:
         print("bench.py: --gpus %d but the launcher started %d rank(s); n_gpus reports the ranks that ran" % (args.gpus, world), file=sys.stderr)
+    if args.dry_run:
+        try:
+            code = dry_run(args, rank, world)
+        except Exception as e:   # (a peer that vanished inside a blocking call of the rendezvous: same verdict, bounded time)
+            print("bench.py --dry-run rank %d: %s" % (rank, repr(e)[:200]), file=sys.stderr)
+            code = 3
+        raise SystemExit(code)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a ROCm GPU: the ICP hot path has no CPU fallback")
     torch.cuda.set_device(local_rank)
@@ -391,6 +496,9 @@ def main():
         ne_ms += stp.t_ne_ms
         comm_ms += stp.t_comm_ms
         comm_calls += stp.comm_calls
+    # the last profiled step's searches one by one (search kernel + hand-over pass, us): the first launches and the settled
+    # ones are different kernels with different costs, the average alone hides which is which
+    knn_per_iter = [round(float(t["knn_main_us"] + t["knn_fallback_us"]), 1) for t in hp.trace()]
     loop_equals_compute = bool(np.array_equal(Tp, T))   # (chain F keeps every point: the loop on filtered clouds is the same alignment)
 
     # ---- the same compute handed HOST buffers (H2D + D2H inclusive), chains F and P, pageable and pinned
@@ -421,6 +529,25 @@ def main():
                 ms = float(np.median(ts[1:]))
                 value_e2e[f"{chain}_{mem}"] = {"ms_per_scan": ms, "scans_per_s": 1e3 / ms, "iterations": ste.iterations}
         value_e2e["value"] = value_e2e["F_full_density_pageable"]["scans_per_s"]
+        # what the link itself takes for one raw cloud (16.7 MB), from either kind of host memory: the pinned path's copies
+        # are true DMA from the caller's buffer, the pageable path's go through the runtime's own staging buffers in chunks
+        # on the calling / helper thread -- on this box the latter is no slower, and the compute overlaps more of it
+        # (the reading's copy runs on a helper thread beside the reference filter either way)
+        try:
+            d_tmp = torch.empty_like(d_raw_ref)
+            pc = {}
+            for mem, src_t in (("pageable", torch.from_numpy(raw_ref)), ("pinned", p_ref)):
+                ts = []
+                for rep in range(5):
+                    torch.cuda.synchronize(); tc0 = time.perf_counter()
+                    d_tmp.copy_(src_t, non_blocking=False); torch.cuda.synchronize()
+                    ts.append((time.perf_counter() - tc0) * 1e3)
+                pc["h2d_ms_" + mem] = float(np.median(ts[1:]))
+                pc["h2d_GBps_" + mem] = raw_ref.nbytes / (pc["h2d_ms_" + mem] * 1e-3) / 1e9
+            pc["bytes"] = int(raw_ref.nbytes)
+            value_e2e["host_to_device_copy_of_one_raw_cloud"] = pc
+        except Exception as e:   # (a side figure: never fails the bench)
+            value_e2e["host_to_device_copy_of_one_raw_cloud"] = {"error": str(e)}
         h.set_reference(d_ref, d_nrm)
 
     info = h.info()
@@ -497,6 +624,7 @@ def main():
     out["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                        "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_note,
                        "kernel": "k_knn_cone (direction-indexed search, iterations >= 2) / k_knn_tile + k_knn_fallback (voxel-grid search, iterations 0-1) -- exact 1-NN correspondence search",
+                       "per_iteration_us": knn_per_iter,
                        "algorithmic_bytes_per_launch": b_knn,
                        "avg_launch_us": t_knn * 1e6,
                        "avg_main_us": knn_main_ms / max(knn_launches, 1) * 1e3,
@@ -536,6 +664,12 @@ def main():
         out["value_loop"] = value_loop
     if value_e2e is not None:
         out["value_e2e"] = value_e2e
+        # SURVEY.md 8d words scans/sec as "end-to-end compute calls incl. H2D ... D2H"; the task statement keeps PCIe out of
+        # `value` ("inputs already resident in HBM when the timed region starts ... the PCIe-inclusive rate ... is never
+        # `value`").  Both figures therefore stand next to each other at the top level: `value` (resident) and this one.
+        out["value_host_buffers"] = {"value": value_e2e["value"], "unit": "scans/s",
+                                     "is": "SURVEY.md 8d's scans/sec: the same lsgpu_icp_compute handed HOST buffers (pageable), H2D of both raw "
+                                           "clouds and D2H of the result inside the timed call; details in value_e2e"}
     if variants is not None:
         out["compute_variants"] = variants
 
@@ -560,7 +694,9 @@ def main():
         }
         # second row of SURVEY.md §8d: the same oracle with OpenMP over the queries on all host cores (what a
         # libnabo built with OpenMP does); reported next to the single-thread figure, never as the baseline value
-        nthr = min(os.cpu_count() or 1, 64)
+        # every hardware thread of the host (rounds 1-5 stopped at 64; the query loop is the only parallel part of the
+        # oracle -- filters, kd-tree build, select and the 6x6 sums are serial, like libpointmatcher's)
+        nthr = os.cpu_count() or 1
         if nthr > args.cpu_threads:
             ocfg.num_threads = nthr
             tc = time.perf_counter()

@@ -166,6 +166,21 @@ typedef struct lsgpu_icp_info {
 } lsgpu_icp_info;
 int lsgpu_icp_get_info(lsgpu_icp* h, lsgpu_icp_info* out);
 
+/* What the handle's launch policy remembers ACROSS calls (nothing of it changes a result; it decides what a call costs).
+ * The per-alignment decisions are in lsgpu_icp_stats; these outlive an alignment. */
+typedef struct lsgpu_policy_info {
+  int   index_rest;          /* alignments that will still leave the direction index alone: the handle found it slower than
+                                the voxel grid (two timed searches per alignment); LSGPU_NO_INDEX_REST=1 switches the
+                                judgement off, a reference of another size resets it */
+  float pay_voxel_us;        /* the two timings of the last alignment that took them (0: none yet): the voxel-grid search in */
+  float pay_index_us;        /* front of the index's first use / the first settled search through the index */
+  int   ssn_sort_fallbacks;  /* reference filters this handle had to repeat with the segmented sorts because the sort-free
+                                levels gave up (more candidates around a median than a workgroup selects among) */
+  int   ssn_calls;           /* reference filters run by this handle */
+  int   reserved[3];
+} lsgpu_policy_info;
+int lsgpu_icp_get_policy_info(lsgpu_icp* h, lsgpu_policy_info* out);
+
 /* The float mean subtracted from the reference (T_refIn_refMean translation). */
 int lsgpu_icp_get_reference_mean(lsgpu_icp* h, float mean[3]);
 

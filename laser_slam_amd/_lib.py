@@ -21,7 +21,7 @@ ABI_SYMBOLS = [
     "lsgpu_chain_config_yaml", "lsgpu_chain_config_default", "lsgpu_icp_filter_reference",
     "lsgpu_icp_filter_reading", "lsgpu_icp_compute", "lsgpu_cloud_upload", "lsgpu_cloud_release",
     "lsgpu_cloud_size", "lsgpu_icp_compute_clouds", "lsgpu_icp_compute_clouds_upload", "lsgpu_filter_cylinder", "lsgpu_filter_voxel_grid",
-    "lsgpu_icp_get_reference_mean", "lsgpu_icp_get_info", "lsgpu_comm_get_unique_id", "lsgpu_icp_comm_init", "lsgpu_knn", "lsgpu_trim_limit", "lsgpu_normal_eq",
+    "lsgpu_icp_get_reference_mean", "lsgpu_icp_get_info", "lsgpu_icp_get_policy_info", "lsgpu_comm_get_unique_id", "lsgpu_icp_comm_init", "lsgpu_knn", "lsgpu_trim_limit", "lsgpu_normal_eq",
     "lsgpu_transform_points", "lsgpu_rotate_descriptors", "lsgpu_filter_random_sampling",
     "lsgpu_filter_sampling_surface_normal", "lsgpu_check_rigid", "lsgpu_correct_rigid", "lsgpu_rotation_distance",
     "lsgpu_strerror", "lsgpu_last_error", "lsgpu_abi_version", "lsgpu_apply_point_filters",
@@ -78,6 +78,12 @@ class IcpStats(C.Structure):
         ("direction_index_occupancy", C.c_float),
         ("direction_index_heavy_share", C.c_float),
     ]
+
+
+class PolicyInfo(C.Structure):
+    """lsgpu_policy_info: what the handle's launch policy remembers across calls."""
+    _fields_ = [("index_rest", C.c_int), ("pay_voxel_us", C.c_float), ("pay_index_us", C.c_float),
+                ("ssn_sort_fallbacks", C.c_int), ("ssn_calls", C.c_int), ("reserved", C.c_int * 3)]
 
 
 class IterTrace(C.Structure):
@@ -180,6 +186,8 @@ def lib() -> C.CDLL:
     L.lsgpu_icp_get_trace.argtypes = [vp, C.POINTER(IterTrace), C.c_int]
     L.lsgpu_icp_get_reference_mean.argtypes = [vp, C.POINTER(C.c_float)]
     L.lsgpu_icp_get_info.argtypes = [vp, C.POINTER(IcpInfo)]
+    L.lsgpu_icp_get_policy_info.argtypes = [vp, C.POINTER(PolicyInfo)]
+    L.lsgpu_icp_get_policy_info.restype = C.c_int
     L.lsgpu_comm_get_unique_id.argtypes = [C.c_char_p]
     L.lsgpu_icp_comm_init.argtypes = [vp, C.c_int, C.c_int, C.c_char_p]
     L.lsgpu_knn.argtypes = [vp, fp, i64, C.POINTER(C.c_float), fp, fp]

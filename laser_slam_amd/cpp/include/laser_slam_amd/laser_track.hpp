@@ -422,8 +422,20 @@ class LaserTrack {
         const int reading_slot = reading_resident ? deviceSlot(n - 1) : claimSlot(n - 1);
         stage_times_.upload_ms = msSince(t_up);
         const auto t_icp = std::chrono::steady_clock::now();
-        solution = reading_resident ? icp_.computeClouds(reading_slot, slots, member_T, T_init)
-                                    : icp_.computeCloudsUploading(reading_slot, reading, slots, member_T, T_init);
+        if (reading_resident) {
+          solution = icp_.computeClouds(reading_slot, slots, member_T, T_init);
+        } else {
+          // the slot counts as holding the new scan only once the fused call has stored it there: on return, or on a
+          // ConvergenceError (the upload is done whatever the registration's outcome); anything else -- a size mismatch,
+          // a failed copy -- leaves the slot unowned, so that the next scan uploads instead of matching a stale cloud
+          try {
+            solution = icp_.computeCloudsUploading(reading_slot, reading, slots, member_T, T_init);
+            confirmSlot(reading_slot, n - 1);
+          } catch (const ConvergenceError&) {
+            confirmSlot(reading_slot, n - 1);
+            throw;
+          }
+        }
         stage_times_.icp_ms = msSince(t_icp);
 #ifdef LSGPU_TEST_SEAMS
         if (icp_.hasComputeObserver()) {   // parity drivers: hand the observer the clouds the device just matched
@@ -462,7 +474,8 @@ class LaserTrack {
     icp_transformations_.push_back(icp);
   }
 
-  // (is scan `index` in its slot already?  /  its slot, marked as holding it: the caller uploads, lsgpu_icp_compute_clouds_upload)
+  // (is scan `index` in its slot already?  /  its slot, reserved for it: the fused call uploads (lsgpu_icp_compute_clouds_upload),
+  // confirmSlot() marks the slot as holding the scan once it does)
   bool slotHolds(size_t index) {
     const int slot = (int)(index % (size_t)params_.scans_on_device);
     return slot_generation_ == icp_.generation() && (size_t)slot < slot_owner_.size() && slot_owner_[(size_t)slot] == index &&
@@ -472,8 +485,13 @@ class LaserTrack {
     const int slot = (int)(index % (size_t)params_.scans_on_device);
     if (slot_generation_ != icp_.generation()) { slot_owner_.clear(); slot_generation_ = icp_.generation(); }
     if ((int)slot_owner_.size() < params_.scans_on_device) slot_owner_.resize((size_t)params_.scans_on_device, (size_t)-1);
-    slot_owner_[(size_t)slot] = index;
+    slot_owner_[(size_t)slot] = (size_t)-1;   // nobody's until confirmSlot()
+    (void)index;
     return slot;
+  }
+  void confirmSlot(int slot, size_t index) {
+    if ((size_t)slot < slot_owner_.size()) slot_owner_[(size_t)slot] = index;
+    slot_generation_ = icp_.generation();
   }
   // Device slot of scan `index`: scan i lives in slot i % scans_on_device while it is among the most recent
   // ones; anything else (or everything, after the ICP object was reconfigured) is uploaded on demand.

@@ -233,6 +233,9 @@ struct lsgpu_icp {
   hipEvent_t ev_pay[4] = {nullptr, nullptr, nullptr, nullptr};
   bool pay_voxel_timed = false, pay_index_timed = false;
   int index_rest = 0;         // alignments that still leave the index alone
+  int64_t index_rest_nr = 0;  // ... decided on a reference of this size (another size: the judgement starts over)
+  float pay_voxel_us = 0.f, pay_index_us = 0.f;   // the two timings behind it (lsgpu_icp_get_policy_info)
+  int ssn_sort_fallbacks = 0, ssn_calls = 0;
   DevBuf<uint4> knn_dbg_wave;
   DevBuf<unsigned long long> knn_dbg;  // LSGPU_KNN_STATS builds: 8 counters
   DevBuf<uint2> cell_cache;  // ntiles x 64
@@ -1100,6 +1103,14 @@ int lsgpu_icp_comm_init(lsgpu_icp* h, int rank, int nranks, const void* id) {
   return LSGPU_OK;
 }
 
+int lsgpu_icp_get_policy_info(lsgpu_icp* h, lsgpu_policy_info* out) {
+  if (!h || !out) return LSGPU_BAD_ARG;
+  std::memset(out, 0, sizeof(*out));
+  out->index_rest = h->index_rest; out->pay_voxel_us = h->pay_voxel_us; out->pay_index_us = h->pay_index_us;
+  out->ssn_sort_fallbacks = h->ssn_sort_fallbacks; out->ssn_calls = h->ssn_calls;
+  return LSGPU_OK;
+}
+
 int lsgpu_icp_get_info(lsgpu_icp* h, lsgpu_icp_info* out) {
   if (!h || !out || h->nr <= 0) return LSGPU_BAD_ARG;
   *out = h->info;
@@ -1400,6 +1411,7 @@ static int scan_totals(lsgpu_icp* h, const uint32_t* in_a, const uint32_t* sc_a,
 static int ssn_device(lsgpu_icp* h, const float4* src, int64_t n, int knn, float ratio, int64_t seed,
                       float4* out_xyz1, float* out_nrm, int64_t* n_out, DrawAhead* ahead = nullptr, bool force_sort_levels = false) {
   *n_out = 0;
+  if (!force_sort_levels) ++h->ssn_calls;
   DrawAhead own;
   if (!ahead) {   // at most one draw per point, produced while the levels below are enqueued and run
     const int rc0 = own.begin(h, seed, (size_t)n);
@@ -1655,7 +1667,9 @@ static int ssn_device(lsgpu_icp* h, const float4* src, int64_t n, int knn, float
     if (getenv("LSGPU_GS_DEBUG")) fprintf(stderr, "lsgpu: sort-free levels gave up (n %lld): code %u seg %u a %u b %u | part %u seg %u dst %u\n", (long long)n,
                                           h->h_gs_err[1], h->h_gs_err[2], h->h_gs_err[3], h->h_gs_err[4], h->h_gs_err[5], h->h_gs_err[6], h->h_gs_err[7]);
     // thousands of equal coordinates around a median (more candidates than a workgroup selects among): the segmented
-    // sorts do not care -- the same filter again with them (same draws: nothing has been consumed yet)
+    // sorts do not care -- the same filter again with them (same draws: nothing has been consumed yet).  Counted:
+    // lsgpu_icp_get_policy_info shows a handle that pays the filter twice on every call.
+    ++h->ssn_sort_fallbacks;
     return ssn_device(h, src, n, knn, ratio, seed, out_xyz1, out_nrm, n_out, ahead, true);
   }
   ahead->used = first_draw + (size_t)n_draws;  // dropped boxes drew nothing
@@ -2177,6 +2191,7 @@ int lsgpu_cloud_upload(lsgpu_icp* h, int slot, const float* xyz1, int64_t n) {
   h->err.clear();
   HIPC(hipSetDevice(h->device));
   if ((size_t)slot >= h->clouds.size()) { h->clouds.resize((size_t)slot + 1); h->cloud_n.resize((size_t)slot + 1, -1); }
+  h->cloud_n[slot] = -1;   // (whatever the slot held is gone from here on: a failed copy must not leave a half-written cloud behind)
   HIPC(h->clouds[slot].reserve(n ? n : 1));
   if (n) HIPC(hipMemcpyAsync(h->clouds[slot].p, xyz1, (size_t)n * 16, hipMemcpyDefault, h->stream));
   HIPC(hipStreamSynchronize(h->stream));  // the caller's buffer is free again on return
@@ -2320,6 +2335,12 @@ int lsgpu_icp_align(lsgpu_icp* h, const float* reading_xyz1, int64_t nq, const f
   std::memset(&st, 0, sizeof(st));
   if (stats) *stats = st;
   h->trace.clear();
+  // queries that lsgpu_icp_compute ordered and moved on its side stream belong to THIS call and to no later one, whatever
+  // way it ends (a guess that is refused below would otherwise leave queries moved by that guess to the next call with the
+  // same pointer and size)
+  const float* const prepared_rd = h->prepared_rd;
+  const int64_t prepared_nq = h->prepared_nq;
+  h->prepared_rd = nullptr; h->prepared_nq = 0;
   // Local reasons not to start.  In the split-scan mode they are NOT returned yet: a rank that left here would
   // leave its peers blocked in the first collective, so every rank first takes part in the entry handshake below.
   int local_rc = LSGPU_OK;
@@ -2334,7 +2355,7 @@ int lsgpu_icp_align(lsgpu_icp* h, const float* reading_xyz1, int64_t nq, const f
     h->err = "align: the initial guess is not a rigid transformation (|1 - det R| > 1e-3)";
     local_rc = LSGPU_BAD_ARG;
   }
-  if (local_rc && !h->comm) return local_rc;
+  if (local_rc && !h->comm) { h->cone_build_in_align = false; return local_rc; }
   HIPC(hipSetDevice(h->device));
   const double t0 = wall_ms();
   h->knn_events_used = 0;
@@ -2348,8 +2369,7 @@ int lsgpu_icp_align(lsgpu_icp* h, const float* reading_xyz1, int64_t nq, const f
   for (int d = 0; d < 3; ++d) T_rm_in[12 + d] = T_init[12 + d] - h->mean[d];
   // (lsgpu_icp_compute may have ordered and moved these very queries on its side stream already: the loop's stream
   // only has to wait for that)
-  const bool prepared = !local_rc && !h->comm && h->prepared_rd == reading_xyz1 && h->prepared_nq == nq;
-  h->prepared_rd = nullptr; h->prepared_nq = 0;
+  const bool prepared = !local_rc && !h->comm && prepared_rd == reading_xyz1 && prepared_nq == nq;
   int rc = local_rc;
   if (!rc) {
     if (prepared) HIPC(hipStreamWaitEvent(h->stream, h->side_done, 0));
@@ -2433,6 +2453,8 @@ int lsgpu_icp_align(lsgpu_icp* h, const float* reading_xyz1, int64_t nq, const f
   if (h->cone_build_in_align) { h->cone_ok = cone_wanted(h); h->cone_decided = false; }   // (its build follows the first iteration, below)
   // a handle whose last alignments found the index slower than the voxel grid leaves it alone for a while (and spares
   // itself the build when that is still to come)
+  // (a reference of a markedly different size is another scene or another sub-map depth: the judgement starts over)
+  if (h->index_rest > 0 && (h->nr > 2 * h->index_rest_nr || 2 * h->nr < h->index_rest_nr)) h->index_rest = 0;
   const bool index_rests = h->index_rest > 0 && h->cone_ok;
   if (index_rests) { --h->index_rest; if (h->cone_build_in_align) { h->cone_build_in_align = false; h->cone_ok = false; } }
   pol.begin_align(h->cone_ok && !index_rests, h->cone_decided, h->cone_dense, h->cone_occupancy);
@@ -2579,7 +2601,8 @@ int lsgpu_icp_align(lsgpu_icp* h, const float* reading_xyz1, int64_t nq, const f
   if (h->pay_voxel_timed && h->pay_index_timed) {   // (both launches are long over: the loop's end was seen behind them)
     float t_voxel = 0.f, t_index = 0.f;
     if (hipEventElapsedTime(&t_voxel, h->ev_pay[0], h->ev_pay[1]) == hipSuccess && hipEventElapsedTime(&t_index, h->ev_pay[2], h->ev_pay[3]) == hipSuccess) {
-      if (policy::index_not_paying(t_voxel * 1e3f, t_index * 1e3f)) h->index_rest = policy::kIndexRestAligns;
+      h->pay_voxel_us = t_voxel * 1e3f; h->pay_index_us = t_index * 1e3f;
+      if (tuning().index_rest && policy::index_not_paying(t_voxel * 1e3f, t_index * 1e3f)) { h->index_rest = policy::kIndexRestAligns; h->index_rest_nr = h->nr; }
     } else {
       (void)hipGetLastError();
     }

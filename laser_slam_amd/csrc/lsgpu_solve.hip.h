@@ -507,7 +507,7 @@ __global__ __launch_bounds__(256) void k_normal_eq_loop(const float4* __restrict
   // kernel's end, of which 8 us in the update lane, before this and the LDS staging below.)
   // The fence-free form leans on gfx9 behaviour (stores are counted in vmcnt, sc1 accesses are served by the memory
   // side of the L2): it is compiled for gfx942 / gfx950 only, any other target gets the release / acquire pair of the
-  // HIP memory model (tests/test_gpu_parity.py::test_ne_handoff_matches_fenced_build compares the two builds).
+  // HIP memory model (tests/test_gpu_parity.py::test_experiment_switches_do_not_change_results compares the two builds digest by digest).
 #if (defined(__gfx950__) || defined(__gfx942__)) && !defined(LSGPU_NE_FENCED)
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #else

@@ -79,6 +79,8 @@ struct Tuning {
   bool front = true;
   bool lazy_need = true;
   bool lookahead = true;     // LSGPU_NO_LOOKAHEAD: the host waits for the whole stream when it looks at the loop state
+  bool index_rest = true;    // LSGPU_NO_INDEX_REST: the handle never rests the direction index on the evidence of two timed searches
+                             // (the one launch decision that depends on wall-clock timings: off => the same kernels every run)
   bool side_stream = true;   // LSGPU_NO_SIDE_STREAM: lsgpu_icp_compute runs the reading's filter + query order after the grid build instead of beside it
   int front_guess = 2048;
   bool route_all = true, rowq = true;
@@ -143,6 +145,7 @@ inline Tuning read() {
   t.lazy_need = !flag("LSGPU_NO_LAZY");
   t.side_stream = !flag("LSGPU_NO_SIDE_STREAM");
   t.lookahead = !flag("LSGPU_NO_LOOKAHEAD");
+  t.index_rest = !flag("LSGPU_NO_INDEX_REST");
   t.front_guess = (int)number("LSGPU_FRONT_GUESS", 2048, 0, 8192);
   t.route_all = !flag("LSGPU_NO_ROUTE_ALL");
   t.rowq = !flag("LSGPU_NO_ROWQ");
@@ -174,7 +177,7 @@ inline Tuning read() {
   t.cone_cols = (int)number("LSGPU_CONE_COLS", 8192, 64, 65536) & ~3;
   static const char* known[] = {"LSGPU_QUERY_ORDER", "LSGPU_Q_ELEV", "LSGPU_Q_SECT", "LSGPU_GAP", "LSGPU_BUDGET", "LSGPU_BUDGET_WIDE", "LSGPU_WIDE_ITERS",
                                 "LSGPU_ROUTE_R", "LSGPU_ROUTE_CHUNKS", "LSGPU_ROUTE_DENSE", "LSGPU_SPLIT_UPDATE", "LSGPU_NO_PREDICT", "LSGPU_NO_COMMIT",
-                                "LSGPU_NO_COMM_COMMIT", "LSGPU_NO_SEED_CAP", "LSGPU_NO_FRONT", "LSGPU_NO_LAZY", "LSGPU_NO_SIDE_STREAM", "LSGPU_NO_LOOKAHEAD", "LSGPU_FRONT_GUESS", "LSGPU_NO_ROUTE_ALL",
+                                "LSGPU_NO_COMM_COMMIT", "LSGPU_NO_SEED_CAP", "LSGPU_NO_FRONT", "LSGPU_NO_LAZY", "LSGPU_NO_SIDE_STREAM", "LSGPU_NO_LOOKAHEAD", "LSGPU_NO_INDEX_REST", "LSGPU_FRONT_GUESS", "LSGPU_NO_ROUTE_ALL",
                                 "LSGPU_NO_ROWQ", "LSGPU_ROWQ_BLOCKS", "LSGPU_SORT_ITEMS", "LSGPU_SSN_GLOBAL", "LSGPU_SSN_FULL_SORT", "LSGPU_SSN_OLD_FINISH", "LSGPU_SSN_ROOT", "LSGPU_SSN_SORT_LEVELS",
                                 "LSGPU_NE_BLOCKS", "LSGPU_COMM_TIMEOUT_MS", "LSGPU_KNN_DBG", "LSGPU_NO_CONE", "LSGPU_NO_CONE_PROBE", "LSGPU_CONE_ROWS", "LSGPU_CONE_COLS", "LSGPU_CONE_FROM", "LSGPU_CONE_MAX_OCC", "LSGPU_CONE_HEAVY_STEPS", "LSGPU_CONE_HEAVY_SHARE",
                                 // read by the Python / C++ hosts and the test drivers, not by this library:

@@ -137,6 +137,14 @@ class IcpHandle:
             _raise(rc, "lsgpu_icp_get_info", self._h)
         return out
 
+    def policy_info(self):
+        """lsgpu_icp_get_policy_info: what the handle's launch policy remembers across calls (index rest, fallbacks)."""
+        out = _lib.PolicyInfo()
+        rc = _lib.lib().lsgpu_icp_get_policy_info(self._h, C.byref(out))
+        if rc:
+            _raise(rc, "lsgpu_icp_get_policy_info", self._h)
+        return out
+
     # ---- ICP::compute steps 5-7
     def align(self, reading_xyz1, T_init):
         """-> (T 4x4 float32, IcpStats).  Raises ConvergenceError like PointMatcher."""

@@ -2,6 +2,7 @@
 engine is injected; here it is the oracle, on the GPU box bench.py injects the HIP path."""
 import os
 import socket
+import time
 import sys
 
 import numpy as np
@@ -210,3 +211,30 @@ def test_bench_relaunches_itself_for_more_than_one_gpu():
     ns = get_args_parser().parse_args(argv[3:])
     assert ns.nproc_per_node == "8" and ns.training_script == os.path.join(ROOT, "bench.py")
     assert ns.training_script_args == ["--gpus", "8", "--steps", "5", "--warmup", "1", "--split"]
+
+
+def test_bench_dry_run_two_ranks_on_gloo():
+    """`bench.py --dry-run` (round-5 verdict, multi-GPU readiness without hardware): the launch / rendezvous / sharding /
+    unique-id broadcast / entry handshake / per-iteration exchange / max-over-ranks plumbing of all three modes with two ranks
+    on the gloo backend, through the very relaunch path `python bench.py --gpus N` takes on a GPU node; and a rank that dies
+    before the first exchange makes its peer give up in bounded time instead of hanging."""
+    import json
+    import subprocess
+    env = dict(os.environ, LSGPU_COMM_TIMEOUT_MS="3000")
+    for mode, want in ((["--split"], ("handshake", "unique_id_equal_on_all_ranks", "decisions_equal_on_all_ranks")),
+                       (["--batch"], ("pairs_owned_exactly_once",)), ([], ("pair_of_this_rank_differs_from_rank0s",))):
+        p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run"] + mode,
+                           capture_output=True, text=True, timeout=180, env=env, cwd=ROOT)
+        assert p.returncode == 0, p.stderr[-800:]
+        line = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+        assert len(line) == 1, p.stdout[-400:]
+        out = json.loads(line[0])
+        assert out["dry_run"] is True and out["n_gpus"] == 2 and out["backend"] == "gloo"
+        for k in want:
+            v = out[k]
+            assert (v["covers_the_reading"] and v["cannot_start"] == 0) if isinstance(v, dict) else v is True, (k, v)
+    t0 = time.perf_counter()
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run", "--split", "--dry-run-dead-rank", "1"],
+                       capture_output=True, text=True, timeout=180, env=env, cwd=ROOT)
+    assert p.returncode != 0 and time.perf_counter() - t0 < 90
+    assert not [ln for ln in p.stdout.splitlines() if ln.startswith("{")]     # no result line from a run that lost a rank
