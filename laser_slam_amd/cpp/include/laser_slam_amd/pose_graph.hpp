@@ -2,9 +2,20 @@
 // (SURVEY.md §8f row N2): SE3 variables, prior and relative-pose factors with diagonal sigmas
 // [translation; rotation] and an optional Cauchy(1) m-estimator
 // (laser_slam/src/laser_track.cpp:37-64,431-458, incremental_estimator.cpp:28-46), solved by
-// Gauss-Newton steps on the whole graph: each IncrementalEstimator update runs as many steps as the
-// reference runs iSAM2 updates (incremental_estimator.cpp:151-163).  O(1)-per-scan host arithmetic
-// in double, not on the accelerated path.
+// Gauss-Newton steps: each IncrementalEstimator update runs as many steps as the reference runs iSAM2
+// updates (incremental_estimator.cpp:151-163).  Host arithmetic in double, not on the accelerated path.
+//
+// Like iSAM2 -- and unlike rounds 1-5, whose every step re-linearised and re-solved the WHOLE graph: 21 ms
+// per pose at 2000 poses, O(N^2) over a sequence -- a step only touches the variables that still move (round 6):
+//   * a new variable and the variables of a new factor are ACTIVE; a loop-closure factor or a removed factor
+//     activates every variable (the whole loop moves);
+//   * a step linearises the factors of the active variables only, the others are constants in them;
+//   * a variable whose update stayed below kSettled leaves the active set; one whose update exceeded kExpand
+//     activates its neighbours (so that a correction can travel as far as it has to).
+// New odometry / ICP factors hang a new pose on the end of the chain: relative factors are invariant under a
+// common motion of their two poses, so the optimum of the older poses does not change and the active set stays
+// a handful of poses between loop closures; after one it is the whole graph for the few steps Gauss-Newton needs.
+// The result equals whole-graph steps to the two thresholds (tests/cpp/host_checks.cpp compares both).
 //
 // Error of a factor: localCoordinates(measurement, prediction) in minkindr's chart
 // [position; rotation vector] (se3.hpp), whitened by the sigmas.  Linear solve: block elimination
@@ -142,18 +153,32 @@ class PoseGraph {
  public:
   // new variables; a key that already exists keeps its current estimate (gtsam would throw)
   void insert(const Values& v) {
-    for (const auto& kv : v) values_.insert(kv);
+    for (const auto& kv : v)
+      if (values_.insert(kv).second) active_.insert(kv.first);
   }
   // returns the factor's index (what ISAM2Result::newFactorsIndices reports)
   size_t addFactor(const Factor& f) {
     factors_.push_back(f);
     alive_.push_back(true);
-    return factors_.size() - 1;
+    const size_t idx = factors_.size() - 1;
+    const bool has_a = f.type != Factor::PRIOR && !f.fix_first_node;
+    if (has_a) { adjacency_[f.key_a].push_back(idx); active_.insert(f.key_a); }
+    adjacency_[f.key_b].push_back(idx);
+    active_.insert(f.key_b);
+    if (f.type == Factor::LOOP_CLOSURE) activateAll();
+    return idx;
   }
   void removeFactor(size_t index) {
     if (index >= alive_.size() || !alive_[index]) throw std::out_of_range("pose graph: no such factor");
     alive_[index] = false;
+    activateAll();
   }
+  void activateAll() {
+    for (const auto& kv : values_) active_.insert(kv.first);
+  }
+  // whole-graph steps as rounds 1-5 took them (host_checks.cpp compares; a caller that wants them sets this once)
+  void setWholeGraphSteps(bool on) { whole_graph_ = on; }
+  size_t numActive() const { return active_.size(); }
   size_t numFactors() const { return (size_t)std::count(alive_.begin(), alive_.end(), true); }
   const Values& values() const { return values_; }
 
@@ -181,15 +206,20 @@ class PoseGraph {
     return e;
   }
 
-  // `iterations` Gauss-Newton steps on the whole graph; returns the largest update component of the last one
+  // `iterations` Gauss-Newton steps over the variables that still move; returns the largest update component of the last one
   double optimize(int iterations) {
     double last = 0;
     for (int it = 0; it < iterations; ++it) {
+      if (whole_graph_) activateAll();
+      if (active_.empty()) return 0;
       last = step();
       if (last < 1e-12) break;
     }
     return last;
   }
+
+  static constexpr double kSettled = 1e-11;   // a variable whose update stayed below this leaves the active set
+  static constexpr double kExpand = 1e-9;     // a variable whose update exceeded this activates its neighbours
 
  private:
   SE3 poseA(const Factor& f) const {
@@ -200,8 +230,8 @@ class PoseGraph {
   double step() {
     using namespace detail;
     std::map<Key, int> index;
-    std::vector<Key> keys;
-    for (const auto& kv : values_) { index[kv.first] = (int)keys.size(); keys.push_back(kv.first); }
+    std::vector<Key> keys(active_.begin(), active_.end());
+    for (size_t i = 0; i < keys.size(); ++i) index[keys[i]] = (int)i;
     const int n = (int)keys.size();
     if (n == 0) return 0;
     std::vector<std::map<int, M6>> H(n);
@@ -212,17 +242,30 @@ class PoseGraph {
       H[i][i] = d;
     }
     const double h = 1e-6;
-    for (size_t k = 0; k < factors_.size(); ++k) {
-      if (!alive_[k]) continue;
+    // the factors of the active variables, each once, in index order (the order the whole-graph loop takes them in)
+    std::vector<size_t> todo;
+    for (const Key key : keys) {
+      const auto it = adjacency_.find(key);
+      if (it == adjacency_.end()) continue;
+      for (size_t k : it->second)
+        if (alive_[k]) todo.push_back(k);
+    }
+    std::sort(todo.begin(), todo.end());
+    todo.erase(std::unique(todo.begin(), todo.end()), todo.end());
+    for (size_t k : todo) {
       const Factor& f = factors_[k];
       const bool has_a = f.type != Factor::PRIOR && !f.fix_first_node;
       const SE3 Ta = poseA(f), Tb = values_.at(f.key_b);
+      // a variable outside the active set is a constant of this step
+      const auto fa = has_a ? index.find(f.key_a) : index.end();
+      const auto fb = index.find(f.key_b);
+      const int ia = fa != index.end() ? fa->second : -1, ib = fb != index.end() ? fb->second : -1;
       double r0[6], w;
       residual(f, Ta, Tb, r0, &w);
       // numerical Jacobians w.r.t. the retraction coordinates of each variable (central differences)
       double J[2][36];
       for (int v = 0; v < 2; ++v) {
-        if (v == 0 && !has_a) continue;
+        if ((v == 0 && ia < 0) || (v == 1 && ib < 0)) continue;
         for (int c = 0; c < 6; ++c) {
           double d[6] = {0, 0, 0, 0, 0, 0}, rp[6], rm[6], wu;
           d[c] = h;
@@ -232,7 +275,6 @@ class PoseGraph {
           for (int i = 0; i < 6; ++i) J[v][i * 6 + c] = (rp[i] - rm[i]) / (2 * h);
         }
       }
-      const int ia = has_a ? index.at(f.key_a) : -1, ib = index.at(f.key_b);
       auto accumulate = [&](int vi, int vj, int bi, int bj) {  // H_bi,bj += w J_vi^T J_vj
         M6& dst = H[bi][bj];
         for (int a = 0; a < 6; ++a)
@@ -249,21 +291,40 @@ class PoseGraph {
           g[bi][a] -= w * s;
         }
       };
-      accumulate(1, 1, ib, ib);
-      gradient(1, ib);
-      if (has_a) {
+      if (ib >= 0) {
+        accumulate(1, 1, ib, ib);
+        gradient(1, ib);
+      }
+      if (ia >= 0) {
         accumulate(0, 0, ia, ia);
-        accumulate(0, 1, ia, ib);
-        accumulate(1, 0, ib, ia);
         gradient(0, ia);
+        if (ib >= 0) {
+          accumulate(0, 1, ia, ib);
+          accumulate(1, 0, ib, ia);
+        }
       }
     }
     const std::vector<V6> dx = solveBlockSparse(H, g);
     double biggest = 0;
+    std::vector<Key> wake;
     for (int i = 0; i < n; ++i) {
       SE3& T = values_.at(keys[i]);
       T = T.retract(dx[i].data());
-      for (double v : dx[i]) biggest = std::max(biggest, std::fabs(v));
+      double mine = 0;
+      for (double v : dx[i]) mine = std::max(mine, std::fabs(v));
+      biggest = std::max(biggest, mine);
+      if (mine < kSettled) active_.erase(keys[i]);
+      else if (mine > kExpand) wake.push_back(keys[i]);
+    }
+    for (const Key key : wake) {   // a variable that still moves takes its neighbours along
+      const auto it = adjacency_.find(key);
+      if (it == adjacency_.end()) continue;
+      for (size_t k : it->second) {
+        if (!alive_[k]) continue;
+        const Factor& f = factors_[k];
+        if (f.type != Factor::PRIOR && !f.fix_first_node) active_.insert(f.key_a);
+        active_.insert(f.key_b);
+      }
     }
     return biggest;
   }
@@ -271,6 +332,9 @@ class PoseGraph {
   Values values_;
   std::vector<Factor> factors_;
   std::vector<bool> alive_;
+  std::map<Key, std::vector<size_t>> adjacency_;   // variable -> the factors it takes part in
+  std::set<Key> active_;                           // variables the next step moves
+  bool whole_graph_ = false;
 };
 
 }  // namespace laser_slam_amd

@@ -233,6 +233,56 @@ int main(int argc, char** argv) {
     try { g.removeFactor(lc_index); } catch (const std::out_of_range&) { threw = true; }
     CHECK(threw);
   }
+  // --- the active-set steps of the pose graph (round 6) against whole-graph steps: a 300-pose chain built pose by pose the
+  // way IncrementalEstimator::estimate does (two disagreeing between-factors per new pose, three steps per pose), a loop
+  // closure two thirds in, the chain carried on behind it.  Same estimates to 1e-8 m / rad at every pose; between loop
+  // closures only a handful of poses are touched per update.
+  {
+    auto yaw = [](double a) { return std::array<double, 4>{std::cos(a / 2), 0, 0, std::sin(a / 2)}; };
+    const int n = 300, lc_at = 200;
+    PoseGraph inc, whole;
+    whole.setWholeGraphSteps(true);
+    std::vector<SE3> truth;
+    SE3 cur;
+    for (int i = 0; i < n; ++i) { truth.push_back(cur); cur = cur * SE3(yaw(2.0 * M_PI / 180), {0.8, 0.02 * std::sin(0.1 * i), 0.0}); }
+    size_t most_active_between = 0, active_after_lc = 0;
+    SE3 dead = truth[0];
+    for (int i = 0; i < n; ++i) {
+      for (PoseGraph* g : {&inc, &whole}) {
+        if (i == 0) {
+          Values v; v[0] = truth[0]; g->insert(v);
+          Factor prior; prior.type = Factor::PRIOR; prior.key_b = 0; prior.measurement = truth[0]; prior.sigmas.fill(1e-4);
+          g->addFactor(prior);
+        } else {
+          const SE3 rel = truth[i - 1].inverse() * truth[i];
+          const SE3 odo = rel * SE3(yaw(0.3 * M_PI / 180), {0.01, -0.004, 0.002});             // drifting odometry
+          const SE3 icp = rel * SE3(yaw(0.01 * std::sin(1.3 * i) * M_PI / 180), {0.001 * std::cos(0.7 * i), 0.0, 0.0});
+          if (g == &inc) dead = g->values().at((Key)i - 1) * odo;
+          Values v; v[(Key)i] = dead; g->insert(v);
+          Factor fo; fo.type = Factor::ODOMETRY; fo.key_a = (Key)i - 1; fo.key_b = (Key)i; fo.measurement = odo;
+          fo.sigmas = {0.05, 0.05, 0.05, 0.01, 0.01, 0.01};
+          Factor fi = fo; fi.type = Factor::ICP; fi.measurement = icp; fi.sigmas = {0.01, 0.01, 0.01, 0.002, 0.002, 0.002}; fi.cauchy = true;
+          g->addFactor(fo); g->addFactor(fi);
+        }
+        if (i == lc_at) {
+          Factor lc; lc.type = Factor::LOOP_CLOSURE; lc.key_a = 5; lc.key_b = (Key)i;
+          lc.measurement = truth[5].inverse() * truth[i]; lc.sigmas = {0.005, 0.005, 0.005, 0.001, 0.001, 0.001}; lc.cauchy = true;
+          g->addFactor(lc);
+        }
+        g->optimize(3);
+      }
+      if (i == lc_at) active_after_lc = inc.numActive();
+      else if (i > 10 && (i < lc_at || i > lc_at + 10)) most_active_between = std::max(most_active_between, inc.numActive());
+    }
+    double worst = 0;
+    for (int i = 0; i < n; ++i) {
+      double d[6]; whole.values().at((Key)i).localCoordinates(inc.values().at((Key)i), d);
+      for (double v : d) worst = std::max(worst, std::fabs(v));
+    }
+    CHECK(worst < 1e-8);
+    CHECK(most_active_between <= 12);        // (a handful: the new pose and the ones its factors still nudge)
+    CHECK(active_after_lc > 100);            // the loop closure moved the whole loop
+  }
   // --- IncrementalEstimator bookkeeping (no ICP: use_icp_factors off, loop closure without ICP step):
   // two robots, priors 100 m apart (force_priors), linked by a loop closure -> robot 1's prior is removed,
   // the first-association noise model is used, and both trajectories end up in one frame
