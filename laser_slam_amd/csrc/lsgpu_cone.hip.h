@@ -236,7 +236,7 @@ __device__ __forceinline__ void cone_eval_window(const ConeDev& c, uint32_t g0, 
 #define LSGPU_CONE_WAVES 4
 #endif
 #ifndef LSGPU_CONE_OCC
-#define LSGPU_CONE_OCC 8   // waves per SIMD the register budget is cut for
+#define LSGPU_CONE_OCC 7   // waves per SIMD the register budget is cut for
 #endif
 constexpr int kConeRowSlots = 4;           // occupied rows a wave looks up per table round trip
 
@@ -246,10 +246,28 @@ __device__ __forceinline__ void cone_barrier_lds() {   // workgroup barrier that
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // atomics of phase 1 need not have landed
 }
 __device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) { return ~wave_max_u32(~v); }
+__device__ __forceinline__ uint32_t wave_scan_incl_u32(uint32_t v, int lane, uint32_t& total) {
+  const uint32_t r = row_scan_incl_u32(v);
+  const uint32_t t0 = rl_u(r, 15), t1 = rl_u(r, 31), t2 = rl_u(r, 47), t3 = rl_u(r, 63);
+  total = t0 + t1 + t2 + t3;
+  const int row = lane >> 4;
+  return r + (row > 0 ? t0 : 0u) + (row > 1 ? t1 : 0u) + (row > 2 ? t2 : 0u);
+}
+// running maximum over the lanes 0 .. lane (values >= 0; row_shr fills with 0 where a lane has no source)
+__device__ __forceinline__ uint32_t wave_scan_max_u32(uint32_t v, int lane) {
+  v = max(v, (uint32_t)LSGPU_DPP((int)v, 0x111));
+  v = max(v, (uint32_t)LSGPU_DPP((int)v, 0x112));
+  v = max(v, (uint32_t)LSGPU_DPP((int)v, 0x114));
+  v = max(v, (uint32_t)LSGPU_DPP((int)v, 0x118));
+  const uint32_t t0 = rl_u(v, 15), t1 = max(t0, rl_u(v, 31)), t2 = max(t1, rl_u(v, 47));
+  const int row = lane >> 4;
+  return max(v, row == 1 ? t0 : row == 2 ? t1 : row == 3 ? t2 : 0u);
+}
 
 template <int WAVES, bool PROBE = false>
 __global__ __launch_bounds__(WAVES * 64, LSGPU_CONE_OCC) void k_knn_cone(KnnArgs a, ConeDev c) {
   __shared__ ConeRec rec[WAVES * 64];          // the searching queries of the block's tiles, packed
+  __shared__ uint32_t bal_all[WAVES][256];     // per wave and round of pieces: owner marks, then {minimum, runner-up, group} per piece
   __shared__ unsigned long long ne_mask[16];   // occupied rows, one bit each (<= 1024 rows)
   __shared__ uint32_t wcount[WAVES];
   extern __shared__ float4 rowz_sh[];          // the rows' records {min zeta, max zeta, 1 / (4 min cos e), -}
@@ -361,6 +379,7 @@ __global__ __launch_bounds__(WAVES * 64, LSGPU_CONE_OCC) void k_knn_cone(KnnArgs
 #endif
   if ((uint32_t)(w * 64) >= total) return;
   const bool ing = (uint32_t)(w * 64 + lane) < total;
+  uint32_t* const bal = bal_all[w];
   {
     const ConeRec r = rec[w * 64 + lane];   // (beyond `total`: stale or uninitialised words, never used)
     qx = r.qx; qy = r.qy; qz = r.qz; ub = r.ub; lbn = r.lbn; id_in = r.id_in; j = r.j;
@@ -397,8 +416,9 @@ __global__ __launch_bounds__(WAVES * 64, LSGPU_CONE_OCC) void k_knn_cone(KnnArgs
     }
     ubs = fminf(ub, pb);
   }
-  const float lim0 = prune_lim(ubs, gap, cap2s);                // squared search radius: every point inside is evaluated
+  float lim0 = prune_lim(ubs, gap, cap2s);                      // squared search radius: every point inside is evaluated
   const float R = __builtin_amdgcn_sqrtf(lim0) * (1.0f + 1e-5f) + 1e-7f;
+  rec[w * 64 + lane].pad = __float_as_uint(lim0);               // (what only the end of the kernel needs again waits in LDS: see there)
   bool fb = false;                 // this lane searches the voxel grid instead
   float best = INFINITY, sec = INFINITY, bs4 = INFINITY;   // evaluated minimum, second smallest group minimum, runner-up inside the leading group
   float4 bpt = make_float4(0.f, 0.f, 0.f, 0.f);            // the point at the minimum {x, y, z, Morton index}
@@ -487,44 +507,83 @@ __global__ __launch_bounds__(WAVES * 64, LSGPU_CONE_OCC) void k_knn_cone(KnnArgs
 #ifdef LSGPU_KNN_STATS
       if (!n_rowslots) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); t_rows += clock64() - t_r0; }
 #endif
-      // ---- every lane steps through its own window, two groups per step: all six loads of a step are issued before the
-      // first is waited for (one memory round trip for eight candidates), a lane past its own end sits the step out
+      // ---- the windows' groups, two per PIECE, shared out over the wave: a lane with a window of thirty groups next to
+      // lanes with three made the whole wave take fifteen steps, a memory round trip each (the slowest waves of a launch
+      // spent 20 k of their 50 k cycles there, and a launch is as long as its slowest wave); now a round of 64 pieces is
+      // ONE round trip whoever the pieces belong to.  Piece p of the slot belongs to the lane whose range of pieces
+      // [excl, excl + np) holds it; the lane that evaluates it takes the owner's window through ds_bpermute and the
+      // owner's query from the pack buffer, and leaves {minimum, runner-up, group} in LDS for the owner to merge -- in
+      // piece order, i.e. in the order a lane stepping through its own window would have met the groups.
       if (w_in && w_en - w_st > kConeMaxWin) { fb = true; cone = false; }
       const bool wv = w_in && cone && w_en > w_st;
       const uint32_t g0 = w_st >> 2, g1 = wv ? (w_en + 3u) >> 2 : 0u;   // this lane's groups [g0, g1)
       if (!__ballot(wv)) continue;
+      const uint32_t np = wv ? (g1 - g0 + 1u) >> 1 : 0u;                // its pieces
 #ifdef LSGPU_KNN_STATS
       ++n_rowslots; n_groups += wave_sum_u32(wv ? g1 - g0 : 0u);
       const long long t_s1 = clock64();
 #endif
-      for (uint32_t t = g0; __ballot(wv && t < g1); t += 2u) {
+      {
+        uint32_t P;
+        const uint32_t excl = wave_scan_incl_u32(np, lane, P) - np;
+        for (uint32_t base = 0; base < P; base += 64u) {
 #ifdef LSGPU_KNN_STATS
-        ++n_steps;
+          ++n_steps;
 #endif
-        if (wv && t < g1) {
-          const bool two = t + 1u < g1;
-          const float4* __restrict__ p0 = c.soa + 4u * (size_t)t;
-          const float4* __restrict__ p1 = two ? p0 + 4 : p0;   // (no second group: the first once more, left out of the minimum below)
-          const float4 X = p0[0], Y = p0[1], Z = p0[2];
-          const float4 X1 = p1[0], Y1 = p1[1], Z1 = p1[2];
-          const f32x2 d0 = dist2_pair(q2x, q2y, q2z, f32x2{X.x, X.y}, f32x2{Y.x, Y.y}, f32x2{Z.x, Z.y});
-          const f32x2 d1 = dist2_pair(q2x, q2y, q2z, f32x2{X.z, X.w}, f32x2{Y.z, Y.w}, f32x2{Z.z, Z.w});
-          const f32x2 e0 = dist2_pair(q2x, q2y, q2z, f32x2{X1.x, X1.y}, f32x2{Y1.x, Y1.y}, f32x2{Z1.x, Z1.y});
-          const f32x2 e1 = dist2_pair(q2x, q2y, q2z, f32x2{X1.z, X1.w}, f32x2{Y1.z, Y1.w}, f32x2{Z1.z, Z1.w});
-          const float m4 = fminf(fminf(fminf(d0.x, d0.y), d1.x), d1.y);
-          const float n4 = two ? fminf(fminf(fminf(e0.x, e0.y), e1.x), e1.y) : INFINITY;
-          sec = __builtin_amdgcn_fmed3f(best, m4, sec);
-          bgrp = m4 < best ? t : bgrp;
-          best = fminf(best, m4);
-          sec = __builtin_amdgcn_fmed3f(best, n4, sec);
-          bgrp = n4 < best ? t + 1u : bgrp;
-          best = fminf(best, n4);
+          // who owns piece base + lane: every owner with pieces in this round marks its first one, a running maximum
+          // over the marks carries the owner forward (owners' ranges follow each other in lane order)
+          const uint32_t s0 = max(excl, base), s1 = min(excl + np, base + 64u);   // this lane's pieces of the round: [s0, s1)
+          bal[lane] = 0u;
+          if (s0 < s1) bal[s0 - base] = (uint32_t)lane + 1u;
+          const uint32_t owner1 = wave_scan_max_u32(bal[lane], lane);
+          const bool has = base + (uint32_t)lane < P;
+          const uint32_t o = has ? owner1 - 1u : (uint32_t)lane;
+          const uint32_t og0 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(o << 2), (int)g0);
+          const uint32_t og1 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(o << 2), (int)g1);
+          const uint32_t oex = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(o << 2), (int)excl);
+          float pb = INFINITY, ps = INFINITY;
+          uint32_t pg = 0u;
+          if (has) {
+            const uint32_t t = og0 + 2u * (base + (uint32_t)lane - oex);
+            const bool two = t + 1u < og1;
+            const ConeRec* __restrict__ orec = rec + (w * 64 + (int)o);
+            const float oqx = orec->qx, oqy = orec->qy, oqz = orec->qz;
+            const f32x2 o2x = {oqx, oqx}, o2y = {oqy, oqy}, o2z = {oqz, oqz};
+            const float4* __restrict__ p0 = c.soa + 4u * (size_t)t;
+            const float4* __restrict__ p1 = two ? p0 + 4 : p0;
+            const float4 X = p0[0], Y = p0[1], Z = p0[2];
+            const float4 X1 = p1[0], Y1 = p1[1], Z1 = p1[2];
+            const f32x2 d0 = dist2_pair(o2x, o2y, o2z, f32x2{X.x, X.y}, f32x2{Y.x, Y.y}, f32x2{Z.x, Z.y});
+            const f32x2 d1 = dist2_pair(o2x, o2y, o2z, f32x2{X.z, X.w}, f32x2{Y.z, Y.w}, f32x2{Z.z, Z.w});
+            const f32x2 e0 = dist2_pair(o2x, o2y, o2z, f32x2{X1.x, X1.y}, f32x2{Y1.x, Y1.y}, f32x2{Z1.x, Z1.y});
+            const f32x2 e1 = dist2_pair(o2x, o2y, o2z, f32x2{X1.z, X1.w}, f32x2{Y1.z, Y1.w}, f32x2{Z1.z, Z1.w});
+            const float m4 = fminf(fminf(fminf(d0.x, d0.y), d1.x), d1.y);
+            const float n4 = two ? fminf(fminf(fminf(e0.x, e0.y), e1.x), e1.y) : INFINITY;
+            pb = fminf(m4, n4); ps = fmaxf(m4, n4);
+            pg = n4 < m4 ? t + 1u : t;                      // (equal minima: the first group, as a lane stepping through would record it)
+          }
+          bal[64 + lane] = __float_as_uint(pb); bal[128 + lane] = __float_as_uint(ps); bal[192 + lane] = pg;
+          // the owners take their pieces' results, in piece order
+          for (uint32_t p = s0; p < s1; ++p) {
+            const float rb = __uint_as_float(bal[64u + p - base]), rs = __uint_as_float(bal[128u + p - base]);
+            const uint32_t rg = bal[192u + p - base];
+            sec = fminf(fmaxf(best, rb), fminf(sec, rs));   // second smallest of {best <= sec, rb <= rs}
+            bgrp = rb < best ? rg : bgrp;
+            best = fminf(best, rb);
+          }
         }
       }
 #ifdef LSGPU_KNN_STATS
       t_eval += clock64() - t_s1;
 #endif
     }
+  }
+  // ---- the query and its bookkeeping come back from the pack buffer: nothing of it occupied a register while the wave
+  // worked through the rows (the evaluation needs two dozen for the candidates in flight)
+  asm volatile("" ::: "memory");
+  {
+    const ConeRec r = rec[w * 64 + lane];
+    qx = r.qx; qy = r.qy; qz = r.qz; ub = r.ub; lbn = r.lbn; id_in = r.id_in; j = r.j; lim0 = __uint_as_float(r.pad);
   }
   // ---- the group that holds the evaluated minimum, once more: which of its points, the runner-up inside the group, the
   // point's Morton index (the group minima of all other groups are in `sec` already)
