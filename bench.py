@@ -39,6 +39,14 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+# HIP maps a process' streams onto GPU_MAX_HW_QUEUES hardware queues (default 4) round robin, and streams that share a queue
+# serialise.  A handle has four streams of its own (loop, side chain, upload, draws): with 4 queues the upload shared one with
+# the filters -- the whole reason a compute from PINNED host buffers was slower than from pageable ones in rounds 3-5 (198 vs
+# 207 scans/s; with 8 queues 210 vs 205, same box, alternating runs) -- and four handles' loops shared theirs (--batch: 1 504
+# pairs/s with 4 queues against 2 170 with 8; five or more busy queues collapse again, so --batch runs four handles per rank).
+# Read by the runtime when it starts: it has to be in the environment before torch / the library touch the device.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s peak
 
 
@@ -276,7 +284,9 @@ def main():
     ap.add_argument("--track-scans", type=int, default=22)
     ap.add_argument("--batch", action="store_true", help="BASELINE configs[2]: 256 x 200 k-point pairs sharded over the ranks")
     ap.add_argument("--batch-pairs", type=int, default=256)
-    ap.add_argument("--batch-handles", type=int, default=16)
+    ap.add_argument("--batch-handles", type=int, default=4,
+                    help="handles (= host threads = busy streams) per rank: 4 with GPU_MAX_HW_QUEUES=8 is the measured optimum\n"
+                         "(2 170 pairs/s per GPU; 5 and more fall back to 1 300-1 700, profiles/r06_batch200k.json)")
     ap.add_argument("--split", action="store_true", help="BASELINE configs[3]: one 8.4 M local map vs one 1 M scan, reading sharded, RCCL")
     ap.add_argument("--split-pair", action="store_true", help="(with --split) the configs[1] pair instead of the 8-scan local map")
     ap.add_argument("--dry-run", action="store_true",
@@ -335,7 +345,8 @@ def main():
     cfg.profile_kernels = 0
 
     base = {"n_gpus": world, "steps": args.steps, "warmup": args.warmup, "higher_is_better": True, "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic", "csrc_sha": csrc_digest()}
+            "dtype": "f32", "data": "synthetic", "csrc_sha": csrc_digest(),
+            "gpu_max_hw_queues": os.environ.get("GPU_MAX_HW_QUEUES")}
 
     # ------------------------------------------------------------------------------------------ configs[2]: --batch
     if args.batch:
@@ -590,6 +601,29 @@ def main():
                            "resident in HBM; value_loop = the loop alone on filtered clouds; value_e2e = the same compute from host "
                            "buffers (PCIe inclusive)")
     if args.split:
+        # The differential checker at 1e-4 m / 1e-5 rad (configs[1]'s tolerance) does not stop this registration before
+        # max_iterations: against an 8-scan map -- eight noisy samples of every surface -- the trimmed point-to-plane steps
+        # shrink to ~1e-4 m and stay there for dozens of iterations, whatever the guess (3 cm: 35 iterations at 0.5 M points
+        # per scan) and whatever the scene (street or open field; CPU oracle).  With the reference's OWN
+        # thresholds (icp_default.yaml:24-27: 1e-3 rad / 1e-2 m) it stops after a handful: the same step once more that way,
+        # so that the line also carries a registration that ends by its checker.
+        cfg_y = IcpConfig()
+        lib().lsgpu_icp_config_yaml(C.byref(cfg_y))
+        with icp.IcpHandle(cfg_y, local_rank) as hy:
+            sharding.init_split_comm(hy, device="cuda")
+            ty, ity, cvy = [], 0, 0
+            for rep in range(4):
+                barrier()
+                tq = time.perf_counter()
+                Ty, sty = step_loop(hy)
+                barrier()
+                ty.append(max_over_ranks(time.perf_counter() - tq) * 1e3)
+                if rep:
+                    ity += sty.iterations; cvy += int(sty.converged)
+            out["yaml_checker"] = {"ms_per_step": float(np.median(ty[1:])), "scans_per_s": 1e3 / float(np.median(ty[1:])),
+                                   "iterations": ity / 3.0, "steps_stopped_by_the_differential_checker": cvy, "of": 3,
+                                   "thresholds": "icp_default.yaml:24-27 (minDiffRotErr 0.001 rad, minDiffTransErr 0.01 m, smoothLength 4)",
+                                   "trans_err_m": synth.pose_error(Ty.astype(np.float64), T_true)[0]}
         # what the exchange costs ("all-reduce us / iteration"): HIP events around every RCCL call of
         # the profiled steps; and, on rank 0, the SAME map, reading and guess through a plain handle (no communicator,
         # the whole reading on this GPU) -- split mode against the plain path on identical inputs, side by side

@@ -2,6 +2,7 @@
 the number of handles (streams) -- the per-GPU share of "256 pairs over 8 GPUs" is 32 pairs.
 usage: batch_bench.py [n_az=3125] [pairs=32] [out.json]      (writes the JSON artifact kept under profiles/)"""
 import json, sys, os, time
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")   # (see bench.py: streams that share a hardware queue serialise)
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from laser_slam_amd import synth, icp
@@ -19,7 +20,7 @@ pairs = [(uniq[i % 4][0].clone(), uniq[i % 4][1].clone(), uniq[i % 4][2].clone()
 refs, nrms, rds, Tis, Tts = map(list, zip(*pairs))
 print("points per cloud", rds[0].shape[0], "pairs", B)
 rows = []
-for pool in (1, 2, 4, 8, 16):
+for pool in [int(x) for x in os.environ.get("LSGPU_BATCH_POOLS", "1,2,3,4,5,6,8,16").split(",")]:
     hs = [icp.IcpHandle() for _ in range(pool)]
     icp.align_batch(hs, refs, nrms, rds, Tis)
     best = None
@@ -35,5 +36,5 @@ for pool in (1, 2, 4, 8, 16):
     for h in hs: h.close()
 if out_path:
     json.dump({"workload": "configs[2] per-GPU share: %d independent pairs of %d x %d points (64 x %d rays), default yaml checker, chain F clouds resident in HBM"
-                           % (B, rds[0].shape[0], refs[0].shape[0], n_az), "entry_point": "lsgpu_icp_align_batch", "rows": rows,
+                           % (B, rds[0].shape[0], refs[0].shape[0], n_az), "entry_point": "lsgpu_icp_align_batch", "gpu_max_hw_queues": os.environ.get("GPU_MAX_HW_QUEUES"), "rows": rows,
                "command": "python devtools/batch_bench.py %d %d %s" % (n_az, B, out_path)}, open(out_path, "w"), indent=1)
