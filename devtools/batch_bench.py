@@ -9,14 +9,15 @@ from laser_slam_amd import synth, icp
 n_az = int(sys.argv[1]) if len(sys.argv) > 1 else 3125
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 32
 out_path = sys.argv[3] if len(sys.argv) > 3 else None
+NU = int(os.environ.get("LSGPU_BATCH_UNIQ", "4"))
 uniq = []
-for i in range(4):
+for i in range(NU):
     ref, rd, Tt, Ti = synth.scan_pair(n_az, noise_seeds=(1000 + i, 2000 + i), guess_seed=1000 + i)
     rf, rn = icp.sampling_surface_normal(ref, 10, 1.0, 0)
     uniq.append((torch.from_numpy(rf).cuda(), torch.from_numpy(rn).cuda(), torch.from_numpy(rd).cuda(), Ti, Tt))
 torch.cuda.synchronize()
 # every pair owns its buffers (equal pointers would let align_batch keep a shared reference's structures)
-pairs = [(uniq[i % 4][0].clone(), uniq[i % 4][1].clone(), uniq[i % 4][2].clone(), uniq[i % 4][3], uniq[i % 4][4]) for i in range(B)]
+pairs = [(uniq[i % NU][0].clone(), uniq[i % NU][1].clone(), uniq[i % NU][2].clone(), uniq[i % NU][3], uniq[i % NU][4]) for i in range(B)]
 refs, nrms, rds, Tis, Tts = map(list, zip(*pairs))
 print("points per cloud", rds[0].shape[0], "pairs", B)
 rows = []

@@ -11,7 +11,7 @@ for s in $steps; do
   case $s in
     tests)   timeout 600 python -m pytest tests -m gpu -x -q > gpurun_out/${tag}_tests.log 2>&1; echo "tests rc=$?"; tail -3 gpurun_out/${tag}_tests.log ;;
     rows2)   LSGPU_SO=$PWD/devtools/liblsgpu_exp.so LSGPU_KNN_ROWS=2 timeout 600 python -m pytest tests/test_gpu_parity.py -m gpu -q > gpurun_out/${tag}_rows2.log 2>&1; echo "rows2 rc=$?"; tail -3 gpurun_out/${tag}_rows2.log ;;
-    bench)   timeout 600 python bench.py --steps 10 --warmup 2 > gpurun_out/${tag}_bench.json 2> gpurun_out/${tag}_bench.err; echo "bench rc=$?"; cut -c1-1500 gpurun_out/${tag}_bench.json ;;
+    bench)   timeout 600 python bench.py > gpurun_out/${tag}_bench.json 2> gpurun_out/${tag}_bench.err; echo "bench rc=$?"; cut -c1-1500 gpurun_out/${tag}_bench.json ;;
     bench0)  timeout 600 python bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-compute-e2e > gpurun_out/${tag}_bench0.json 2> gpurun_out/${tag}_bench0.err; echo "bench0 rc=$?"; cut -c1-600 gpurun_out/${tag}_bench0.json ;;
     prof)    rm -rf gpurun_out/prof_${tag}
              (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d $OLDPWD/gpurun_out/prof_${tag} -- python $OLDPWD/bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-compute-e2e > $OLDPWD/gpurun_out/${tag}_profbench.json 2> $OLDPWD/gpurun_out/${tag}_prof.err)
