@@ -30,6 +30,11 @@
 
 namespace lsgpu {
 
+// float4s per group of four points: {x0..x3}{y0..y3}{z0..z3}, 48 bytes, + a separate position map.  (Round 6 measured 64-byte
+// groups that carry the Morton indices as a fourth quarter -- one aligned line per group, no map: the settled launch 30.2 ->
+// 31.2-31.7 us, the probing one 108 -> 121-123: a third more index bytes for the caches, and the map read never was a dependent
+// read -- it goes out with the re-read of the winning group.  rocprofv3 averages over 476 launches, devtools/prof_variants.sh.)
+constexpr int kConeGF4 = 3;
 constexpr int kConePad = 16;            // far points behind the direction-sorted arrays (group loads run to a multiple of 4)
 constexpr uint32_t kConeMaxWin = 512;   // longest run (points) a lane takes from one row
 
@@ -38,10 +43,9 @@ struct ConeDev {
   float z0, rs;            // row = floor((zeta - z0) * rs), clamped to [0, rows)
   float cs;                // column = floor(p * cs), cs = cols / 4
   int rows, cols;
-  const float4* soa;       // direction-sorted copy of the reference in groups of four points: group g = {x0..x3}{y0..y3}{z0..z3}{m0..m3},
-                           // m = index of the point in the Morton-sorted reference (pts) -- 64 bytes, ONE aligned cache line for the
-                           // four loads of an evaluation step (round 6; rounds 4-5: 48-byte groups + a separate position map, whose
-                           // read was one more dependent round trip per searching lane); + kConePad far points
+  const float4* soa;       // direction-sorted copy of the reference in groups of four points: group g = {x0..x3}{y0..y3}{z0..z3}
+                           // (48 bytes, one cache line for all three loads of an evaluation step); + kConePad far points
+  const uint32_t* map;     // direction-sorted position -> index in the Morton-sorted reference (pts)
   const uint32_t* tab;     // rows * cols + 1: first position whose key is >= row * cols + column
   const float4* rowz;      // per row: {min zeta, max zeta, 1 / (4 min cos(elevation)), -} over its points; empty row: min > max
 };
@@ -88,7 +92,8 @@ __global__ __launch_bounds__(256) void k_cone_keys(const float4* __restrict__ pt
 // long -- 16 k waves waiting 15 us each for 50 MB of traffic)
 __global__ __launch_bounds__(256) void k_cone_gather(const float4* __restrict__ pts, const uint32_t* __restrict__ perm,
                                                      const uint64_t* __restrict__ keys, int64_t n, ConeDev c,
-                                                     float* __restrict__ soa, uint32_t* __restrict__ tab) {
+                                                     float* __restrict__ soa, uint32_t* __restrict__ map,
+                                                     uint32_t* __restrict__ tab) {
   const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
   const int lane = threadIdx.x & 63;
   const int64_t npad = ((n + 3) & ~(int64_t)3) + kConePad;
@@ -99,15 +104,15 @@ __global__ __launch_bounds__(256) void k_cone_gather(const float4* __restrict__ 
   if (valid) {
     const uint32_t i = perm[j];
     const float4 p = pts[i];
-    float* g = soa + 16 * (j >> 2) + (j & 3);
-    g[0] = p.x; g[4] = p.y; g[8] = p.z; g[12] = __uint_as_float(i);
+    float* g = soa + 4 * kConeGF4 * (j >> 2) + (j & 3);
+    g[0] = p.x; g[4] = p.y; g[8] = p.z; map[j] = i;
     const uint32_t key = (uint32_t)keys[j];
     gap_lo = j > 0 ? (uint32_t)keys[j - 1] + 1u : 0u;
     gap_hi = key + 1u;
     pos = (uint32_t)j;
   } else if (j < npad) {
-    float* g = soa + 16 * (j >> 2) + (j & 3);
-    g[0] = kPadCoord; g[4] = kPadCoord; g[8] = kPadCoord; g[12] = __uint_as_float(0u);
+    float* g = soa + 4 * kConeGF4 * (j >> 2) + (j & 3);
+    g[0] = kPadCoord; g[4] = kPadCoord; g[8] = kPadCoord; map[j] = 0u;
     if (j == n) { gap_lo = (uint32_t)keys[n - 1] + 1u; gap_hi = nkeys + 1u; pos = (uint32_t)n; }   // everything behind the last key
   }
   // ---- table: a thread whose key follows its predecessor's closely writes the few entries in between itself; longer
@@ -139,7 +144,7 @@ __global__ __launch_bounds__(256) void k_cone_rows(ConeDev c, float4* __restrict
   const float* __restrict__ soa = reinterpret_cast<const float*>(c.soa);
   float mn = INFINITY, mx = -INFINITY;
   for (uint32_t p = st + threadIdx.x; p < en; p += 256u) {
-    const float* g = soa + 16u * (size_t)(p >> 2) + (p & 3u);
+    const float* g = soa + (uint32_t)(4 * kConeGF4) * (size_t)(p >> 2) + (p & 3u);
     float inv_rho, zeta, pa, rxy, inv_h;
     cone_dir(g[0] - c.ox, g[4] - c.oy, g[8] - c.oz, inv_rho, zeta, pa, rxy, inv_h);
     if (!(fabsf(zeta) <= 1.5f)) zeta = 0.f;   // (as k_cone_keys)
@@ -189,8 +194,8 @@ __device__ __forceinline__ void cone_eval_window(const ConeDev& c, uint32_t g0, 
   // two groups per step, all six loads issued before the first is waited for: one memory round trip for eight candidates
   for (uint32_t t = 0; __ballot(t < len); t += 2u) {
     if (t < len) {
-      const float4* __restrict__ p = c.soa + 4u * (size_t)(g0 + t);
-      const float4* __restrict__ p1 = t + 1u < len ? p + 4 : p;   // (no second group: the first once more, it changes nothing)
+      const float4* __restrict__ p = c.soa + (uint32_t)kConeGF4 * (size_t)(g0 + t);
+      const float4* __restrict__ p1 = t + 1u < len ? p + kConeGF4 : p;   // (no second group: the first once more, it changes nothing)
       const float4 X = p[0], Y = p[1], Z = p[2];
       const float4 X1 = p1[0], Y1 = p1[1], Z1 = p1[2];
       const f32x2 d0 = dist2_pair(q2x, q2y, q2z, f32x2{X.x, X.y}, f32x2{Y.x, Y.y}, f32x2{Z.x, Z.y});
@@ -224,8 +229,8 @@ __device__ __forceinline__ void cone_eval_window(const ConeDev& c, uint32_t g0, 
 //     row was 3.5 k cycles);
 //   * both groups of an evaluation step are loaded before the first is waited for (the conditional second load used to
 //     follow the first one's wait: two round trips per step);
-//   * a group's record carries its points' Morton indices (64-byte groups, one aligned cache line for a step's loads):
-//     the re-read of the winning group needs no second, dependent read of a position map.
+//   (64-byte groups carrying the Morton indices, instead of 48-byte groups + a position map, were measured slower and are not
+//   used: kConeGF4 above.)
 // Built and measured on the way, and dropped (same results, slower launches): every lane's windows cut into groups and
 // shared out over the wave through an LDS list with per-owner LDS minima (balanced lanes, three round trips per wave --
 // but 27 KB of LDS per workgroup held until its slowest wave ends: 35-38 us per late launch against 25-28); the union of
@@ -503,8 +508,9 @@ __global__ __launch_bounds__(WAVES * 64, LSGPU_CONE_OCC) void k_knn_cone(KnnArgs
 #endif
         if (wv && t < g1) {
           const bool two = t + 1u < g1;
-          const float4* __restrict__ p0 = c.soa + 4u * (size_t)t;
-          const float4* __restrict__ p1 = two ? p0 + 4 : p0;   // (no second group: the first once more, left out of the minimum below)
+          const float4* __restrict__ p0 = c.soa + (uint32_t)kConeGF4 * (size_t)t;
+          const float4* __restrict__ p1 = two ? p0 + kConeGF4 : p0;   // (no second group: the first once more -- its line is on its way
+                                                                         //  anyway; one fixed line for all such lanes measured slower)   // (no second group: the first once more, left out of the minimum below)
           const float4 X = p0[0], Y = p0[1], Z = p0[2];
           const float4 X1 = p1[0], Y1 = p1[1], Z1 = p1[2];
           const f32x2 d0 = dist2_pair(q2x, q2y, q2z, f32x2{X.x, X.y}, f32x2{Y.x, Y.y}, f32x2{Z.x, Z.y});
@@ -529,8 +535,10 @@ __global__ __launch_bounds__(WAVES * 64, LSGPU_CONE_OCC) void k_knn_cone(KnnArgs
   // ---- the group that holds the evaluated minimum, once more: which of its points, the runner-up inside the group, the
   // point's Morton index (the group minima of all other groups are in `sec` already)
   if (bgrp != 0xFFFFFFFFu) {
-    const float4* __restrict__ p = c.soa + 4u * (size_t)bgrp;
-    const float4 X = p[0], Y = p[1], Z = p[2], M = p[3];
+    const float4* __restrict__ p = c.soa + (uint32_t)kConeGF4 * (size_t)bgrp;
+    const float4 X = p[0], Y = p[1], Z = p[2];
+    const uint4 m = reinterpret_cast<const uint4*>(c.map)[bgrp];   // (goes out with the three loads above: no extra round trip)
+    const float4 M = make_float4(__uint_as_float(m.x), __uint_as_float(m.y), __uint_as_float(m.z), __uint_as_float(m.w));
     const float e0 = dist2(qx - X.x, qy - Y.x, qz - Z.x), e1 = dist2(qx - X.y, qy - Y.y, qz - Z.y);
     const float e2 = dist2(qx - X.z, qy - Y.z, qz - Z.z), e3 = dist2(qx - X.w, qy - Y.w, qz - Z.w);
     if (e3 == best) bpt = make_float4(X.w, Y.w, Z.w, M.w);

@@ -207,7 +207,7 @@ struct lsgpu_icp {
   uint32_t nchunks = 0;
   // direction index of the reference (lsgpu_cone.hip.h): the settled launches of an align search it instead of the voxel grid
   DevBuf<float> cone_soa;
-  DevBuf<uint32_t> cone_tab;
+  DevBuf<uint32_t> cone_tab, cone_map;
   DevBuf<float4> cone_rowz;
   ConeDev cone;
   bool cone_ok = false;       // built (or being built on the side stream: cone_pending) for the current reference
@@ -268,7 +268,6 @@ struct lsgpu_icp {
   DevBuf<int> ssn_axis_a, ssn_axis_b;       // per segment: the axis its current order follows (segmented level sorts)
   DevBuf<uint32_t> ssn_seg_fb;
   DevBuf<SegBlock> ssn_blocktab;
-  DevBuf<uint32_t> ssn_seg_orig;
   DevBuf<uint32_t> ssn_seg_of, ssn_box_pts, ssn_box_base, ssn_keep, ssn_out_pos, ssn_bb, ssn_bounds_ws;
   DevBuf<float> ssn_box_normal, ssn_draws;
   // sort-free upper levels of the reference filter (lsgpu_ssn_select.hip.h)
@@ -459,8 +458,8 @@ void lsgpu_icp_destroy(lsgpu_icp* h) {
   h->work.release();
 #endif
   h->pts.release();
-  h->cone_soa.release(); h->cone_occ.release(); h->cone_tab.release(); h->cone_rowz.release();
-  h->nrm.release(); h->ref_inv.release(); h->tables.release(); h->flags.release(); h->cidx.release(); h->bounds.release(); h->chunks.release(); h->chunk_groups.release(); h->soa.release(); h->soa_base.release(); h->soa_cnt4.release(); h->soa_first.release(); h->prev.release(); h->state.release(); h->lb.release(); h->cell_cache.release(); h->cell_tags.release(); h->ssn_seg_a.release(); h->ssn_seg_b.release(); h->ssn_axis_a.release(); h->ssn_axis_b.release(); h->ssn_seg_fb.release(); h->ssn_blocktab.release(); h->ssn_seg_of.release(); h->ssn_seg_orig.release(); h->ssn_box_pts.release(); h->ssn_box_base.release(); h->ssn_keep.release(); h->ssn_out_pos.release(); h->ssn_bb.release(); h->ssn_bounds_ws.release(); h->ssn_box_normal.release(); h->ssn_draws.release(); h->flt_in.release(); h->flt_in2.release(); h->flt_ref.release(); h->flt_rd.release(); h->flt_nrm.release(); h->chk_hist.release(); h->trace_dev.release(); h->knn_dbg.release(); h->knn_dbg_wave.release(); h->stat_partials.release(); h->geom.release();
+  h->cone_soa.release(); h->cone_occ.release(); h->cone_tab.release(); h->cone_map.release(); h->cone_rowz.release();
+  h->nrm.release(); h->ref_inv.release(); h->tables.release(); h->flags.release(); h->cidx.release(); h->bounds.release(); h->chunks.release(); h->chunk_groups.release(); h->soa.release(); h->soa_base.release(); h->soa_cnt4.release(); h->soa_first.release(); h->prev.release(); h->state.release(); h->lb.release(); h->cell_cache.release(); h->cell_tags.release(); h->ssn_seg_a.release(); h->ssn_seg_b.release(); h->ssn_axis_a.release(); h->ssn_axis_b.release(); h->ssn_seg_fb.release(); h->ssn_blocktab.release(); h->ssn_seg_of.release(); h->ssn_box_pts.release(); h->ssn_box_base.release(); h->ssn_keep.release(); h->ssn_out_pos.release(); h->ssn_bb.release(); h->ssn_bounds_ws.release(); h->ssn_box_normal.release(); h->ssn_draws.release(); h->flt_in.release(); h->flt_in2.release(); h->flt_ref.release(); h->flt_rd.release(); h->flt_nrm.release(); h->chk_hist.release(); h->trace_dev.release(); h->knn_dbg.release(); h->knn_dbg_wave.release(); h->stat_partials.release(); h->geom.release();
   h->counters.release(); h->price_cnt.release(); h->ang_cells.release(); h->sel_aux.release(); h->sel_win.release(); h->spread_flag.release(); h->spread_list.release(); h->spread_cnt.release(); h->q_in.release(); h->rdq.release(); h->ids.release(); h->d2.release();
   h->ids_io.release(); h->d2_io.release(); h->strag.release(); h->hist.release();
   h->sel.release(); h->ne_partials.release(); h->ne_gpartials.release(); h->ne_tickets.release(); h->ne_out.release(); h->limit_dev.release();
@@ -497,7 +496,7 @@ void lsgpu_icp_destroy(lsgpu_icp* h) {
 
 // ---------------------------------------------------------------- internals
 
-static int scan_u32(lsgpu_icp* h, const uint32_t* in, uint32_t* out, size_t n, bool inclusive = false);
+static int scan_u32(lsgpu_icp* h, const uint32_t* in, uint32_t* out, size_t n, bool inclusive = false, bool nonzero = false);
 
 template <int ITEMS>
 static void radix_pass(lsgpu_icp* h, const uint64_t* kin, const uint32_t* vin, uint64_t* kout, uint32_t* vout, int64_t n,
@@ -893,10 +892,11 @@ static int build_cone_index(lsgpu_icp* h) {
   c.rs = (float)c.rows / (zr * 1.0002f + 2e-5f);
   c.cs = (float)c.cols * 0.25f;
   const size_t npad = (((size_t)nr + 3) & ~(size_t)3) + kConePad, nkeys = (size_t)c.rows * (size_t)c.cols;
-  HIPC(h->cone_soa.reserve(4 * npad));
+  HIPC(h->cone_soa.reserve((size_t)kConeGF4 * npad));
+  HIPC(h->cone_map.reserve(npad));
   HIPC(h->cone_tab.reserve(nkeys + 1)); HIPC(h->cone_rowz.reserve((size_t)c.rows));
   HIPC(h->sc->keys.reserve(nr)); HIPC(h->sc->vals.reserve(nr));
-  c.soa = reinterpret_cast<const float4*>(h->cone_soa.p); c.tab = h->cone_tab.p; c.rowz = h->cone_rowz.p;
+  c.soa = reinterpret_cast<const float4*>(h->cone_soa.p); c.map = h->cone_map.p; c.tab = h->cone_tab.p; c.rowz = h->cone_rowz.p;
   hipLaunchKernelGGL(k_cone_keys, dim3(nblk(nr)), dim3(256), 0, h->cur, h->pts.p, nr, c,
                      h->sc->keys.p, h->sc->vals.p);
   int nbits = 1;
@@ -906,7 +906,7 @@ static int build_cone_index(lsgpu_icp* h) {
   HIPC(h->cone_occ.reserve(1));
   HIPC(hipMemsetAsync(h->cone_occ.p, 0, sizeof(uint32_t), h->cur));
   hipLaunchKernelGGL(k_cone_gather, dim3(nblk((int64_t)npad)), dim3(256), 0, h->cur, h->pts.p, h->sc->vals_alt.p,
-                     h->sc->keys_alt.p, nr, c, h->cone_soa.p, h->cone_tab.p);
+                     h->sc->keys_alt.p, nr, c, h->cone_soa.p, h->cone_map.p, h->cone_tab.p);
   hipLaunchKernelGGL(k_cone_rows, dim3(c.rows), dim3(256), 0, h->cur, c, h->cone_rowz.p, h->cone_occ.p);
   HIPC(hipGetLastError());
   // the number of occupied bins travels to the host behind the build; lsgpu_icp_align looks at it before its first
@@ -1261,18 +1261,20 @@ int lsgpu_rotate_descriptors(lsgpu_icp* h, const float T[16], const float* desc3
 }  // extern "C"
 
 // prefix sum of n uint32 on the handle's current stream (lsgpu_scan.hip.h; in == out is fine)
-static int scan_u32(lsgpu_icp* h, const uint32_t* in, uint32_t* out, size_t n, bool inclusive) {
+static int scan_u32(lsgpu_icp* h, const uint32_t* in, uint32_t* out, size_t n, bool inclusive, bool nonzero) {
   if (n == 0) return LSGPU_OK;
   const int nb = (int)((n + kScanTile - 1) / kScanTile);
   uint32_t* sums = nullptr;
   if (nb > 1) {
     HIPC(h->sc->sort_tmp.reserve((size_t)nb * sizeof(uint32_t)));
     sums = reinterpret_cast<uint32_t*>(h->sc->sort_tmp.p);
-    hipLaunchKernelGGL(k_scan_sums, dim3(nb), dim3(256), 0, h->cur, in, n, sums);
+    if (nonzero) hipLaunchKernelGGL(k_scan_sums<true>, dim3(nb), dim3(256), 0, h->cur, in, n, sums);
+    else hipLaunchKernelGGL(k_scan_sums<false>, dim3(nb), dim3(256), 0, h->cur, in, n, sums);
     hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(1024), 0, h->cur, sums, nb);
   }
-  if (inclusive) hipLaunchKernelGGL(k_scan_write<true>, dim3(nb), dim3(256), 0, h->cur, in, out, n, (const uint32_t*)sums);
-  else hipLaunchKernelGGL(k_scan_write<false>, dim3(nb), dim3(256), 0, h->cur, in, out, n, (const uint32_t*)sums);
+  if (nonzero) hipLaunchKernelGGL((k_scan_write<false, true>), dim3(nb), dim3(256), 0, h->cur, in, out, n, (const uint32_t*)sums);   // (exclusive: the one use)
+  else if (inclusive) hipLaunchKernelGGL((k_scan_write<true, false>), dim3(nb), dim3(256), 0, h->cur, in, out, n, (const uint32_t*)sums);
+  else hipLaunchKernelGGL((k_scan_write<false, false>), dim3(nb), dim3(256), 0, h->cur, in, out, n, (const uint32_t*)sums);
   HIPC(hipGetLastError());
   return LSGPU_OK;
 }
@@ -1392,18 +1394,18 @@ static int scan_totals_enqueue(lsgpu_icp* h, const uint32_t* in_a, const uint32_
   return LSGPU_OK;
 }
 // ... and the host's wait for them (synchronises the current stream)
-static int scan_totals_wait(lsgpu_icp* h, uint32_t* tot_a, uint32_t* tot_b) {
+static int scan_totals_wait(lsgpu_icp* h, uint32_t* tot_a, uint32_t* tot_b, bool b_flags = false) {
   const uint32_t* hp = reinterpret_cast<const uint32_t*>(h->h_pinned + 100 + 4 * h->side_totals_slot);
   HIPC(hipStreamSynchronize(h->cur));
   *tot_a = hp[0] + hp[1];
-  *tot_b = hp[2] + hp[3];
+  *tot_b = (b_flags ? (hp[2] ? 1u : 0u) : hp[2]) + hp[3];   // (b_flags: the scanned words are flags, any non-zero word counts 1)
   return LSGPU_OK;
 }
 static int scan_totals(lsgpu_icp* h, const uint32_t* in_a, const uint32_t* sc_a, size_t na,
                        const uint32_t* in_b, const uint32_t* sc_b, size_t nb, uint32_t* tot_a, uint32_t* tot_b,
-                       const void* extra_src = nullptr, void* extra_dst = nullptr, size_t extra_bytes = 0) {
+                       const void* extra_src = nullptr, void* extra_dst = nullptr, size_t extra_bytes = 0, bool b_flags = false) {
   const int rc = scan_totals_enqueue(h, in_a, sc_a, na, in_b, sc_b, nb, extra_src, extra_dst, extra_bytes);
-  return rc ? rc : scan_totals_wait(h, tot_a, tot_b);
+  return rc ? rc : scan_totals_wait(h, tot_a, tot_b, b_flags);
 }
 
 // SamplingSurfaceNormal on device memory: src (n points) -> out_xyz1 / out_nrm (device, room for n)
@@ -1425,7 +1427,6 @@ static int ssn_device(lsgpu_icp* h, const float4* src, int64_t n, int knn, float
   HIPC(h->ssn_seg_a.reserve(nseg));
   HIPC(h->ssn_seg_b.reserve(nseg));
   HIPC(h->ssn_seg_of.reserve(n));
-  HIPC(h->ssn_seg_orig.reserve(n));
   HIPC(h->ssn_box_pts.reserve(nseg));
   HIPC(h->ssn_box_base.reserve(nseg));
   HIPC(h->ssn_box_normal.reserve(3 * nseg));
@@ -1651,17 +1652,17 @@ static int ssn_device(lsgpu_icp* h, const float4* src, int64_t n, int knn, float
   rc = ahead->ready();
   if (rc) return rc;
   hipLaunchKernelGGL(k_ssn_select, dim3(nblk(n)), dim3(256), 0, h->stream, (int)n, idx, h->ssn_seg_of.p, cur,
-                     h->ssn_box_pts.p, h->ssn_box_base.p, h->ssn_draws.p + first_draw, ratio, h->ssn_keep.p, h->ssn_seg_orig.p);
-  rc = scan_u32(h, h->ssn_keep.p, h->ssn_out_pos.p, (size_t)n);
+                     h->ssn_box_pts.p, h->ssn_box_base.p, h->ssn_draws.p + first_draw, ratio, h->ssn_keep.p);
+  rc = scan_u32(h, h->ssn_keep.p, h->ssn_out_pos.p, (size_t)n, false, /*nonzero*/ true);
   if (rc == LSGPU_OK) {
-    hipLaunchKernelGGL(k_ssn_emit, dim3(nblk(n)), dim3(256), 0, h->stream, src, (int)n, h->ssn_seg_orig.p,
+    hipLaunchKernelGGL(k_ssn_emit, dim3(nblk(n)), dim3(256), 0, h->stream, src, (int)n,
                        h->ssn_box_normal.p, h->ssn_keep.p, h->ssn_out_pos.p, out_xyz1, out_nrm);
   }
   uint32_t n_draws = 0, kept = 0;
   if (rc == LSGPU_OK)
     // (the sort-free levels' error words travel with the totals)
     rc = scan_totals(h, h->ssn_box_pts.p, h->ssn_box_base.p, nseg, h->ssn_keep.p, h->ssn_out_pos.p, (size_t)n, &n_draws, &kept,
-                     select_levels ? h->gs_err.p : nullptr, h->h_gs_err, 8 * sizeof(uint32_t));
+                     select_levels ? h->gs_err.p : nullptr, h->h_gs_err, 8 * sizeof(uint32_t), /*b_flags*/ true);
   if (rc) return rc;
   if (select_levels && *h->h_gs_err) {
     if (getenv("LSGPU_GS_DEBUG")) fprintf(stderr, "lsgpu: sort-free levels gave up (n %lld): code %u seg %u a %u b %u | part %u seg %u dst %u\n", (long long)n,

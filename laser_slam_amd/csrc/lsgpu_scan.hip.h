@@ -37,13 +37,21 @@ __device__ __forceinline__ uint4 scan_load4(const uint32_t* __restrict__ in, siz
   return v;
 }
 
+// NZ: the input is read as flags -- any non-zero word counts 1 (a compaction whose flag word carries something else as well,
+// e.g. the surface-normal filter's "kept, and this is your box": one scattered store per point instead of two)
+__device__ __forceinline__ uint4 scan_flags(uint4 v) {
+  return make_uint4(v.x ? 1u : 0u, v.y ? 1u : 0u, v.z ? 1u : 0u, v.w ? 1u : 0u);
+}
+
+template <bool NZ = false>
 __global__ __launch_bounds__(256) void k_scan_sums(const uint32_t* __restrict__ in, size_t n, uint32_t* __restrict__ sums) {
   __shared__ uint32_t ws[4];
   const size_t base = (size_t)blockIdx.x * kScanTile;
   uint32_t s = 0;
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
-    const uint4 v = scan_load4(in, base + (size_t)k * kScanSub + 4u * threadIdx.x, n);
+    uint4 v = scan_load4(in, base + (size_t)k * kScanSub + 4u * threadIdx.x, n);
+    if (NZ) v = scan_flags(v);
     s += v.x + v.y + v.z + v.w;
   }
 #pragma unroll
@@ -73,7 +81,7 @@ __global__ __launch_bounds__(1024) void k_scan_top(uint32_t* __restrict__ sums, 
   }
 }
 
-template <bool INCLUSIVE>
+template <bool INCLUSIVE, bool NZ = false>
 __global__ __launch_bounds__(256) void k_scan_write(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, size_t n,
                                                     const uint32_t* __restrict__ offsets /* nullable: single tile */) {
   __shared__ uint32_t ws[4];
@@ -83,7 +91,8 @@ __global__ __launch_bounds__(256) void k_scan_write(const uint32_t* __restrict__
 #pragma unroll 1
   for (int k = 0; k < 4; ++k) {
     const size_t i = base + (size_t)k * kScanSub + 4u * threadIdx.x;
-    const uint4 v = scan_load4(in, i, n);
+    uint4 v = scan_load4(in, i, n);
+    if (NZ) v = scan_flags(v);
     const uint32_t t = v.x + v.y + v.z + v.w;
     const uint32_t incl = scan_wave_incl(t, lane);
     if (lane == 63) ws[w] = incl;

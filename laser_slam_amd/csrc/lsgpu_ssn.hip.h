@@ -503,16 +503,17 @@ __global__ __launch_bounds__(128) void k_ssn_boxes(const float4* __restrict__ p,
 }
 
 // per position (box-traversal order): does the point survive?  r = the rand() draw of this point = draws[box_base + rank]
-// (dropped boxes draw nothing, exactly like the sequential filter).  The verdict and the point's box go to the point's
-// ORIGINAL index: upstream sorts indicesToKeep before it compacts the cloud in place, so the filtered cloud is in original
-// order (round 6; rounds 1-5 emitted in traversal order).
+// (dropped boxes draw nothing, exactly like the sequential filter).  The verdict goes to the point's ORIGINAL index, as ONE
+// word -- 0: dropped, box + 1: kept, with the normal of that box -- because upstream sorts indicesToKeep before it compacts the
+// cloud in place: the filtered cloud is in original order (round 6; rounds 1-5 emitted in traversal order).  The scan
+// behind it counts the non-zero words (scan_u32's `nonzero`).
 __global__ __launch_bounds__(256) void k_ssn_select(int n, const uint32_t* __restrict__ idx,
                                                     const uint32_t* __restrict__ seg_of,
                                                     const SsnSeg* __restrict__ segs,
                                                     const uint32_t* __restrict__ box_pts,
                                                     const uint32_t* __restrict__ box_base,
                                                     const float* __restrict__ draws, float ratio,
-                                                    uint32_t* __restrict__ keep, uint32_t* __restrict__ seg_orig) {
+                                                    uint32_t* __restrict__ keep) {
   const int pos = blockIdx.x * 256 + threadIdx.x;
   if (pos >= n) return;
   const uint32_t s = seg_of[pos];
@@ -521,21 +522,18 @@ __global__ __launch_bounds__(256) void k_ssn_select(int n, const uint32_t* __res
     const float r = draws[box_base[s] + ((uint32_t)pos - segs[s].start)];
     k = r < ratio ? 1u : 0u;
   }
-  const uint32_t i = idx[pos];
-  keep[i] = k;
-  seg_orig[i] = s;
+  keep[idx[pos]] = k ? s + 1u : 0u;
 }
 
 // the compaction by original index: point i, if kept, with the normal of its box
 __global__ __launch_bounds__(256) void k_ssn_emit(const float4* __restrict__ p, int n,
-                                                  const uint32_t* __restrict__ seg_orig,
                                                   const float* __restrict__ box_normal,
                                                   const uint32_t* __restrict__ keep,
                                                   const uint32_t* __restrict__ out_pos,
                                                   float4* __restrict__ out_xyz1, float* __restrict__ out_nrm) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= n || !keep[i]) return;
-  const uint32_t o = out_pos[i], s = seg_orig[i];
+  const uint32_t o = out_pos[i], s = keep[i] - 1u;
   out_xyz1[o] = p[i];
   out_nrm[3 * (size_t)o + 0] = box_normal[3 * (size_t)s + 0];
   out_nrm[3 * (size_t)o + 1] = box_normal[3 * (size_t)s + 1];
