@@ -54,3 +54,29 @@ for it in (3, 10, 20, st.iterations - 1):
     for t in order:
         print("  tile %6d total %6d ph1 %5d rows %6d stage %6d eval %6d rowslots %2d chunks %3d steps %3d groups %4d lanes %2d fb %2d tail %5d body %6d" % (
             t, r[t, 10], r[t, 0] + r[t, 1] + r[t, 2], r[t, 4], r[t, 15], r[t, 5], r[t, 13], r[t, 6], r[t, 7], r[t, 8], (int(r[t, 3]) >> 8) & 0xff, (int(r[t, 3]) >> 16) & 0xff, r[t, 9], r[t, 14]))
+
+# the launch's timeline on the device-wide 100 MHz clock: when waves start and end, and who ends last
+print("timeline (us from the first wave's start): iter | length | starts p50/p90/max | searching waves' starts p50/p90/max | the ten last to end: tile start dur(us) steps")
+raw = out.reshape(ITERS, nt, 16)
+for it in range(2, st.iterations):
+    r = raw[it]
+    live = r[:, 3] > 0
+    if not live.any(): continue
+    s0 = r[:, 11].astype(np.int64); e0 = r[:, 12].astype(np.int64)
+    base = s0[live].min()
+    s_us = (s0 - base) / 100.0; e_us = (e0 - base) / 100.0
+    p2 = ((r[:, 3].astype(np.int64) & 2) > 0) & live
+    last = np.argsort(-np.where(live, e_us, -1))[:10]
+    print("%2d | %5.1f | %5.1f/%5.1f/%5.1f | %5.1f/%5.1f/%5.1f | %s" % (
+        it, e_us[live].max(), pct(s_us[live], 50), pct(s_us[live], 90), s_us[live].max(),
+        pct(s_us[p2], 50), pct(s_us[p2], 90), s_us[p2].max() if p2.any() else 0,
+        " ".join("%d:%.1f+%.1f(%d)" % (t, s_us[t], e_us[t] - s_us[t], r[t, 7]) for t in last)))
+    if it in (3, 10, 20, st.iterations - 1):
+        d = e_us - s_us
+        heavy = np.argsort(-np.where(p2, d, -1))[:256]
+        print("     the 256 longest waves: durations p50 %.1f max %.1f us, starts p10 %.1f p50 %.1f p90 %.1f; if they had started at 0 the launch would end at max(%.1f, the rest)" % (
+            pct(d[heavy], 50), d[heavy].max(), pct(s_us[heavy], 10), pct(s_us[heavy], 50), pct(s_us[heavy], 90), d[heavy].max()))
+        hist, edges = np.histogram(s_us[live], bins=12)
+        print("     starts histogram:", " ".join("%.0f-%.0f:%d" % (edges[k], edges[k + 1], hist[k]) for k in range(12)))
+        hist, edges = np.histogram(e_us[live], bins=12)
+        print("     ends histogram:  ", " ".join("%.0f-%.0f:%d" % (edges[k], edges[k + 1], hist[k]) for k in range(12)))

@@ -18,3 +18,6 @@ print("set_reference ms", (t1-t)*1e3, "align ms", (t2-t1)*1e3, "iters", st.itera
 info = h.info(); print("chunks", info.n_chunks, "cells", list(info.cells)[:12], "h0", info.cell_size)
 for i, tr in enumerate(h.trace()):
     print(i, "limit %.5f used %d knn_main %.1f us fb %.1f us strag %d" % (tr["limit"], tr["n_used"], tr["knn_main_us"], tr["knn_fallback_us"], tr["stragglers"]))
+tr = h.trace()
+tot = lambda a, b: sum(t["knn_main_us"] + t["knn_fallback_us"] for t in tr[a:b])
+print("SUM knn us: all %.0f  it0-2 %.0f  it3-15 %.0f  it16-end %.0f  last8 avg %.1f" % (tot(0, len(tr)), tot(0, 3), tot(3, 16), tot(16, len(tr)), tot(len(tr) - 8, len(tr)) / 8))

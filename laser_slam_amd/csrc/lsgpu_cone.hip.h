@@ -261,6 +261,7 @@ __global__ __launch_bounds__(WAVES * 64, LSGPU_CONE_OCC) void k_knn_cone(KnnArgs
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
 #ifdef LSGPU_KNN_STATS
   const long long ts0 = clock64();
+  const uint32_t wall0 = (uint32_t)wall_clock64();   // (100 MHz, one counter for the whole device: the launch's timeline)
   long long t_rows = 0, t_stage = 0, t_eval = 0;
   uint32_t n_chunks = 0, n_steps = 0, n_groups = 0, n_rowslots = 0;
 #endif
@@ -360,7 +361,7 @@ __global__ __launch_bounds__(WAVES * 64, LSGPU_CONE_OCC) void k_knn_cone(KnnArgs
   const long long ts3 = clock64();
   if (lane == 0 && dbg) {
     dbg[0] = (uint32_t)(ts1 - ts0); dbg[1] = (uint32_t)(ts2 - ts1); dbg[2] = (uint32_t)(ts3 - ts2);
-    dbg[3] = 1u; dbg[10] = (uint32_t)(ts3 - ts0); dbg[11] = (uint32_t)ts0; dbg[12] = (uint32_t)ts3;
+    dbg[3] = 1u; dbg[10] = (uint32_t)(ts3 - ts0); dbg[11] = wall0; dbg[12] = (uint32_t)wall_clock64();
     dbg[13] = (uint32_t)__popcll(sm);
   }
 #endif
@@ -604,7 +605,7 @@ __global__ __launch_bounds__(WAVES * 64, LSGPU_CONE_OCC) void k_knn_cone(KnnArgs
     if (lane == 0 && dbg) {
       dbg[3] = 2u | (n_ing << 8) | (n_fb << 16); dbg[4] = (uint32_t)t_rows; dbg[5] = (uint32_t)t_eval; dbg[6] = n_chunks;
       dbg[7] = n_steps; dbg[8] = n_groups; dbg[15] = (uint32_t)t_stage | 0u; dbg[13] = n_rowslots;
-      dbg[9] = (uint32_t)(ts9 - ts5); dbg[10] = (uint32_t)(ts9 - ts0); dbg[12] = (uint32_t)ts9; dbg[14] = (uint32_t)(ts5 - ts3);
+      dbg[9] = (uint32_t)(ts9 - ts5); dbg[10] = (uint32_t)(ts9 - ts0); dbg[12] = (uint32_t)wall_clock64(); dbg[14] = (uint32_t)(ts5 - ts3);
     }
   }
 #endif
