@@ -15,7 +15,7 @@ dref, dn = dref.clone(), dn.clone()
 drd = torch.from_numpy(rd).cuda()
 L = lib()
 L.lsgpu_dev_ne_phases.argtypes = [C.c_void_p, C.POINTER(C.c_ulonglong)]
-buf = (C.c_ulonglong * 16)()
+buf = (C.c_ulonglong * 24)()
 h.set_reference(dref, dn); T, st = h.align(drd, Ti)
 L.lsgpu_dev_ne_phases(h._h, buf); a0 = np.array(list(buf), np.float64)
 h.set_reference(dref, dn); T, st = h.align(drd, Ti)
@@ -26,4 +26,6 @@ print("launches %d, blocks per launch %.0f, iterations %d" % (n, blocks / n, st.
 print("per block (shader cycles): prologue %.0f | main loop %.0f | wave+block reduce, hand-off %.0f" % (d[1] / blocks, d[2] / blocks, d[3] / blocks))
 print("wall (us, 100 MHz clock): first start -> first loop start %.2f | first start -> last loop end %.2f | last loop end -> kernel end %.2f (update lane %.2f)"
       % (d[9] / n / 100, d[7] / n / 100, d[8] / n / 100, d[11] / n / 100))
+print("tail (us): last loop end -> last block knows it is last %.2f | partials + state + set-aside loads, first sums %.2f | set-aside ranking + sums %.2f | final sums, publish %.2f" % tuple(d[16:20] / n / 100))
 print("update lane (shader cycles per launch): unpack + LLT %.0f | delta, T update %.0f | trace record %.0f | checker %.0f" % tuple(d[12:16] / n))
+print("distances set aside per iteration (stats build):", [t["searching"] for t in h.trace()])

@@ -109,7 +109,21 @@ struct IcpState {
   // front rows of the tile kernel: tiles on the spread list as of the last completed iteration (the host sizes the
   // front of the grid from the copy it fetches with the rest of the state)
   uint32_t n_spread;
-  uint32_t pad_;
+  // fused select (round 6, sel_wide = 1; not in the split-scan mode).  The distances' bit patterns are cut into SLICES of
+  // 2^kSelSliceShift steps (a relative width of 1.2e-4 .. 2.4e-4).  The normal equations' sum is DEFINED as: every inlier
+  // outside the slice that holds the limit, in block / thread order, plus the inliers inside that slice in query order
+  // (at most kSelAmbCap of them; a fuller slice is summed in place) -- whichever way the limit was found.  So the
+  // normal-equation kernel can find the limit itself: the search kernels count the distances below a window of
+  // kSelSlices slices that starts at 0.7 x the last limit (one octave) and histogram those inside it by slice; the
+  // kernel's prologue finds the slice that holds the order statistic, its main pass takes everything below that slice as an
+  // inlier and sets the slice's few dozen distances aside with their contributions, its last block ranks them: the one of
+  // the remaining rank is the limit, those up to it are added.  No select launch, no window table; valid while the limit
+  // stays inside [0.7, 1.4] x its predecessor
+  uint32_t sel_lo;    // bit pattern of the window's lower edge (aligned mode: sel_bin1 << 20)
+  uint32_t sel_span;  // ... its width in bit steps (aligned mode: 2^20)
+  int sel_shift;      // ... log2 of a slice's width (aligned mode: 9)
+  int sel_wide;       // set by the host at the start of an align
+  int sel_fails;      // iterations the fused / predicted select voided; after the second the alignment keeps to the select kernels
 };
 constexpr int kSelBelowSlots = 64;   // counters of "distance below the predicted bin", hashed by tile ...
 constexpr int kSelBelowStride = 32;  // ... one per 128-byte line (atomics on one line serialise in L2)
@@ -117,6 +131,11 @@ constexpr int kSelFailFlag = kSelBelowSlots * kSelBelowStride;  // word index of
 constexpr int kSelWinRows = 128;     // committed select: second-level bins covered by the window table ...
 constexpr int kSelWinHalf = 64;      // ... centred on the last limit's bin (relative width of a bin: 2^-14)
 constexpr int kSelStreakBins = 40;   // a limit that moved less than this many second-level bins counts as "stayed"
+constexpr int kSelSliceShift = 11;   // fused select: a slice is 2^11 bit steps of the distance ...
+constexpr int kSelSlices = 2 * kHistBins;   // ... the window 4096 of them = one octave (counted into the select's second and third table)
+constexpr int kSelAmbCap = 256;      // ... and at most this many distances of the limit's slice are set aside (a fuller slice: summed in place, select in full)
+constexpr float kSelWideLo = 0.7f;   // the window starts at this x the last limit ...
+constexpr float kSelArmLo = 0.8f, kSelArmHi = 1.2f;     // ... and is used once a limit has moved by no more than this from its predecessor
 constexpr int kStatusCapFailed = 100;
 constexpr int kStatusSelFailed = 101;  // predicted select missed: the host repeats select + normal equations only
 

@@ -296,7 +296,8 @@ __global__ __launch_bounds__(WAVES * 64, LSGPU_CONE_OCC) void k_knn_cone(KnnArgs
   for (int i = 0; i < 12; ++i) { T.m[i] = st->T_rows[i]; To.m[i] = st->T_rows_prev[i]; }
   const float cap2 = st->cap2;
   const bool sel_on = a.sel_below && (st->sel_mode || a.sel_force);
-  const uint32_t sel_b1 = sel_on ? st->sel_bin1 : 0u;
+  const uint32_t sel_lo = sel_on ? st->sel_lo : 0u, sel_span = sel_on ? st->sel_span : 0u;
+  const uint32_t sel_sh = sel_on ? (uint32_t)st->sel_shift : 0u;
   const uint32_t sel_b2 = sel_on ? st->sel_bin2 : 0u;
   const float cap2s = cap2 * kCapSearchMargin2;
   const float gap = a.gap;
@@ -307,7 +308,7 @@ __global__ __launch_bounds__(WAVES * 64, LSGPU_CONE_OCC) void k_knn_cone(KnnArgs
 #endif
   // one final distance's share of the predicted / committed select (as sel_count_inside, the state's words already here)
   auto sel_inside = [&](uint32_t bits) {
-    const uint32_t bin2 = (bits >> 9) & 0x7FFu;
+    const uint32_t bin2 = (bits - sel_lo) >> sel_sh;
     atomicAdd(&a.sel_hist2[bin2], 1u);
     if (a.sel_hist3w) {
       const uint32_t d = bin2 - sel_b2 + (uint32_t)kSelWinHalf;
@@ -335,9 +336,9 @@ __global__ __launch_bounds__(WAVES * 64, LSGPU_CONE_OCC) void k_knn_cone(KnnArgs
     }
   }
   if (sel_on) {   // the skipped lanes' share of the trimmed-distance select (first two passes, as k_knn_tile)
-    const uint32_t bits = __float_as_uint(ub), top = bits >> 20;
-    const unsigned long long below = __ballot(act && skip && top < sel_b1);
-    if (act && skip && top == sel_b1) sel_inside(bits);
+    const uint32_t bits = __float_as_uint(ub);
+    const unsigned long long below = __ballot(act && skip && bits < sel_lo);
+    if (act && skip && bits >= sel_lo && bits - sel_lo < sel_span) sel_inside(bits);
     if (lane == 0 && below) atomicAdd(&a.sel_below[(tile & (kSelBelowSlots - 1)) * kSelBelowStride], (uint32_t)__popcll(below));
   }
   // ---- pack the searching lanes of the block: slot s of the block goes to wave s / 64, entry s % 64 of its area
@@ -593,9 +594,9 @@ __global__ __launch_bounds__(WAVES * 64, LSGPU_CONE_OCC) void k_knn_cone(KnnArgs
     a.lb[j] = nb;
   }
   if (sel_on) {   // the searching lanes' share of the select
-    const uint32_t bits = __float_as_uint(best), top = bits >> 20;
-    const unsigned long long below = __ballot(ing && top < sel_b1);
-    if (ing && top == sel_b1) sel_inside(bits);
+    const uint32_t bits = __float_as_uint(best);
+    const unsigned long long below = __ballot(ing && bits < sel_lo);
+    if (ing && bits >= sel_lo && bits - sel_lo < sel_span) sel_inside(bits);
     if (lane == 0 && below) atomicAdd(&a.sel_below[((tile + 32u) & (kSelBelowSlots - 1)) * kSelBelowStride], (uint32_t)__popcll(below));
   }
 #ifdef LSGPU_KNN_STATS

@@ -258,7 +258,9 @@ struct lsgpu_icp {
   bool n_spread_known = false;
   DevBuf<uint32_t> spread_flag, spread_list, spread_cnt;  // front rows of the tile kernel (tiles whose queries share no candidates)
   DevBuf<uint32_t> sel_aux;   // predicted select: kSelBelowSlots counters + failure flag
-  DevBuf<uint32_t> sel_win;   // committed select: kSelWinRows x 512 window histogram
+  DevBuf<uint32_t> sel_win;   // committed select (split-scan mode): kSelWinRows x 512 window histogram
+  DevBuf<uint2> amb_key;      // fused select: the distances of the limit's slice the normal equations set aside ...
+  DevBuf<double> amb_val;     // ... and their contributions (kSelAmbCap x 32)
 #ifdef LSGPU_EXPERIMENTS
   DevBuf<uint32_t> work;      // compacted list of searching queries (k_knn_classify -> k_knn_rows)
 #endif
@@ -460,7 +462,7 @@ void lsgpu_icp_destroy(lsgpu_icp* h) {
   h->pts.release();
   h->cone_soa.release(); h->cone_occ.release(); h->cone_tab.release(); h->cone_map.release(); h->cone_rowz.release();
   h->nrm.release(); h->ref_inv.release(); h->tables.release(); h->flags.release(); h->cidx.release(); h->bounds.release(); h->chunks.release(); h->chunk_groups.release(); h->soa.release(); h->soa_base.release(); h->soa_cnt4.release(); h->soa_first.release(); h->prev.release(); h->state.release(); h->lb.release(); h->cell_cache.release(); h->cell_tags.release(); h->ssn_seg_a.release(); h->ssn_seg_b.release(); h->ssn_axis_a.release(); h->ssn_axis_b.release(); h->ssn_seg_fb.release(); h->ssn_blocktab.release(); h->ssn_seg_of.release(); h->ssn_box_pts.release(); h->ssn_box_base.release(); h->ssn_keep.release(); h->ssn_out_pos.release(); h->ssn_bb.release(); h->ssn_bounds_ws.release(); h->ssn_box_normal.release(); h->ssn_draws.release(); h->flt_in.release(); h->flt_in2.release(); h->flt_ref.release(); h->flt_rd.release(); h->flt_nrm.release(); h->chk_hist.release(); h->trace_dev.release(); h->knn_dbg.release(); h->knn_dbg_wave.release(); h->stat_partials.release(); h->geom.release();
-  h->counters.release(); h->price_cnt.release(); h->ang_cells.release(); h->sel_aux.release(); h->sel_win.release(); h->spread_flag.release(); h->spread_list.release(); h->spread_cnt.release(); h->q_in.release(); h->rdq.release(); h->ids.release(); h->d2.release();
+  h->counters.release(); h->price_cnt.release(); h->ang_cells.release(); h->sel_aux.release(); h->sel_win.release(); h->amb_key.release(); h->amb_val.release(); h->spread_flag.release(); h->spread_list.release(); h->spread_cnt.release(); h->q_in.release(); h->rdq.release(); h->ids.release(); h->d2.release();
   h->ids_io.release(); h->d2_io.release(); h->strag.release(); h->hist.release();
   h->sel.release(); h->ne_partials.release(); h->ne_gpartials.release(); h->ne_tickets.release(); h->ne_out.release(); h->limit_dev.release();
   for (auto& e : h->comm_events) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
@@ -701,7 +703,7 @@ static int run_knn(lsgpu_icp* h, const Mat34& T, const IcpState* st, const polic
     }
   }
   if (predicted && !wide && capped && st) { a.sel_hist2 = h->hist.p + kHistBins; a.sel_below = h->sel_aux.p; }
-  if (committed && a.sel_below) { a.sel_hist3w = h->sel_win.p; a.sel_force = 1; }
+  if (committed && a.sel_below) { a.sel_hist3w = (h->comm || !tuning().fused_select) ? h->sel_win.p : nullptr; a.sel_force = 1; }   // (the window table: aligned mode only)
   a.route_chunks = tn.route_chunks; a.route_dense = tn.route_dense;
   // the search before the first one through the direction index prices the index (lsgpu_knn.hip.h: cone_price)
   const bool pricing = pol.pricing(pc, it, st != nullptr);
@@ -2424,6 +2426,8 @@ int lsgpu_icp_align(lsgpu_icp* h, const float* reading_xyz1, int64_t nq, const f
   HIPC(h->sel_aux.reserve(kSelFailFlag + 4));
   HIPC(h->spread_flag.reserve((size_t)((nq + 63) / 64))); HIPC(h->spread_list.reserve(kFrontMax)); HIPC(h->spread_cnt.reserve(2));
   HIPC(h->sel_win.reserve((size_t)kSelWinRows * 512));
+  HIPC(h->amb_key.reserve((size_t)kSelAmbCap)); HIPC(h->amb_val.reserve((size_t)kSelAmbCap * 32));
+  hst->sel_wide = (!h->comm && tuning().fused_select) ? 1 : 0;
   h->n_spread_host = 0; h->n_spread_known = false;
   ia.state = *hst;
   ia.sel0 = SelState{0u, k};   // sel[0] = {0, rank}: constant during an align
@@ -2493,7 +2497,8 @@ int lsgpu_icp_align(lsgpu_icp* h, const float* reading_xyz1, int64_t nq, const f
                        h->state.p, h->prev.p, h->d2.p, h->nrm.p, h->hist.p, h->sel.p + 2,
                        h->counters.p + 32, h->ne_tickets.p, h->ne_partials.p, h->ne_gpartials.p, h->ne_out.p,
                        h->chk_hist.p, h->trace_dev.p, max_it, itn.capped ? 1 : 0, (h->comm || split_update) ? 0 : 1,
-                       h->sel_aux.p, h->sel_win.p, itn.committed ? 1 : 0, h->spread_cnt.p);   // 6d (+6e)
+                       h->sel_aux.p, (h->comm || !tuning().fused_select) ? h->sel_win.p : nullptr, itn.committed ? 1 : 0, h->spread_cnt.p,
+                       (itn.predicted && itn.knn) ? 1 : 0, h->sel_aux.p + kSelFailFlag + 2, h->amb_key.p, h->amb_val.p, tuning().sel_amb_cap);   // 6d (+6e)
     if (h->comm || split_update) {   // split scan: every rank gets the sums over all shards (the limit, slot 29, is already global)
       if (h->comm) comm_mark(h, true);
       if (h->comm && rccl_api()->AllReduce(h->ne_out.p, h->ne_out.p, kNe, ncclDouble, ncclSum, h->comm, h->stream) != ncclSuccess) {
@@ -2753,10 +2758,10 @@ int lsgpu_dev_cone_phases(lsgpu_icp* h, unsigned int* out, int ntiles) {  // sta
   HIPC(hipMemcpy(out, rec, words * 4, hipMemcpyDeviceToHost));
   return LSGPU_OK;
 }
-int lsgpu_dev_ne_phases(lsgpu_icp* h, unsigned long long out[16]) {  // stats build only (devtools/ne_phases.py)
+int lsgpu_dev_ne_phases(lsgpu_icp* h, unsigned long long out[24]) {  // stats build only (devtools/ne_phases.py)
   if (!h) return LSGPU_BAD_ARG;
   HIPC(hipStreamSynchronize(h->stream));
-  HIPC(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_ne_dbg), 128));
+  HIPC(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_ne_dbg), 192));
   return LSGPU_OK;
 }
 #endif

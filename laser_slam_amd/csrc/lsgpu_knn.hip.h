@@ -97,7 +97,7 @@ struct KnnArgs {
   int front_blocks;
   // the search before the first one through the direction index (lsgpu_cone.hip.h) prices that index for this align
   ConePrice price;          // price.count == nullptr: not this launch
-  uint32_t* sel_hist2;      // predicted select (IcpState::sel_mode): 2048-bin histogram of bits [19:9] inside the bin
+  uint32_t* sel_hist2;      // predicted select (IcpState::sel_mode): 2048-slice histogram of the distances inside the window
   uint32_t* sel_below;      //   kSelBelowSlots counters of distances below the bin (nullable: launch without prediction)
   uint32_t* sel_hist3w;     // committed select: kSelWinRows x 512 histogram of bits [8:0] around the last limit (nullable)
   int sel_force;            //   1: histogram against the last limit's bins whatever IcpState::sel_mode says
@@ -130,10 +130,12 @@ __device__ __forceinline__ float box_dist2(float lx, float ly, float lz, float h
   return dx * dx + dy * dy + dz * dz;
 }
 
-// One final distance's share of the predicted / committed select (inside the predicted 12-bit bin): second-level
-// histogram, and the third-level window table where the launch carries one.
+// The predicted / committed / fused select counts against a window of the distances' bit patterns
+// [sel_lo, sel_lo + sel_span) in slices of 2^sel_shift (IcpState; the aligned mode's window is the last limit's 12-bit
+// float bin in 2048 slices of 512, the fused mode's [0.7, 1.1] x the last limit).  One final distance INSIDE the window:
+// the slice histogram, and the third-level window table where the launch carries one (aligned mode only).
 __device__ __forceinline__ void sel_count_inside(const KnnArgs& a, uint32_t bits) {
-  const uint32_t bin2 = (bits >> 9) & 0x7FFu;
+  const uint32_t bin2 = (bits - a.st->sel_lo) >> a.st->sel_shift;
   atomicAdd(&a.sel_hist2[bin2], 1u);
   if (a.sel_hist3w) {
     const uint32_t d = bin2 - a.st->sel_bin2 + (uint32_t)kSelWinHalf;
@@ -579,9 +581,9 @@ __device__ __forceinline__ void rowq_search(const KnnArgs& a, float cap2s, float
 
 __device__ __forceinline__ void sel_count_query(const KnnArgs& a, int j, uint32_t bits) {
   if (a.sel_below && (a.st->sel_mode || a.sel_force)) {  // predicted select: this query's share (see k_knn_tile)
-    const uint32_t top = bits >> 20, b1 = a.st->sel_bin1;
-    if (top < b1) atomicAdd(&a.sel_below[(j & (kSelBelowSlots - 1)) * kSelBelowStride], 1u);
-    else if (top == b1) sel_count_inside(a, bits);
+    const uint32_t lo = a.st->sel_lo;
+    if (bits < lo) atomicAdd(&a.sel_below[(j & (kSelBelowSlots - 1)) * kSelBelowStride], 1u);
+    else if (bits - lo < a.st->sel_span) sel_count_inside(a, bits);
   }
 }
 
@@ -1004,9 +1006,9 @@ __global__ __launch_bounds__(WAVES * 64, LSGPU_TILE_OCC) void k_knn_tile(KnnArgs
     // final here; the lanes routed to the wave-per-query pass are counted there)
     // (lanes handed to the wave-per-query pass get their final distance, and their count, there)
     const bool fin = act && !routed && !straggler;
-    const uint32_t bits = __float_as_uint(best), top = bits >> 20, b1 = a.st->sel_bin1;
-    const unsigned long long below = __ballot(fin && top < b1);
-    if (fin && top == b1) sel_count_inside(a, bits);
+    const uint32_t bits = __float_as_uint(best), lo = a.st->sel_lo;
+    const unsigned long long below = __ballot(fin && bits < lo);
+    if (fin && bits >= lo && bits - lo < a.st->sel_span) sel_count_inside(a, bits);
     if (lane == 0 && below) atomicAdd(&a.sel_below[(tile & (kSelBelowSlots - 1)) * kSelBelowStride], (uint32_t)__popcll(below));
   }
 #ifdef LSGPU_KNN_STATS
@@ -1132,9 +1134,9 @@ __global__ __launch_bounds__(256) void k_knn_fallback(KnnArgs a) {
       a.ids[j] = id;
       a.d2[j] = __uint_as_float((uint32_t)(bestp >> 32));
       if (a.sel_below && (a.st->sel_mode || a.sel_force)) {  // predicted select: this query's share (see k_knn_tile)
-        const uint32_t bits = (uint32_t)(bestp >> 32), top = bits >> 20, b1 = a.st->sel_bin1;
-        if (top < b1) atomicAdd(&a.sel_below[(j & (kSelBelowSlots - 1)) * kSelBelowStride], 1u);
-        else if (top == b1) sel_count_inside(a, bits);
+        const uint32_t bits = (uint32_t)(bestp >> 32), lo = a.st->sel_lo;
+        if (bits < lo) atomicAdd(&a.sel_below[(j & (kSelBelowSlots - 1)) * kSelBelowStride], 1u);
+        else if (bits - lo < a.st->sel_span) sel_count_inside(a, bits);
       }
       a.prev[j] = make_float4(p.x, p.y, p.z, __int_as_float(id));
       if (a.lb) {

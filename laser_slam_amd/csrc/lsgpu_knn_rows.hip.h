@@ -35,7 +35,7 @@ __global__ __launch_bounds__(256) void k_knn_classify(KnnArgs a) {
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int blk0 = blockIdx.x * kClassifyPerBlock;
   const bool predict = a.sel_below && a.st->sel_mode;
-  const uint32_t b1 = predict ? a.st->sel_bin1 : 0u;
+  const uint32_t w_lo = predict ? a.st->sel_lo : 0u, w_span = predict ? a.st->sel_span : 0u, w_sh = predict ? (uint32_t)a.st->sel_shift : 0u;
   bool search[4];
   uint32_t pos[4];
   uint32_t below_cnt = 0;
@@ -68,9 +68,9 @@ __global__ __launch_bounds__(256) void k_knn_classify(KnnArgs a) {
     pos[u] = (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
     if (lane == 0) wsum[u * 4 + w] = (uint32_t)__popcll(bal);
     if (predict) {  // first half of the trimmed-distance select for the distances that are final here
-      const uint32_t bits = __float_as_uint(dfin), top = bits >> 20;
-      below_cnt += (uint32_t)__popcll(__ballot(fin && top < b1));
-      if (fin && top == b1) atomicAdd(&a.sel_hist2[(bits >> 9) & 0x7FFu], 1u);
+      const uint32_t bits = __float_as_uint(dfin);
+      below_cnt += (uint32_t)__popcll(__ballot(fin && bits < w_lo));
+      if (fin && bits >= w_lo && bits - w_lo < w_span) atomicAdd(&a.sel_hist2[(bits - w_lo) >> w_sh], 1u);
     }
   }
   __syncthreads();
@@ -372,9 +372,9 @@ __global__ __launch_bounds__(64, 4) void k_knn_rows(KnnArgs a) {
     if (straggler) a.strag[atomicAdd(a.strag_count, 1u)] = (uint32_t)j;
   }
   if (a.sel_below && a.st->sel_mode) {  // first half of the trimmed-distance select (see k_knn_tile)
-    const uint32_t bits = __float_as_uint(best), top = bits >> 20, b1 = a.st->sel_bin1;
-    const unsigned long long below = __ballot(act && top < b1);
-    if (act && top == b1) atomicAdd(&a.sel_hist2[(bits >> 9) & 0x7FFu], 1u);
+    const uint32_t bits = __float_as_uint(best), w_lo = a.st->sel_lo;
+    const unsigned long long below = __ballot(act && bits < w_lo);
+    if (act && bits >= w_lo && bits - w_lo < a.st->sel_span) atomicAdd(&a.sel_hist2[(bits - w_lo) >> a.st->sel_shift], 1u);
     if (lane == 0 && below)
       atomicAdd(&a.sel_below[(tile & (kSelBelowSlots - 1)) * kSelBelowStride], (uint32_t)__popcll(below));
   }

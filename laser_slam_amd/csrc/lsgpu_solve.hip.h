@@ -21,11 +21,11 @@ struct SelState {
 __device__ void find_bin(const uint32_t* __restrict__ hist, int nbins, uint32_t k, uint32_t* bin,
                          uint32_t* krem, uint32_t* sh /* >= 260 words */) {
   const int t = threadIdx.x, lane = t & 63, w = t >> 6;
-  const int per = nbins / 256;  // nbins is a multiple of 256, per <= 8
-  uint32_t c[8];
+  const int per = nbins / 256;  // nbins is a multiple of 256, per <= 16
+  uint32_t c[16];
   uint32_t loc = 0;
 #pragma unroll
-  for (int i = 0; i < 8; ++i) { c[i] = i < per ? hist[t * per + i] : 0u; loc += c[i]; }
+  for (int i = 0; i < 16; ++i) { c[i] = i < per ? hist[t * per + i] : 0u; loc += c[i]; }
   uint32_t incl = loc;
 #pragma unroll
   for (int o = 1; o < 64; o <<= 1) {
@@ -42,7 +42,7 @@ __device__ void find_bin(const uint32_t* __restrict__ hist, int nbins, uint32_t 
   if (excl <= k && k < incl) {
     uint32_t cum = excl;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
+    for (int i = 0; i < 16; ++i) {
       if (i < per) {
         if (k < cum + c[i]) { sh[256] = (uint32_t)(t * per + i); sh[257] = k - cum; break; }
         cum += c[i];
@@ -85,6 +85,7 @@ __global__ __launch_bounds__(256) void k_hist_refine(const float* __restrict__ d
   SelState in = *st_in;
   if (predicted && ist->sel_mode) {
     if (PASS == 2) return;  // done by the kNN kernel
+    if (ist->sel_wide) return;  // fused select: the normal-equation kernel settles the rest
     // PASS 3 after a predicted first half: `parent` (the 11-bit histogram inside the predicted bin) and the
     // counters of smaller distances come from the kNN kernel; st_in[-1] is the select's input {0, k}.  The rank must
     // fall inside the bin, otherwise the prediction failed and the iteration is repeated with the full select.
@@ -253,7 +254,8 @@ constexpr float kCapFactor = 1.1f;  // next search cap = this x the current trim
 // {prologue (limit), main loop, wave+block reduce and hand-off}, [4] blocks, [5] first block start (100 MHz wall clock,
 // re-armed by the last block), [6] latest end of a main loop, [7] sum of (last loop end - first start), [8] sum of
 // (kernel end - last loop end), [9] sum of (first loop START - first start) i.e. prologue wall time of the earliest block
-__device__ unsigned long long g_ne_dbg[16] = {0, 0, 0, 0, 0, ~0ull, 0, 0, 0, 0, ~0ull, 0, 0, 0, 0, 0};
+__device__ unsigned long long g_ne_dbg[24] = {0, 0, 0, 0, 0, ~0ull, 0, 0, 0, 0, ~0ull, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+__device__ unsigned long long g_ne_tail[4];   // (wall clock at points of the last block's tail)
 #endif
 // ---------------------------------------------------------------- per-iteration update (device side)
 // One lane: 6x6 float LLT solve, AngleAxis update, T_iter <- dT * T_iter, Counter + Differential
@@ -269,6 +271,7 @@ __device__ inline void icp_update_lane(IcpState* st, const double* ne_out, float
   if (sel_failed) {
     // the predicted select missed (the limit left its 12-bit bin): nothing of this iteration is usable
     st->sel_mode = 0;
+    st->sel_fails += 1;
     st->status = kStatusSelFailed;  // the distances of this iteration stand: the host re-runs the full select on them
     st->done = 1;
     return;
@@ -314,15 +317,33 @@ __device__ inline void icp_update_lane(IcpState* st, const double* ne_out, float
 #ifdef LSGPU_KNN_STATS
   const long long u3 = clock64();
 #endif
-  st->prev_limit = limit;
   {
     const uint32_t lb = __float_as_uint(limit), b1 = lb >> 20, b2 = (lb >> 9) & 0x7FFu;
-    const uint32_t moved = b2 > st->sel_bin2 ? b2 - st->sel_bin2 : st->sel_bin2 - b2;
-    st->sel_streak = (b1 == st->sel_bin1 && moved <= (uint32_t)kSelStreakBins) ? st->sel_streak + 1 : 0;
-    st->sel_mode = (b1 == st->sel_bin1) ? 1 : 0;  // predict only a bin that has just been confirmed
+    if (st->sel_wide) {
+      // the next limit is looked for in the octave that starts at 0.7 x this one; armed (and the streak counted) once a
+      // limit has moved by less than - 20 % / + 20 %: the steps of an alignment shrink, so will the limit's
+      const float prev = st->prev_limit;
+      const bool armed = limit > 1e-30f && limit < 1e30f && prev < 1e30f && limit >= kSelArmLo * prev && limit <= kSelArmHi * prev && st->sel_fails < 2;
+      // the window: as far around this limit as four times its last move plus 1 %, at most [0.7, 1.4] x (a narrow window
+      // means few lanes of the search add to the slice histogram; the counters of the distances below it cost one atomic per wave)
+      const float move = armed ? fabsf(limit - prev) / prev : 1.f;
+      const float f_lo = fmaxf(kSelWideLo, 1.f - 4.f * move - 0.01f), f_hi = fminf(2.f * kSelWideLo, 1.f + 4.f * move + 0.01f);
+      const uint32_t lo_s = __float_as_uint(limit * f_lo) >> kSelSliceShift, hi_s = (__float_as_uint(limit * f_hi) >> kSelSliceShift) + 1u;
+      st->sel_lo = lo_s << kSelSliceShift;
+      st->sel_span = (hi_s - lo_s < (uint32_t)kSelSlices ? hi_s - lo_s : (uint32_t)kSelSlices) << kSelSliceShift;
+      st->sel_shift = kSelSliceShift;
+      st->sel_streak = armed ? st->sel_streak + 1 : 0;
+      st->sel_mode = armed ? 1 : 0;
+    } else {
+      const uint32_t moved = b2 > st->sel_bin2 ? b2 - st->sel_bin2 : st->sel_bin2 - b2;
+      st->sel_streak = (b1 == st->sel_bin1 && moved <= (uint32_t)kSelStreakBins) ? st->sel_streak + 1 : 0;
+      st->sel_mode = (b1 == st->sel_bin1) ? 1 : 0;  // predict only a bin that has just been confirmed
+      st->sel_lo = b1 << 20; st->sel_span = 1u << 20; st->sel_shift = 9;
+    }
     st->sel_bin1 = b1;
     st->sel_bin2 = b2;
   }
+  st->prev_limit = limit;
   st->cap2 = st->cap_enabled ? limit * kCapFactor : INFINITY;
   st->iter = it + 1;
   hostmath::CheckerState cs{st->counter, st->n_hist};
@@ -379,12 +400,22 @@ __global__ __launch_bounds__(256) void k_normal_eq_loop(const float4* __restrict
                                                         uint32_t* __restrict__ sel_aux,
                                                         uint32_t* __restrict__ hist3w /* committed select: window table */,
                                                         int committed,
-                                                        uint32_t* __restrict__ spread_cnt /* front rows of k_knn_tile (nullable) */) {
+                                                        uint32_t* __restrict__ spread_cnt /* front rows of k_knn_tile (nullable) */,
+                                                        int predicted /* the search of this iteration counted against the select's window if IcpState::sel_mode */,
+                                                        uint32_t* __restrict__ amb_cnt, uint2* __restrict__ amb_key /* kSelAmbCap x {query, distance bits} */,
+                                                        double* __restrict__ amb_val /* kSelAmbCap x 32 */,
+                                                        int amb_cap /* <= kSelAmbCap: a slice with more distances is summed in place */) {
   __shared__ uint32_t sc[260];
   __shared__ double fin[32];
   __shared__ double red[8][33];
   __shared__ int is_last;
   if (ist->done) return;
+  // fused select (IcpState::sel_wide, lsgpu_common.hip.h): the search kernel left {distances below the window, slice
+  // histogram}; no select kernel has run (committed) or they all exited at once (predicted and armed)
+  const bool wide = ist->sel_wide && amb_cnt;
+  const bool fused = wide && (committed || (predicted && ist->sel_mode));
+  uint32_t s_slice = 0xFFFFFFFFu;   // the slice whose distances are set aside (none: 0xFFFFFFFF -- no distance is that large)
+  uint32_t f_krem2 = 0u, f_cnt2 = 0u;   // rank of the limit inside its slice (fused), distances in the slice
 #ifdef LSGPU_KNN_STATS
   const long long c0 = clock64();
   if (threadIdx.x == 0) atomicMin(&g_ne_dbg[5], (unsigned long long)wall_clock64());
@@ -394,7 +425,60 @@ __global__ __launch_bounds__(256) void k_normal_eq_loop(const float4* __restrict
   for (int i = 0; i < 12; ++i) T.m[i] = ist->T_rows[i];
   float limit;
   bool sel_ok = true;
-  if (committed) {
+  if (fused) {
+    // every block: the slice that holds the order statistic, the rank inside it, how many distances it holds -- one batch
+    // of loads (the thread's 16 slices, the counters of the distances below the window), one scan
+    __shared__ uint32_t wsum[4], fres[4];
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    const uint4* h4 = reinterpret_cast<const uint4*>(hist + kHistBins) + t * (kSelSlices / 256 / 4);
+    static_assert(kSelSlices == 256 * 16, "16 slices per thread");
+    uint4 c4[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) c4[i] = h4[i];
+    uint32_t bel = t < kSelBelowSlots ? sel_aux[t * kSelBelowStride] : 0u;
+    const uint32_t k = st[-2].k;  // sel[0] = {0, rank}: constant during an align
+    uint32_t c[16];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { c[4 * i] = c4[i].x; c[4 * i + 1] = c4[i].y; c[4 * i + 2] = c4[i].z; c[4 * i + 3] = c4[i].w; }
+    uint32_t loc = 0u;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) loc += c[i];
+    uint32_t incl = loc;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const uint32_t v = __shfl_up(incl, o, 64);
+      if (lane >= o) incl += v;
+    }
+    bel = wave_sum_u32(bel);   // (the counters sit in the first wave's lanes)
+    if (lane == 63) wsum[w] = incl;
+    if (t == 0) { fres[0] = 0u; fres[1] = 0u; fres[2] = 0u; fres[3] = bel; }
+    __syncthreads();
+    const uint32_t below = fres[3], inside = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    uint32_t base = 0u;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) base += i < w ? wsum[i] : 0u;
+    incl += base;
+    const uint32_t excl = incl - loc;
+    const bool in_window = k >= below && k - below < inside;
+    const uint32_t kk = k - below;
+    if (in_window && excl <= kk && kk < incl) {
+      uint32_t cum = excl;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        if (kk < cum + c[i]) { fres[0] = (uint32_t)(t * 16 + i); fres[1] = kk - cum; fres[2] = c[i]; break; }
+        cum += c[i];
+      }
+    }
+    __syncthreads();
+    limit = 0.f;
+    if (!in_window) {
+      sel_ok = false;
+    } else {
+      f_krem2 = fres[1]; f_cnt2 = fres[2];
+      s_slice = (ist->sel_lo >> kSelSliceShift) + fres[0];
+      if (f_cnt2 > (uint32_t)amb_cap || f_krem2 >= f_cnt2) sel_ok = false;   // (a fuller slice is summed in place: the select runs in full)
+    }
+  } else if (committed) {
     // No select kernel ran: the search kernels left {counts below the last limit's 12-bit bin, the 11-bit histogram
     // inside it, the 9-bit histograms of a window of second-level bins around it}.  Every block derives the order
     // statistic from them (3 short scans); a rank outside the bin or the window voids the iteration.
@@ -425,6 +509,16 @@ __global__ __launch_bounds__(256) void k_normal_eq_loop(const float4* __restrict
     }
   } else {
     limit = select_limit(hist + 2 * kHistBins, st, sc);
+    if (wide) {
+      // the same sum as the fused select's: the inliers of the limit's slice are set aside and added in query order --
+      // if the slice holds no more than the fused path could have set aside (its count: four bins of the select's
+      // second table, which covers the limit's 12-bit float bin in steps of 2^9)
+      const uint32_t lb = __float_as_uint(limit), sl = lb >> kSelSliceShift;
+      const uint32_t i0 = (sl << (kSelSliceShift - 9)) & (uint32_t)(kHistBins - 1);
+      uint32_t cnt = 0u;
+      for (uint32_t i = 0; i < (1u << (kSelSliceShift - 9)); ++i) cnt += hist[kHistBins + i0 + i];
+      if (cnt <= (uint32_t)amb_cap) { s_slice = sl; f_cnt2 = cnt; }   // (f_cnt2: at most this many will be set aside)
+    }
   }
 #ifdef LSGPU_KNN_STATS
   const long long c1 = clock64();
@@ -437,13 +531,21 @@ __global__ __launch_bounds__(256) void k_normal_eq_loop(const float4* __restrict
   // are still taken in index order, so the result does not depend on the unrolling
   const int stride = gridDim.x * 256;
   for (int j0 = blockIdx.x * 256 + threadIdx.x; j0 < (sel_ok ? nq : 0); j0 += kNeUnroll * stride) {
-    float dd[kNeUnroll]; float4 qq[kNeUnroll], rr[kNeUnroll], nn[kNeUnroll]; bool use[kNeUnroll];
+    float dd[kNeUnroll]; float4 qq[kNeUnroll], rr[kNeUnroll], nn[kNeUnroll]; bool use[kNeUnroll], amb[kNeUnroll];
 #pragma unroll
     for (int u = 0; u < kNeUnroll; ++u) {
       const int j = j0 + u * stride;
       use[u] = j < nq;
       dd[u] = use[u] ? d2[j] : INFINITY;
-      use[u] = use[u] && dd[u] <= limit;
+      {
+        const uint32_t sl = __float_as_uint(dd[u]) >> kSelSliceShift;
+        const bool in_s = sl == s_slice;
+        // fused: below the limit's slice = an inlier, inside it = set aside (the exact limit is one of those);
+        // otherwise the limit is known and only the slice's inliers are set aside
+        const bool inl = fused ? sl <= s_slice : dd[u] <= limit;
+        amb[u] = use[u] && inl && in_s;
+        use[u] = use[u] && inl;
+      }
       qq[u] = use[u] ? match[j] : make_float4(0.f, 0.f, 0.f, __int_as_float(-1));
       rr[u] = use[u] ? rdq[j] : make_float4(0.f, 0.f, 0.f, 0.f);
       use[u] = use[u] && __float_as_int(qq[u].w) >= 0;
@@ -466,6 +568,22 @@ __global__ __launch_bounds__(256) void k_normal_eq_loop(const float4* __restrict
     J[2] = p.x * n.y - p.y * n.x;
     J[3] = n.x; J[4] = n.y; J[5] = n.z;
     const float res = (p.x - q.x) * n.x + (p.y - q.y) * n.y + (p.z - q.z) * n.z;
+    if (amb[u]) {   // its contribution waits for the exact limit (the last block adds it, or not)
+      const uint32_t slot = __hip_atomic_fetch_add(amb_cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (slot < (uint32_t)kSelAmbCap) {
+        double* v = amb_val + (size_t)slot * 32;
+        int kk = 0;
+        for (int a = 0; a < 6; ++a)
+          for (int c = a; c < 6; ++c) __hip_atomic_store(&v[kk++], (double)J[a] * (double)J[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int a = 0; a < 6; ++a) __hip_atomic_store(&v[21 + a], -((double)J[a] * (double)res), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&v[27], 1.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&v[28], (double)res * (double)res, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(reinterpret_cast<unsigned long long*>(&amb_key[slot]),
+                           ((unsigned long long)__float_as_uint(dd[u]) << 32) | (unsigned long long)(uint32_t)(j0 + u * stride),
+                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      continue;
+    }
     int k = 0;
 #pragma unroll
     for (int a = 0; a < 6; ++a) {
@@ -526,6 +644,9 @@ __global__ __launch_bounds__(256) void k_normal_eq_loop(const float4* __restrict
   }
   __syncthreads();
   if (!is_last) return;
+#ifdef LSGPU_KNN_STATS
+  if (threadIdx.x == 0) g_ne_tail[0] = (unsigned long long)wall_clock64();
+#endif
 #if !((defined(__gfx950__) || defined(__gfx942__)) && !defined(LSGPU_NE_FENCED))
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
 #endif
@@ -541,6 +662,31 @@ __global__ __launch_bounds__(256) void k_normal_eq_loop(const float4* __restrict
 #pragma unroll
     for (int i = 0; i < (kStWords + 255) / 256; ++i)
       st_word[i] = (int)threadIdx.x + 256 * i < kStWords ? gw[threadIdx.x + 256 * i] : 0u;
+  }
+  // the distances set aside: their keys travel with the same round trip as the partials (the whole area, whatever its fill)
+  const bool s_on = sel_ok && s_slice != 0xFFFFFFFFu;
+  __shared__ __attribute__((aligned(16))) uint32_t akj[kSelAmbCap];
+  __shared__ __attribute__((aligned(16))) uint32_t akb[kSelAmbCap];
+  __shared__ uint32_t aord[kSelAmbCap];
+  __shared__ uint32_t alim_sh, am_sh;
+  __shared__ double red2[8][33];
+  constexpr int kAmbLds = 64;           // slots whose contributions also travel with that round trip (fuller: one more trip for the rest)
+  __shared__ double aval[kAmbLds * 32];
+  uint32_t an = 0u;
+  unsigned long long akey = 0ull;
+  double av[kAmbLds * 32 / 256];
+  if (s_on) {
+    // (only slots this launch can have written -- the prologue knows how many distances the slice holds; a slot nobody wrote
+    // comes from far away, and loads return in order.  Clamped addresses, not predicated loads: a select on a loaded value
+    // would wait for it here, in front of the partials' loads)
+    an = __hip_atomic_load(amb_cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const uint32_t kmax = f_cnt2 ? f_cnt2 - 1u : 0u, vmax = kmax * 32u + 31u;
+    akey = __hip_atomic_load(reinterpret_cast<unsigned long long*>(&amb_key[threadIdx.x < kmax ? threadIdx.x : kmax]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+    for (int u = 0; u < kAmbLds * 32 / 256; ++u) {
+      const uint32_t i = threadIdx.x + 256u * (uint32_t)u;
+      av[u] = __hip_atomic_load(&amb_val[i < vmax ? i : vmax], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
   }
   uint32_t fail_word = 0u, ns_word = 0u, nw_word = 0u;
   if (threadIdx.x == 255) {
@@ -571,8 +717,73 @@ __global__ __launch_bounds__(256) void k_normal_eq_loop(const float4* __restrict
     for (int i = 0; i < (kStWords + 255) / 256; ++i)
       if ((int)threadIdx.x + 256 * i < kStWords) sw[threadIdx.x + 256 * i] = st_word[i];
   }
+  if (s_on) {
+#pragma unroll
+    for (int u = 0; u < kAmbLds * 32 / 256; ++u) aval[threadIdx.x + 256 * u] = av[u];
+    const uint32_t n_in = an < (uint32_t)kSelAmbCap ? an : (uint32_t)kSelAmbCap;
+    akj[threadIdx.x] = threadIdx.x < n_in ? (uint32_t)akey : 0xFFFFFFFFu;            // (slots beyond the fill: keys that
+    akb[threadIdx.x] = threadIdx.x < n_in ? (uint32_t)(akey >> 32) : 0xFFFFFFFFu;    //  rank behind everything)
+    if (threadIdx.x == 0) { alim_sh = fused ? 0xFFFFFFFFu : __float_as_uint(limit); am_sh = 0u; }
+  }
+  __syncthreads();
+#ifdef LSGPU_KNN_STATS
+  if (threadIdx.x == 0) g_ne_tail[1] = (unsigned long long)wall_clock64();
+#endif
+  bool amb_ok = true;
+  if (s_on) {
+    if (fused) amb_ok = an == f_cnt2;   // (every distance the search counted into the slice has been seen here)
+    const uint32_t n = amb_ok ? (an < (uint32_t)kSelAmbCap ? an : (uint32_t)kSelAmbCap) : 0u;
+    const uint32_t mb = akb[threadIdx.x], mj = akj[threadIdx.x];
+    // eight keys per step (the padding behind the fill ranks behind every real key)
+    if (fused) {   // the limit is the distance of rank f_krem2 inside its slice
+      if (threadIdx.x < n) {
+        uint32_t cl = 0u, cle = 0u;
+        for (uint32_t e0 = 0; e0 < n; e0 += 8u) {
+          const uint4 b0 = *reinterpret_cast<const uint4*>(&akb[e0]), b1 = *reinterpret_cast<const uint4*>(&akb[e0 + 4u]);
+          const uint32_t eb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+#pragma unroll
+          for (int q = 0; q < 8; ++q) { cl += eb[q] < mb ? 1u : 0u; cle += eb[q] <= mb ? 1u : 0u; }
+        }
+        if (cl <= f_krem2 && f_krem2 < cle) alim_sh = mb;
+      }
+      __syncthreads();
+    }
+    const uint32_t lim_bits = alim_sh;
+    amb_ok = amb_ok && lim_bits != 0xFFFFFFFFu;
+    limit = __uint_as_float(lim_bits);
+    // the slice's inliers in the order of their queries, whatever order they were set aside in: row r of that order is
+    // added by group r mod 8, the groups' sums in group order
+    if (threadIdx.x < n && mb <= lim_bits) {
+      uint32_t jr = 0u;
+      for (uint32_t e0 = 0; e0 < n; e0 += 8u) {
+        const uint4 b0 = *reinterpret_cast<const uint4*>(&akb[e0]), b1 = *reinterpret_cast<const uint4*>(&akb[e0 + 4u]);
+        const uint4 j0 = *reinterpret_cast<const uint4*>(&akj[e0]), j1 = *reinterpret_cast<const uint4*>(&akj[e0 + 4u]);
+        const uint32_t eb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w}, ej[8] = {j0.x, j0.y, j0.z, j0.w, j1.x, j1.y, j1.z, j1.w};
+#pragma unroll
+        for (int q = 0; q < 8; ++q) jr += (eb[q] <= lim_bits && ej[q] < mj) ? 1u : 0u;
+      }
+      aord[jr] = threadIdx.x;
+      atomicAdd(&am_sh, 1u);
+    }
+    __syncthreads();
+    {
+      const uint32_t m = am_sh;
+      const uint32_t col = threadIdx.x & 31u, grp = threadIdx.x >> 5;
+      double t = 0.0;
+      for (uint32_t r = grp; r < m; r += 8u) {
+        const uint32_t e = aord[r];
+        t += e < (uint32_t)kAmbLds ? aval[e * 32u + col]
+                                   : __hip_atomic_load(&amb_val[(size_t)e * 32 + col], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      red2[grp][col] = t;
+    }
+    __syncthreads();
+  }
+#ifdef LSGPU_KNN_STATS
+  if (threadIdx.x == 0) g_ne_tail[2] = (unsigned long long)wall_clock64();
+#endif
   if (threadIdx.x == 255) {
-    fail_sh = fail_word | (sel_ok ? 0u : 1u);  // (a missed committed select: same handling as a missed prediction)
+    fail_sh = fail_word | ((sel_ok && amb_ok) ? 0u : 1u);  // (a missed committed / fused select: same handling as a missed prediction)
     cnt_sh[0] = ns_word; cnt_sh[1] = nw_word;
   }
   __syncthreads();
@@ -580,14 +791,24 @@ __global__ __launch_bounds__(256) void k_normal_eq_loop(const float4* __restrict
     double t = red[0][threadIdx.x];
 #pragma unroll
     for (int g = 1; g < 8; ++g) t += red[g][threadIdx.x];
+    if (s_on) {
+#pragma unroll
+      for (int g = 0; g < 8; ++g) t += red2[g][threadIdx.x];
+    }
     out[threadIdx.x] = t; fin[threadIdx.x] = t;
   }
   if (threadIdx.x == 32) {
+    if (wide) __hip_atomic_store(amb_cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const double ns = (double)cnt_sh[0];
     out[29] = (double)limit; fin[29] = (double)limit;
     out[30] = ns; fin[30] = ns;
     const double nw = (double)cnt_sh[1];
+#ifdef LSGPU_KNN_STATS
+    const double nw_dbg = s_on ? (double)an : nw;   // (stats build: the trace's `searching` field shows how many distances were set aside)
+    out[31] = nw_dbg; fin[31] = nw_dbg;
+#else
     out[31] = nw; fin[31] = nw;  // queries that had to search in this iteration (k_knn_classify), for the trace
+#endif
     __hip_atomic_store(strag_count, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __hip_atomic_store(strag_count + 2, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // work-list length (k_knn_classify)
     __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -630,6 +851,7 @@ __global__ __launch_bounds__(256) void k_normal_eq_loop(const float4* __restrict
     const unsigned long long w0 = g_ne_dbg[5], w2 = g_ne_dbg[6], w1 = g_ne_dbg[10];
     g_ne_dbg[0] += 1ull; g_ne_dbg[7] += w2 - w0; g_ne_dbg[8] += wend - w2; g_ne_dbg[9] += w1 - w0;
     g_ne_dbg[11] += wend - w_pre;  // the update lane alone
+    g_ne_dbg[16] += g_ne_tail[0] - w2; g_ne_dbg[17] += g_ne_tail[1] - g_ne_tail[0]; g_ne_dbg[18] += g_ne_tail[2] - g_ne_tail[1]; g_ne_dbg[19] += w_pre - g_ne_tail[2];
     g_ne_dbg[5] = ~0ull; g_ne_dbg[6] = 0ull; g_ne_dbg[10] = ~0ull;
   }
 #endif

@@ -48,7 +48,7 @@ def main():
     print("SWITCH_RESULT " + json.dumps({"digest": dg.hexdigest(), "digest_order_free": di.hexdigest(),
                                          "T": [float(v) for v in np.asarray(T, np.float64).ravel()],
                                          "iterations": int(st.iterations),
-                                         "committed": int(st.committed_select_iterations), "spread_tiles": int(st.spread_tiles),
+                                         "committed": int(st.committed_select_iterations), "sel_retries": int(st.pad_), "spread_tiles": int(st.spread_tiles),
                                          "n_ref": int(rf.shape[0])}))
 
 

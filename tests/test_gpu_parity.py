@@ -338,7 +338,9 @@ def test_experiment_switches_do_not_change_results():
     bit-identical transform, per-iteration limit / inlier count / normal matrix / T, distances and filtered reference.
     LSGPU_QUERY_ORDER changes the order in which the 29 double sums of the normal equations are added, hence their last
     bits: for it the search results, the first iteration's limit and inlier count are bit-identical, the transform
-    agrees to 1e-6 and the iteration count is the same."""
+    agrees to 1e-6 and the iteration count is the same.  So do LSGPU_NO_FUSED_SELECT and LSGPU_SEL_AMB_CAP: the sum is
+    DEFINED with the inliers of the limit's slice added last (lsgpu_common.hip.h), those two switches change that
+    definition; predicted / committed / plain select under the same definition stay bit-identical."""
     import json
     import subprocess
     import sys
@@ -355,7 +357,10 @@ def test_experiment_switches_do_not_change_results():
                 dict(tile, LSGPU_FRONT_GUESS="8"), {"LSGPU_SSN_GLOBAL": "1"}, {"LSGPU_SSN_FULL_SORT": "1"}, {"LSGPU_SSN_FULL_SORT": "1", "LSGPU_SSN_GLOBAL": "1"},
                 {"LSGPU_SSN_OLD_FINISH": "1"}, {"LSGPU_SSN_ROOT": "2048"}, {"LSGPU_SSN_ROOT": "4096"},   # k_ssn_finish / smaller roots of k_ssn_tree
                 {"LSGPU_SSN_SORT_LEVELS": "1"}, {"LSGPU_SSN_SORT_LEVELS": "1", "LSGPU_SSN_OLD_FINISH": "1"},   # a segmented sort per upper level (round 4) / all of round 4's filter
-                {"LSGPU_QUERY_ORDER": "0"}]
+                {"LSGPU_QUERY_ORDER": "0"},
+                # the fused select (round 6): without it (select kernels / window table), and with room for only 3 distances of
+                # the limit's slice -- fuller slices void the fused iteration, which is repeated with the select in full
+                {"LSGPU_NO_FUSED_SELECT": "1"}, {"LSGPU_SEL_AMB_CAP": "3"}, {"LSGPU_SEL_AMB_CAP": "0"}]
     # the measured-slower variants only exist in the -DLSGPU_EXPERIMENTS build (devtools/build.sh); when that build is
     # around it has to give the same bits as the product, switch by switch
     fenced_so = os.path.join(ROOT, "tests", "liblsgpu_icp_fenced.so")   # built by `make -C laser_slam_amd/csrc` (build())
@@ -379,8 +384,10 @@ def test_experiment_switches_do_not_change_results():
     assert base["iterations"] >= 10 and base["committed"] > 0 and base["spread_tiles"] > 0, base
     for env_add, res in results[1:]:
         assert res["iterations"] == base["iterations"] and res["digest_order_free"] == base["digest_order_free"], (env_add, res, base)
-        if "LSGPU_QUERY_ORDER" in env_add:
+        if "LSGPU_QUERY_ORDER" in env_add or "LSGPU_NO_FUSED_SELECT" in env_add or "LSGPU_SEL_AMB_CAP" in env_add:
             assert max(abs(a - b) for a, b in zip(res["T"], base["T"])) < 1e-6, (env_add, res["T"], base["T"])
+            if "LSGPU_SEL_AMB_CAP" in env_add:   # (the voided iterations really happened, and were repeated)
+                assert res["sel_retries"] > 0, (env_add, res)
         else:
             assert res["digest"] == base["digest"], (env_add, res, base)
 
