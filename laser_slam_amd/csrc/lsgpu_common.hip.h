@@ -135,7 +135,7 @@ constexpr int kSelSliceShift = 11;   // fused select: a slice is 2^11 bit steps 
 constexpr int kSelSlices = 2 * kHistBins;   // ... the window 4096 of them = one octave (counted into the select's second and third table)
 constexpr int kSelAmbCap = 256;      // ... and at most this many distances of the limit's slice are set aside (a fuller slice: summed in place, select in full)
 constexpr float kSelWideLo = 0.7f;   // the window starts at this x the last limit ...
-constexpr float kSelArmLo = 0.8f, kSelArmHi = 1.2f;     // ... and is used once a limit has moved by no more than this from its predecessor
+constexpr float kSelArmLo = 0.75f, kSelArmHi = 1.2f;     // ... and is used once a limit has moved by no more than this from its predecessor
 constexpr int kStatusCapFailed = 100;
 constexpr int kStatusSelFailed = 101;  // predicted select missed: the host repeats select + normal equations only
 
