@@ -624,7 +624,7 @@ static int prepare_queries(lsgpu_icp* h, const float* q_xyz1, int64_t nq, const 
 }
 
 static int run_select(lsgpu_icp* h, const float* d2, int n, uint32_t k, bool zero_hist, const IcpState* st,
-                      bool use_comm, bool predicted);
+                      bool use_comm, bool predicted, int passes = 3);
 
 static float price_share(const lsgpu_icp* h) {   // heavy lanes / searching lanes of the priced launch (its counters are on the host)
   uint64_t heavy = 0, searching = 0;
@@ -849,7 +849,7 @@ static int run_knn(lsgpu_icp* h, const Mat34& T, const IcpState* st, const polic
 
 // TrimmedDist order statistic of d2[0..n) -> rank k; leaves hist3 + sel[2] for select_limit().
 static int run_select(lsgpu_icp* h, const float* d2, int n, uint32_t k, bool zero_hist, const IcpState* st,
-                      bool use_comm, bool predicted) {
+                      bool use_comm, bool predicted, int passes) {
   if (zero_hist) HIPC(hipMemsetAsync(h->hist.p, 0, 3 * kHistBins * sizeof(uint32_t), h->stream));
   if (zero_hist) {  // sel[0] = {0, k}: constant during an align, uploaded once
     SelState s0{0u, k};
@@ -863,6 +863,7 @@ static int run_select(lsgpu_icp* h, const float* d2, int n, uint32_t k, bool zer
   hipLaunchKernelGGL(k_hist_refine<2>, dim3(nb), dim3(256), 0, h->stream, d2, n, h->hist.p,
                      h->sel.p, h->sel.p + 1, h->hist.p + kHistBins, st, pr, h->sel_aux.p);
   if (use_comm && h->comm) { comm_mark(h, true); RCCLC(rccl_api()->AllReduce(h->hist.p + kHistBins, h->hist.p + kHistBins, kHistBins, ncclUint32, ncclSum, h->comm, h->stream)); comm_mark(h, false); }
+  if (passes < 3) { HIPC(hipGetLastError()); return LSGPU_OK; }   // (fused select: k_normal_eq_loop settles the limit inside its slice)
   hipLaunchKernelGGL(k_hist_refine<3>, dim3(nb), dim3(256), 0, h->stream, d2, n,
                      h->hist.p + kHistBins, h->sel.p + 1, h->sel.p + 2, h->hist.p + 2 * kHistBins, st, pr,
                      h->sel_aux.p);
@@ -2453,6 +2454,7 @@ int lsgpu_icp_align(lsgpu_icp* h, const float* reading_xyz1, int64_t nq, const f
   pc.predict_select = tuning().predict_select; pc.commit_select = tuning().commit_select; pc.comm_commit = tuning().comm_commit;
   pc.lookahead = tuning().lookahead; pc.comm = h->comm != nullptr;
   pc.seed_cap = tuning().seed_cap; pc.cap_enabled = h->cfg.reserved[0] == 0;
+  pc.two_pass_select = !h->comm && tuning().fused_select && tuning().two_pass_select;
   pc.cone_probe = tuning().cone_probe; pc.cone_heavy_share = tuning().cone_heavy_share; pc.cone_max_occupancy = tuning().cone_max_occupancy;
   policy::State& pol = h->pol;
   if (h->cone_build_in_align) { h->cone_ok = cone_wanted(h); h->cone_decided = false; }   // (its build follows the first iteration, below)
@@ -2488,7 +2490,7 @@ int lsgpu_icp_align(lsgpu_icp* h, const float* reading_xyz1, int64_t nq, const f
     }
     if (!itn.committed) {
       r = run_select(h, h->d2.p, (int)nq, k, false /* armed by k_align_init / k_seed_cap / the previous k_normal_eq_loop */,
-                     h->state.p, true, itn.predicted);       // 6c
+                     h->state.p, true, itn.predicted, itn.full_select ? 3 : 2);       // 6c
       if (r) return r;
     }
     lsgpu_icp::KnnEv* ev = (timed && itn.knn && h->knn_events_used) ? &h->knn_events[h->knn_events_used - 1] : nullptr;
@@ -2498,7 +2500,8 @@ int lsgpu_icp_align(lsgpu_icp* h, const float* reading_xyz1, int64_t nq, const f
                        h->counters.p + 32, h->ne_tickets.p, h->ne_partials.p, h->ne_gpartials.p, h->ne_out.p,
                        h->chk_hist.p, h->trace_dev.p, max_it, itn.capped ? 1 : 0, (h->comm || split_update) ? 0 : 1,
                        h->sel_aux.p, (h->comm || !tuning().fused_select) ? h->sel_win.p : nullptr, itn.committed ? 1 : 0, h->spread_cnt.p,
-                       (itn.predicted && itn.knn) ? 1 : 0, h->sel_aux.p + kSelFailFlag + 2, h->amb_key.p, h->amb_val.p, tuning().sel_amb_cap);   // 6d (+6e)
+                       (itn.predicted && itn.knn) ? 1 : 0, h->sel_aux.p + kSelFailFlag + 2, h->amb_key.p, h->amb_val.p, tuning().sel_amb_cap,
+                       (!itn.full_select && !itn.committed) ? 1 : 0);   // 6d (+6e)
     if (h->comm || split_update) {   // split scan: every rank gets the sums over all shards (the limit, slot 29, is already global)
       if (h->comm) comm_mark(h, true);
       if (h->comm && rccl_api()->AllReduce(h->ne_out.p, h->ne_out.p, kNe, ncclDouble, ncclSum, h->comm, h->stream) != ncclSuccess) {
@@ -2567,6 +2570,7 @@ int lsgpu_icp_align(lsgpu_icp* h, const float* reading_xyz1, int64_t nq, const f
     h->n_spread_host = hst->n_spread; h->n_spread_known = true;
     policy::LookInput li;
     li.done = hst->done; li.status = hst->status; li.iter = hst->iter; li.sel_streak = hst->sel_streak;
+    if (hst->sel_fails >= 2) pc.two_pass_select = false;   // (slices fuller than the normal equations can set aside: the select's third pass is back)
     li.stragglers = hst->stragglers; li.nq = nq; li.status_cap_failed = kStatusCapFailed; li.status_sel_failed = kStatusSelFailed;
     const policy::LookVerdict verdict = pol.on_look(pc, li, ahead, repriced ? price_share(h) : -1.f);
     if (verdict == policy::LookVerdict::RepeatUncapped) {

@@ -23,6 +23,7 @@ struct Config {               // constant during an alignment (from Tuning and t
   int group = 6;              // iterations between two looks at the loop state
   int enq_limit = 0;          // guards against a device that never finishes
   bool predict_select = true, commit_select = true, comm_commit = true;
+  bool two_pass_select = false;   // the select stops after its second pass, the normal-equation kernel settles the rest (fused select)
   bool lookahead = true;      // one iteration enqueued behind a look's state copy
   bool comm = false;          // split-scan mode (RCCL): per-shard tables, no look-ahead
   bool seed_cap = true, cap_enabled = true;
@@ -37,6 +38,7 @@ struct Iteration {            // one enqueued iteration: what the search, the se
   bool seed = false, capped = true, wide = false;
   bool predicted = false;     // first half of the select in the search kernel's epilogue
   bool committed = false;     // ... and no select launch at all
+  bool full_select = true;    // a select that is launched runs all three passes
   bool cone_iter = false;     // this search may go through the direction index
   bool dense_wait = false;    // (its first one: a denser reference waits one iteration more)
   bool price = false;         // this search prices the index for the one behind it
@@ -100,6 +102,7 @@ struct State {
     const bool can_commit = c.commit_select && commit_ok && !first_select && (!c.comm || c.comm_commit);
     it.predicted = c.predict_select && knn && capped && !wide && (!c.comm || can_commit);
     it.committed = it.predicted && can_commit;
+    it.full_select = !c.two_pass_select;
     it.cone_iter = knn && !seed && capped && enq >= c.cone_from;
     it.dense_wait = enq == c.cone_from;
     it.price = knn && (enq == c.cone_from - 1 || price_next);
@@ -193,6 +196,7 @@ struct State {
   }
   Iteration repeat_select(const Config& c) {
     Iteration it = plan(c, false, true, false, false, false);
+    it.full_select = true;   // (whatever voided the iteration: this time the limit comes from the select itself)
     since_check = 1;
     return it;
   }

@@ -423,7 +423,8 @@ __global__ __launch_bounds__(256) void k_normal_eq_loop(const float4* __restrict
                                                         int predicted /* the search of this iteration counted against the select's window if IcpState::sel_mode */,
                                                         uint32_t* __restrict__ amb_cnt, uint2* __restrict__ amb_key /* kSelAmbCap x {query, distance bits} */,
                                                         double* __restrict__ amb_val /* kSelAmbCap x 32 */,
-                                                        int amb_cap /* <= kSelAmbCap: a slice with more distances is summed in place */) {
+                                                        int amb_cap /* <= kSelAmbCap: a slice with more distances is summed in place */,
+                                                        int two_pass /* the select stopped after its second pass: the limit's slice is known, the limit is not */) {
   __shared__ uint32_t sc[260];
   __shared__ double fin[32];
   __shared__ double red[8][33];
@@ -433,6 +434,8 @@ __global__ __launch_bounds__(256) void k_normal_eq_loop(const float4* __restrict
   // histogram}; no select kernel has run (committed) or they all exited at once (predicted and armed)
   const bool wide = ist->sel_wide && amb_cnt;
   const bool fused = wide && (committed || (predicted && ist->sel_mode));
+  const bool plain2 = wide && !fused && two_pass;
+  const bool resolve = fused || plain2;   // the limit is one of the distances set aside: the last block finds it
   uint32_t s_slice = 0xFFFFFFFFu;   // the slice whose distances are set aside (none: 0xFFFFFFFF -- no distance is that large)
   uint32_t f_krem2 = 0u, f_cnt2 = 0u;   // rank of the limit inside its slice (fused), distances in the slice
 #ifdef LSGPU_KNN_STATS
@@ -497,6 +500,21 @@ __global__ __launch_bounds__(256) void k_normal_eq_loop(const float4* __restrict
       s_slice = (ist->sel_lo >> kSelSliceShift) + fres[0];
       if (f_cnt2 > (uint32_t)amb_cap || f_krem2 >= f_cnt2) sel_ok = false;   // (a fuller slice is summed in place: the select runs in full)
     }
+  } else if (plain2) {
+    // the select's first two passes ran: its second table covers the limit's 12-bit float bin in steps of 2^9, a slice
+    // is four of its bins
+    const SelState in = st[-1];
+    uint32_t bin2, krem;
+    find_bin(hist + kHistBins, kHistBins, in.k, &bin2, &krem, sc);
+    const uint32_t i0 = bin2 & ~3u;
+    uint32_t cnt = 0u, before = 0u;
+#pragma unroll
+    for (uint32_t i = 0; i < 4u; ++i) { const uint32_t c = hist[kHistBins + i0 + i]; cnt += c; before += i0 + i < bin2 ? c : 0u; }
+    static_assert(kSelSliceShift == 11, "a slice = four bins of the second pass");
+    s_slice = (in.prefix << 9) | (bin2 >> 2);
+    f_cnt2 = cnt; f_krem2 = krem + before;
+    limit = 0.f;
+    if (cnt > (uint32_t)amb_cap) sel_ok = false;   // (a fuller slice is summed in place: the select runs its third pass)
   } else if (committed) {
     // No select kernel ran: the search kernels left {counts below the last limit's 12-bit bin, the 11-bit histogram
     // inside it, the 9-bit histograms of a window of second-level bins around it}.  Every block derives the order
@@ -561,7 +579,7 @@ __global__ __launch_bounds__(256) void k_normal_eq_loop(const float4* __restrict
         const bool in_s = sl == s_slice;
         // fused: below the limit's slice = an inlier, inside it = set aside (the exact limit is one of those);
         // otherwise the limit is known and only the slice's inliers are set aside
-        const bool inl = fused ? sl <= s_slice : dd[u] <= limit;
+        const bool inl = resolve ? sl <= s_slice : dd[u] <= limit;
         amb[u] = use[u] && inl && in_s;
         use[u] = use[u] && inl;
       }
@@ -742,7 +760,7 @@ __global__ __launch_bounds__(256) void k_normal_eq_loop(const float4* __restrict
     const uint32_t n_in = an < (uint32_t)kSelAmbCap ? an : (uint32_t)kSelAmbCap;
     akj[threadIdx.x] = threadIdx.x < n_in ? (uint32_t)akey : 0xFFFFFFFFu;            // (slots beyond the fill: keys that
     akb[threadIdx.x] = threadIdx.x < n_in ? (uint32_t)(akey >> 32) : 0xFFFFFFFFu;    //  rank behind everything)
-    if (threadIdx.x == 0) { alim_sh = fused ? 0xFFFFFFFFu : __float_as_uint(limit); am_sh = 0u; }
+    if (threadIdx.x == 0) { alim_sh = resolve ? 0xFFFFFFFFu : __float_as_uint(limit); am_sh = 0u; }
   }
   __syncthreads();
 #ifdef LSGPU_KNN_STATS
@@ -750,11 +768,11 @@ __global__ __launch_bounds__(256) void k_normal_eq_loop(const float4* __restrict
 #endif
   bool amb_ok = true;
   if (s_on) {
-    if (fused) amb_ok = an == f_cnt2;   // (every distance the search counted into the slice has been seen here)
+    if (resolve) amb_ok = an == f_cnt2;   // (every distance counted into the slice has been seen here)
     const uint32_t n = amb_ok ? (an < (uint32_t)kSelAmbCap ? an : (uint32_t)kSelAmbCap) : 0u;
     const uint32_t mb = akb[threadIdx.x], mj = akj[threadIdx.x];
     // eight keys per step (the padding behind the fill ranks behind every real key)
-    if (fused) {   // the limit is the distance of rank f_krem2 inside its slice
+    if (resolve) {   // the limit is the distance of rank f_krem2 inside its slice
       if (threadIdx.x < n) {
         uint32_t cl = 0u, cle = 0u;
         for (uint32_t e0 = 0; e0 < n; e0 += 8u) {

@@ -357,6 +357,7 @@ def test_experiment_switches_do_not_change_results():
                 dict(tile, LSGPU_FRONT_GUESS="8"), {"LSGPU_SSN_GLOBAL": "1"}, {"LSGPU_SSN_FULL_SORT": "1"}, {"LSGPU_SSN_FULL_SORT": "1", "LSGPU_SSN_GLOBAL": "1"},
                 {"LSGPU_SSN_OLD_FINISH": "1"}, {"LSGPU_SSN_ROOT": "2048"}, {"LSGPU_SSN_ROOT": "4096"},   # k_ssn_finish / smaller roots of k_ssn_tree
                 {"LSGPU_SSN_SORT_LEVELS": "1"}, {"LSGPU_SSN_SORT_LEVELS": "1", "LSGPU_SSN_OLD_FINISH": "1"},   # a segmented sort per upper level (round 4) / all of round 4's filter
+                {"LSGPU_THREE_PASS_SELECT": "1"},   # (the select's third pass instead of the normal equations' set-aside ranking: same limit, same sums)
                 {"LSGPU_QUERY_ORDER": "0"},
                 # the fused select (round 6): without it (select kernels / window table), and with room for only 3 distances of
                 # the limit's slice -- fuller slices void the fused iteration, which is repeated with the select in full
