@@ -462,11 +462,11 @@ __device__ __forceinline__ HashEntry* cell_of_key(const TableSet& ts, int l, uin
 // that change there and closes the previous point's cells.
 __global__ __launch_bounds__(256) void k_cells_fill(const uint64_t* __restrict__ keys,
                                                     const uint32_t* __restrict__ bounds,
-                                                    uint32_t nchunks, int fine, int bits, TableSet ts) {
+                                                    uint32_t nchunks, int fine, int bits, TableSet ts, int level0 = 0) {
   // one thread per (chunk, level): the inserts are device-scope CAS round trips, so the levels of one
   // chunk must not queue up behind each other in a single thread
   const uint32_t c = blockIdx.x * 256u + threadIdx.x;
-  const int l = (int)blockIdx.y;
+  const int l = (int)blockIdx.y + level0;
   if (c >= nchunks) return;
   const uint32_t i = bounds[c];
   const uint64_t k = keys[i];

@@ -1024,7 +1024,7 @@ int lsgpu_icp_set_reference(lsgpu_icp* h, const float* ref_xyz1, const float* re
   for (int l = 0; l <= bits; ++l) ncell[l] = hc[l];
   for (int l = 0; l <= bits; ++l) {
     uint32_t c = 4;
-    while (c < 2u * ncell[l]) c <<= 1;
+    while (c < 4u * ncell[l]) c <<= 1;   // (load <= 0.25: the longest probe chain of the benchmark scan's tables is 7 slots)
     cap[l] = c; off[l] = total; total += c;
   }
   HIPC(h->bounds.reserve((size_t)nchunks + 1));
@@ -1051,8 +1051,12 @@ int lsgpu_icp_set_reference(lsgpu_icp* h, const float* ref_xyz1, const float* re
     ts.tab[l] = h->tables.p + off[l]; ts.mask[l] = cap[l] - 1;
     g.tab[l] = ts.tab[l]; g.mask[l] = ts.mask[l];
   }
+  if (getenv("LSGPU_CELLS_SPLIT")) {   // (dev: one launch per level, to time them)
+    for (int l = 0; l <= bits; ++l)
+      hipLaunchKernelGGL(k_cells_fill, dim3((nchunks + 255) / 256, 1), dim3(256), 0, h->stream, h->sc->keys_alt.p, h->bounds.p, nchunks, fine, bits, ts, l);
+  } else
   hipLaunchKernelGGL(k_cells_fill, dim3((nchunks + 255) / 256, bits + 1), dim3(256), 0, h->stream, h->sc->keys_alt.p,
-                     h->bounds.p, nchunks, fine, bits, ts);
+                     h->bounds.p, nchunks, fine, bits, ts, 0);
   HIPC(hipGetLastError());  // (no sync: align / knn follow on the same stream)
   h->grid = g;
   h->nr = nr;
