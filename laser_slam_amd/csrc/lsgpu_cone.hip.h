@@ -256,7 +256,7 @@ template <int WAVES, bool PROBE = false>
 __global__ __launch_bounds__(WAVES * 64, LSGPU_CONE_OCC) void k_knn_cone(KnnArgs a, ConeDev c) {
   __shared__ ConeRec rec[WAVES * 64];          // the searching queries of the block's tiles, packed
   __shared__ unsigned long long ne_mask[16];   // occupied rows, one bit each (<= 1024 rows)
-  __shared__ uint32_t wcount[WAVES];
+  __shared__ uint32_t wcount[WAVES], wbelow[WAVES];
   extern __shared__ float4 rowz_sh[];          // the rows' records {min zeta, max zeta, 1 / (4 min cos e), -}
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
 #ifdef LSGPU_KNN_STATS
@@ -335,22 +335,29 @@ __global__ __launch_bounds__(WAVES * 64, LSGPU_CONE_OCC) void k_knn_cone(KnnArgs
       a.lb[j] = lbn;
     }
   }
+  uint32_t nbelow1 = 0u;
   if (sel_on) {   // the skipped lanes' share of the trimmed-distance select (first two passes, as k_knn_tile)
     const uint32_t bits = __float_as_uint(ub);
     const unsigned long long below = __ballot(act && skip && bits < sel_lo);
     if (act && skip && bits >= sel_lo && bits - sel_lo < sel_span) sel_inside(bits);
-    if (lane == 0 && below) atomicAdd(&a.sel_below[(tile & (kSelBelowSlots - 1)) * kSelBelowStride], (uint32_t)__popcll(below));
+    nbelow1 = (uint32_t)__popcll(below);   // (one atomic per workgroup, behind the pack's first barrier)
   }
   // ---- pack the searching lanes of the block: slot s of the block goes to wave s / 64, entry s % 64 of its area
 #ifdef LSGPU_KNN_STATS
   const long long ts2 = clock64();
 #endif
   const unsigned long long sm = __ballot(act && !skip);
-  if (lane == 0) wcount[w] = (uint32_t)__popcll(sm);
+  if (lane == 0) { wcount[w] = (uint32_t)__popcll(sm); wbelow[w] = nbelow1; }
   cone_barrier_lds();
   uint32_t before = 0, total = 0;
 #pragma unroll
   for (int k = 0; k < WAVES; ++k) { const uint32_t n = wcount[k]; before += k < w ? n : 0u; total += n; }
+  if (sel_on && threadIdx.x == 0) {
+    uint32_t nb = 0u;
+#pragma unroll
+    for (int k = 0; k < WAVES; ++k) nb += wbelow[k];
+    if (nb) atomicAdd(&a.sel_below[(blockIdx.x & (kSelBelowSlots - 1)) * kSelBelowStride], nb);
+  }
   if (act && !skip) {
     ConeRec r;
     r.qx = qx; r.qy = qy; r.qz = qz; r.ub = ub; r.lbn = lbn; r.id_in = id_in; r.j = j; r.pad = 0u;
