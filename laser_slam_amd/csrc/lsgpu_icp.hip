@@ -190,7 +190,7 @@ struct lsgpu_icp {
   SortScratch* sc = &scr_main;
   hipStream_t cur = nullptr;           // == stream except while lsgpu_icp_compute enqueues its side work
   hipStream_t draw_stream = nullptr;   // H2D of the filters' draws, issued by the helper thread that produces them
-  hipEvent_t draws_done = nullptr;
+  hipEvent_t draws_done = nullptr, draws_first_done = nullptr;
   hipStream_t side_stream = nullptr;   // lsgpu_icp_compute: reading filter + query order, beside the grid build
   hipEvent_t side_done = nullptr;
   int side_totals_slot = 0;            // scan_totals staging: the side path uses its own words of h_pinned
@@ -486,6 +486,7 @@ void lsgpu_icp_destroy(lsgpu_icp* h) {
   if (h->copy_done) (void)hipEventDestroy(h->copy_done);
   if (h->ref_up_done) (void)hipEventDestroy(h->ref_up_done);
   if (h->draws_done) (void)hipEventDestroy(h->draws_done);
+  if (h->draws_first_done) (void)hipEventDestroy(h->draws_first_done);
   if (h->draw_stream) { (void)hipStreamSynchronize(h->draw_stream); (void)hipStreamDestroy(h->draw_stream); }
   if (h->side_done) (void)hipEventDestroy(h->side_done);
   if (h->side_stream) { (void)hipStreamSynchronize(h->side_stream); (void)hipStreamDestroy(h->side_stream); }
@@ -1313,15 +1314,18 @@ static int upload_draws_begin(lsgpu_icp* h, int64_t seed, size_t kmax) {
 // reading filter's draws start where the reference filter's end (known once its kernels ran).
 struct DrawAhead {
   lsgpu_icp* h = nullptr;
-  size_t kmax = 0, used = 0;
+  size_t kmax = 0, used = 0, kfirst = 0;
   bool open = false, waited = false, unlocked_early = false;
   hipError_t upload_err = hipSuccess;
+  std::atomic<int> first_sent{0};   // the first `kfirst` draws are on their way to the device (their own event)
   std::thread worker;
   DrawAhead() = default;
   DrawAhead(const DrawAhead&) = delete;
   DrawAhead& operator=(const DrawAhead&) = delete;
-  int begin(lsgpu_icp* hh, int64_t seed, size_t k) {
-    h = hh; kmax = k;
+  // (k_first: draws [0, k_first) are sent off and can be waited for -- ready(k_first) -- before the rest exists)
+  int begin(lsgpu_icp* hh, int64_t seed, size_t k, size_t k_first = 0) {
+    h = hh; kmax = k; kfirst = (k_first && k_first < k) ? k_first : 0;
+    first_sent.store(0, std::memory_order_relaxed);
     if (kmax + 1 > h->draws_pinned_cap) {
       if (h->draws_pinned) (void)hipHostFree(h->draws_pinned);
       h->draws_pinned = nullptr; h->draws_pinned_cap = 0;
@@ -1331,6 +1335,7 @@ struct DrawAhead {
     HIPC(h->ssn_draws.reserve(kmax + 1));
     if (!h->draw_stream) HIPC(hipStreamCreateWithFlags(&h->draw_stream, hipStreamNonBlocking));
     if (!h->draws_done) HIPC(hipEventCreateWithFlags(&h->draws_done, hipEventDisableTiming));
+    if (!h->draws_first_done) HIPC(hipEventCreateWithFlags(&h->draws_first_done, hipEventDisableTiming));
     order_after_tail(h, h->draw_stream);
     DrawStream::global().lock(seed);
     open = true;
@@ -1339,11 +1344,24 @@ struct DrawAhead {
       // 1 M-point clouds) used to sit on the filter's stream in front of k_ssn_select, 0.18 ms of idle device
       lsgpu_icp* hh2 = h;
       auto produce = [hh2, k, this] {
-        DrawStream::global().generate(k, hh2->draws_pinned);
         hipError_t e = hipSetDevice(hh2->device);
-        if (e == hipSuccess) e = hipMemcpyAsync(hh2->ssn_draws.p, hh2->draws_pinned, k * sizeof(float), hipMemcpyHostToDevice, hh2->draw_stream);
+        const size_t kf = kfirst;
+        if (kf) {
+          // the first filter's share leaves as soon as it exists; the rest is still being produced
+          DrawStream::global().generate(k, hh2->draws_pinned, kf, [&] {
+            if (e == hipSuccess) e = hipMemcpyAsync(hh2->ssn_draws.p, hh2->draws_pinned, kf * sizeof(float), hipMemcpyHostToDevice, hh2->draw_stream);
+            if (e == hipSuccess) e = hipEventRecord(hh2->draws_first_done, hh2->draw_stream);
+            upload_err = e;
+            first_sent.store(1, std::memory_order_release);
+          });
+          if (e == hipSuccess) e = hipMemcpyAsync(hh2->ssn_draws.p + kf, hh2->draws_pinned + kf, (k - kf) * sizeof(float), hipMemcpyHostToDevice, hh2->draw_stream);
+        } else {
+          DrawStream::global().generate(k, hh2->draws_pinned);
+          if (e == hipSuccess) e = hipMemcpyAsync(hh2->ssn_draws.p, hh2->draws_pinned, k * sizeof(float), hipMemcpyHostToDevice, hh2->draw_stream);
+        }
         if (e == hipSuccess) e = hipEventRecord(hh2->draws_done, hh2->draw_stream);
         upload_err = e;
+        first_sent.store(1, std::memory_order_release);
       };
       try {
         worker = std::thread(produce);
@@ -1353,7 +1371,13 @@ struct DrawAhead {
     }
     return LSGPU_OK;
   }
-  int ready() {   // the stream the caller enqueues on (h->cur) waits for the draws
+  int ready(size_t upto = ~(size_t)0) {   // the stream the caller enqueues on (h->cur) waits for the draws [0, upto)
+    if (kmax && kfirst && upto <= kfirst) {   // the first part has its own event: no need for the rest to exist yet
+      while (!first_sent.load(std::memory_order_acquire)) std::this_thread::yield();
+      if (upload_err != hipSuccess) { (void)hipGetLastError(); HIPC(upload_err); }
+      HIPC(hipStreamWaitEvent(h->cur, h->draws_first_done, 0));
+      return LSGPU_OK;
+    }
     if (worker.joinable()) worker.join();
     if (kmax) {
       if (upload_err != hipSuccess) { (void)hipGetLastError(); HIPC(upload_err); }
@@ -1656,7 +1680,7 @@ static int ssn_device(lsgpu_icp* h, const float4* src, int64_t n, int knn, float
   int rc = scan_u32(h, h->ssn_box_pts.p, h->ssn_box_base.p, nseg);
   if (rc) return rc;
   // the draws: at most one per point; produced on the helper thread while the kernels above were enqueued
-  rc = ahead->ready();
+  rc = ahead->ready(first_draw + (size_t)n);
   if (rc) return rc;
   hipLaunchKernelGGL(k_ssn_select, dim3(nblk(n)), dim3(256), 0, h->stream, (int)n, idx, h->ssn_seg_of.p, cur,
                      h->ssn_box_pts.p, h->ssn_box_base.p, h->ssn_draws.p + first_draw, ratio, h->ssn_keep.p);
@@ -1790,7 +1814,7 @@ int lsgpu_icp_compute(lsgpu_icp* h, const float* reading_xyz1, int64_t nq, const
   // reading point
   DrawAhead draws;
   {
-    const int rc0 = draws.begin(h, -1, (size_t)nr + (chain->reading_prob < 0.f ? (size_t)0 : (size_t)nq));
+    const int rc0 = draws.begin(h, -1, (size_t)nr + (chain->reading_prob < 0.f ? (size_t)0 : (size_t)nq), (size_t)nr);   // (the reference filter's share first)
     if (rc0) return rc0;
   }
   // step 1: reference filter (yaml:5-7)

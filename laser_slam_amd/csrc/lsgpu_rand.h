@@ -7,16 +7,23 @@
 // r >> 1, seeded by the Lehmer recurrence 16807 and 310 discarded outputs), so that
 //   * a seeded filter call selects exactly the points the sequential CPU chain selects,
 //   * no global libc state is touched (handles on different threads do not race on rand()),
-//   * the draws of a whole cloud can be produced while the device works: ~1.3 ns each on one core, and for requests of
-//     16 segments (about a million draws) or more on up to 8 threads -- the recurrence is linear over Z/2^32, so the state
+//   * the draws of a whole cloud can be produced while the device works: ~0.8-1.3 ns each on one core, and for requests of
+//     8 segments (half a million draws) or more on up to 8 threads -- the recurrence is linear over Z/2^32, so the state
 //     65536 draws ahead is one 31 x 31 matrix product away (jump-ahead), and the segments are filled independently
 //     (3.1 M draws of a three-scan sub-map: 4.2 ms -> 0.7 ms; it used to be the longest item of a LaserTrack scan).
+//     Round 6: the threads are a standing pool (spawning eight cost 0.1 ms of a 0.5 ms request), they take the segments
+//     IN ORDER, and the caller can be told as soon as the first k_first draws are there -- the reference filter's share
+//     of a compute's draws goes to the device while the reading filter's is still being produced (the device used to
+//     idle 0.3 ms in front of k_ssn_select, the whole request's production and upload ahead of it).
 // seed >= 0 reseeds the stream; seed < 0 continues it (like calling rand() again).  An unseeded
 // stream starts as srand(1), the C default.  tests/test_abi.py compares the sequence with libc's.
 #pragma once
 #include <cstddef>
 #include <cstdint>
 #include <algorithm>
+#include <atomic>
+#include <condition_variable>
+#include <functional>
 #include <mutex>
 #include <thread>
 #include <vector>
@@ -64,7 +71,10 @@ class DrawStream {
     mu_.lock();
     if (seed >= 0) reseed_locked((unsigned)seed);
   }
-  void generate(size_t kmax, float* out) { generate_locked(kmax, out); }
+  // (k_first / on_first: called on this thread once draws [0, k_first) are in `out` -- the rest follows)
+  void generate(size_t kmax, float* out, size_t k_first = 0, const std::function<void()>& on_first = nullptr) {
+    generate_locked(kmax, out, k_first, on_first);
+  }
 
   static DrawStream& global() {
     static DrawStream s;
@@ -123,10 +133,59 @@ class DrawStream {
     for (size_t j = 0; j * kSub <= len; ++j)
       for (int i = 0; i < 31; ++i) snaps[j * 31 + i] = w[j * kSub + i];
   }
+  // ---- a standing pool for the parallel requests (the stream is locked while it works: one job at a time)
+  struct Pool {
+    std::mutex mu;
+    std::condition_variable cv;
+    std::vector<std::thread> threads;
+    std::function<void()> job;     // every worker runs it once per generation
+    unsigned generation = 0;
+    int running = 0;
+    bool stop = false;
+    explicit Pool(size_t n) {
+      for (size_t t = 0; t < n; ++t)
+        threads.emplace_back([this] {
+          unsigned seen = 0;
+          for (;;) {
+            std::function<void()> f;
+            {
+              std::unique_lock<std::mutex> lk(mu);
+              cv.wait(lk, [&] { return stop || generation != seen; });
+              if (stop) return;
+              seen = generation;
+              f = job;
+            }
+            f();
+            {
+              std::lock_guard<std::mutex> lk(mu);
+              --running;
+            }
+            cv.notify_all();
+          }
+        });
+    }
+    ~Pool() {
+      { std::lock_guard<std::mutex> lk(mu); stop = true; }
+      cv.notify_all();
+      for (auto& t : threads) t.join();
+    }
+    void start(const std::function<void()>& f) {
+      { std::lock_guard<std::mutex> lk(mu); job = f; running = (int)threads.size(); ++generation; }
+      cv.notify_all();
+    }
+    void wait() {
+      std::unique_lock<std::mutex> lk(mu);
+      cv.wait(lk, [&] { return running == 0; });
+    }
+  };
+  static Pool& pool() {
+    static Pool p(std::min<size_t>(7, std::max(1u, std::thread::hardware_concurrency()) - 1));   // (+ the calling thread)
+    return p;
+  }
   // raw_[0..31) = the last 31 raw words (oldest first), raw_[31 + i] = the i-th not yet consumed word
-  void generate_locked(size_t k, float* out) {
+  void generate_locked(size_t k, float* out, size_t k_first = 0, const std::function<void()>& on_first = nullptr) {
     seg_states_.clear();
-    if (out && k >= 16 * kSeg) {   // large request (a sub-map of several scans): segment start states by jump-ahead, segments filled in parallel
+    if (out && k >= 8 * kSeg && pool().threads.size() > 0) {   // large request: segment start states by jump-ahead, segments filled in parallel
       const size_t nseg = (k + kSeg - 1) / kSeg;
       const Mat& J = jump();
       seg_states_.resize((nseg + 1) * 31);
@@ -140,20 +199,43 @@ class DrawStream {
           b[i] = t;
         }
       }
-      const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
-      const size_t nthreads = std::min<size_t>(std::min<size_t>(nseg, 8), hw);
       constexpr size_t kSnapsPerSeg = kSeg / kSub + 1;
       sub_states_.resize(nseg * kSnapsPerSeg * 31);
-      auto work = [&](size_t t) {
+      // the segments are taken in order (one counter); done[] says which are complete
+      std::atomic<size_t> next{0};
+      std::vector<std::atomic<unsigned char>> done(nseg);
+      for (auto& d : done) d.store(0, std::memory_order_relaxed);
+      auto work = [&] {
         std::vector<uint32_t> scratch;
-        for (size_t sg = t; sg < nseg; sg += nthreads)
+        for (;;) {
+          const size_t sg = next.fetch_add(1, std::memory_order_relaxed);
+          if (sg >= nseg) return;
           fill_segment(&seg_states_[sg * 31], std::min(kSeg, k - sg * kSeg), out + sg * kSeg, &scratch,
                        &sub_states_[sg * kSnapsPerSeg * 31]);
+          done[sg].store(1, std::memory_order_release);
+        }
       };
-      std::vector<std::thread> pool;
-      for (size_t t = 1; t < nthreads; ++t) pool.emplace_back(work, t);
-      work(0);
-      for (auto& th : pool) th.join();
+      pool().start(work);
+      const size_t first_segs = on_first ? std::min(nseg, (k_first + kSeg - 1) / kSeg) : 0;
+      if (on_first && first_segs < nseg) {
+        // this thread helps with the first part's segments, then tells the caller, then helps with the rest
+        std::vector<uint32_t> scratch;
+        for (;;) {
+          const size_t seen = next.load(std::memory_order_relaxed);
+          if (seen >= first_segs) break;
+          const size_t sg = next.fetch_add(1, std::memory_order_relaxed);
+          if (sg >= nseg) break;
+          fill_segment(&seg_states_[sg * 31], std::min(kSeg, k - sg * kSeg), out + sg * kSeg, &scratch,
+                       &sub_states_[sg * kSnapsPerSeg * 31]);
+          done[sg].store(1, std::memory_order_release);
+        }
+        for (size_t sg = 0; sg < first_segs; ++sg)
+          while (!done[sg].load(std::memory_order_acquire)) std::this_thread::yield();
+        on_first();
+      }
+      work();
+      pool().wait();
+      if (on_first && first_segs >= nseg) on_first();
       seg_k_ = k;
       return;
     }
@@ -163,6 +245,7 @@ class DrawStream {
     for (size_t i = 0; i < k; ++i) w[i + 31] = w[i] + w[i + 28];
     if (out)
       for (size_t i = 0; i < k; ++i) out[i] = (float)(w[i + 31] >> 1) / 2147483648.0f;  // (float)RAND_MAX == 2^31
+    if (on_first) on_first();
   }
   void commit_locked(size_t k) {
     if (!seg_states_.empty()) {   // (parallel request: replay from the last snapshot in front of draw k, < kSub steps)
