@@ -1482,7 +1482,10 @@ static int ssn_device(lsgpu_icp* h, const float4* src, int64_t n, int knn, float
   int glevels = 0;
   // (k_ssn_tree: up to ssn_root points and log2(ssn_root / 8) levels per workgroup; k_ssn_finish, LSGPU_SSN_OLD_FINISH: 2048 / 8)
   const bool tree_finish = !tuning().ssn_old_finish;
-  const int root_max = tree_finish ? tuning().ssn_root : kSsnLdsMax;
+  // (one workgroup per root: 8192-point roots leave half the chip idle on a scan of a million points -- 128 roots, 248 us --
+  // where 4096-point roots and one more global level take 50 us less; a three-scan sub-map has 383 roots of 8192)
+  const int root_auto = n >= 200ll * 8192 ? 8192 : n >= 200ll * 4096 ? 4096 : 2048;
+  const int root_max = tree_finish ? (tuning().ssn_root ? tuning().ssn_root : root_auto) : kSsnLdsMax;
   int root_levels = kSsnLdsLevels;
   if (tree_finish) { root_levels = 0; while ((8 << root_levels) < root_max) ++root_levels; }
   {

@@ -93,7 +93,7 @@ struct Tuning {
   bool ssn_full_sort = false;
   bool ssn_old_finish = false;
   bool ssn_sort_levels = false;
-  int ssn_root = 8192;
+  int ssn_root = 0;   // points per root of k_ssn_tree (2048 / 4096 / 8192); 0: by the cloud's size, so that there are about as many roots as compute units
   int ne_blocks = 256;
   bool split_update = false;
   double comm_timeout_ms = 30000.0;
@@ -165,10 +165,10 @@ inline Tuning read() {
   t.ssn_full_sort = flag("LSGPU_SSN_FULL_SORT");
   t.ssn_old_finish = flag("LSGPU_SSN_OLD_FINISH");
   t.ssn_sort_levels = flag("LSGPU_SSN_SORT_LEVELS");
-  t.ssn_root = (int)number("LSGPU_SSN_ROOT", 8192, 2048, 8192);
-  if (t.ssn_root != 2048 && t.ssn_root != 4096 && t.ssn_root != 8192) {
-    fprintf(stderr, "liblsgpu_icp: LSGPU_SSN_ROOT must be 2048, 4096 or 8192; using 8192\n");
-    t.ssn_root = 8192;
+  t.ssn_root = (int)number("LSGPU_SSN_ROOT", 0, 0, 8192);
+  if (t.ssn_root != 0 && t.ssn_root != 2048 && t.ssn_root != 4096 && t.ssn_root != 8192) {
+    fprintf(stderr, "liblsgpu_icp: LSGPU_SSN_ROOT must be 2048, 4096 or 8192; choosing by size\n");
+    t.ssn_root = 0;
   }
   t.ne_blocks = (int)number("LSGPU_NE_BLOCKS", 256, 64, 2048);
   t.comm_timeout_ms = number("LSGPU_COMM_TIMEOUT_MS", 30000, 1, 1e9);
