@@ -721,9 +721,9 @@ static int run_knn(lsgpu_icp* h, const Mat34& T, const IcpState* st, const polic
   if (seed) hipLaunchKernelGGL(k_knn_seed, dim3(nblk(nq)), dim3(256), 0, h->stream, a);
   if (seed && capped && st && seed_rank != 0xFFFFFFFFu) {
     // first iteration of an align: cap = trim quantile of the seed distances (k_knn_seed left them in d2)
-    const int rs = run_select(h, h->d2.p, nq, seed_rank, false /* k_align_init armed the tables */, st, true, false);
+    const int rs = run_select(h, h->d2.p, nq, seed_rank, false /* k_align_init armed the tables */, st, true, false, 2);
     if (rs) return rs;
-    hipLaunchKernelGGL(k_seed_cap, dim3(1), dim3(256), 0, h->stream, h->hist.p, h->sel.p + 2, h->state.p);
+    hipLaunchKernelGGL(k_seed_cap, dim3(1), dim3(256), 0, h->stream, h->hist.p, h->sel.p + 1, h->state.p);
   }
   // two launches of every alignment are timed for policy::index_not_paying (not in profiled runs: they time everything)
   const bool pay_probe = !timed && st && pol.cone_ok && h->ev_pay[0];

@@ -166,7 +166,12 @@ __global__ __launch_bounds__(256) void k_seed_cap(uint32_t* __restrict__ hist /*
                                                   const SelState* __restrict__ st, IcpState* __restrict__ ist) {
   __shared__ uint32_t sc[260];
   if (ist->done) return;
-  const float lim = select_limit(hist + 2 * kHistBins, st, sc);
+  // (two passes of the select ran: the UPPER edge of the second pass's bin that holds the order statistic -- a bound
+  // is all the cap has to be, and that edge lies within 6e-5 of the exact value; st = the state after the first pass)
+  const SelState in = *st;
+  uint32_t bin, krem;
+  find_bin(hist + kHistBins, kHistBins, in.k, &bin, &krem, sc);
+  const float lim = __uint_as_float((((in.prefix << 11) | bin) << 9) | 0x1FFu);
   if (threadIdx.x == 0) ist->cap2 = lim;
   for (int i = threadIdx.x; i < 3 * kHistBins; i += 256) hist[i] = 0u;   // re-armed for the iteration's own select
 }
