@@ -183,11 +183,11 @@ inline Tuning read() {
   t.cone_cols = (int)number("LSGPU_CONE_COLS", 8192, 64, 65536) & ~3;
   static const char* known[] = {"LSGPU_QUERY_ORDER", "LSGPU_Q_ELEV", "LSGPU_Q_SECT", "LSGPU_GAP", "LSGPU_BUDGET", "LSGPU_BUDGET_WIDE", "LSGPU_WIDE_ITERS",
                                 "LSGPU_ROUTE_R", "LSGPU_ROUTE_CHUNKS", "LSGPU_ROUTE_DENSE", "LSGPU_SPLIT_UPDATE", "LSGPU_NO_PREDICT", "LSGPU_NO_COMMIT",
-                                "LSGPU_NO_COMM_COMMIT", "LSGPU_NO_SEED_CAP", "LSGPU_NO_FRONT", "LSGPU_NO_LAZY", "LSGPU_NO_SIDE_STREAM", "LSGPU_NO_LOOKAHEAD", "LSGPU_NO_INDEX_REST", "LSGPU_NO_FUSED_SELECT", "LSGPU_THREE_PASS_SELECT", "LSGPU_SEL_AMB_CAP", "LSGPU_FRONT_GUESS", "LSGPU_NO_ROUTE_ALL",
+                                "LSGPU_NO_COMM_COMMIT", "LSGPU_NO_SEED_CAP", "LSGPU_NO_FRONT", "LSGPU_NO_LAZY", "LSGPU_NO_SIDE_STREAM", "LSGPU_NO_LOOKAHEAD", "LSGPU_NO_INDEX_REST", "LSGPU_CELLS_SPLIT", "LSGPU_NO_FUSED_SELECT", "LSGPU_THREE_PASS_SELECT", "LSGPU_SEL_AMB_CAP", "LSGPU_FRONT_GUESS", "LSGPU_NO_ROUTE_ALL",
                                 "LSGPU_NO_ROWQ", "LSGPU_ROWQ_BLOCKS", "LSGPU_SORT_ITEMS", "LSGPU_SSN_GLOBAL", "LSGPU_SSN_FULL_SORT", "LSGPU_SSN_OLD_FINISH", "LSGPU_SSN_ROOT", "LSGPU_SSN_SORT_LEVELS",
                                 "LSGPU_NE_BLOCKS", "LSGPU_COMM_TIMEOUT_MS", "LSGPU_KNN_DBG", "LSGPU_NO_CONE", "LSGPU_NO_CONE_PROBE", "LSGPU_CONE_ROWS", "LSGPU_CONE_COLS", "LSGPU_CONE_FROM", "LSGPU_CONE_MAX_OCC", "LSGPU_CONE_HEAVY_STEPS", "LSGPU_CONE_HEAVY_SHARE",
                                 // read by the Python / C++ hosts and the test drivers, not by this library:
-                                "LSGPU_SO", "LSGPU_STATS_SO", "LSGPU_GS_DEBUG", "LSGPU_GOLDEN_DIR", "LSGPU_SEQ_PERTURB", "LSGPU_SEQ_POSES", "LSGPU_TEST_INPUT_FILTERS",
+                                "LSGPU_SO", "LSGPU_STATS_SO", "LSGPU_BATCH_POOLS", "LSGPU_BATCH_UNIQ", "LSGPU_GS_DEBUG", "LSGPU_GOLDEN_DIR", "LSGPU_SEQ_PERTURB", "LSGPU_SEQ_POSES", "LSGPU_TEST_INPUT_FILTERS",
 #ifdef LSGPU_EXPERIMENTS
                                 "LSGPU_KNN_ROWS", "LSGPU_KNN_LANE", "LSGPU_SPARSE_LANES", "LSGPU_TILE_WAVES", "LSGPU_XCD_SWIZZLE", "LSGPU_ROCPRIM_SORT",
 #endif
