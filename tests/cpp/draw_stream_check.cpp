@@ -47,6 +47,32 @@ int main() {
     if (mism) { std::printf("two-step kmax %zu k %zu: %zu mismatches\n", kmax, k1 + k2, mism); ++bad; }
     ++seed;
   }
+  // round 6: the caller is told as soon as the first k_first draws exist (the reference filter's share leaves for the
+  // device while the reading filter's is still being produced) -- they must be final at that moment, whichever threads
+  // of the pool filled them, and the whole request must still be the rand() sequence afterwards
+  const size_t early[][2] = {{2092367, 1046335}, {4185022, 3139020}, {1048576, 65536}, {600000, 599999}, {100000, 50000}, {2000000, 2000000}};
+  for (const auto& c : early) {
+    const size_t kmax = c[0], kfirst = c[1];
+    std::vector<float> got(kmax), first_copy;
+    lsgpu::DrawStream::global().lock((int64_t)seed);
+    float* dst = got.data();
+    int calls = 0;
+    std::thread worker([&] {
+      lsgpu::DrawStream::global().generate(kmax, dst, kfirst, [&] { ++calls; first_copy.assign(dst, dst + kfirst); });
+    });
+    worker.join();
+    lsgpu::DrawStream::global().commit(kmax);
+    srand(seed);
+    size_t mism = calls == 1 ? 0 : 1;
+    for (size_t i = 0; i < kmax; ++i) {
+      const float want = (float)rand() / (float)RAND_MAX;
+      mism += got[i] != want;
+      if (i < kfirst && i < first_copy.size()) mism += first_copy[i] != want;
+    }
+    mism += first_copy.size() != kfirst;
+    if (mism) { std::printf("early kmax %zu kfirst %zu: %zu mismatches (%d calls)\n", kmax, kfirst, mism, calls); ++bad; }
+    ++seed;
+  }
   std::printf(bad ? "DRAWS_FAIL\n" : "DRAWS_OK\n");
   return bad ? 1 : 0;
 }
