@@ -124,6 +124,9 @@ struct IcpState {
   int sel_shift;      // ... log2 of a slice's width (aligned mode: 9)
   int sel_wide;       // set by the host at the start of an align
   int sel_fails;      // iterations the fused / predicted select voided; after the second the alignment keeps to the select kernels
+  // the differential checker's two smoothed changes of the last completed iteration (0: history still short): the host
+  // estimates from them how many iterations are left and does not enqueue a full group of launches in front of the end
+  float chk_rot, chk_trans;
 };
 constexpr int kSelBelowSlots = 64;   // counters of "distance below the predicted bin", hashed by tile ...
 constexpr int kSelBelowStride = 32;  // ... one per 128-byte line (atomics on one line serialise in L2)

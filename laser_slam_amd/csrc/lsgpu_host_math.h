@@ -165,8 +165,11 @@ LSGPU_HD void checker_push(CheckerState* s, float* hist, const float* T) {
 }
 
 // false => NaN (ConvergenceError).  *iterate is cleared when a checker says stop.
+// (out2: the two smoothed changes the differential checker compared with its limits, 0 while its history is short --
+// the device's loop state carries them to the host, which sizes its next group of launches from them)
 LSGPU_HD bool checker_check(CheckerState* s, float* hist, int max_iter, int smooth, float lim_rot,
-                            float lim_trans, const float* T, bool* iterate, bool* by_diff) {
+                            float lim_trans, const float* T, bool* iterate, bool* by_diff, float* out2 = nullptr) {
+  if (out2) { out2[0] = 0.f; out2[1] = 0.f; }
   if (++s->counter >= max_iter) { *iterate = false; return true; }  // MaxNumIterationsReached
   checker_push(s, hist, T);
   float rot = 0.f, trans = 0.f;
@@ -181,6 +184,7 @@ LSGPU_HD bool checker_check(CheckerState* s, float* hist, int max_iter, int smoo
     }
     rot /= (float)smooth;
     trans /= (float)smooth;
+    if (out2) { out2[0] = rot; out2[1] = trans; }
     if (rot < lim_rot && trans < lim_trans) { *iterate = false; *by_diff = true; }
   }
   return !(rot != rot || trans != trans);

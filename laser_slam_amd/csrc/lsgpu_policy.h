@@ -12,6 +12,7 @@
 // None of the decisions changes a result (every path is an exact search / an exact order statistic); they decide what
 // an iteration costs.
 #pragma once
+#include <cmath>
 #include <cstdint>
 
 namespace lsgpu {
@@ -63,6 +64,7 @@ enum class LookVerdict { Continue, RepeatUncapped, RepeatSelect, Done, GiveUp };
 
 struct LookInput {            // what a look at the loop state shows (IcpState fields)
   int done = 0, status = 0, iter = 0, sel_streak = 0;
+  float chk_rot = 0.f, chk_trans = 0.f, lim_rot = 0.f, lim_trans = 0.f;   // the differential checker's smoothed changes and limits (0: not known)
   unsigned long long stragglers = 0;
   int64_t nq = 0;
   int status_cap_failed = 100, status_sel_failed = 101;
@@ -87,6 +89,11 @@ struct State {
   int cone_launches = 0;
   int look_iter = 0;
   unsigned long long look_strag = 0;
+  // ---- the end of the alignment, as far as the checker's trend shows it: launches enqueued behind the iteration that
+  // raises `done` exit at once but still cost ~10 us each, and a group of six put four or five of them there
+  int group_now = 0;            // iterations of the group being enqueued (0: Config::group)
+  float trend_rot = 0.f, trend_trans = 0.f;   // the smoothed changes at the last look ...
+  int trend_iter = -1;          // ... and its iteration
 
   void begin_align(bool index_built, bool decided, bool dense, float occupancy) {
     *this = State();
@@ -113,10 +120,10 @@ struct State {
 
   // the loop between two looks: true -> enqueue a plain iteration (fills `it`), false -> look at the loop state
   bool next_in_group(const Config& c, Iteration* it) {
-    if (!(enq < c.enq_limit && since_check < c.group)) return false;
+    if (!(enq < c.enq_limit && since_check < (group_now > 0 ? group_now : c.group))) return false;
     // an alignment the index was too dear for prices it again with the LAST launch in front of the look: the counters
     // travel in front of the look's state copy
-    const bool price_next = cone_off_price && since_check == c.group - 1;
+    const bool price_next = cone_off_price && since_check == (group_now > 0 ? group_now : c.group) - 1;
     *it = plan(c, false, true, enq < c.wide_iters, true, price_next);
     ++enq; ++since_check;
     return true;
@@ -176,6 +183,7 @@ struct State {
         (double)(s.stragglers - look_strag) > c.straggler_share * (double)s.nq * (double)(s.iter - look_iter))
       cone_off = true;
     look_iter = s.iter; look_strag = s.stragglers;
+    group_now = estimate_group(c, s, enqueued_ahead);
     if (wants_reprice() && repriced_share >= 0.f) {   // priced again by the last launch in front of this look: cheap enough by now?
       cone_heavy = repriced_share;
       if (repriced_share <= c.cone_heavy_share) { cone_off = false; cone_off_price = false; }
@@ -186,6 +194,29 @@ struct State {
     if (s.done) return LookVerdict::Done;
     if (enq >= c.enq_limit) return LookVerdict::GiveUp;
     return LookVerdict::Continue;
+  }
+  // How many iterations the next group should hold: the smoothed changes shrink geometrically towards their limits (the
+  // factor per iteration from this look and the last, between 0.5 and 0.97); the alignment ends with the first iteration
+  // at which BOTH are below.  One iteration of margin; never more than Config::group, never fewer than one.
+  int estimate_group(const Config& c, const LookInput& s, int enqueued_ahead) {
+    int g = c.group;
+    const bool known = s.chk_trans > 0.f && s.chk_rot >= 0.f && s.lim_trans > 0.f && s.lim_rot > 0.f;
+    if (known && trend_iter >= 0 && s.iter > trend_iter && trend_trans > 0.f) {
+      auto left = [&](float now, float then, float lim) -> float {
+        if (!(now > lim)) return 0.f;
+        float f = then > 0.f && now < then ? std::pow(now / then, 1.f / (float)(s.iter - trend_iter)) : 0.97f;
+        f = f < 0.5f ? 0.5f : f > 0.97f ? 0.97f : f;
+        return std::log(now / lim) / std::log(1.f / f);
+      };
+      const float rem = std::fmax(left(s.chk_trans, trend_trans, s.lim_trans), left(s.chk_rot, trend_rot, s.lim_rot));
+      // the group counts the iteration that is already out behind this look (next_in_group starts at `enqueued_ahead`):
+      // the iterations still needed + one of margin
+      (void)enqueued_ahead;
+      const int want = (int)std::ceil(rem) + 1;
+      g = want < 1 ? 1 : want > c.group ? c.group : want;
+    }
+    if (known) { trend_rot = s.chk_rot; trend_trans = s.chk_trans; trend_iter = s.iter; }
+    return g;
   }
   // the repeat paths: the cap prediction failed (repeat the iteration uncapped), the select prediction missed (the
   // distances stand: select + normal equations again, no search)

@@ -372,8 +372,10 @@ __device__ inline void icp_update_lane(IcpState* st, const double* ne_out, float
   st->iter = it + 1;
   hostmath::CheckerState cs{st->counter, st->n_hist};
   bool iterate = true, by_diff = false;
+  float chk2[2];
   const bool ok = hostmath::checker_check(&cs, chk_hist, st->max_iter, st->smooth, st->lim_rot,
-                                          st->lim_trans, Tn, &iterate, &by_diff);
+                                          st->lim_trans, Tn, &iterate, &by_diff, chk2);
+  st->chk_rot = chk2[0]; st->chk_trans = chk2[1];
   st->counter = cs.counter; st->n_hist = cs.n_hist;
 #ifdef LSGPU_KNN_STATS
   {

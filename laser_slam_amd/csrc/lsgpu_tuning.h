@@ -78,6 +78,7 @@ struct Tuning {
   bool predict_select = true, commit_select = true, comm_commit = true, seed_cap = true;
   int sel_amb_cap = 256;      // ... setting aside at most this many distances of the limit's slice (<= kSelAmbCap; a test knob: the sums' order changes with it)
   bool two_pass_select = true;   // ... also where the select kernels run: they stop after their second pass (LSGPU_THREE_PASS_SELECT)
+  bool short_last_group = true;   // the host sizes a group of launches from the checker's trend (LSGPU_FULL_GROUPS: always six)
   bool fused_select = true;   // the normal-equation kernel finds the trim limit itself (LSGPU_NO_FUSED_SELECT: the select kernels / the window table)
   bool front = true;
   bool lazy_need = true;
@@ -143,6 +144,7 @@ inline Tuning read() {
   t.predict_select = !flag("LSGPU_NO_PREDICT") && !t.split_update;
   t.commit_select = !flag("LSGPU_NO_COMMIT");
   t.fused_select = !flag("LSGPU_NO_FUSED_SELECT");
+  t.short_last_group = !flag("LSGPU_FULL_GROUPS");
   t.two_pass_select = !flag("LSGPU_THREE_PASS_SELECT");
   t.sel_amb_cap = (int)number("LSGPU_SEL_AMB_CAP", 256, 0, 256);
   t.comm_commit = !flag("LSGPU_NO_COMM_COMMIT");
@@ -183,7 +185,7 @@ inline Tuning read() {
   t.cone_cols = (int)number("LSGPU_CONE_COLS", 8192, 64, 65536) & ~3;
   static const char* known[] = {"LSGPU_QUERY_ORDER", "LSGPU_Q_ELEV", "LSGPU_Q_SECT", "LSGPU_GAP", "LSGPU_BUDGET", "LSGPU_BUDGET_WIDE", "LSGPU_WIDE_ITERS",
                                 "LSGPU_ROUTE_R", "LSGPU_ROUTE_CHUNKS", "LSGPU_ROUTE_DENSE", "LSGPU_SPLIT_UPDATE", "LSGPU_NO_PREDICT", "LSGPU_NO_COMMIT",
-                                "LSGPU_NO_COMM_COMMIT", "LSGPU_NO_SEED_CAP", "LSGPU_NO_FRONT", "LSGPU_NO_LAZY", "LSGPU_NO_SIDE_STREAM", "LSGPU_NO_LOOKAHEAD", "LSGPU_NO_INDEX_REST", "LSGPU_CELLS_SPLIT", "LSGPU_NO_FUSED_SELECT", "LSGPU_THREE_PASS_SELECT", "LSGPU_SEL_AMB_CAP", "LSGPU_FRONT_GUESS", "LSGPU_NO_ROUTE_ALL",
+                                "LSGPU_NO_COMM_COMMIT", "LSGPU_NO_SEED_CAP", "LSGPU_NO_FRONT", "LSGPU_NO_LAZY", "LSGPU_NO_SIDE_STREAM", "LSGPU_NO_LOOKAHEAD", "LSGPU_NO_INDEX_REST", "LSGPU_CELLS_SPLIT", "LSGPU_NO_FUSED_SELECT", "LSGPU_FULL_GROUPS", "LSGPU_THREE_PASS_SELECT", "LSGPU_SEL_AMB_CAP", "LSGPU_FRONT_GUESS", "LSGPU_NO_ROUTE_ALL",
                                 "LSGPU_NO_ROWQ", "LSGPU_ROWQ_BLOCKS", "LSGPU_SORT_ITEMS", "LSGPU_SSN_GLOBAL", "LSGPU_SSN_FULL_SORT", "LSGPU_SSN_OLD_FINISH", "LSGPU_SSN_ROOT", "LSGPU_SSN_SORT_LEVELS",
                                 "LSGPU_NE_BLOCKS", "LSGPU_COMM_TIMEOUT_MS", "LSGPU_KNN_DBG", "LSGPU_NO_CONE", "LSGPU_NO_CONE_PROBE", "LSGPU_CONE_ROWS", "LSGPU_CONE_COLS", "LSGPU_CONE_FROM", "LSGPU_CONE_MAX_OCC", "LSGPU_CONE_HEAVY_STEPS", "LSGPU_CONE_HEAVY_SHARE",
                                 // read by the Python / C++ hosts and the test drivers, not by this library:
