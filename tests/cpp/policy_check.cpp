@@ -11,6 +11,7 @@
 //   * the split-scan mode: no look-ahead, predicted select only in committed iterations.
 #include <cstdio>
 #include <cstdlib>
+#include <cmath>
 #include <vector>
 #include "../../laser_slam_amd/csrc/lsgpu_policy.h"
 
@@ -32,6 +33,7 @@ struct Sim {
   int searches = 0;
   int sel_streak_from = 1 << 30;       // iteration from which the device reports a steady limit
   int fail_cap_at = -1, fail_sel_at = -1;
+  float trend0 = 0.f, trend_factor = 0.f;   // the checker's smoothed translation change: trend0 * factor^iteration (0: the device reports none)
 
   void run_search(const Iteration& it, bool lookahead) {
     // exactly what run_knn does with the policy (lsgpu_icp.hip)
@@ -67,6 +69,7 @@ struct Sim {
       li.iter = iter_at_copy < device_done_after ? iter_at_copy : device_done_after;
       li.done = iter_at_copy >= device_done_after;
       li.sel_streak = li.iter >= sel_streak_from ? 3 : 0;
+      if (trend0 > 0.f) { li.lim_rot = 1e-5f; li.lim_trans = 1e-4f; li.chk_rot = 1e-6f; li.chk_trans = trend0 * std::pow(trend_factor, (float)li.iter); }
       if (fail_cap_at >= 0 && iter_at_copy > fail_cap_at) { li.done = 1; li.status = li.status_cap_failed; li.iter = fail_cap_at; fail_cap_at = -1; }
       else if (fail_sel_at >= 0 && iter_at_copy > fail_sel_at) { li.done = 1; li.status = li.status_sel_failed; li.iter = fail_sel_at; fail_sel_at = -1; }
       float share = -1.f;
@@ -101,6 +104,19 @@ int main() {
     CHECK(m.log[6].lookahead && m.log[12].lookahead && !m.log[5].lookahead && !m.log[7].lookahead);
     CHECK(looks == 4 && m.s.cone_launches == (int)m.log.size() - 2);
     for (auto& e : m.log) CHECK(!e.it.committed);   // the device never reported a steady limit
+  }
+  {  // ---- the last groups follow the checker's trend: the smoothed change shrinks by 0.86 per iteration and falls below its
+     // limit at iteration 32 -- no more than two launches may be left behind the end (a fixed group of six leaves up to six)
+    Sim m; m.c = base_config(); m.trend0 = 1e-4f / std::pow(0.86f, 31.5f); m.trend_factor = 0.86f; m.device_done_after = 32;
+    const int looks = m.align(true);
+    CHECK((int)m.log.size() >= 32 && (int)m.log.size() <= 32 + 2);
+    CHECK(looks >= 6 && looks <= 10);
+    Sim f; f.c = base_config(); f.device_done_after = 32;     // no trend reported: groups of six as ever
+    f.align(true);
+    CHECK((int)f.log.size() > 32 + 2);
+    // a trend that stalls (factor 1) must not shrink the groups to nothing for ever: the estimate is clamped, groups stay >= 1
+    Sim st; st.c = base_config(); st.trend0 = 5e-4f; st.trend_factor = 1.0f; st.device_done_after = 40;
+    CHECK(st.align(true) < 100);
   }
   {  // ---- a denser reference: the index waits one iteration more; a too dense one is never used
     Sim m; m.c = base_config(); m.occupancy = 4.3f; m.align(true);
