@@ -127,6 +127,7 @@ struct IcpState {
   // the differential checker's two smoothed changes of the last completed iteration (0: history still short): the host
   // estimates from them how many iterations are left and does not enqueue a full group of launches in front of the end
   float chk_rot, chk_trans;
+  float chk_rot_prev, chk_trans_prev;   // ... and of the iteration before it (a first look has no earlier look to compare with)
 };
 constexpr int kSelBelowSlots = 64;   // counters of "distance below the predicted bin", hashed by tile ...
 constexpr int kSelBelowStride = 32;  // ... one per 128-byte line (atomics on one line serialise in L2)

@@ -2603,7 +2603,7 @@ int lsgpu_icp_align(lsgpu_icp* h, const float* reading_xyz1, int64_t nq, const f
     li.done = hst->done; li.status = hst->status; li.iter = hst->iter; li.sel_streak = hst->sel_streak;
     if (hst->sel_fails >= 2) pc.two_pass_select = false;   // (slices fuller than the normal equations can set aside: the select's third pass is back)
     li.stragglers = hst->stragglers; li.nq = nq; li.status_cap_failed = kStatusCapFailed; li.status_sel_failed = kStatusSelFailed;
-    if (tuning().short_last_group) { li.chk_rot = hst->chk_rot; li.chk_trans = hst->chk_trans; li.lim_rot = hst->lim_rot; li.lim_trans = hst->lim_trans; }
+    if (tuning().short_last_group) { li.chk_rot = hst->chk_rot; li.chk_trans = hst->chk_trans; li.lim_rot = hst->lim_rot; li.lim_trans = hst->lim_trans; li.chk_rot_prev = hst->chk_rot_prev; li.chk_trans_prev = hst->chk_trans_prev; }
     const policy::LookVerdict verdict = pol.on_look(pc, li, ahead, repriced ? price_share(h) : -1.f);
     if (verdict == policy::LookVerdict::RepeatUncapped) {
       // the cap prediction failed for iteration hst->iter: repeat it uncapped, then carry on

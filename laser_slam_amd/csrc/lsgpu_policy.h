@@ -65,6 +65,7 @@ enum class LookVerdict { Continue, RepeatUncapped, RepeatSelect, Done, GiveUp };
 struct LookInput {            // what a look at the loop state shows (IcpState fields)
   int done = 0, status = 0, iter = 0, sel_streak = 0;
   float chk_rot = 0.f, chk_trans = 0.f, lim_rot = 0.f, lim_trans = 0.f;   // the differential checker's smoothed changes and limits (0: not known)
+  float chk_rot_prev = 0.f, chk_trans_prev = 0.f;                          // ... one iteration earlier
   unsigned long long stragglers = 0;
   int64_t nq = 0;
   int status_cap_failed = 100, status_sel_failed = 101;
@@ -201,14 +202,18 @@ struct State {
   int estimate_group(const Config& c, const LookInput& s, int enqueued_ahead) {
     int g = c.group;
     const bool known = s.chk_trans > 0.f && s.chk_rot >= 0.f && s.lim_trans > 0.f && s.lim_rot > 0.f;
-    if (known && trend_iter >= 0 && s.iter > trend_iter && trend_trans > 0.f) {
+    const bool two_looks = trend_iter >= 0 && s.iter > trend_iter && trend_trans > 0.f;
+    if (known && (two_looks || s.chk_trans_prev > 0.f)) {
+      // the factor per iteration: from this look and the last one, or -- at a first look -- from the last two iterations
+      const int span = two_looks ? s.iter - trend_iter : 1;
+      const float then_t = two_looks ? trend_trans : s.chk_trans_prev, then_r = two_looks ? trend_rot : s.chk_rot_prev;
       auto left = [&](float now, float then, float lim) -> float {
         if (!(now > lim)) return 0.f;
-        float f = then > 0.f && now < then ? std::pow(now / then, 1.f / (float)(s.iter - trend_iter)) : 0.97f;
+        float f = then > 0.f && now < then ? std::pow(now / then, 1.f / (float)span) : 0.97f;
         f = f < 0.5f ? 0.5f : f > 0.97f ? 0.97f : f;
         return std::log(now / lim) / std::log(1.f / f);
       };
-      const float rem = std::fmax(left(s.chk_trans, trend_trans, s.lim_trans), left(s.chk_rot, trend_rot, s.lim_rot));
+      const float rem = std::fmax(left(s.chk_trans, then_t, s.lim_trans), left(s.chk_rot, then_r, s.lim_rot));
       // the group counts the iteration that is already out behind this look (next_in_group starts at `enqueued_ahead`):
       // the iterations still needed + one of margin
       (void)enqueued_ahead;

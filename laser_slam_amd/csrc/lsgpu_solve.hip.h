@@ -375,6 +375,7 @@ __device__ inline void icp_update_lane(IcpState* st, const double* ne_out, float
   float chk2[2];
   const bool ok = hostmath::checker_check(&cs, chk_hist, st->max_iter, st->smooth, st->lim_rot,
                                           st->lim_trans, Tn, &iterate, &by_diff, chk2);
+  st->chk_rot_prev = st->chk_rot; st->chk_trans_prev = st->chk_trans;
   st->chk_rot = chk2[0]; st->chk_trans = chk2[1];
   st->counter = cs.counter; st->n_hist = cs.n_hist;
 #ifdef LSGPU_KNN_STATS
