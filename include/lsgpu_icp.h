@@ -151,7 +151,8 @@ int lsgpu_icp_align_batch(lsgpu_icp* const* handles, int n_handles, int64_t n_pa
 int lsgpu_comm_get_unique_id(void* id /* LSGPU_COMM_ID_BYTES */);
 int lsgpu_icp_comm_init(lsgpu_icp* h, int rank, int nranks, const void* id);
 
-/* Per-iteration records of the last align; returns the number written. */
+/* Per-iteration records of the last align; returns the number written.  The records stay in device memory until this
+ * call fetches them (one synchronous copy); the next alignment on the handle overwrites them. */
 int lsgpu_icp_get_trace(lsgpu_icp* h, lsgpu_iter_trace* out, int cap);
 
 /* Geometry of the voxel-hash pyramid built by the last set_reference (for roofline accounting). */

@@ -128,6 +128,11 @@ struct IcpState {
   // estimates from them how many iterations are left and does not enqueue a full group of launches in front of the end
   float chk_rot, chk_trans;
   float chk_rot_prev, chk_trans_prev;   // ... and of the iteration before it (a first look has no earlier look to compare with)
+  // the last completed iteration's trim limit and inlier count (the alignment's statistics; the per-iteration trace stays on
+  // the device until somebody asks for it)
+  float last_limit;
+  uint32_t pad2_;
+  long long last_used;
 };
 constexpr int kSelBelowSlots = 64;   // counters of "distance below the predicted bin", hashed by tile ...
 constexpr int kSelBelowStride = 32;  // ... one per 128-byte line (atomics on one line serialise in L2)

@@ -321,6 +321,8 @@ struct lsgpu_icp {
   bool time_comm = false;
   size_t knn_events_used = 0;
   std::vector<lsgpu_iter_trace> trace;
+  size_t trace_on_device = 0;   // records of the last alignment still in trace_dev (fetched by lsgpu_icp_get_trace)
+  std::vector<std::pair<float, float>> trace_knn_us;   // their search timings (profiled runs), merged in on the fetch
 };
 
 // Wait for the handle's stream.  Plain handles block; a handle with a communicator polls with a deadline
@@ -2369,7 +2371,7 @@ int lsgpu_icp_align(lsgpu_icp* h, const float* reading_xyz1, int64_t nq, const f
   lsgpu_icp_stats st;
   std::memset(&st, 0, sizeof(st));
   if (stats) *stats = st;
-  h->trace.clear();
+  h->trace.clear(); h->trace_on_device = 0;
   // queries that lsgpu_icp_compute ordered and moved on its side stream belong to THIS call and to no later one, whatever
   // way it ends (a guess that is refused below would otherwise leave queries moved by that guess to the next call with the
   // same pointer and size)
@@ -2659,12 +2661,13 @@ int lsgpu_icp_align(lsgpu_icp* h, const float* reading_xyz1, int64_t nq, const f
   st.stragglers = (int64_t)hst->stragglers;
   float T_iter[16];
   std::memcpy(T_iter, hst->T_iter, sizeof(T_iter));
-  h->trace.resize((size_t)std::min(it, max_it));
-  if (!h->trace.empty()) {
-    HIPC(hipMemcpy(h->trace.data(), h->trace_dev.p, h->trace.size() * sizeof(lsgpu_iter_trace), hipMemcpyDeviceToHost));
-    st.final_limit = h->trace.back().limit;
-    st.final_n_used = h->trace.back().n_used;
-  }
+  // The per-iteration trace stays in device memory until lsgpu_icp_get_trace asks for it (the synchronous copy cost every
+  // alignment 37 us -- 5 % of a 200 k-point pair -- for a record nobody but the tests and the profiler reads); the two
+  // statistics that came out of it travel with the loop state.
+  h->trace.clear();
+  h->trace_on_device = (size_t)std::min(it, max_it);
+  h->trace_knn_us.clear();
+  if (it > 0) { st.final_limit = hst->last_limit; st.final_n_used = (int64_t)hst->last_used; }
   if (rc == LSGPU_OK) {  // step 7
     float Tmean[16], tmp[16];
     hostmath::identity4(Tmean);
@@ -2688,7 +2691,7 @@ int lsgpu_icp_align(lsgpu_icp* h, const float* reading_xyz1, int64_t nq, const f
       float m3 = 0.f, m4 = 0.f;
       if (hipEventElapsedTime(&m3, e.second ? e.c : e.b, e.d) == hipSuccess && hipEventElapsedTime(&m4, e.d, e.e) == hipSuccess) { st.t_select_ms += m3; st.t_ne_ms += m4; }
       else (void)hipGetLastError();
-      if (t < h->trace.size()) { h->trace[t].knn_main_us = m1 * 1e3f; h->trace[t].knn_fallback_us = m2 * 1e3f; ++t; }
+      if (t < h->trace_on_device) { h->trace_knn_us.push_back({m1 * 1e3f, m2 * 1e3f}); ++t; }
     }
   }
   if (h->time_comm) {   // time inside the collectives (launches enqueued behind the end exit at once and add next to nothing)
@@ -2817,6 +2820,18 @@ int lsgpu_dev_knn_counters(lsgpu_icp* h, unsigned long long out[8]) {
 
 int lsgpu_icp_get_trace(lsgpu_icp* h, lsgpu_iter_trace* out, int cap) {
   if (!h || !out || cap <= 0) return 0;
+  if (h->trace_on_device) {   // the last alignment's records are still where the device wrote them
+    h->trace.resize(h->trace_on_device);
+    if (hipSetDevice(h->device) != hipSuccess ||
+        hipMemcpy(h->trace.data(), h->trace_dev.p, h->trace.size() * sizeof(lsgpu_iter_trace), hipMemcpyDeviceToHost) != hipSuccess) {
+      (void)hipGetLastError();
+      h->trace.clear();
+    }
+    for (size_t t = 0; t < h->trace.size() && t < h->trace_knn_us.size(); ++t) {
+      h->trace[t].knn_main_us = h->trace_knn_us[t].first; h->trace[t].knn_fallback_us = h->trace_knn_us[t].second;
+    }
+    h->trace_on_device = 0;
+  }
   const int n = std::min<int>(cap, (int)h->trace.size());
   std::memcpy(out, h->trace.data(), (size_t)n * sizeof(lsgpu_iter_trace));
   return n;

@@ -330,6 +330,7 @@ __device__ inline void icp_update_lane(IcpState* st, const double* ne_out, float
   const long long u2 = clock64();
 #endif
   const int it = st->iter;
+  st->last_limit = limit; st->last_used = used;
   if (it < trace_cap) {
     lsgpu_iter_trace& tr = trace[it];
     for (int i = 0; i < 16; ++i) tr.T_iter[i] = Tn[i];
