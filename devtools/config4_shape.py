@@ -24,7 +24,7 @@ T_init = synth.se3(0.25, -0.1, 0.05, yaw=np.deg2rad(1.2)) @ T_true
 print("gen", time.time() - t, ref.shape, rd.shape)
 hf = icp.IcpHandle()
 t = time.time(); d_rf, d_rn = hf.filter_reference(torch.from_numpy(ref).cuda(), 10, 1.0, 0); rf, rn = d_rf.cpu().numpy(), d_rn.cpu().numpy(); hf.close(); print("normals (device filter)", time.time() - t)
-cfg = IcpConfig(); lib().lsgpu_icp_config_yaml(C.byref(cfg)); cfg.min_diff_rot, cfg.min_diff_trans = 1e-5, 1e-4; cfg.profile_kernels = 1
+cfg = IcpConfig(); lib().lsgpu_icp_config_yaml(C.byref(cfg)); cfg.min_diff_rot, cfg.min_diff_trans = 1e-5, 1e-4; cfg.profile_kernels = 1; cfg.cell_size = float(os.environ.get('CELL', '0'))
 h = icp.IcpHandle(cfg)
 dref, dn, drd = torch.from_numpy(rf).cuda(), torch.from_numpy(rn).cuda(), torch.from_numpy(rd).cuda()
 for rep in range(3):

@@ -424,6 +424,40 @@ def test_direction_index_returns_after_a_price_off():
     assert back["heavy_share"] <= 0.5 * s0, (back, never_off)     # the share the look found when it let the index back in
 
 
+def test_wall_scan_search_walk_is_bounded():
+    """Behaviour, not results (results cannot show it): next to a wall 0.8 m from the sensor (scan 18 of the track drive:
+    a 3-scan sub-map of 1.57 M points, thousands of reference points per level-0 cell) no 64-query tile of the voxel-grid
+    search may walk or evaluate more than a bounded number of 64-point chunks.  Round 4 shipped without that bound: 64
+    lanes of a spread wave each walked 1 700 chunk boxes and held one wave for 550 us (csrc/lsgpu_tuning.h,
+    LSGPU_ROUTE_DENSE); since then dense spread waves are handed to the row-per-query pass and a lane's walk goes through
+    the 16-chunk group boxes.  Measured with the -DLSGPU_KNN_STATS build (tests/liblsgpu_icp_stats.so: per tile of the LAST
+    launch the chunk boxes that survived the tile-level cull and the chunks fetched and evaluated): 8.1 chunks evaluated per
+    tile in the mean, 28 at p99, 182 at most; 465 survivors at most.  The bounds below leave a factor of two."""
+    import json
+    import subprocess
+    import sys
+
+    so = os.path.join(ROOT, "tests", "liblsgpu_icp_stats.so")
+    assert os.path.exists(so), "tests/liblsgpu_icp_stats.so is missing: run __graft_entry__.build()"
+
+    def run(env_add):
+        env = dict(os.environ)
+        env.update(env_add)
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "walk_worker.py"), "18", "4"], env=env, capture_output=True, text=True, timeout=400)
+        line = [ln for ln in r.stdout.splitlines() if ln.startswith("WALK_RESULT ")]
+        assert r.returncode == 0 and line, (env_add, r.stdout[-1500:], r.stderr[-1500:])
+        return json.loads(line[0][len("WALK_RESULT "):])
+
+    for env_add in ({"LSGPU_NO_CONE": "1"}, {}):     # the voxel grid in every launch; the product's own choice of kernels
+        w = run(env_add)
+        assert w["nearest_return_m"] < 1.0, w                       # (the wall is there)
+        assert w["iterations"] == 4 and w["tiles"] >= 0.9 * w["of"], w
+        assert w["evals_mean"] <= 16 and w["evals_p99"] <= 64 and w["evals_max"] <= 400, (env_add, w)
+        assert w["survivors_mean"] <= 32 and w["survivors_max"] <= 1000, (env_add, w)
+        # the wave-per-query / row-per-query pass is for the first wide launches: nothing is handed over once the balls are small
+        assert all(n <= 0.08 * w["n_reading"] for n in w["handed_over"]) and w["handed_over"][-1] <= 0.01 * w["n_reading"], (env_add, w)
+
+
 def test_sort_free_levels_keep_walls_and_lattices():
     """Behaviour beside results: the box tree's sort-free upper levels (csrc/lsgpu_ssn_select.hip.h) must KEEP clouds that
     put thousands of equal coordinates around a median -- a wall square to a frame axis (scans 18-19 of the track drive put
