@@ -2,6 +2,7 @@
 8 aggregated scans (8.4 M-point local map) vs one 1 M-point scan (the workload of devtools/config4_shape.py).  Needs
 devtools/liblsgpu_stats.so.      python devtools/cfg3_waves.py [iterations=12] [n_az=16384]"""
 import ctypes as C, sys, os
+if os.environ.get("CFG3_PHASES"): os.environ["LSGPU_KNN_DBG"] = str(4096)   # second record per tile: prologue | chunk loop | fetch + evaluate | epilogue
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import numpy as np, torch
@@ -30,11 +31,22 @@ cfg = IcpConfig(); lib().lsgpu_icp_config_yaml(C.byref(cfg)); cfg.min_diff_rot, 
 cfg.max_iterations = iters; cfg.profile_kernels = 1
 h = icp.IcpHandle(cfg)
 nw = (rd.shape[0] + 255) // 256 * 4
-lib().lsgpu_dev_knn_wave_stats(h._h, None, nw)
+nt = (rd.shape[0] + 63) // 64
+phases = bool(os.environ.get("CFG3_PHASES"))
+lib().lsgpu_dev_knn_wave_stats(h._h, None, 2 * nw if phases else nw)
 h.set_reference(rf, rn)
 T, st = h.align(rd, T_init)
-buf = np.zeros((nw, 4), np.uint32)
-lib().lsgpu_dev_knn_wave_stats(h._h, buf.ctypes.data_as(C.POINTER(C.c_uint)), nw)
+buf = np.zeros((2 * nw if phases else nw, 4), np.uint32)
+lib().lsgpu_dev_knn_wave_stats(h._h, buf.ctypes.data_as(C.POINTER(C.c_uint)), buf.shape[0])
+if phases:
+    b = buf[nt:2 * nt].astype(np.float64); a0 = buf[:nt].astype(np.float64)
+    na0 = buf[:nt, 3] >> 16
+    for name, v in (("total", a0[:, 0]), ("prologue (loads, reductions, lookup)", b[:, 0]), ("chunk loop", b[:, 1]), ("  of which fetch + evaluate", b[:, 2]), ("epilogue", b[:, 3])):
+        print("%-40s mean %8.0f  p50 %8.0f  p90 %8.0f  share %.2f" % (name, v.mean(), np.percentile(v, 50), np.percentile(v, 90), v.sum() / a0[:, 0].sum()))
+    for lo, hi in ((1, 8), (9, 16), (17, 32), (33, 64)):
+        m = (na0 >= lo) & (na0 <= hi)
+        if m.any(): print("tiles with %2d-%2d searching lanes: %5d  total %7.0f  loop %7.0f  fetch+eval %7.0f  evals %.1f" % (lo, hi, m.sum(), a0[m, 0].mean(), b[m, 1].mean(), b[m, 2].mean(), a0[m, 1].mean()))
+    buf = buf[:nw]
 cyc, ev, sv, gl = buf[:, 0].astype(np.float64), buf[:, 1], buf[:, 2], buf[:, 3]
 grp, lvl, nact = (gl >> 8) & 255, gl & 255, gl >> 16
 print("reference", rf.shape[0], "reading", rd.shape[0], "iterations", st.iterations, "knn avg us %.1f" % (st.t_knn_ms / max(st.knn_launches, 1) * 1e3),

@@ -31,6 +31,10 @@ for rep in range(3):
     t = time.perf_counter(); h.set_reference(dref, dn); torch.cuda.synchronize(); t1 = time.perf_counter()
     T, st = h.align(drd, T_init); t2 = time.perf_counter()
 print("set_reference ms %.2f align ms %.2f iters %d knn avg us %.1f cap_retries %d" % ((t1 - t) * 1e3, (t2 - t1) * 1e3, st.iterations, st.t_knn_ms / max(st.knn_launches, 1) * 1e3, st.cap_retries))
+if os.environ.get("PER_ITER"):
+    tr = h.trace()
+    print("per-iteration kNN us:", [round(float(t["knn_main_us"] + t["knn_fallback_us"]), 1) for t in tr])
+    print("per-iteration searching queries (k):", [int(t["searching"]) // 1000 for t in tr])
 print("err vs truth", synth.pose_error(T.astype(np.float64), T_true), "info chunks", h.info().n_chunks, list(h.info().cells)[:6])
 if len(sys.argv) > 2 and sys.argv[2] == "oracle":
     from oracle import oracle_py as O

@@ -814,6 +814,8 @@ static int run_knn(lsgpu_icp* h, const Mat34& T, const IcpState* st, const polic
 #endif
   if (wide && tn.lazy_need)   // balls still as wide as the last ICP step: the instantiation that re-tests chunks before fetching them
     hipLaunchKernelGGL((k_knn_tile<1, true>), dim3(a.ntiles + a.front_blocks), dim3(64), 0, h->stream, a);
+  else if (!wide && tn.lane_split)   // settled: most tiles have fewer than 32 searching lanes -- their candidates are shared out over the idle ones
+    hipLaunchKernelGGL((k_knn_tile<1, false, true>), dim3(a.ntiles + a.front_blocks), dim3(64), 0, h->stream, a);
   else
     hipLaunchKernelGGL((k_knn_tile<1, false>), dim3(a.ntiles + a.front_blocks), dim3(64), 0, h->stream, a);
   if (timed) HIPC(hipEventRecord(ev->b, h->stream));

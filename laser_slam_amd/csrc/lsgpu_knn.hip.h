@@ -324,6 +324,71 @@ __device__ __forceinline__ void tile_eval_slot(const float4* __restrict__ slot, 
   }
 }
 
+// ---- lane split (k_knn_tile<1, false, true>: the settled launches of the voxel search -- dense local maps, scans whose
+// direction index rests).  A settled wave has 22-26 searching lanes of 64 (keep / far lanes have left), yet the broadcast
+// evaluation above runs every candidate through all 64 lanes.  With no more than 32 (16, 8) searching lanes the wave is cut
+// into 2 (4, 8) PARTS of S = 32 (16, 8) lanes: lane L serves the (L mod S)-th searching query and takes every ways-th group
+// of four of each staged chunk, so a chunk costs a half (quarter, eighth) of the steps.  The parts' partial results {smallest
+// group minimum, second smallest, its group} are merged over the parts by xor-shuffles and handed to the query's own lane at
+// the end of every batch -- the same (min, second, group) algebra as one more step of tile_eval_slot; two parts that found the
+// same minimum leave second == best, which sends the lane to canonical_tie as any tie does.  Results are those of the
+// plain evaluation (the order candidates are looked at does not enter them).
+struct SplitState {
+  int ways;          // 1: plain evaluation (wave-uniform)
+  float qx, qy, qz;  // the served query
+  float best, sec;   // partial result of this lane's share of the batch
+  int grp;
+};
+
+__device__ __forceinline__ void split_setup(SplitState& sp, unsigned long long ing_mask, int lane, float qx, float qy, float qz) {
+  const int nin = __popcll(ing_mask);
+  sp.ways = nin <= 8 ? 8 : nin <= 16 ? 4 : nin <= 32 ? 2 : 1;
+  int own = lane; sp.qx = 0.f; sp.qy = 0.f; sp.qz = 0.f; sp.best = INFINITY; sp.sec = INFINITY; sp.grp = -1;
+  if (sp.ways == 1) return;
+  const int slot = lane & (64 / sp.ways - 1);
+  unsigned long long mm = ing_mask;
+  for (int idx = 0; mm; ++idx) {
+    const int k = __ffsll((long long)mm) - 1;
+    mm &= mm - 1;
+    if (slot == idx) own = k;
+  }
+  sp.qx = __shfl(qx, own, 64); sp.qy = __shfl(qy, own, 64); sp.qz = __shfl(qz, own, 64);   // (a lane without a query to serve keeps its own: harmless)
+}
+
+// this lane's share of one staged chunk: groups part, part + ways, ... for the served query
+__device__ __forceinline__ void tile_eval_slot_split(const float4* __restrict__ slot, uint32_t st, uint32_t cnt, int lane,
+                                                     SplitState& sp) {
+  const uint32_t c4 = (cnt + 3u) >> 2;
+  const uint32_t ways = (uint32_t)sp.ways, part = (uint32_t)lane / (64u / ways);
+  const f32x2 q2x = {sp.qx, sp.qx}, q2y = {sp.qy, sp.qy}, q2z = {sp.qz, sp.qz};
+  for (uint32_t t = part; t < c4; t += ways) {
+    const float4 x = slot[t], y = slot[c4 + t], z = slot[2u * c4 + t];
+    const f32x2 d0 = dist2_pair(q2x, q2y, q2z, f32x2{x.x, x.y}, f32x2{y.x, y.y}, f32x2{z.x, z.y});
+    const f32x2 d1 = dist2_pair(q2x, q2y, q2z, f32x2{x.z, x.w}, f32x2{y.z, y.w}, f32x2{z.z, z.w});
+    const float m4 = fminf(fminf(fminf(d0.x, d0.y), d1.x), d1.y);
+    sp.sec = __builtin_amdgcn_fmed3f(sp.best, m4, sp.sec);
+    if (m4 < sp.best) { sp.best = m4; sp.grp = (int)(st + 4u * t); }
+  }
+}
+
+// end of a batch: parts -> one partial result per served query -> the query's own lane; the parts start afresh
+__device__ __forceinline__ void split_merge(SplitState& sp, bool ing, unsigned long long ing_mask, int lane, float& best, float& sec, int& grp) {
+  for (int o = 32; o >= 64 / sp.ways; o >>= 1) {
+    const float ob = __shfl_xor(sp.best, o, 64), os = __shfl_xor(sp.sec, o, 64);
+    const int og = __shfl_xor(sp.grp, o, 64);
+    sp.sec = fminf(fmaxf(sp.best, ob), fminf(sp.sec, os));
+    if (ob < sp.best) { sp.best = ob; sp.grp = og; }   // (equal minima: sec == best now, either group will do)
+  }
+  const int rank = __popcll(ing_mask & ((1ull << lane) - 1ull));   // this lane's position among the searching lanes = the slot that served it
+  const float mb = __shfl(sp.best, rank, 64), ms = __shfl(sp.sec, rank, 64);
+  const int mg = __shfl(sp.grp, rank, 64);
+  if (ing) {
+    sec = fminf(fmaxf(best, mb), fminf(sec, ms));
+    if (mb < best) { best = mb; grp = mg; }
+  }
+  sp.best = INFINITY; sp.sec = INFINITY; sp.grp = -1;
+}
+
 // Cull 64 queued chunks (one per lane) against the group's query box, test the survivors per lane
 // against each lane's own bound, then fetch the needed chunks FOUR AT A TIME with LDS-DMA (one memory
 // latency per four chunks, no staging registers) and broadcast-evaluate them.
@@ -334,13 +399,14 @@ __device__ __forceinline__ void tile_eval_slot(const float4* __restrict__ slot, 
 // final distances, a skipped chunk lies beyond the final search radius.  Worth 35-40 us in each of the first two launches;
 // compiled into its own instantiation of the kernel, because the same code in the settled launches costs them 8 % (it
 // lengthens the live ranges of a kernel that sits at its register budget; profiles/r03_knn_variants.txt).
-template <bool LAZY>
+template <bool LAZY, bool SPLIT>
 __device__ __forceinline__ void tile_process_batch(const KnnArgs& a, float cap2, TileLds& lds, int lane, bool valid,
                                                    uint32_t ch, bool ing, float qx, float qy, float qz,
                                                    float tlx, float tly, float tlz, float thx, float thy,
                                                    float thz, float& maxbest, float ub, float gap, float& best,
                                                    float& sec, int& grp, uint32_t& n_eval, uint32_t& n_surv,
-                                                   uint32_t& c_eval /* stats builds: cycles spent fetching + evaluating */) {
+                                                   uint32_t& c_eval /* stats builds: cycles spent fetching + evaluating */,
+                                                   SplitState& sp) {
   float4 b0 = make_float4(0.f, 0.f, 0.f, 0.f), b1 = b0;
   uint32_t sbase = 0;
   bool pass = false, near = false;
@@ -442,8 +508,13 @@ __device__ __forceinline__ void tile_process_batch(const KnnArgs& a, float cap2,
     else if (nb == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     n_eval += na;
-    tile_eval_slot(lds.slot[0], sa0, ca0, qx, qy, qz, best, sec, grp);
-    if (na > 1) tile_eval_slot(lds.slot[1], sa1, ca1, qx, qy, qz, best, sec, grp);
+    if (SPLIT && sp.ways > 1) {
+      tile_eval_slot_split(lds.slot[0], sa0, ca0, lane, sp);
+      if (na > 1) tile_eval_slot_split(lds.slot[1], sa1, ca1, lane, sp);
+    } else {
+      tile_eval_slot(lds.slot[0], sa0, ca0, qx, qy, qz, best, sec, grp);
+      if (na > 1) tile_eval_slot(lds.slot[1], sa1, ca1, qx, qy, qz, best, sec, grp);
+    }
     if (!nb) break;
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // slots 0,1 are no longer being read
     na = issue(0, sa0, ca0);
@@ -452,9 +523,15 @@ __device__ __forceinline__ void tile_process_batch(const KnnArgs& a, float cap2,
     else if (na == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     n_eval += nb;
-    tile_eval_slot(lds.slot[2], sb0, cb0, qx, qy, qz, best, sec, grp);
-    if (nb > 1) tile_eval_slot(lds.slot[3], sb1, cb1, qx, qy, qz, best, sec, grp);
+    if (SPLIT && sp.ways > 1) {
+      tile_eval_slot_split(lds.slot[2], sb0, cb0, lane, sp);
+      if (nb > 1) tile_eval_slot_split(lds.slot[3], sb1, cb1, lane, sp);
+    } else {
+      tile_eval_slot(lds.slot[2], sb0, cb0, qx, qy, qz, best, sec, grp);
+      if (nb > 1) tile_eval_slot(lds.slot[3], sb1, cb1, qx, qy, qz, best, sec, grp);
+    }
   }
+  if (SPLIT && sp.ways > 1) split_merge(sp, ing, __ballot(ing), lane, best, sec, grp);
   maxbest = wave_max(ing ? prune_lim(fminf(best, ub), gap, cap2) : 0.f);
 #ifdef LSGPU_KNN_STATS
   c_eval += (uint32_t)(clock64() - t_ev0);
@@ -695,8 +772,12 @@ __device__ __forceinline__ void tile_front_rows(const KnnArgs& a, uint32_t* lds_
 #ifndef LSGPU_TILE_OCC
 #define LSGPU_TILE_OCC 7   // waves per SIMD the register budget is cut for (7: 72 VGPRs, no spills; 8 spills 48 B per lane)
 #endif
-template <int WAVES, bool LAZY = false>
-__global__ __launch_bounds__(WAVES * 64, LSGPU_TILE_OCC) void k_knn_tile(KnnArgs a) {
+#ifndef LSGPU_TILE_OCC_SPLIT
+#define LSGPU_TILE_OCC_SPLIT 6   // the lane-split instantiation carries nine more live registers through the batch loop
+#endif
+template <int WAVES, bool LAZY = false, bool SPLIT = false>
+__global__ __launch_bounds__(WAVES * 64, SPLIT ? LSGPU_TILE_OCC_SPLIT : LSGPU_TILE_OCC) void k_knn_tile(KnnArgs a) {
+  static_assert(!(LAZY && SPLIT), "the lazy instantiation re-tests chunks against bounds the parts have not merged yet");
   __shared__ TileLds lds_all[WAVES];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   TileLds& lds = lds_all[w];
@@ -922,6 +1003,9 @@ __global__ __launch_bounds__(WAVES * 64, LSGPU_TILE_OCC) void k_knn_tile(KnnArgs
 #ifdef LSGPU_KNN_STATS
       if (a.dbg_flags & 64) return;
 #endif
+      SplitState sp;
+      sp.ways = 1;
+      if (SPLIT) split_setup(sp, ing_mask, lane, qx, qy, qz);
       // ---- flatten the cells' chunk ranges into the LDS list, 64 at a time into the cull
       unsigned long long cells = __ballot(ce > cs);
       uint32_t fill = 0;
@@ -936,16 +1020,16 @@ __global__ __launch_bounds__(WAVES * 64, LSGPU_TILE_OCC) void k_knn_tile(KnnArgs
           while (fill >= 64u) {  // a full batch is ready
             fill -= 64u;
             const uint32_t ch = lds.list[fill + lane];
-            tile_process_batch<LAZY>(a, cap2s, lds, lane, true, ch, ing, qx, qy, qz, tlx, tly, tlz, thx, thy, thz,
-                               maxbest, ub, gap, best, sec, grp, n_eval, n_surv, c_eval);
+            tile_process_batch<LAZY, SPLIT>(a, cap2s, lds, lane, true, ch, ing, qx, qy, qz, tlx, tly, tlz, thx, thy, thz,
+                               maxbest, ub, gap, best, sec, grp, n_eval, n_surv, c_eval, sp);
           }
         }
       }
       if (fill) {
         const bool v = (uint32_t)lane < fill;
         const uint32_t ch = v ? lds.list[lane] : 0u;
-        tile_process_batch<LAZY>(a, cap2s, lds, lane, v, ch, ing, qx, qy, qz, tlx, tly, tlz, thx, thy, thz,
-                           maxbest, ub, gap, best, sec, grp, n_eval, n_surv, c_eval);
+        tile_process_batch<LAZY, SPLIT>(a, cap2s, lds, lane, v, ch, ing, qx, qy, qz, tlx, tly, tlz, thx, thy, thz,
+                           maxbest, ub, gap, best, sec, grp, n_eval, n_surv, c_eval, sp);
       }
     }
   }

@@ -25,6 +25,7 @@
 //   LSGPU_NO_FRONT              spread tiles go through the separate row pass instead of the front of the tile launch
 //   LSGPU_FRONT_GUESS     2048  tiles the front of the grid is sized for before the host has seen the list
 //   LSGPU_NO_LAZY               wide launches (first iterations) use the plain tile kernel instead of the instantiation that re-tests chunks before fetching them
+//   LSGPU_NO_SPLIT              settled launches of the voxel search evaluate every candidate in all 64 lanes (no lane split, lsgpu_knn.hip.h)
 //   LSGPU_NO_SIDE_STREAM        lsgpu_icp_compute: reading filter + query order AFTER the grid build, on the same stream (not beside it)
 //   LSGPU_NO_LOOKAHEAD          no iteration enqueued behind the copy of the loop state: the device idles while the host looks at it
 //   LSGPU_NO_ROUTE_ALL          (with NO_FRONT) settled spread waves search per lane inside the tile kernel
@@ -82,6 +83,7 @@ struct Tuning {
   bool fused_select = true;   // the normal-equation kernel finds the trim limit itself (LSGPU_NO_FUSED_SELECT: the select kernels / the window table)
   bool front = true;
   bool lazy_need = true;
+  bool lane_split = true;    // LSGPU_NO_SPLIT: k_knn_tile<1, false> instead of <1, false, true> for the settled voxel searches
   bool lookahead = true;     // LSGPU_NO_LOOKAHEAD: the host waits for the whole stream when it looks at the loop state
   bool index_rest = true;    // LSGPU_NO_INDEX_REST: the handle never rests the direction index on the evidence of two timed searches
                              // (the one launch decision that depends on wall-clock timings: off => the same kernels every run)
@@ -151,6 +153,7 @@ inline Tuning read() {
   t.seed_cap = !flag("LSGPU_NO_SEED_CAP");
   t.front = !flag("LSGPU_NO_FRONT");
   t.lazy_need = !flag("LSGPU_NO_LAZY");
+  t.lane_split = !flag("LSGPU_NO_SPLIT");
   t.side_stream = !flag("LSGPU_NO_SIDE_STREAM");
   t.lookahead = !flag("LSGPU_NO_LOOKAHEAD");
   t.index_rest = !flag("LSGPU_NO_INDEX_REST");
@@ -185,7 +188,7 @@ inline Tuning read() {
   t.cone_cols = (int)number("LSGPU_CONE_COLS", 8192, 64, 65536) & ~3;
   static const char* known[] = {"LSGPU_QUERY_ORDER", "LSGPU_Q_ELEV", "LSGPU_Q_SECT", "LSGPU_GAP", "LSGPU_BUDGET", "LSGPU_BUDGET_WIDE", "LSGPU_WIDE_ITERS",
                                 "LSGPU_ROUTE_R", "LSGPU_ROUTE_CHUNKS", "LSGPU_ROUTE_DENSE", "LSGPU_SPLIT_UPDATE", "LSGPU_NO_PREDICT", "LSGPU_NO_COMMIT",
-                                "LSGPU_NO_COMM_COMMIT", "LSGPU_NO_SEED_CAP", "LSGPU_NO_FRONT", "LSGPU_NO_LAZY", "LSGPU_NO_SIDE_STREAM", "LSGPU_NO_LOOKAHEAD", "LSGPU_NO_INDEX_REST", "LSGPU_CELLS_SPLIT", "LSGPU_NO_FUSED_SELECT", "LSGPU_FULL_GROUPS", "LSGPU_THREE_PASS_SELECT", "LSGPU_SEL_AMB_CAP", "LSGPU_FRONT_GUESS", "LSGPU_NO_ROUTE_ALL",
+                                "LSGPU_NO_COMM_COMMIT", "LSGPU_NO_SEED_CAP", "LSGPU_NO_FRONT", "LSGPU_NO_LAZY", "LSGPU_NO_SPLIT", "LSGPU_NO_SIDE_STREAM", "LSGPU_NO_LOOKAHEAD", "LSGPU_NO_INDEX_REST", "LSGPU_CELLS_SPLIT", "LSGPU_NO_FUSED_SELECT", "LSGPU_FULL_GROUPS", "LSGPU_THREE_PASS_SELECT", "LSGPU_SEL_AMB_CAP", "LSGPU_FRONT_GUESS", "LSGPU_NO_ROUTE_ALL",
                                 "LSGPU_NO_ROWQ", "LSGPU_ROWQ_BLOCKS", "LSGPU_SORT_ITEMS", "LSGPU_SSN_GLOBAL", "LSGPU_SSN_FULL_SORT", "LSGPU_SSN_OLD_FINISH", "LSGPU_SSN_ROOT", "LSGPU_SSN_SORT_LEVELS",
                                 "LSGPU_NE_BLOCKS", "LSGPU_COMM_TIMEOUT_MS", "LSGPU_KNN_DBG", "LSGPU_NO_CONE", "LSGPU_NO_CONE_PROBE", "LSGPU_CONE_ROWS", "LSGPU_CONE_COLS", "LSGPU_CONE_FROM", "LSGPU_CONE_MAX_OCC", "LSGPU_CONE_HEAVY_STEPS", "LSGPU_CONE_HEAVY_SHARE",
                                 // read by the Python / C++ hosts and the test drivers, not by this library:

@@ -347,7 +347,8 @@ def test_experiment_switches_do_not_change_results():
     # settled launches search the direction index (k_knn_cone) by default; LSGPU_NO_CONE sends them back to the voxel
     # grid (k_knn_tile), whose own switches only act there
     tile = {"LSGPU_NO_CONE": "1"}
-    variants = [{}, tile, dict(tile, LSGPU_NO_FRONT="1"), dict(tile, LSGPU_NO_FRONT="1", LSGPU_NO_ROWQ="1"),
+    variants = [{}, tile, dict(tile, LSGPU_NO_SPLIT="1"),   # (the settled voxel searches share a tile's candidates out over its idle lanes: k_knn_tile<1, false, true>; without: every lane looks at every candidate)
+                dict(tile, LSGPU_NO_FRONT="1"), dict(tile, LSGPU_NO_FRONT="1", LSGPU_NO_ROWQ="1"),
                 dict(tile, LSGPU_NO_FRONT="1", LSGPU_NO_ROUTE_ALL="1"), {"LSGPU_NO_COMMIT": "1"}, dict(tile, LSGPU_NO_COMMIT="1"),
                 {"LSGPU_NO_PREDICT": "1"}, dict(tile, LSGPU_NO_PREDICT="1"),
                 {"LSGPU_CONE_ROWS": "32", "LSGPU_CONE_COLS": "1024"}, {"LSGPU_CONE_ROWS": "512", "LSGPU_CONE_COLS": "32768"},
