@@ -641,7 +641,7 @@ static KnnArgs knn_args(lsgpu_icp* h, const Mat34& T) {
   a.chunks = h->chunks.p; a.cgroups = h->chunk_groups.p; a.soa = reinterpret_cast<const float4*>(h->soa.p); a.chunk_soa = h->soa_base.p; a.ids = h->ids.p; a.d2 = h->d2.p; a.prev = h->prev.p;
   a.strag = h->strag.p; a.strag_count = h->counters.p + 32;
   a.r_cap = 1.0f; a.group_r = 0.75f; a.cap2 = INFINITY; a.st = nullptr; a.use_state_cap = 0; a.lb = nullptr;
-  a.spread_route_r = 0.f; a.route_chunks = 1 << 30; a.route_dense = 1 << 30; a.sel_hist2 = nullptr; a.sel_below = nullptr;
+  a.spread_route_r = 0.f; a.route_chunks = 1 << 30; a.route_dense = 1 << 30; a.route_heavy_max = -1; a.sel_hist2 = nullptr; a.sel_below = nullptr;
   a.sel_hist3w = nullptr; a.sel_force = 0; a.write_all = 1; a.spread_flag = nullptr; a.spread_list = nullptr; a.spread_cnt = nullptr; a.front_blocks = 0;
   a.price.count = nullptr;
   a.gap = tuning().gap;
@@ -707,7 +707,9 @@ static int run_knn(lsgpu_icp* h, const Mat34& T, const IcpState* st, const polic
   }
   if (predicted && !wide && capped && st) { a.sel_hist2 = h->hist.p + kHistBins; a.sel_below = h->sel_aux.p; }
   if (committed && a.sel_below) { a.sel_hist3w = (h->comm || !tuning().fused_select) ? h->sel_win.p : nullptr; a.sel_force = 1; }   // (the window table: aligned mode only)
-  a.route_chunks = tn.route_chunks; a.route_dense = tn.route_dense;
+  a.route_chunks = tn.route_chunks;
+  a.route_heavy_max = st ? tn.route_heavy_max : -1;   // (the ticket lives in the loop's scratch, re-armed every iteration)
+  a.route_dense = tn.route_dense;
   // the search before the first one through the direction index prices the index (lsgpu_knn.hip.h: cone_price)
   const bool pricing = pol.pricing(pc, it, st != nullptr);
   if (pricing) {

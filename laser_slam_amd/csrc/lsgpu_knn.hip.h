@@ -75,6 +75,7 @@ struct KnnArgs {
   float4* prev;             // in/out: warm start = the query's current match {x,y,z, sorted index bits}
   uint32_t* strag;          // out: straggler list
   uint32_t* strag_count;
+  int route_heavy_max;   // heavy tiles (see k_knn_tile) handed to the wave-per-query pass per launch; < 0: all of them (no ticket)
   float r_cap;              // lanes with a larger ball go to the fallback
   float group_r;            // half extent of one search group inside a wave
   float cap2;               // only neighbours with d2 <= cap2 must be exact (INF: all)
@@ -982,11 +983,20 @@ __global__ __launch_bounds__(WAVES * 64, SPLIT ? LSGPU_TILE_OCC_SPLIT : LSGPU_TI
       const uint32_t idx = atomicAdd(&a.spread_cnt[1], 1u);
       if (idx < (uint32_t)kFrontMax) { a.spread_list[idx] = tile; a.spread_flag[tile] = idx + 1u; }
     }
+    // a tile with wide balls and a heavy cell block (more than route_chunks chunks): a few such tiles are the tail of a launch
+    // (one wave culling thousands of chunk boxes batch by batch) and go to the wave-per-query pass; when a launch has
+    // thousands of them -- a 0.3 m guess on an aggregated local map -- that pass pays the map's density once per query
+    // (3.8 ms for 468 k queries) where this kernel pays it once per 64, so only the first route_heavy_max tiles to ask go there
+    bool heavy = Rmax > a.spread_route_r && !spread && block_chunks > (uint32_t)a.route_chunks;
+    if (a.spread_route_r > 0.f && heavy && a.route_heavy_max >= 0) {
+      uint32_t t = 0u;
+      if (lane == 0) t = atomicAdd(a.strag_count + 2, 1u);   // (third word of the loop's per-iteration counters: zeroed by k_align_init, re-armed by k_normal_eq_loop)
+      heavy = (uint32_t)__builtin_amdgcn_readfirstlane((int)t) < (uint32_t)a.route_heavy_max;
+    }
 #ifdef LSGPU_KNN_STATS
     if (spread && (a.dbg_flags & 32)) { /* ablation: drop spread waves */ } else
 #endif
-    if (a.spread_route_r > 0.f && ((Rmax > a.spread_route_r && (spread || block_chunks > (uint32_t)a.route_chunks)) ||
-                                   (spread && block_chunks > (uint32_t)a.route_dense))) {
+    if (a.spread_route_r > 0.f && (heavy || (spread && (Rmax > a.spread_route_r || block_chunks > (uint32_t)a.route_dense)))) {
       // wide balls and no shared candidates: 64 divergent per-lane searches would hold this wave for up
       // to a millisecond (the tail of the first launches); one wave per query (k_knn_fallback) instead
       routed = ing;

@@ -16,6 +16,10 @@
 //   LSGPU_WIDE_ITERS         3  first iterations of an align whose wide-ball spread waves go to the wave-per-query pass
 //   LSGPU_ROUTE_R         0.02  ... if their largest ball exceeds this (metres)
 //   LSGPU_ROUTE_CHUNKS    1024  ... or the cell block holds more chunks than this
+//   LSGPU_ROUTE_HEAVY_MAX 1024  ... but only the first so many such tiles of a launch (a ticket); the others stay in the tile kernel.  A few
+//                               heavy tiles are a launch's tail, thousands (a 0.29 m / 1.5 deg guess on an 8-scan local map,
+//                               devtools/split_first.py: 468 k + 165 k queries handed over in the first two searches, 3.8 + 1.2 ms)
+//                               cost the wave-per-query pass the map's density once per query.  -1: all of them (rounds 3-5)
 //   LSGPU_ROUTE_DENSE     512   a spread wave whose cell block holds more chunks than this goes there whatever its balls (a wall
 //                               next to the sensor: 64 lanes each walking 1 700 chunk boxes held one wave for 550 us)
 //   LSGPU_NO_PREDICT            always the three-pass select (no first two passes in the search epilogue)
@@ -75,6 +79,7 @@ struct Tuning {
   int wide_iters = 3;
   float route_r = 0.02f;
   int route_chunks = 1024;
+  int route_heavy_max = 1024;      // LSGPU_ROUTE_HEAVY_MAX
   int route_dense = 512;           // ... and a SPREAD wave whose cell block holds more chunks than this goes there whatever its balls (LSGPU_ROUTE_DENSE)
   bool predict_select = true, commit_select = true, comm_commit = true, seed_cap = true;
   int sel_amb_cap = 256;      // ... setting aside at most this many distances of the limit's slice (<= kSelAmbCap; a test knob: the sums' order changes with it)
@@ -141,6 +146,7 @@ inline Tuning read() {
   t.wide_iters = (int)number("LSGPU_WIDE_ITERS", 3, 0, 1 << 20);
   t.route_r = (float)number("LSGPU_ROUTE_R", 0.02, 1e-6, 1e6);
   t.route_chunks = (int)number("LSGPU_ROUTE_CHUNKS", 1024, 1, 1 << 30);
+  t.route_heavy_max = (int)number("LSGPU_ROUTE_HEAVY_MAX", 1024, -1, 1 << 30);
   t.route_dense = (int)number("LSGPU_ROUTE_DENSE", 512, 1, 1 << 30);
   t.split_update = flag("LSGPU_SPLIT_UPDATE");
   t.predict_select = !flag("LSGPU_NO_PREDICT") && !t.split_update;
@@ -187,7 +193,7 @@ inline Tuning read() {
   t.cone_rows = (int)number("LSGPU_CONE_ROWS", 128, 8, 1024);
   t.cone_cols = (int)number("LSGPU_CONE_COLS", 8192, 64, 65536) & ~3;
   static const char* known[] = {"LSGPU_QUERY_ORDER", "LSGPU_Q_ELEV", "LSGPU_Q_SECT", "LSGPU_GAP", "LSGPU_BUDGET", "LSGPU_BUDGET_WIDE", "LSGPU_WIDE_ITERS",
-                                "LSGPU_ROUTE_R", "LSGPU_ROUTE_CHUNKS", "LSGPU_ROUTE_DENSE", "LSGPU_SPLIT_UPDATE", "LSGPU_NO_PREDICT", "LSGPU_NO_COMMIT",
+                                "LSGPU_ROUTE_R", "LSGPU_ROUTE_CHUNKS", "LSGPU_ROUTE_HEAVY_MAX", "LSGPU_ROUTE_DENSE", "LSGPU_SPLIT_UPDATE", "LSGPU_NO_PREDICT", "LSGPU_NO_COMMIT",
                                 "LSGPU_NO_COMM_COMMIT", "LSGPU_NO_SEED_CAP", "LSGPU_NO_FRONT", "LSGPU_NO_LAZY", "LSGPU_NO_SPLIT", "LSGPU_NO_SIDE_STREAM", "LSGPU_NO_LOOKAHEAD", "LSGPU_NO_INDEX_REST", "LSGPU_CELLS_SPLIT", "LSGPU_NO_FUSED_SELECT", "LSGPU_FULL_GROUPS", "LSGPU_THREE_PASS_SELECT", "LSGPU_SEL_AMB_CAP", "LSGPU_FRONT_GUESS", "LSGPU_NO_ROUTE_ALL",
                                 "LSGPU_NO_ROWQ", "LSGPU_ROWQ_BLOCKS", "LSGPU_SORT_ITEMS", "LSGPU_SSN_GLOBAL", "LSGPU_SSN_FULL_SORT", "LSGPU_SSN_OLD_FINISH", "LSGPU_SSN_ROOT", "LSGPU_SSN_SORT_LEVELS",
                                 "LSGPU_NE_BLOCKS", "LSGPU_COMM_TIMEOUT_MS", "LSGPU_KNN_DBG", "LSGPU_NO_CONE", "LSGPU_NO_CONE_PROBE", "LSGPU_CONE_ROWS", "LSGPU_CONE_COLS", "LSGPU_CONE_FROM", "LSGPU_CONE_MAX_OCC", "LSGPU_CONE_HEAVY_STEPS", "LSGPU_CONE_HEAVY_SHARE",

@@ -354,6 +354,7 @@ def test_experiment_switches_do_not_change_results():
                 {"LSGPU_CONE_ROWS": "32", "LSGPU_CONE_COLS": "1024"}, {"LSGPU_CONE_ROWS": "512", "LSGPU_CONE_COLS": "32768"},
                 {"LSGPU_NO_CONE_PROBE": "1"}, {"LSGPU_CONE_FROM": "1"}, {"LSGPU_CONE_HEAVY_SHARE": "2"}, dict(tile, LSGPU_ROUTE_DENSE="16"), dict(tile, LSGPU_ROUTE_DENSE="1073741824"),
                 {"LSGPU_CONE_HEAVY_STEPS": "8", "LSGPU_CONE_HEAVY_SHARE": "0.5"},   # (too dear at first, priced again before every look)
+                {"LSGPU_ROUTE_HEAVY_MAX": "-1"}, {"LSGPU_ROUTE_HEAVY_MAX": "0"}, {"LSGPU_ROUTE_HEAVY_MAX": "3", "LSGPU_ROUTE_CHUNKS": "64"},   # heavy tiles of the wide launches: all / none / the first three to the wave-per-query pass
                 {"LSGPU_SORT_ITEMS": "4"}, {"LSGPU_NO_SEED_CAP": "1"}, {"LSGPU_NO_LAZY": "1"}, {"LSGPU_NO_SIDE_STREAM": "1"}, {"LSGPU_NO_LOOKAHEAD": "1"},
                 dict(tile, LSGPU_FRONT_GUESS="8"), {"LSGPU_SSN_GLOBAL": "1"}, {"LSGPU_SSN_FULL_SORT": "1"}, {"LSGPU_SSN_FULL_SORT": "1", "LSGPU_SSN_GLOBAL": "1"},
                 {"LSGPU_SSN_OLD_FINISH": "1"}, {"LSGPU_SSN_ROOT": "2048"}, {"LSGPU_SSN_ROOT": "4096"},   # k_ssn_finish / smaller roots of k_ssn_tree
