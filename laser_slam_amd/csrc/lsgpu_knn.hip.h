@@ -1194,20 +1194,20 @@ __global__ __launch_bounds__(256) void k_knn_fallback(KnnArgs a) {
       for (uint32_t base = ccs; base < cce; base += 64) {
         const uint32_t ch = base + lane;
         float4 b0 = make_float4(0.f, 0.f, 0.f, 0.f), b1 = b0;
-        bool pass = false;
-        if (ch < cce) {
+        float bd = INFINITY;   // (shrunk) distance from the query to this lane's chunk box
+        bool live = ch < cce;  // this lane's chunk has not been evaluated yet
+        if (live) {
           const float4* cd = reinterpret_cast<const float4*>(a.chunks + ch);
           b0 = cd[0]; b1 = cd[1];
-          pass = box_dist2(b0.x, b0.y, b0.z, b1.x, b1.y, b1.z, q.x, q.y, q.z) * kPruneShrink <= best;
+          bd = box_dist2(b0.x, b0.y, b0.z, b1.x, b1.y, b1.z, q.x, q.y, q.z) * kPruneShrink;
         }
-        unsigned long long m = __ballot(pass);
+        // NEAREST BOX FIRST: every evaluated chunk is one dependent round trip, and the bound only shrinks when a closer
+        // point turns up -- in cell order a 25 cm ball on an aggregated map walked ~100 chunks per query (6.6 ns per
+        // query over a launch); the nearest box usually holds the neighbour and the re-test drops most of the others
+        unsigned long long m = __ballot(live && bd <= best);
         while (m) {
-          const int k = __ffsll((long long)m) - 1;
-          m &= m - 1;
-          // the bound may have shrunk since the cull: re-test (uniform)
-          const float lx = rl_f(b0.x, k), ly = rl_f(b0.y, k), lz = rl_f(b0.z, k);
-          const float hx = rl_f(b1.x, k), hy = rl_f(b1.y, k), hz = rl_f(b1.z, k);
-          if (!(box_dist2(lx, ly, lz, hx, hy, hz, q.x, q.y, q.z) * kPruneShrink <= best)) continue;
+          const unsigned long long key = (live && bd <= best) ? (((unsigned long long)__float_as_uint(bd) << 32) | (unsigned long long)lane) : ~0ull;
+          const int k = __builtin_amdgcn_readfirstlane((int)(wave_min_u64(key) & 63ull));
           const uint32_t st = rl_u(__float_as_uint(b0.w), k);
           const uint32_t cnt = rl_u(__float_as_uint(b1.w), k);
           float d = INFINITY;
@@ -1218,6 +1218,8 @@ __global__ __launch_bounds__(256) void k_knn_fallback(KnnArgs a) {
             bestp = pk < bestp ? pk : bestp;
           }
           best = fminf(best, wave_min(d));
+          if (lane == k) live = false;
+          m = __ballot(live && bd <= best);   // (boxes at exactly the bound stay in: a point there at the same distance may carry the smaller index)
         }
       }
     }
