@@ -105,7 +105,8 @@ typedef struct lsgpu_iter_trace {
   float   knn_main_us;      /* k_knn_tile duration (HIP events; 0 unless profile_kernels) */
   float   knn_fallback_us;  /* k_knn_fallback duration                                    */
   uint32_t stragglers;      /* queries resolved by the fallback in this iteration         */
-  uint32_t reserved;        /* queries that had to search in this iteration (0: every query searched) */
+  uint32_t reserved;        /* development counter: heavy tiles a wide launch (first iterations) counted -- the first 1024 go to the
+                             * wave-per-query pass; 0 in the settled iterations */
 } lsgpu_iter_trace;
 
 int  lsgpu_icp_create(const lsgpu_icp_config* cfg, int device, lsgpu_icp** out);
