@@ -411,6 +411,7 @@ __device__ __forceinline__ void tile_process_batch(const KnnArgs& a, float cap2,
   float4 b0 = make_float4(0.f, 0.f, 0.f, 0.f), b1 = b0;
   uint32_t sbase = 0;
   bool pass = false, near = false;
+  float gdl = INFINITY;   // (LAZY, heavy tiles) distance of this lane's chunk box to the box of the tile's queries
   if (valid) {
     const float4* cd = reinterpret_cast<const float4*>(a.chunks + ch);
     b0 = cd[0]; b1 = cd[1];
@@ -421,6 +422,7 @@ __device__ __forceinline__ void tile_process_batch(const KnnArgs& a, float cap2,
     const float gd = gx * gx + gy * gy + gz * gz;
     pass = gd * kPruneShrink <= maxbest;
     if (LAZY) near = gd == 0.f;   // the chunk's box overlaps the box of the tile's own queries
+    if (LAZY) gdl = gd;
   }
   unsigned long long m = __ballot(pass);
   if (!m) return;
@@ -479,6 +481,13 @@ __device__ __forceinline__ void tile_process_batch(const KnnArgs& a, float cap2,
         if (!pick) pick = needm;
         if (!pick) return 0;
         k = __ffsll((long long)pick) - 1;
+        if (sp.ways < 0 && !(needm & nearm)) {
+          // a HEAVY tile (cell block above route_chunks, wide balls -- a large guess on an aggregated map evaluated 64 chunks per
+          // tile in cell order): around the tile's own box the chunk NEAREST to it goes first -- the sooner the lanes' bounds
+          // shrink, the more of the farther chunks the re-test below drops (32 per tile)
+          const unsigned long long key = ((needm >> lane) & 1ull) ? (((unsigned long long)__float_as_uint(gdl) << 32) | (unsigned long long)lane) : ~0ull;
+          k = __builtin_amdgcn_readfirstlane((int)(wave_min_u64(key) & 63ull));
+        }
         needm &= ~(1ull << k);
         const float lx = rl_f(b0.x, k), ly = rl_f(b0.y, k), lz = rl_f(b0.z, k);
         const float hx = rl_f(b1.x, k), hy = rl_f(b1.y, k), hz = rl_f(b1.z, k);
@@ -1016,6 +1025,7 @@ __global__ __launch_bounds__(WAVES * 64, SPLIT ? LSGPU_TILE_OCC_SPLIT : LSGPU_TI
       SplitState sp;
       sp.ways = 1;
       if (SPLIT) split_setup(sp, ing_mask, lane, qx, qy, qz);
+      if (LAZY && block_chunks > (uint32_t)a.route_chunks) sp.ways = -1;   // (the lazy instantiation has no lane split: the field marks a heavy tile)
       // ---- flatten the cells' chunk ranges into the LDS list, 64 at a time into the cull
       unsigned long long cells = __ballot(ce > cs);
       uint32_t fill = 0;
